@@ -1,0 +1,275 @@
+# -*- coding: utf-8 -*-
+'''
+Triangle meshes for the host side of the path: storage, derived topology
+(edges, boundary facets) and the structured generators the reference drivers
+use -- `UnitSquareMesh(n, n, 'crossed'|'left/right')`
+(tests/test_navier_stokes.py:82,176), `RectangleMesh(Point, Point, n, n,
+'crossed')` (:144) -- plus a structured rectangle-with-circular-hole generator
+that stands in for the pygmsh meshes of tests/test_karman_vortex_street.py:26-53
+and tests/test_boussinesq.py:46-79 (gmsh is not available offline).
+'''
+import numpy
+
+
+class Point(object):
+    def __init__(self, *xy):
+        self.xy = numpy.array(xy, dtype=float)
+
+    def __getitem__(self, i):
+        return self.xy[i]
+
+
+class Mesh(object):
+    '''points: (Nv, 2) float64, cells: (Nc, 3) int32 vertex ids.
+
+    Derived (lazily):
+      edges        (Ne, 2)  sorted vertex pairs
+      cell_edges   (Nc, 3)  edge id opposite local vertex i
+      bfacets      (Nb,)    ids of edges with exactly one incident cell
+      bfacet_cell  (Nb,), bfacet_local (Nb,)  the cell and its local facet index
+    '''
+    def __init__(self, points, cells):
+        self.points = numpy.ascontiguousarray(points, dtype=numpy.float64)
+        self.cell_vertices = numpy.ascontiguousarray(cells, dtype=numpy.int32)
+        assert self.points.ndim == 2 and self.points.shape[1] == 2
+        assert self.cell_vertices.ndim == 2 and self.cell_vertices.shape[1] == 3
+        assert self.cell_vertices.min() >= 0
+        assert self.cell_vertices.max() < len(self.points)
+        self._topology = None
+        self._cache = {}
+        return
+
+    # -- dolfin-flavoured accessors ------------------------------------------
+    def num_vertices(self):
+        return len(self.points)
+
+    def num_cells(self):
+        return len(self.cell_vertices)
+
+    def coordinates(self):
+        return self.points
+
+    def cells(self):
+        return self.cell_vertices
+
+    def ufl_cell(self):
+        return 'triangle'
+
+    def _edge_lengths(self):
+        p = self.points
+        c = self.cell_vertices
+        e = numpy.stack([
+            p[c[:, 1]] - p[c[:, 2]],
+            p[c[:, 0]] - p[c[:, 2]],
+            p[c[:, 0]] - p[c[:, 1]],
+            ], axis=1)
+        return numpy.sqrt((e**2).sum(axis=2))
+
+    def hmax(self):
+        '''Largest cell diameter (= longest edge for a triangle).'''
+        return float(self._edge_lengths().max())
+
+    def hmin(self):
+        return float(self._edge_lengths().max(axis=1).min())
+
+    def cell_areas(self):
+        p = self.points
+        c = self.cell_vertices
+        d1 = p[c[:, 1]] - p[c[:, 0]]
+        d2 = p[c[:, 2]] - p[c[:, 0]]
+        return 0.5 * numpy.abs(d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0])
+
+    # -- topology ------------------------------------------------------------
+    def _build_topology(self):
+        c = self.cell_vertices.astype(numpy.int64)
+        nv = len(self.points)
+        # local edge i is opposite local vertex i
+        a = numpy.stack([c[:, 1], c[:, 0], c[:, 0]], axis=1)
+        b = numpy.stack([c[:, 2], c[:, 2], c[:, 1]], axis=1)
+        lo = numpy.minimum(a, b)
+        hi = numpy.maximum(a, b)
+        key = (lo * nv + hi).ravel()
+        ukey, inverse, counts = numpy.unique(
+            key, return_inverse=True, return_counts=True
+            )
+        edges = numpy.stack([ukey // nv, ukey % nv], axis=1).astype(numpy.int32)
+        cell_edges = inverse.reshape(-1, 3).astype(numpy.int32)
+        bmask = counts == 1
+        bfacets = numpy.nonzero(bmask)[0].astype(numpy.int32)
+        # owner cell / local index of each boundary facet
+        flat_is_b = bmask[inverse]
+        flat_idx = numpy.nonzero(flat_is_b)[0]
+        order = numpy.argsort(inverse[flat_idx], kind='stable')
+        flat_idx = flat_idx[order]
+        assert numpy.array_equal(inverse[flat_idx], bfacets)
+        self._topology = {
+            'edges': edges,
+            'cell_edges': cell_edges,
+            'bfacets': bfacets,
+            'bfacet_cell': (flat_idx // 3).astype(numpy.int32),
+            'bfacet_local': (flat_idx % 3).astype(numpy.int32),
+            }
+        return
+
+    def _topo(self, name):
+        if self._topology is None:
+            self._build_topology()
+        return self._topology[name]
+
+    @property
+    def edges(self):
+        return self._topo('edges')
+
+    @property
+    def cell_edges(self):
+        return self._topo('cell_edges')
+
+    @property
+    def bfacets(self):
+        return self._topo('bfacets')
+
+    @property
+    def bfacet_cell(self):
+        return self._topo('bfacet_cell')
+
+    @property
+    def bfacet_local(self):
+        return self._topo('bfacet_local')
+
+    def num_edges(self):
+        return len(self.edges)
+
+    def cell_bfacet_mask(self):
+        '''Per cell: bit i set iff local facet i lies on the boundary.'''
+        mask = numpy.zeros(self.num_cells(), dtype=numpy.int32)
+        numpy.bitwise_or.at(
+            mask, self.bfacet_cell, (1 << self.bfacet_local).astype(numpy.int32)
+            )
+        return mask
+
+
+def _quad_cells(nx, ny, diagonal, vid, mid=None):
+    '''Triangles of a structured nx x ny quad grid.  vid(ix, iy) -> vertex id
+    arrays; mid(ix, iy) -> centre-vertex ids for 'crossed'.
+    '''
+    ix, iy = numpy.meshgrid(numpy.arange(nx), numpy.arange(ny), indexing='xy')
+    ix = ix.ravel()
+    iy = iy.ravel()
+    v0 = vid(ix, iy)
+    v1 = vid(ix + 1, iy)
+    v2 = vid(ix, iy + 1)
+    v3 = vid(ix + 1, iy + 1)
+    if diagonal == 'crossed':
+        vm = mid(ix, iy)
+        tris = numpy.stack([
+            numpy.stack([v0, v1, vm], axis=1),
+            numpy.stack([v0, v2, vm], axis=1),
+            numpy.stack([v1, v3, vm], axis=1),
+            numpy.stack([v2, v3, vm], axis=1),
+            ], axis=1)
+        return tris.reshape(-1, 3)
+    if diagonal == 'right':
+        is_right = numpy.ones(len(ix), dtype=bool)
+    elif diagonal == 'left':
+        is_right = numpy.zeros(len(ix), dtype=bool)
+    elif diagonal == 'left/right':
+        is_right = ((ix + iy) % 2) == 1
+    elif diagonal == 'right/left':
+        is_right = ((ix + iy) % 2) == 0
+    else:
+        raise ValueError('unknown diagonal %r' % diagonal)
+    # right: diagonal v0-v3; left: diagonal v1-v2
+    t0 = numpy.where(
+        is_right[:, None],
+        numpy.stack([v0, v1, v3], axis=1), numpy.stack([v0, v1, v2], axis=1)
+        )
+    t1 = numpy.where(
+        is_right[:, None],
+        numpy.stack([v0, v2, v3], axis=1), numpy.stack([v1, v2, v3], axis=1)
+        )
+    return numpy.stack([t0, t1], axis=1).reshape(-1, 3)
+
+
+# pylint: disable=invalid-name
+def RectangleMesh(p0, p1, nx, ny, diagonal='right'):
+    '''Structured rectangle mesh; vertex (ix, iy) has id iy*(nx+1)+ix, the
+    centre vertices of 'crossed' follow.'''
+    x = numpy.linspace(p0[0], p1[0], nx + 1)
+    y = numpy.linspace(p0[1], p1[1], ny + 1)
+    X, Y = numpy.meshgrid(x, y, indexing='xy')
+    pts = numpy.stack([X.ravel(), Y.ravel()], axis=1)
+
+    def vid(ix, iy):
+        return iy * (nx + 1) + ix
+
+    mid = None
+    if diagonal == 'crossed':
+        xm = 0.5 * (x[:-1] + x[1:])
+        ym = 0.5 * (y[:-1] + y[1:])
+        XM, YM = numpy.meshgrid(xm, ym, indexing='xy')
+        pts = numpy.concatenate(
+            [pts, numpy.stack([XM.ravel(), YM.ravel()], axis=1)]
+            )
+
+        def mid(ix, iy):
+            return (nx + 1) * (ny + 1) + iy * nx + ix
+
+    cells = _quad_cells(nx, ny, diagonal, vid, mid)
+    return Mesh(pts, cells)
+
+
+def UnitSquareMesh(nx, ny, diagonal='right'):
+    return RectangleMesh(Point(0.0, 0.0), Point(1.0, 1.0), nx, ny, diagonal)
+
+
+def rectangle_with_hole(
+        x0, x1, y0, y1, centre, radius, nx, ny, diagonal='right'
+        ):
+    '''Structured nx x ny-cell rectangle [x0,x1]x[y0,y1] with the cells whose
+    centroid lies inside the circle (centre, radius) removed (staircase
+    obstacle).  Vertices are numbered x-major (all vertices of one grid column
+    are consecutive), so that with ny <= nx the operator bandwidth is O(ny):
+    this is the layout the row-block sharding of the pressure solve assumes
+    (SURVEY.md section 8e).  Geometry constants of the Karman channel:
+    tests/test_karman_vortex_street.py:18-23,35-45.
+    '''
+    x = numpy.linspace(x0, x1, nx + 1)
+    y = numpy.linspace(y0, y1, ny + 1)
+    X, Y = numpy.meshgrid(x, y, indexing='ij')
+    pts = numpy.stack([X.ravel(), Y.ravel()], axis=1)
+
+    def vid(ix, iy):
+        return ix * (ny + 1) + iy
+
+    cells = _quad_cells(nx, ny, diagonal, vid)
+    cen = pts[cells].mean(axis=1)
+    keep = (
+        (cen[:, 0] - centre[0])**2 + (cen[:, 1] - centre[1])**2 > radius**2
+        )
+    cells = cells[keep]
+    # drop unused vertices, keeping the x-major order
+    used = numpy.zeros(len(pts), dtype=bool)
+    used[cells.ravel()] = True
+    new_id = numpy.cumsum(used) - 1
+    return Mesh(pts[used], new_id[cells])
+
+
+def karman_channel(nx, ny=None, diagonal='right'):
+    '''Channel [0, 0.6] x [-0.07, 0.07] with a circular obstacle of diameter
+    0.04 at (0.1, 0.01): tests/test_karman_vortex_street.py:18-23, 35-38.'''
+    if ny is None:
+        ny = max(2, int(round(nx * 0.14 / 0.6)))
+    return rectangle_with_hole(
+        0.0, 0.6, -0.07, 0.07, (0.1, 1.0e-2), 0.02, nx, ny, diagonal
+        )
+
+
+def heater_box(nx, ny=None, diagonal='right'):
+    '''Box [0, 0.1] x [0, 0.2] with a circular heater of radius 0.02 at
+    (0.05, 0.05): tests/test_boussinesq.py:27-30, 62-64 and
+    tests/test_sealed_box.py:35-40.'''
+    if ny is None:
+        ny = 2 * nx
+    return rectangle_with_hole(
+        0.0, 0.1, 0.0, 0.2, (0.05, 0.05), 0.02, nx, ny, diagonal
+        )
