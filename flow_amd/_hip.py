@@ -1,0 +1,196 @@
+# -*- coding: utf-8 -*-
+'''
+ctypes binding of libflow_hip.so (C ABI: include/flow_hip.h).
+
+There is NO fallback: if the library is missing, or a call is made without a
+GPU, this raises.  Wrappers check operand dtypes / sizes / devices on the host
+before a kernel is launched (an out-of-bounds access on the device can take
+the whole node down).
+'''
+import ctypes
+import os
+
+import torch
+
+from . import device
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libflow_hip.so')
+
+REDUCE_WORK = 4096
+SPMV_ROWS_PER_BLOCK = 256
+SPMV_NNZ_PER_BLOCK = 2048
+
+c_double_p = ctypes.c_void_p
+c_int_p = ctypes.c_void_p
+
+
+class Operator(ctypes.Structure):
+    _fields_ = [
+        ('kind', ctypes.c_int),
+        ('n', ctypes.c_int),
+        ('nnz', ctypes.c_int),
+        ('nblocks', ctypes.c_int),
+        ('rowptr', ctypes.c_void_p),
+        ('cols', ctypes.c_void_p),
+        ('rowblocks', ctypes.c_void_p),
+        ('vals', ctypes.c_void_p * 4),
+        ]
+
+
+class MeshS(ctypes.Structure):
+    _fields_ = [('nc', ctypes.c_int), ('xy', ctypes.c_void_p)]
+
+
+class SpaceS(ctypes.Structure):
+    _fields_ = [
+        ('deg', ctypes.c_int),
+        ('n', ctypes.c_int),
+        ('nnz', ctypes.c_int),
+        ('cell_dofs', ctypes.c_void_p),
+        ('cptr', ctypes.c_void_p),
+        ('csrc', ctypes.c_void_p),
+        ('vptr', ctypes.c_void_p),
+        ('vsrc', ctypes.c_void_p),
+        ]
+
+
+class CoefS(ctypes.Structure):
+    _fields_ = [
+        ('nl', ctypes.c_int),
+        ('cell_stride', ctypes.c_int),
+        ('values', ctypes.c_void_p),
+        ('G', ctypes.c_void_p),
+        ]
+
+
+class NsParams(ctypes.Structure):
+    _fields_ = [
+        ('dt', ctypes.c_double), ('rho', ctypes.c_double),
+        ('mu', ctypes.c_double), ('theta_i', ctypes.c_double),
+        ('theta_e', ctypes.c_double),
+        ]
+
+
+# every symbol include/flow_hip.h declares: (name, argtypes)
+_VP = ctypes.c_void_p
+_I = ctypes.c_int
+_D = ctypes.c_double
+_P = ctypes.POINTER
+SYMBOLS = {
+    'flow_abi_version': [],
+    'flow_operator_apply': [_P(Operator), _VP, _VP, _VP],
+    'flow_operator_diag_inv': [_P(Operator), _VP, _VP, _VP],
+    'flow_dot_host': [_I, _VP, _VP, _VP, _P(_D), _VP],
+    'flow_norm_host': [_I, _VP, _I, _VP, _P(_D), _VP],
+    'flow_axpby': [_I, _D, _VP, _D, _VP, _VP],
+    'flow_cg_solve': [_P(Operator), _VP, _VP, _VP, _D, _D, _I, _I, _VP,
+                      ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_bicgstab_solve': [_P(Operator), _VP, _VP, _VP, _D, _D, _I, _I, _VP,
+                            ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_assemble_scalar_matrix': [_I, _P(MeshS), _P(SpaceS), _VP, _VP, _VP],
+    'flow_assemble_pressure_rhs': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _VP,
+                                   _D, _D, _I, _VP, _VP, _VP],
+    'flow_assemble_correction_rhs': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP,
+                                     _VP, _VP, _D, _D, _I, _VP, _VP, _VP],
+    'flow_assemble_momentum': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _VP, _VP,
+                               _VP, _P(CoefS), _P(CoefS), _P(NsParams), _VP,
+                               _VP, _VP, _VP],
+    'flow_assemble_source': [_P(MeshS), _P(SpaceS), _I, _P(CoefS), _VP, _VP,
+                             _VP],
+    'flow_bc_identity_rows': [_P(Operator), _VP, _VP, _I, _VP, _VP],
+    'flow_bc_residual': [_I, _VP, _VP, _VP, _VP, _VP],
+    'flow_bc_set_values': [_I, _VP, _VP, _VP, _VP],
+    'flow_bc_symmetric_matrix': [_I, _VP, _VP, _VP, _VP, _VP, _VP],
+    'flow_assemble_heat': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _D, _D, _I,
+                           _VP, _VP, _VP, _VP, _VP, _VP],
+    }
+
+_LIB = None
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class NotConverged(RuntimeError):
+    '''Krylov / Newton non-convergence.  A RuntimeError, because callers of the
+    reference catch exactly that (tests/test_boussinesq.py:254).'''
+
+
+def load_library():
+    '''dlopen the in-tree library and set the prototypes (no GPU needed).'''
+    global _LIB
+    if _LIB is None:
+        if not os.path.isfile(LIB_PATH):
+            raise HipError(
+                'libflow_hip.so not found at %s -- build it with '
+                '`python -c "import __graft_entry__ as g; g.build()"` or '
+                '`make -C flow_amd/csrc`' % LIB_PATH
+                )
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.flow_last_error.restype = ctypes.c_char_p
+        lib.flow_last_error.argtypes = []
+        for name, argtypes in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = argtypes
+        _LIB = lib
+    return _LIB
+
+
+def lib():
+    '''The library, for compute calls: requires a GPU.'''
+    handle = load_library()
+    if not device.on_gpu():
+        raise HipError(
+            'flow_amd needs an AMD GPU (MI355X): the hot path has no CPU '
+            'fallback'
+            )
+    return handle
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = load_library().flow_last_error().decode('utf-8', 'replace')
+    if rc == 1:
+        raise NotConverged(msg)
+    if rc == 2:
+        raise ValueError(msg)
+    raise HipError(msg)
+
+
+# -- operand checks -----------------------------------------------------------
+def _ptr(t, dtype, numel=None, name='operand'):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s: expected a torch tensor' % name)
+    if t.dtype != dtype:
+        raise TypeError('%s: dtype %s, expected %s' % (name, t.dtype, dtype))
+    if not t.is_cuda:
+        raise HipError('%s is not in device memory' % name)
+    if not t.is_contiguous():
+        raise ValueError('%s is not contiguous' % name)
+    if numel is not None and t.numel() < numel:
+        raise ValueError(
+            '%s has %d elements, needs %d' % (name, t.numel(), numel)
+            )
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def f64(t, numel=None, name='fp64 operand'):
+    return _ptr(t, torch.float64, numel, name)
+
+
+def i32(t, numel=None, name='int32 operand'):
+    return _ptr(t, torch.int32, numel, name)
+
+
+def u8(t, numel=None, name='uint8 operand'):
+    return _ptr(t, torch.uint8, numel, name)
+
+
+def stream():
+    return ctypes.c_void_p(device.stream_handle())

@@ -1,0 +1,921 @@
+// Finite-element assembly of the hot path on gfx950 (K1-K7, K13, K14).
+//
+// Replaces FFC-generated tabulate_tensor + DOLFIN Assembler + DirichletBC for
+// the forms of flow/navier_stokes/pressure_correction.py (:135-144, :169-202,
+// :317-323, :442-449) and flow/heat.py (:39-88).
+//
+// Two-phase, atomic-free and therefore bitwise reproducible:
+//   phase 1  cell kernels: coalesced reads of the SoA cell->dof / coordinate
+//            arrays, local element tensor in registers (the Jacobian kernel
+//            stages u(x_q), grad u(x_q) of 64 cells in LDS and gives every
+//            wavefront a wave-uniform list of (i,j) entry pairs), coalesced
+//            stores to scratch[entry][cell];
+//   phase 2  gather kernels: one lane per CSR nonzero / per dof sums its
+//            contributions through the host-built contribution map, fixed
+//            order, coalesced stores of the CSR values.
+// Everything here is HBM-bound integer/fp64 streaming; no MFMA.
+#include "fem_device.h"
+
+namespace flow {
+
+// ---------------------------------------------------------------------------
+// phase 2
+// ---------------------------------------------------------------------------
+__global__ void gather_kernel(int nout, int nplanes, const int* __restrict__ ptr,
+                              const int* __restrict__ src,
+                              const double* __restrict__ scratch,
+                              size_t plane_stride, double* __restrict__ out) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nout;
+       k += gridDim.x * blockDim.x) {
+    const int a = ptr[k];
+    const int b = ptr[k + 1];
+    for (int p = 0; p < nplanes; ++p) {
+      const double* __restrict__ sp = scratch + p * plane_stride;
+      double s = 0.0;
+      for (int t = a; t < b; ++t) s += sp[src[t]];
+      out[static_cast<size_t>(p) * nout + k] = s;
+    }
+  }
+}
+
+static int gather(int nout, int nplanes, const int* ptr, const int* src,
+                  const double* scratch, size_t plane_stride, double* out,
+                  hipStream_t st) {
+  hipLaunchKernelGGL(gather_kernel, dim3(grid_for(nout, kBlock, 1 << 20)),
+                     dim3(kBlock), 0, st, nout, nplanes, ptr, src, scratch,
+                     plane_stride, out);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+template <int NL>
+__device__ __forceinline__ void load_local(const double* __restrict__ u, int n,
+                                           const int* __restrict__ cd, int nc,
+                                           int c, int /*ncomp = 2*/,
+                                           double U[2][NL]) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int d = cd[i * nc + c];
+    U[0][i] = u[d];
+    U[1][i] = u[static_cast<size_t>(n) + d];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1 / K3 / lumped mass: constant-coefficient scalar matrices
+// ---------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void scalar_matrix_kernel(
+    int kind, int nc, const double* __restrict__ xy,
+    double* __restrict__ scratch) {
+  constexpr int NL = Elem<DEG>::NL;
+  constexpr int NQ = Elem<2>::NQ;   // 7-point rule: exact for P2 mass (deg 4)
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const Geom g = load_geom(xy, nc, c);
+  double Ke[NL][NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int j = 0; j < NL; ++j) Ke[i][j] = 0.0;
+  if (kind == 2) {
+    // 'vertex' quadrature scheme: points = cell vertices, weights |T|/3
+    // (flow/heat.py:39-45); only the vertex basis functions are non-zero.
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Ke[i][i] = g.adet / 6.0;
+  } else {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const double L[3] = {kQ7L[q][0], kQ7L[q][1], kQ7L[q][2]};
+      const double w = 0.5 * kQ7W[q] * g.adet;
+      double phi[NL], dphi[NL][3], gphi[NL][2];
+      basis<DEG>(L, phi, dphi);
+      phys_grad<NL>(g, dphi, gphi);
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+          Ke[i][j] += (kind == 0)
+                          ? w * (gphi[i][0] * gphi[j][0] + gphi[i][1] * gphi[j][1])
+                          : w * phi[i] * phi[j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+      scratch[static_cast<size_t>(i * NL + j) * nc + c] = Ke[i][j];
+}
+
+// ---------------------------------------------------------------------------
+// K2: pressure right-hand side
+// ---------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void pressure_rhs_kernel(
+    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    const int* __restrict__ cdp, const double* __restrict__ u,
+    const double* __restrict__ p0, double alpha_rho_dt, double mu,
+    int rotational, double* __restrict__ scratch) {
+  constexpr int NL = Elem<DEG>::NL;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const Geom g = load_geom(xy, nc, c);
+  double U[2][NL];
+  load_local<NL>(u, nu, cdu, nc, c, 2, U);
+  double d[3];
+  div_at_vertices<DEG>(g, U, d);
+  const double area = 0.5 * g.adet;
+  const double dsum = d[0] + d[1] + d[2];
+  double gp[2] = {0.0, 0.0};   // grad p0 [- mu grad div u]
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double coef = p0[cdp[k * nc + c]];
+    if (rotational) coef -= mu * d[k];
+    gp[0] += coef * g.gl[k][0];
+    gp[1] += coef * g.gl[k][1];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double b = -alpha_rho_dt * (area / 12.0) * (dsum + d[i]) +
+                     area * (gp[0] * g.gl[i][0] + gp[1] * g.gl[i][1]);
+    scratch[static_cast<size_t>(i) * nc + c] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K4: velocity-correction right-hand side
+// ---------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void correction_rhs_kernel(
+    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    const int* __restrict__ cdp, const double* __restrict__ u,
+    const double* __restrict__ p1, const double* __restrict__ p0, double dt_rho,
+    double mu, int rotational, double* __restrict__ scratch) {
+  constexpr int NL = Elem<DEG>::NL;
+  constexpr int NQ = Elem<2>::NQ;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const Geom g = load_geom(xy, nc, c);
+  double U[2][NL];
+  load_local<NL>(u, nu, cdu, nc, c, 2, U);
+  double d[3] = {0.0, 0.0, 0.0};
+  if (rotational) div_at_vertices<DEG>(g, U, d);
+  double gphi_f[2] = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int dof = cdp[k * nc + c];
+    const double coef = p1[dof] - p0[dof] + mu * d[k];
+    gphi_f[0] += coef * g.gl[k][0];
+    gphi_f[1] += coef * g.gl[k][1];
+  }
+  double acc[2][NL];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc[a][i] = 0.0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double L[3] = {kQ7L[q][0], kQ7L[q][1], kQ7L[q][2]};
+    const double w = 0.5 * kQ7W[q] * g.adet;
+    double phi[NL], dphi[NL][3];
+    basis<DEG>(L, phi, dphi);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      double uq = 0.0;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) uq += U[a][j] * phi[j];
+      const double val = w * (uq - dt_rho * gphi_f[a]);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) acc[a][i] += val * phi[i];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      scratch[static_cast<size_t>(a * NL + i) * nc + c] = acc[a][i];
+}
+
+// ---------------------------------------------------------------------------
+// source term (f, v) from per-cell lattice values
+// ---------------------------------------------------------------------------
+template <int NL>
+__device__ __forceinline__ void add_source(const flow_coef& f, int nc, int c,
+                                           int dim, double scale,
+                                           double acc[][NL]) {
+  const size_t nce = f.cell_stride ? static_cast<size_t>(nc) : 1;
+  const size_t cc = f.cell_stride ? static_cast<size_t>(c) : 0;
+  for (int a = 0; a < dim; ++a) {
+    for (int l = 0; l < f.nl; ++l) {
+      const double F = scale * f.values[(static_cast<size_t>(a) * f.nl + l) * nce + cc];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) acc[a][i] += F * f.G[l * NL + i];
+    }
+  }
+}
+
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void source_kernel(
+    int nc, const double* __restrict__ xy, int dim, flow_coef f,
+    double* __restrict__ scratch) {
+  constexpr int NL = Elem<DEG>::NL;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const Geom g = load_geom(xy, nc, c);
+  double acc[2][NL];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc[a][i] = 0.0;
+  add_source<NL>(f, nc, c, dim, g.adet, acc);
+  for (int a = 0; a < dim; ++a)
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      scratch[static_cast<size_t>(a * NL + i) * nc + c] = acc[a][i];
+}
+
+// ---------------------------------------------------------------------------
+// K5 + K6: momentum residual
+// ---------------------------------------------------------------------------
+// acc += scale * R(u; v) of _rhs_weak (pressure_correction.py:135-144) without
+// the source term; volume part at one quadrature point
+template <int NL>
+__device__ __forceinline__ void add_rhs_weak_point(
+    double w, double rho, double mu, const double U[2][NL], const double P[3],
+    const double L[3], const double phi[NL], const double gphi[NL][2],
+    double acc[2][NL]) {
+  double uq[2] = {0.0, 0.0};
+  double gu[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // gu[a][b] = d_b u_a
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      uq[a] += U[a][j] * phi[j];
+      gu[a][0] += U[a][j] * gphi[j][0];
+      gu[a][1] += U[a][j] * gphi[j][1];
+    }
+  }
+  const double pq = P[0] * L[0] + P[1] * L[1] + P[2] * L[2];
+  const double conv[2] = {gu[0][0] * uq[0] + gu[0][1] * uq[1],
+                          gu[1][0] * uq[0] + gu[1][1] * uq[1]};
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const double ugp = uq[0] * gphi[i][0] + uq[1] * gphi[i][1];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      double r = -0.5 * rho * (conv[a] * phi[i] - ugp * uq[a]);
+      r -= mu * ((gu[a][0] + gu[0][a]) * gphi[i][0] +
+                 (gu[a][1] + gu[1][a]) * gphi[i][1]);
+      r += pq * gphi[i][a];
+      acc[a][i] += w * r;
+    }
+  }
+}
+
+// exterior facets: - p0 n.v ds + mu ((grad u)^T n).v ds  (:142-143)
+template <int DEG>
+__device__ __forceinline__ void add_rhs_weak_facets(
+    int mask, double scale, double mu, const Geom& g,
+    const double U[2][Elem<DEG>::NL], const double P[3],
+    double acc[2][Elem<DEG>::NL]) {
+  constexpr int NL = Elem<DEG>::NL;
+  for (int lf = 0; lf < 3; ++lf) {
+    if (!((mask >> lf) & 1)) continue;
+    const int v0 = facet_v0(lf), v1 = facet_v1(lf);
+    // outward normal times facet length: -grad(lambda_lf) * |detJ|
+    const double nL[2] = {-g.gl[lf][0] * g.adet, -g.gl[lf][1] * g.adet};
+    for (int gq = 0; gq < 2; ++gq) {
+      const double s = gq == 0 ? FLOW_G2A : FLOW_G2B;
+      double L[3] = {0.0, 0.0, 0.0};
+      L[v0] = 1.0 - s;
+      L[v1] = s;
+      double phi[NL], dphi[NL][3], gphi[NL][2];
+      basis<DEG>(L, phi, dphi);
+      phys_grad<NL>(g, dphi, gphi);
+      double gu[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+      for (int j = 0; j < NL; ++j)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          gu[a][0] += U[a][j] * gphi[j][0];
+          gu[a][1] += U[a][j] * gphi[j][1];
+        }
+      const double pq = P[0] * L[0] + P[1] * L[1] + P[2] * L[2];
+      const double w = 0.5 * scale;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        // ((grad u)^T n)_a = sum_b d_a u_b n_b = sum_b gu[b][a] n_b
+        const double t = -pq * nL[a] + mu * (gu[0][a] * nL[0] + gu[1][a] * nL[1]);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) acc[a][i] += w * t * phi[i];
+      }
+    }
+  }
+}
+
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void momentum_residual_kernel(
+    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    const int* __restrict__ cdp, const int* __restrict__ bfmask,
+    const double* __restrict__ ui, const double* __restrict__ u0,
+    const double* __restrict__ p0, flow_coef f0, flow_coef f1,
+    flow_ns_params prm, double* __restrict__ scratch) {
+  constexpr int NL = Elem<DEG>::NL;
+  constexpr int NQ = Elem<DEG>::NQ;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const Geom g = load_geom(xy, nc, c);
+  double Ui[2][NL], U0[2][NL], P[3];
+  load_local<NL>(ui, nu, cdu, nc, c, 2, Ui);
+  load_local<NL>(u0, nu, cdu, nc, c, 2, U0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) P[k] = p0[cdp[k * nc + c]];
+  const int mask = bfmask[c];
+  const double ci = -prm.dt / prm.rho * prm.theta_i;
+  const double ce = -prm.dt / prm.rho * prm.theta_e;
+  double acc[2][NL];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc[a][i] = 0.0;
+
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double L[3] = {qpoint<DEG>(q, 0), qpoint<DEG>(q, 1), qpoint<DEG>(q, 2)};
+    const double w = 0.5 * qweight<DEG>(q) * g.adet;
+    double phi[NL], dphi[NL][3], gphi[NL][2];
+    basis<DEG>(L, phi, dphi);
+    phys_grad<NL>(g, dphi, gphi);
+    // (ui - u0, v)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      double du = 0.0;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) du += (Ui[a][j] - U0[a][j]) * phi[j];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) acc[a][i] += w * du * phi[i];
+    }
+    if (ci != 0.0)
+      add_rhs_weak_point<NL>(w * ci, prm.rho, prm.mu, Ui, P, L, phi, gphi, acc);
+    if (ce != 0.0)
+      add_rhs_weak_point<NL>(w * ce, prm.rho, prm.mu, U0, P, L, phi, gphi, acc);
+  }
+  if (mask) {
+    if (ci != 0.0) add_rhs_weak_facets<DEG>(mask, ci, prm.mu, g, Ui, P, acc);
+    if (ce != 0.0) add_rhs_weak_facets<DEG>(mask, ce, prm.mu, g, U0, P, acc);
+  }
+  if (ci != 0.0) add_source<NL>(f1, nc, c, 2, ci * g.adet, acc);
+  if (ce != 0.0) add_source<NL>(f0, nc, c, 2, ce * g.adet, acc);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      scratch[static_cast<size_t>(a * NL + i) * nc + c] = acc[a][i];
+}
+
+// ---------------------------------------------------------------------------
+// K5 + K6: Jacobian  J = dF/dui
+// ---------------------------------------------------------------------------
+// basis tables at the quadrature points (wave-uniform index -> scalar loads)
+template <int DEG>
+struct BasisTab {
+  double phi[Elem<DEG>::NQ][Elem<DEG>::NL];
+  double dphi[Elem<DEG>::NQ][Elem<DEG>::NL][3];
+};
+
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void momentum_jacobian_kernel(
+    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    const int* __restrict__ bfmask, const double* __restrict__ ui,
+    flow_ns_params prm, double* __restrict__ scratch) {
+  constexpr int NL = Elem<DEG>::NL;
+  constexpr int NQ = Elem<DEG>::NQ;
+  constexpr int NP = NL * NL;
+  // LDS staging of the per-cell fields at the quadrature points, [item][lane]
+  __shared__ double s_uq[NQ][2][64];
+  __shared__ double s_gu[NQ][4][64];
+  __shared__ BasisTab<DEG> tab;
+
+  const int lane = threadIdx.x & 63;
+  const int grp = threadIdx.x >> 6;          // wavefront id: wave-uniform
+  const int c = blockIdx.x * 64 + lane;
+  const bool active = c < nc;
+  const int cc = active ? c : nc - 1;
+
+  // basis tables: one (q, i) entry per thread
+  for (int t = threadIdx.x; t < NQ * NL; t += kBlock) {
+    const int q = t / NL, i = t % NL;
+    const double L[3] = {qpoint<DEG>(q, 0), qpoint<DEG>(q, 1), qpoint<DEG>(q, 2)};
+    double phi[NL], dphi[NL][3];
+    basis<DEG>(L, phi, dphi);
+    tab.phi[q][i] = phi[i];
+    tab.dphi[q][i][0] = dphi[i][0];
+    tab.dphi[q][i][1] = dphi[i][1];
+    tab.dphi[q][i][2] = dphi[i][2];
+  }
+
+  const Geom g = load_geom(xy, nc, cc);
+  const int mask = bfmask[cc];
+  {
+    double U[2][NL];
+    load_local<NL>(ui, nu, cdu, nc, cc, 2, U);
+    // wave `grp` stages quadrature points grp, grp+4, ...
+    for (int q = grp; q < NQ; q += 4) {
+      const double L[3] = {qpoint<DEG>(q, 0), qpoint<DEG>(q, 1),
+                           qpoint<DEG>(q, 2)};
+      double phi[NL], dphi[NL][3], gphi[NL][2];
+      basis<DEG>(L, phi, dphi);
+      phys_grad<NL>(g, dphi, gphi);
+      double uq[2] = {0.0, 0.0}, gu[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        uq[0] += U[0][j] * phi[j];
+        uq[1] += U[1][j] * phi[j];
+        gu[0] += U[0][j] * gphi[j][0];
+        gu[1] += U[0][j] * gphi[j][1];
+        gu[2] += U[1][j] * gphi[j][0];
+        gu[3] += U[1][j] * gphi[j][1];
+      }
+      s_uq[q][0][lane] = uq[0];
+      s_uq[q][1][lane] = uq[1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_gu[q][k][lane] = gu[k];
+    }
+  }
+  __syncthreads();
+
+  const double c1 = -prm.dt / prm.rho * prm.theta_i;
+  const double hr = 0.5 * prm.rho;
+  const double mu = prm.mu;
+  const size_t plane = static_cast<size_t>(NP) * nc;
+
+  for (int pr = grp; pr < NP; pr += 4) {
+    const int i = pr / NL, j = pr % NL;       // row local dof i, column j
+    double B[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const double w = 0.5 * qweight<DEG>(q) * g.adet;
+      const double pi = tab.phi[q][i], pj = tab.phi[q][j];
+      double gi[2], gj[2];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        gi[d] = tab.dphi[q][i][0] * g.gl[0][d] + tab.dphi[q][i][1] * g.gl[1][d] +
+                tab.dphi[q][i][2] * g.gl[2][d];
+        gj[d] = tab.dphi[q][j][0] * g.gl[0][d] + tab.dphi[q][j][1] * g.gl[1][d] +
+                tab.dphi[q][j][2] * g.gl[2][d];
+      }
+      const double u0 = s_uq[q][0][lane], u1 = s_uq[q][1][lane];
+      const double gu[2][2] = {{s_gu[q][0][lane], s_gu[q][1][lane]},
+                               {s_gu[q][2][lane], s_gu[q][3][lane]}};
+      const double uq[2] = {u0, u1};
+      const double ugj = u0 * gj[0] + u1 * gj[1];
+      const double ugi = u0 * gi[0] + u1 * gi[1];
+      const double kij = gi[0] * gj[0] + gi[1] * gj[1];
+      // diagonal (a == c) part
+      const double diag =
+          pi * pj + c1 * (-hr * (ugj * pi - ugi * pj) - mu * kij);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          double v = c1 * (-hr * (pj * pi * gu[a][cb] - pj * gi[cb] * uq[a]) -
+                           mu * gj[a] * gi[cb]);
+          if (a == cb) v += diag;
+          B[a][cb] += w * v;
+        }
+    }
+    if (mask) {
+      // + dt/rho-scaled  mu int_Gamma d_a phi_j n_c phi_i ds
+      for (int lf = 0; lf < 3; ++lf) {
+        if (!((mask >> lf) & 1)) continue;
+        const int v0 = facet_v0(lf), v1 = facet_v1(lf);
+        const double nL[2] = {-g.gl[lf][0] * g.adet, -g.gl[lf][1] * g.adet};
+        for (int gq = 0; gq < 2; ++gq) {
+          const double s = gq == 0 ? FLOW_G2A : FLOW_G2B;
+          double L[3] = {0.0, 0.0, 0.0};
+          L[v0] = 1.0 - s;
+          L[v1] = s;
+          double phi[NL], dphi[NL][3], gphi[NL][2];
+          basis<DEG>(L, phi, dphi);
+          phys_grad<NL>(g, dphi, gphi);
+          double pi = 0.0, gj0 = 0.0, gj1 = 0.0;
+#pragma unroll
+          for (int t = 0; t < NL; ++t) {
+            if (t == i) pi = phi[t];
+            if (t == j) {
+              gj0 = gphi[t][0];
+              gj1 = gphi[t][1];
+            }
+          }
+          const double w = 0.5 * c1 * mu * pi;
+          B[0][0] += w * gj0 * nL[0];
+          B[0][1] += w * gj0 * nL[1];
+          B[1][0] += w * gj1 * nL[0];
+          B[1][1] += w * gj1 * nL[1];
+        }
+      }
+    }
+    if (active) {
+      const size_t base = static_cast<size_t>(pr) * nc + c;
+      scratch[0 * plane + base] = B[0][0];
+      scratch[1 * plane + base] = B[0][1];
+      scratch[2 * plane + base] = B[1][0];
+      scratch[3 * plane + base] = B[1][1];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K7: Dirichlet conditions
+// ---------------------------------------------------------------------------
+__global__ void bc_identity_rows_kernel(int kind, int n, int nnz,
+                                        const int* __restrict__ rowptr,
+                                        const int* __restrict__ diag_idx,
+                                        int nbc, const int* __restrict__ dofs,
+                                        double* __restrict__ vals) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nbc;
+       t += gridDim.x * blockDim.x) {
+    const int d = dofs[t];
+    const int a = d / n;
+    const int i = d - a * n;
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    if (kind == 2) {
+      double* p0 = vals + static_cast<size_t>(2 * a) * nnz;
+      double* p1 = vals + static_cast<size_t>(2 * a + 1) * nnz;
+      for (int k = k0; k < k1; ++k) {
+        p0[k] = 0.0;
+        p1[k] = 0.0;
+      }
+      vals[static_cast<size_t>(3 * a) * nnz + diag_idx[i]] = 1.0;
+    } else {
+      double* p = vals + static_cast<size_t>(a) * nnz;
+      for (int k = k0; k < k1; ++k) p[k] = 0.0;
+      p[diag_idx[i]] = 1.0;
+    }
+  }
+}
+
+__global__ void bc_residual_kernel(int nbc, const int* __restrict__ dofs,
+                                   const double* __restrict__ g,
+                                   const double* __restrict__ u,
+                                   double* __restrict__ F) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nbc;
+       t += gridDim.x * blockDim.x) {
+    const int d = dofs[t];
+    F[d] = u ? u[d] - g[t] : g[t];
+  }
+}
+
+__global__ void bc_symmetric_kernel(int n, const int* __restrict__ rowptr,
+                                    const int* __restrict__ cols,
+                                    const double* __restrict__ vin,
+                                    const unsigned char* __restrict__ isbc,
+                                    double* __restrict__ vout) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n;
+       r += gridDim.x * blockDim.x) {
+    const bool rb = isbc[r] != 0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      const int c = cols[k];
+      vout[k] = (rb || isbc[c]) ? (r == c ? 1.0 : 0.0) : vin[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K13 / K14: heat operator and SUPG tau
+// ---------------------------------------------------------------------------
+// SupgStab::eval (flow/stabilization.py:50-143)
+__device__ __forceinline__ double supg_tau(const double px[3], const double py[3],
+                                           double area, double bx, double by,
+                                           double eps, int p, int* status) {
+  const double nb = sqrt(bx * bx + by * by);
+  if (nb < 1.0e-10) return 0.0;
+  double sum = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i + 1; j < 3; ++j) {
+      const double e0 = px[i] - px[j];
+      const double e1 = py[i] - py[j];
+      sum += fabs(e1 * bx - e0 * by);
+    }
+  const double h = 4.0 * nb * area / sum;
+  const double Pe = 0.5 * nb * h / (p * eps);
+  const double xi = Pe > 1.0e-5
+                        ? (1.0 / tanh(Pe) - 1.0 / Pe) / Pe
+                        : 1.0 / 3.0 - Pe * Pe / 45.0 +
+                              2.0 / 945.0 * Pe * Pe * Pe * Pe;
+  const double tau = h * h / 4.0 / eps / p * xi;
+  if (tau > 1.0e3) *status = 1;
+  return tau;
+}
+
+template <int DEGQ, int DEGW>
+__global__ __launch_bounds__(kBlock) void heat_kernel(
+    int nc, const double* __restrict__ xy, const int* __restrict__ cdw, int nw,
+    const double* __restrict__ conv, double kappa, double rho_cp, int supg,
+    double* __restrict__ scratch, double* __restrict__ tau_out,
+    int* __restrict__ status) {
+  constexpr int NL = Elem<DEGQ>::NL;
+  constexpr int NW = Elem<DEGW>::NL;
+  constexpr int NQ = 7;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const Geom g = load_geom(xy, nc, c);
+  double Cv[2][NW];
+  load_local<NW>(conv, nw, cdw, nc, c, 2, Cv);
+  double tau_v[3] = {0.0, 0.0, 0.0};
+  double lap[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) lap[i] = 0.0;
+  if (supg) {
+    const double px[3] = {xy[0 * nc + c], xy[1 * nc + c], xy[2 * nc + c]};
+    const double py[3] = {xy[3 * nc + c], xy[4 * nc + c], xy[5 * nc + c]};
+    // tau is Expression(degree=1): evaluated at the cell vertices
+    // (stabilization.py:147); conv at vertex m = its vertex dof value
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+      tau_v[m] = supg_tau(px, py, 0.5 * g.adet, Cv[0][m], Cv[1][m], kappa, DEGQ,
+                          status);
+    if (tau_out) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m) tau_out[static_cast<size_t>(m) * nc + c] = tau_v[m];
+    }
+    if constexpr (DEGQ == 2) {
+      // Laplacians of the P2 basis (constant per cell)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        lap[i] = 4.0 * (g.gl[i][0] * g.gl[i][0] + g.gl[i][1] * g.gl[i][1]);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int j = facet_v0(e), k = facet_v1(e);
+        lap[3 + e] = 8.0 * (g.gl[j][0] * g.gl[k][0] + g.gl[j][1] * g.gl[k][1]);
+      }
+    }
+  }
+  const size_t plane = static_cast<size_t>(NL * NL) * nc;
+  // rows one at a time to bound register use: Ke[i][:] and Me[i][:]
+  for (int i = 0; i < NL; ++i) {
+    double Ka[NL], Ma[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) Ka[j] = Ma[j] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const double L[3] = {kQ7L[q][0], kQ7L[q][1], kQ7L[q][2]};
+      const double w = 0.5 * kQ7W[q] * g.adet;
+      double phi[NL], dphi[NL][3], gphi[NL][2];
+      basis<DEGQ>(L, phi, dphi);
+      phys_grad<NL>(g, dphi, gphi);
+      double wphi[NW], wd[NW][3];
+      basis<DEGW>(L, wphi, wd);
+      double b[2] = {0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < NW; ++t) {
+        b[0] += Cv[0][t] * wphi[t];
+        b[1] += Cv[1][t] * wphi[t];
+      }
+      double pi = 0.0, gi0 = 0.0, gi1 = 0.0;
+#pragma unroll
+      for (int t = 0; t < NL; ++t)
+        if (t == i) {
+          pi = phi[t];
+          gi0 = gphi[t][0];
+          gi1 = gphi[t][1];
+        }
+      const double tq = tau_v[0] * L[0] + tau_v[1] * L[1] + tau_v[2] * L[2];
+      const double cgi = b[0] * gi0 + b[1] * gi1;   // conv . grad v_i
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const double cgj = b[0] * gphi[j][0] + b[1] * gphi[j][1];
+        double k = -kappa / rho_cp * (gphi[j][0] * gi0 + gphi[j][1] * gi1) -
+                   cgj * pi;
+        if (supg) {
+          k += (kappa / rho_cp * lap[j] - cgj) * tq * cgi;
+          Ma[j] += w * phi[j] * tq * cgi;
+        }
+        Ka[j] += w * k;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const size_t idx = static_cast<size_t>(i * NL + j) * nc + c;
+      scratch[idx] = Ka[j];
+      if (supg) scratch[plane + idx] = Ma[j];
+    }
+  }
+}
+
+static int check_mesh_space(const flow_mesh* mesh, const flow_space* V) {
+  FLOW_REQUIRE(mesh && mesh->nc > 0 && mesh->xy, "mesh");
+  FLOW_REQUIRE(V && (V->deg == 1 || V->deg == 2) && V->n > 0 && V->cell_dofs,
+               "space");
+  return FLOW_OK;
+}
+
+}  // namespace flow
+
+using namespace flow;
+
+#define FLOW_DISPATCH_DEG(deg, KERNEL, grid, st, ...)                          \
+  do {                                                                         \
+    if ((deg) == 1)                                                            \
+      hipLaunchKernelGGL(KERNEL<1>, grid, dim3(kBlock), 0, st, __VA_ARGS__);   \
+    else                                                                       \
+      hipLaunchKernelGGL(KERNEL<2>, grid, dim3(kBlock), 0, st, __VA_ARGS__);   \
+    FLOW_CHECK_LAUNCH();                                                       \
+  } while (0)
+
+static inline dim3 cell_grid(int nc) { return dim3((nc + kBlock - 1) / kBlock); }
+
+extern "C" int flow_assemble_scalar_matrix(int kind, const flow_mesh* mesh,
+                                           const flow_space* V, double* scratch,
+                                           double* vals, void* stream) {
+  int rc = check_mesh_space(mesh, V);
+  if (rc) return rc;
+  FLOW_REQUIRE(kind >= 0 && kind <= 2, "matrix kind");
+  FLOW_REQUIRE(scratch && vals && V->cptr && V->csrc && V->nnz > 0, "matrix maps");
+  hipStream_t st = as_stream(stream);
+  FLOW_DISPATCH_DEG(V->deg, scalar_matrix_kernel, cell_grid(mesh->nc), st, kind,
+                    mesh->nc, mesh->xy, scratch);
+  return gather(V->nnz, 1, V->cptr, V->csrc, scratch, 0, vals, st);
+}
+
+extern "C" int flow_assemble_pressure_rhs(const flow_mesh* mesh,
+                                          const flow_space* W,
+                                          const flow_space* P, const double* u,
+                                          const double* p0, double alpha_rho_dt,
+                                          double mu, int rotational,
+                                          double* scratch, double* b,
+                                          void* stream) {
+  int rc = check_mesh_space(mesh, W);
+  if (rc) return rc;
+  if ((rc = check_mesh_space(mesh, P))) return rc;
+  FLOW_REQUIRE(P->deg == 1 && P->vptr && P->vsrc, "pressure space must be P1");
+  FLOW_REQUIRE(u && p0 && scratch && b, "pointers");
+  hipStream_t st = as_stream(stream);
+  FLOW_DISPATCH_DEG(W->deg, pressure_rhs_kernel, cell_grid(mesh->nc), st,
+                    mesh->nc, mesh->xy, W->cell_dofs, W->n, P->cell_dofs, u, p0,
+                    alpha_rho_dt, mu, rotational, scratch);
+  return gather(P->n, 1, P->vptr, P->vsrc, scratch, 0, b, st);
+}
+
+extern "C" int flow_assemble_correction_rhs(
+    const flow_mesh* mesh, const flow_space* W, const flow_space* P,
+    const double* u, const double* p1, const double* p0, double dt_rho,
+    double mu, int rotational, double* scratch, double* b, void* stream) {
+  int rc = check_mesh_space(mesh, W);
+  if (rc) return rc;
+  if ((rc = check_mesh_space(mesh, P))) return rc;
+  FLOW_REQUIRE(P->deg == 1 && W->vptr && W->vsrc, "spaces");
+  FLOW_REQUIRE(u && p1 && p0 && scratch && b, "pointers");
+  hipStream_t st = as_stream(stream);
+  FLOW_DISPATCH_DEG(W->deg, correction_rhs_kernel, cell_grid(mesh->nc), st,
+                    mesh->nc, mesh->xy, W->cell_dofs, W->n, P->cell_dofs, u, p1,
+                    p0, dt_rho, mu, rotational, scratch);
+  const int nl = W->deg == 1 ? 3 : 6;
+  return gather(W->n, 2, W->vptr, W->vsrc, scratch,
+                static_cast<size_t>(nl) * mesh->nc, b, st);
+}
+
+static int check_coef(const flow_coef* f) {
+  FLOW_REQUIRE(f && f->nl >= 1 && f->nl <= 21 && f->values && f->G, "coefficient");
+  FLOW_REQUIRE(f->cell_stride == 0 || f->cell_stride == 1, "coefficient stride");
+  return FLOW_OK;
+}
+
+extern "C" int flow_assemble_source(const flow_mesh* mesh, const flow_space* V,
+                                    int dim, const flow_coef* f, double* scratch,
+                                    double* b, void* stream) {
+  int rc = check_mesh_space(mesh, V);
+  if (rc) return rc;
+  if ((rc = check_coef(f))) return rc;
+  FLOW_REQUIRE(dim == 1 || dim == 2, "dim");
+  FLOW_REQUIRE(scratch && b && V->vptr && V->vsrc, "pointers");
+  hipStream_t st = as_stream(stream);
+  FLOW_DISPATCH_DEG(V->deg, source_kernel, cell_grid(mesh->nc), st, mesh->nc,
+                    mesh->xy, dim, *f, scratch);
+  const int nl = V->deg == 1 ? 3 : 6;
+  return gather(V->n, dim, V->vptr, V->vsrc, scratch,
+                static_cast<size_t>(nl) * mesh->nc, b, st);
+}
+
+extern "C" int flow_assemble_momentum(
+    const flow_mesh* mesh, const flow_space* W, const flow_space* P,
+    const int* bfmask, const double* ui, const double* u0, const double* p0,
+    const flow_coef* f0, const flow_coef* f1, const flow_ns_params* prm,
+    double* scratch, double* F, double* Jvals, void* stream) {
+  int rc = check_mesh_space(mesh, W);
+  if (rc) return rc;
+  if ((rc = check_mesh_space(mesh, P))) return rc;
+  if ((rc = check_coef(f0))) return rc;
+  if ((rc = check_coef(f1))) return rc;
+  FLOW_REQUIRE(P->deg == 1, "pressure space must be P1");
+  FLOW_REQUIRE(bfmask && ui && u0 && p0 && prm && scratch, "pointers");
+  FLOW_REQUIRE(prm->dt > 0.0 && prm->rho > 0.0 && prm->mu > 0.0, "parameters");
+  hipStream_t st = as_stream(stream);
+  const int nl = W->deg == 1 ? 3 : 6;
+  if (F) {
+    FLOW_REQUIRE(W->vptr && W->vsrc, "vector map");
+    FLOW_DISPATCH_DEG(W->deg, momentum_residual_kernel, cell_grid(mesh->nc), st,
+                      mesh->nc, mesh->xy, W->cell_dofs, W->n, P->cell_dofs,
+                      bfmask, ui, u0, p0, *f0, *f1, *prm, scratch);
+    if ((rc = gather(W->n, 2, W->vptr, W->vsrc, scratch,
+                     static_cast<size_t>(nl) * mesh->nc, F, st)))
+      return rc;
+  }
+  if (Jvals) {
+    FLOW_REQUIRE(W->cptr && W->csrc && W->nnz > 0, "matrix map");
+    FLOW_DISPATCH_DEG(W->deg, momentum_jacobian_kernel,
+                      dim3((mesh->nc + 63) / 64), st, mesh->nc, mesh->xy,
+                      W->cell_dofs, W->n, bfmask, ui, *prm, scratch);
+    if ((rc = gather(W->nnz, 4, W->cptr, W->csrc, scratch,
+                     static_cast<size_t>(nl) * nl * mesh->nc, Jvals, st)))
+      return rc;
+  }
+  return FLOW_OK;
+}
+
+extern "C" int flow_bc_identity_rows(const flow_operator* A, double* vals_planes,
+                                     const int* diag_idx, int nbc,
+                                     const int* dofs, void* stream) {
+  FLOW_REQUIRE(A && A->n > 0 && A->nnz > 0 && A->rowptr, "operator");
+  FLOW_REQUIRE(A->kind >= 0 && A->kind <= 2, "operator kind");
+  FLOW_REQUIRE(vals_planes && diag_idx && nbc >= 0, "pointers");
+  if (nbc == 0) return FLOW_OK;
+  FLOW_REQUIRE(dofs != nullptr, "dofs");
+  hipLaunchKernelGGL(bc_identity_rows_kernel, dim3(grid_for(nbc)), dim3(kBlock),
+                     0, as_stream(stream), A->kind, A->n, A->nnz, A->rowptr,
+                     diag_idx, nbc, dofs, vals_planes);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_bc_residual(int nbc, const int* dofs, const double* g,
+                                const double* u, double* F, void* stream) {
+  FLOW_REQUIRE(nbc >= 0, "nbc");
+  if (nbc == 0) return FLOW_OK;
+  FLOW_REQUIRE(dofs && g && u && F, "pointers");
+  hipLaunchKernelGGL(bc_residual_kernel, dim3(grid_for(nbc)), dim3(kBlock), 0,
+                     as_stream(stream), nbc, dofs, g, u, F);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_bc_set_values(int nbc, const int* dofs, const double* g,
+                                  double* x, void* stream) {
+  FLOW_REQUIRE(nbc >= 0, "nbc");
+  if (nbc == 0) return FLOW_OK;
+  FLOW_REQUIRE(dofs && g && x, "pointers");
+  hipLaunchKernelGGL(bc_residual_kernel, dim3(grid_for(nbc)), dim3(kBlock), 0,
+                     as_stream(stream), nbc, dofs, g,
+                     static_cast<const double*>(nullptr), x);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_bc_symmetric_matrix(int n, const int* rowptr,
+                                        const int* cols, const double* vals_in,
+                                        const unsigned char* isbc,
+                                        double* vals_out, void* stream) {
+  FLOW_REQUIRE(n > 0 && rowptr && cols && vals_in && isbc && vals_out, "pointers");
+  hipLaunchKernelGGL(bc_symmetric_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
+                     as_stream(stream), n, rowptr, cols, vals_in, isbc, vals_out);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_assemble_heat(const flow_mesh* mesh, const flow_space* Q,
+                                  const flow_space* W, const double* conv,
+                                  double kappa, double rho_cp, int supg,
+                                  double* scratch, double* Avals,
+                                  double* Msupg_vals, double* tau_out,
+                                  int* status_dev, void* stream) {
+  int rc = check_mesh_space(mesh, Q);
+  if (rc) return rc;
+  if ((rc = check_mesh_space(mesh, W))) return rc;
+  FLOW_REQUIRE(conv && scratch && Avals && status_dev, "pointers");
+  FLOW_REQUIRE(Q->cptr && Q->csrc && Q->nnz > 0, "matrix map");
+  FLOW_REQUIRE(!supg || Msupg_vals, "Msupg_vals required with supg");
+  FLOW_REQUIRE(kappa > 0.0 && rho_cp > 0.0, "coefficients");
+  hipStream_t st = as_stream(stream);
+  const dim3 grid = cell_grid(mesh->nc);
+#define FLOW_HEAT(DQ, DW)                                                      \
+  hipLaunchKernelGGL((heat_kernel<DQ, DW>), grid, dim3(kBlock), 0, st, mesh->nc, \
+                     mesh->xy, W->cell_dofs, W->n, conv, kappa, rho_cp, supg,  \
+                     scratch, tau_out, status_dev)
+  if (Q->deg == 1 && W->deg == 1) FLOW_HEAT(1, 1);
+  else if (Q->deg == 1 && W->deg == 2) FLOW_HEAT(1, 2);
+  else if (Q->deg == 2 && W->deg == 1) FLOW_HEAT(2, 1);
+  else FLOW_HEAT(2, 2);
+#undef FLOW_HEAT
+  FLOW_CHECK_LAUNCH();
+  const int nl = Q->deg == 1 ? 3 : 6;
+  const size_t plane = static_cast<size_t>(nl) * nl * mesh->nc;
+  if ((rc = gather(Q->nnz, 1, Q->cptr, Q->csrc, scratch, 0, Avals, st))) return rc;
+  if (supg)
+    return gather(Q->nnz, 1, Q->cptr, Q->csrc, scratch + plane, 0, Msupg_vals, st);
+  return FLOW_OK;
+}

@@ -1,0 +1,75 @@
+// Shared host-side helpers of libflow_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/flow_hip.h"
+
+namespace flow {
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+#define FLOW_CHECK_HIP(expr)                                                 \
+  do {                                                                       \
+    hipError_t err_ = (expr);                                                \
+    if (err_ != hipSuccess) {                                                \
+      flow::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(err_), \
+                      __FILE__, __LINE__);                                   \
+      return FLOW_HIP_ERROR;                                                 \
+    }                                                                        \
+  } while (0)
+
+#define FLOW_REQUIRE(cond, msg)                                  \
+  do {                                                           \
+    if (!(cond)) {                                               \
+      flow::set_error("invalid argument: %s (%s)", msg, #cond);  \
+      return FLOW_INVALID;                                       \
+    }                                                            \
+  } while (0)
+
+#define FLOW_CHECK_LAUNCH() FLOW_CHECK_HIP(hipGetLastError())
+
+constexpr int kBlock = 256;        // 4 wavefronts of 64
+constexpr int kRedBlocks = 1024;   // partial sums per reduction
+constexpr int kMaxGrid = 2048;     // 256 CUs x 8 blocks: memory-bound grid cap
+
+inline int grid_for(long long n, int per_block = kBlock, int cap = kMaxGrid) {
+  long long g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return static_cast<int>(g);
+}
+
+// block-wide sum, result valid in thread 0 (blockDim.x == 256)
+__device__ inline double block_sum(double v) {
+  __shared__ double wave_part[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();   // protect wave_part across repeated calls
+  if (lane == 0) wave_part[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) v = wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3];
+  return v;
+}
+
+__device__ inline double block_max(double v) {
+  __shared__ double wave_part_m[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) wave_part_m[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    v = fmax(fmax(wave_part_m[0], wave_part_m[1]), fmax(wave_part_m[2], wave_part_m[3]));
+  return v;
+}
+
+}  // namespace flow

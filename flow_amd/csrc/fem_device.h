@@ -1,0 +1,150 @@
+// Device-side P1/P2 triangle element: geometry, Lagrange bases through
+// barycentric coordinates, quadrature tables.  Conventions are those of
+// flow_amd/fem/reference.py: local P2 dofs [v0 v1 v2 e0 e1 e2], edge dof e_i on
+// the edge opposite vertex i.
+#pragma once
+#include "common.h"
+
+namespace flow {
+
+template <int DEG>
+struct Elem;
+template <>
+struct Elem<1> {
+  static constexpr int NL = 3;
+  static constexpr int NQ = 3;   // degree-2 rule
+};
+template <>
+struct Elem<2> {
+  static constexpr int NL = 6;
+  static constexpr int NQ = 7;   // degree-5 Radon rule (skew convection: 1+2+2)
+};
+
+// barycentric quadrature points and weights (weights sum to 1)
+__device__ constexpr double kQ3L[3][3] = {
+    {2.0 / 3.0, 1.0 / 6.0, 1.0 / 6.0},
+    {1.0 / 6.0, 2.0 / 3.0, 1.0 / 6.0},
+    {1.0 / 6.0, 1.0 / 6.0, 2.0 / 3.0}};
+__device__ constexpr double kQ3W[3] = {1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0};
+
+// a = (6 -+ sqrt(15))/21, w = (155 -+ sqrt(15))/1200
+#define FLOW_RA 0.10128650732345633880
+#define FLOW_RB 0.47014206410511508977
+#define FLOW_WA 0.12593918054482715260
+#define FLOW_WB 0.13239415278850618074
+__device__ constexpr double kQ7L[7][3] = {
+    {1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0},
+    {1.0 - 2.0 * FLOW_RA, FLOW_RA, FLOW_RA},
+    {FLOW_RA, 1.0 - 2.0 * FLOW_RA, FLOW_RA},
+    {FLOW_RA, FLOW_RA, 1.0 - 2.0 * FLOW_RA},
+    {1.0 - 2.0 * FLOW_RB, FLOW_RB, FLOW_RB},
+    {FLOW_RB, 1.0 - 2.0 * FLOW_RB, FLOW_RB},
+    {FLOW_RB, FLOW_RB, 1.0 - 2.0 * FLOW_RB}};
+__device__ constexpr double kQ7W[7] = {0.225,   FLOW_WA, FLOW_WA, FLOW_WA,
+                                       FLOW_WB, FLOW_WB, FLOW_WB};
+
+template <int DEG>
+__device__ __forceinline__ double qpoint(int q, int k) {
+  if constexpr (DEG == 1) return kQ3L[q][k];
+  else return kQ7L[q][k];
+}
+template <int DEG>
+__device__ __forceinline__ double qweight(int q) {
+  if constexpr (DEG == 1) return kQ3W[q];
+  else return kQ7W[q];
+}
+
+// 2-point Gauss rule on [0,1]
+#define FLOW_G2A 0.21132486540518711775
+#define FLOW_G2B 0.78867513459481288225
+
+// the two vertices of local facet lf (opposite vertex lf)
+__device__ __forceinline__ int facet_v0(int lf) { return lf == 0 ? 1 : 0; }
+__device__ __forceinline__ int facet_v1(int lf) { return lf == 2 ? 1 : 2; }
+
+struct Geom {
+  double gl[3][2];   // physical gradients of the barycentric coordinates
+  double adet;       // |det J| = 2 * area
+};
+
+__device__ __forceinline__ Geom load_geom(const double* __restrict__ xy, int nc,
+                                          int c) {
+  const double x0 = xy[0 * nc + c], x1 = xy[1 * nc + c], x2 = xy[2 * nc + c];
+  const double y0 = xy[3 * nc + c], y1 = xy[4 * nc + c], y2 = xy[5 * nc + c];
+  const double j00 = x1 - x0, j01 = x2 - x0, j10 = y1 - y0, j11 = y2 - y0;
+  const double det = j00 * j11 - j01 * j10;
+  const double inv = 1.0 / det;
+  Geom g;
+  g.gl[1][0] = j11 * inv;
+  g.gl[1][1] = -j01 * inv;
+  g.gl[2][0] = -j10 * inv;
+  g.gl[2][1] = j00 * inv;
+  g.gl[0][0] = -g.gl[1][0] - g.gl[2][0];
+  g.gl[0][1] = -g.gl[1][1] - g.gl[2][1];
+  g.adet = fabs(det);
+  return g;
+}
+
+// values and d/d(lambda_k) of the basis at barycentric point L
+template <int DEG>
+__device__ __forceinline__ void basis(const double L[3],
+                                      double phi[Elem<DEG>::NL],
+                                      double dphi[Elem<DEG>::NL][3]) {
+  if constexpr (DEG == 1) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      phi[i] = L[i];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dphi[i][k] = (i == k) ? 1.0 : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      phi[i] = L[i] * (2.0 * L[i] - 1.0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dphi[i][k] = (i == k) ? 4.0 * L[i] - 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int j = (e == 0) ? 1 : 0;
+      const int k2 = (e == 2) ? 1 : 2;
+      phi[3 + e] = 4.0 * L[j] * L[k2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        dphi[3 + e][k] = (k == j) ? 4.0 * L[k2] : ((k == k2) ? 4.0 * L[j] : 0.0);
+    }
+  }
+}
+
+template <int NL>
+__device__ __forceinline__ void phys_grad(const Geom& g, const double dphi[NL][3],
+                                          double gphi[NL][2]) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+      gphi[i][d] = dphi[i][0] * g.gl[0][d] + dphi[i][1] * g.gl[1][d] +
+                   dphi[i][2] * g.gl[2][d];
+  }
+}
+
+// div(u) at the three cell vertices (P1 per cell for P2 u, constant for P1 u)
+template <int DEG>
+__device__ __forceinline__ void div_at_vertices(
+    const Geom& g, const double U[2][Elem<DEG>::NL], double d[3]) {
+  constexpr int NL = Elem<DEG>::NL;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const double L[3] = {m == 0 ? 1.0 : 0.0, m == 1 ? 1.0 : 0.0,
+                         m == 2 ? 1.0 : 0.0};
+    double phi[NL], dphi[NL][3], gphi[NL][2];
+    basis<DEG>(L, phi, dphi);
+    phys_grad<NL>(g, dphi, gphi);
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) s += U[0][i] * gphi[i][0] + U[1][i] * gphi[i][1];
+    d[m] = s;
+  }
+}
+
+}  // namespace flow

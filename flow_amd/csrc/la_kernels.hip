@@ -1,0 +1,646 @@
+// Sparse linear algebra of the hot path on gfx950: CSR-stream SpMV (K8), fused
+// BLAS-1 (K9), Jacobi (K10) and the device-resident Krylov drivers (K12).
+//
+// Replaces PETSc MatMult / VecDot / VecAXPY / KSPCG inside dolfin's `solve`
+// (reference: flow/navier_stokes/pressure_correction.py:326-339, 419-432,
+// 451-464) and the `M * uvec`, `A * uvec` products of flow/heat.py:101.
+//
+// All kernels are HBM-bandwidth bound (0.17 flop/B); no MFMA.  Design:
+//  * SpMV = CSR-stream: a 256-thread workgroup owns a block of <=256 consecutive
+//    rows holding <=2048 nonzeros.  Phase 1 streams vals/cols fully coalesced
+//    (every lane busy, independent of the row length ~7) and parks the
+//    products a_ij*x_j in LDS; phase 2 is the segmented reduction: one lane per
+//    row sums its LDS segment [rowptr[r], rowptr[r+1]) -- odd row lengths make
+//    the LDS reads bank-conflict free -- and stores y coalesced.
+//  * reductions never use fp atomics: <=1024 per-block partials + a one-block
+//    finisher => bitwise reproducible.
+//  * Krylov scalars (alpha, beta, ...) live in HBM; the host only reads the
+//    residual norm every `check_every` iterations.
+#include "common.h"
+
+namespace flow {
+
+thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------------
+// SpMV
+// ---------------------------------------------------------------------------
+constexpr int kRowsPerBlock = FLOW_SPMV_ROWS_PER_BLOCK;
+constexpr int kNnzPerBlock = FLOW_SPMV_NNZ_PER_BLOCK;
+
+// scalar plane(s): blockIdx.y selects the component of a block-diagonal operator
+__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
+    int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vals0, const double* __restrict__ vals1,
+    const int* __restrict__ rowblocks, const double* __restrict__ x,
+    double* __restrict__ y) {
+  __shared__ double prod[kNnzPerBlock];
+  const double* __restrict__ vals = blockIdx.y == 0 ? vals0 : vals1;
+  x += static_cast<size_t>(blockIdx.y) * n;
+  y += static_cast<size_t>(blockIdx.y) * n;
+  const int r0 = rowblocks[blockIdx.x];
+  const int r1 = rowblocks[blockIdx.x + 1];
+  const int k0 = rowptr[r0];
+  const int k1 = rowptr[r1];
+  for (int k = k0 + threadIdx.x; k < k1; k += kBlock)
+    prod[k - k0] = vals[k] * x[cols[k]];
+  __syncthreads();
+  const int r = r0 + threadIdx.x;
+  if (r < r1) {
+    const int a = rowptr[r] - k0;
+    const int b = rowptr[r + 1] - k0;
+    double s = 0.0;
+    for (int k = a; k < b; ++k) s += prod[k];
+    y[r] = s;
+  }
+}
+
+// full 2x2 blocks over one scalar pattern (Newton Jacobian)
+__global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
+    int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vxx, const double* __restrict__ vxy,
+    const double* __restrict__ vyx, const double* __restrict__ vyy,
+    const int* __restrict__ rowblocks, const double* __restrict__ x,
+    double* __restrict__ y) {
+  __shared__ double prod0[kNnzPerBlock];
+  __shared__ double prod1[kNnzPerBlock];
+  const int r0 = rowblocks[blockIdx.x];
+  const int r1 = rowblocks[blockIdx.x + 1];
+  const int k0 = rowptr[r0];
+  const int k1 = rowptr[r1];
+  for (int k = k0 + threadIdx.x; k < k1; k += kBlock) {
+    const int c = cols[k];
+    const double x0 = x[c];
+    const double x1 = x[n + c];
+    prod0[k - k0] = vxx[k] * x0 + vxy[k] * x1;
+    prod1[k - k0] = vyx[k] * x0 + vyy[k] * x1;
+  }
+  __syncthreads();
+  const int r = r0 + threadIdx.x;
+  if (r < r1) {
+    const int a = rowptr[r] - k0;
+    const int b = rowptr[r + 1] - k0;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = a; k < b; ++k) {
+      s0 += prod0[k];
+      s1 += prod1[k];
+    }
+    y[r] = s0;
+    y[n + r] = s1;
+  }
+}
+
+static int check_operator(const flow_operator* A) {
+  FLOW_REQUIRE(A != nullptr, "operator is NULL");
+  FLOW_REQUIRE(A->kind >= 0 && A->kind <= 2, "operator kind");
+  FLOW_REQUIRE(A->n > 0 && A->nnz > 0 && A->nblocks > 0, "operator sizes");
+  FLOW_REQUIRE(A->rowptr && A->cols && A->rowblocks, "operator pattern");
+  const int planes = A->kind == 0 ? 1 : (A->kind == 1 ? 2 : 4);
+  for (int p = 0; p < planes; ++p)
+    FLOW_REQUIRE(A->vals[p] != nullptr, "operator value plane");
+  return FLOW_OK;
+}
+
+static inline int op_size(const flow_operator* A) {
+  return A->kind == 0 ? A->n : 2 * A->n;
+}
+
+static int apply(const flow_operator* A, const double* x, double* y,
+                 hipStream_t st) {
+  if (A->kind == 2) {
+    hipLaunchKernelGGL(spmv_stream_block2_kernel, dim3(A->nblocks), dim3(kBlock),
+                       0, st, A->n, A->rowptr, A->cols, A->vals[0], A->vals[1],
+                       A->vals[2], A->vals[3], A->rowblocks, x, y);
+  } else {
+    hipLaunchKernelGGL(spmv_stream_kernel,
+                       dim3(A->nblocks, A->kind == 1 ? 2 : 1), dim3(kBlock), 0,
+                       st, A->n, A->rowptr, A->cols, A->vals[0],
+                       A->kind == 1 ? A->vals[1] : A->vals[0], A->rowblocks, x,
+                       y);
+  }
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+__global__ void diag_inv_kernel(int n, int planes_kind,
+                                const int* __restrict__ diag_idx,
+                                const double* __restrict__ v0,
+                                const double* __restrict__ v1,
+                                double* __restrict__ dinv) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    const int k = diag_idx[i];
+    dinv[i] = 1.0 / v0[k];
+    if (planes_kind > 0) dinv[n + i] = 1.0 / v1[k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// BLAS-1
+// ---------------------------------------------------------------------------
+// up to three dot products in one pass; partial[j*kRedBlocks + block]
+__global__ __launch_bounds__(kBlock) void dot3_kernel(
+    int n, int nd, const double* __restrict__ a0, const double* __restrict__ b0,
+    const double* __restrict__ a1, const double* __restrict__ b1,
+    const double* __restrict__ a2, const double* __restrict__ b2,
+    double* __restrict__ partial) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    s0 += a0[i] * b0[i];
+    if (nd > 1) s1 += a1[i] * b1[i];
+    if (nd > 2) s2 += a2[i] * b2[i];
+  }
+  s0 = block_sum(s0);
+  if (nd > 1) s1 = block_sum(s1);
+  if (nd > 2) s2 = block_sum(s2);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = s0;
+    if (nd > 1) partial[kRedBlocks + blockIdx.x] = s1;
+    if (nd > 2) partial[2 * kRedBlocks + blockIdx.x] = s2;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void absmax_kernel(
+    int n, const double* __restrict__ x, double* __restrict__ partial) {
+  double m = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x)
+    m = fmax(m, fabs(x[i]));
+  m = block_max(m);
+  if (threadIdx.x == 0) partial[blockIdx.x] = m;
+}
+
+// one block: out[j] = reduce(partial[j*kRedBlocks .. +nparts)), fixed order
+__global__ __launch_bounds__(kBlock) void finish_kernel(
+    int nparts, int nd, int is_max, const double* __restrict__ partial,
+    double* __restrict__ out) {
+  for (int j = 0; j < nd; ++j) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) {
+      const double p = partial[j * kRedBlocks + i];
+      v = is_max ? fmax(v, p) : v + p;
+    }
+    v = is_max ? block_max(v) : block_sum(v);
+    if (threadIdx.x == 0) out[j] = v;
+  }
+}
+
+__global__ void axpby_kernel(int n, double a, const double* __restrict__ x,
+                             double b, double* __restrict__ y) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x)
+    y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
+}
+
+// ---------------------------------------------------------------------------
+// Krylov: scalar slots in HBM
+// ---------------------------------------------------------------------------
+enum Slot {
+  kGamma = 0, kAlpha, kBeta, kRes2, kB2, kRho, kOmega, kRhoNew, kTmp,
+  kBreak, kNumSlots = 16
+};
+// work layout: [0, 3*kRedBlocks) partials, [3*kRedBlocks, +kNumSlots) scalars
+static_assert(3 * kRedBlocks + kNumSlots <= FLOW_REDUCE_WORK, "work size");
+
+// r = b - q ; z = dinv*r
+__global__ void residual_kernel(int n, const double* __restrict__ b,
+                                const double* __restrict__ q,
+                                const double* __restrict__ dinv,
+                                double* __restrict__ r, double* __restrict__ z) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    const double ri = b[i] - q[i];
+    r[i] = ri;
+    if (z) z[i] = dinv ? dinv[i] * ri : ri;
+  }
+}
+
+// Chronopoulos-Gear CG scalars from (gamma_new, delta, r.r) partials
+__global__ __launch_bounds__(kBlock) void cg_scalar_kernel(
+    int nparts, int first, const double* __restrict__ partial,
+    double* __restrict__ S) {
+  double g = 0.0, d = 0.0, rr = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) {
+    g += partial[i];
+    d += partial[kRedBlocks + i];
+    rr += partial[2 * kRedBlocks + i];
+  }
+  g = block_sum(g);
+  d = block_sum(d);
+  rr = block_sum(rr);
+  if (threadIdx.x == 0) {
+    double alpha, beta;
+    if (first) {
+      beta = 0.0;
+      alpha = (d != 0.0) ? g / d : 0.0;
+    } else {
+      const double g_old = S[kGamma];
+      const double a_old = S[kAlpha];
+      beta = (g_old != 0.0) ? g / g_old : 0.0;
+      const double den = (a_old != 0.0) ? d - beta * g / a_old : 0.0;
+      alpha = (den != 0.0) ? g / den : 0.0;
+    }
+    S[kGamma] = g;
+    S[kAlpha] = alpha;
+    S[kBeta] = beta;
+    S[kRes2] = rr;
+  }
+}
+
+// p = z + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; z = dinv r
+__global__ void cg_update_kernel(int n, const double* __restrict__ S,
+                                 const double* __restrict__ dinv,
+                                 const double* __restrict__ w,
+                                 double* __restrict__ z, double* __restrict__ p,
+                                 double* __restrict__ s, double* __restrict__ x,
+                                 double* __restrict__ r) {
+  const double alpha = S[kAlpha];
+  const double beta = S[kBeta];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    const double pi = z[i] + beta * p[i];
+    const double si = w[i] + beta * s[i];
+    p[i] = pi;
+    s[i] = si;
+    x[i] += alpha * pi;
+    const double ri = r[i] - alpha * si;
+    r[i] = ri;
+    z[i] = dinv ? dinv[i] * ri : ri;
+  }
+}
+
+static int dots(int n, int nd, const double* a0, const double* b0,
+                const double* a1, const double* b1, const double* a2,
+                const double* b2, double* partial, int* nparts,
+                hipStream_t st) {
+  const int g = grid_for(n, kBlock * 4, kRedBlocks);
+  hipLaunchKernelGGL(dot3_kernel, dim3(g), dim3(kBlock), 0, st, n, nd, a0, b0,
+                     a1, b1, a2, b2, partial);
+  FLOW_CHECK_LAUNCH();
+  *nparts = g;
+  return FLOW_OK;
+}
+
+static int read_slot(const double* S, int slot, double* host, hipStream_t st) {
+  FLOW_CHECK_HIP(hipMemcpyAsync(host, S + slot, sizeof(double),
+                                hipMemcpyDeviceToHost, st));
+  FLOW_CHECK_HIP(hipStreamSynchronize(st));
+  return FLOW_OK;
+}
+
+static int cg(const flow_operator* A, const double* dinv, const double* b,
+              double* x, double rtol, double atol, int maxit, int check_every,
+              double* work, int* iters_host, double* resid_host,
+              hipStream_t st) {
+  const int N = op_size(A);
+  double* partial = work;
+  double* S = work + 3 * kRedBlocks;
+  double* r = work + FLOW_REDUCE_WORK;
+  double* z = r + N;
+  double* w = z + N;
+  double* p = w + N;
+  double* s = p + N;
+  const int gv = grid_for(N);
+  int np = 0, rc;
+
+  FLOW_CHECK_HIP(hipMemsetAsync(S, 0, kNumSlots * sizeof(double), st));
+  FLOW_CHECK_HIP(hipMemsetAsync(p, 0, 2 * sizeof(double) * N, st));
+  // ||b||^2
+  if ((rc = dots(N, 1, b, b, b, b, b, b, partial, &np, st))) return rc;
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 1, 0,
+                     partial, S + kB2);
+  // r = b - A x ; z = dinv r ; w = A z
+  if ((rc = apply(A, x, w, st))) return rc;
+  hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(kBlock), 0, st, N, b, w,
+                     dinv, r, z);
+  if ((rc = apply(A, z, w, st))) return rc;
+  if ((rc = dots(N, 3, r, z, z, w, r, r, partial, &np, st))) return rc;
+  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, 1,
+                     partial, S);
+  FLOW_CHECK_LAUNCH();
+
+  double b2 = 0.0, res2 = 0.0;
+  if ((rc = read_slot(S, kB2, &b2, st))) return rc;
+  if ((rc = read_slot(S, kRes2, &res2, st))) return rc;
+  const double target = fmax(rtol * sqrt(b2), atol);
+  int it = 0;
+  while (true) {
+    if (!(res2 == res2)) {   // NaN
+      *iters_host = it;
+      *resid_host = res2;
+      set_error("CG broke down (NaN residual) at iteration %d", it);
+      return FLOW_NOT_CONVERGED;
+    }
+    if (sqrt(res2) <= target) break;
+    if (it >= maxit) {
+      *iters_host = it;
+      *resid_host = sqrt(res2);
+      set_error("CG did not converge in %d iterations: |r| = %.3e > %.3e", it,
+                sqrt(res2), target);
+      return FLOW_NOT_CONVERGED;
+    }
+    const int todo = (maxit - it < check_every) ? maxit - it : check_every;
+    for (int k = 0; k < todo; ++k) {
+      hipLaunchKernelGGL(cg_update_kernel, dim3(gv), dim3(kBlock), 0, st, N, S,
+                         dinv, w, z, p, s, x, r);
+      if ((rc = apply(A, z, w, st))) return rc;
+      if ((rc = dots(N, 3, r, z, z, w, r, r, partial, &np, st))) return rc;
+      hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, 0,
+                         partial, S);
+    }
+    FLOW_CHECK_LAUNCH();
+    it += todo;
+    if ((rc = read_slot(S, kRes2, &res2, st))) return rc;
+  }
+  *iters_host = it;
+  *resid_host = sqrt(res2);
+  return FLOW_OK;
+}
+
+// ---------------------------------------------------------------------------
+// BiCGStab (right-preconditioned with Jacobi), van der Vorst 1992
+// ---------------------------------------------------------------------------
+// mode 0: rho_new = partial0 ; beta = (rho_new/rho)(alpha/omega)
+// mode 1: alpha = rho_new / partial0 (= rhat.v)
+// mode 2: omega = partial0/partial1 (= t.s / t.t); rho = rho_new;
+//         rho_new = partial2 (= rhat.r of the NEW r needs another pass: see 3)
+// mode 3: rho_new = partial0 (rhat.r), res2 = partial1 (r.r)
+__global__ __launch_bounds__(kBlock) void bicg_scalar_kernel(
+    int nparts, int mode, const double* __restrict__ partial,
+    double* __restrict__ S) {
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) {
+    a += partial[i];
+    b += partial[kRedBlocks + i];
+  }
+  a = block_sum(a);
+  b = block_sum(b);
+  if (threadIdx.x != 0) return;
+  if (mode == 1) {
+    S[kAlpha] = (a != 0.0) ? S[kRhoNew] / a : 0.0;
+    if (a == 0.0) S[kBreak] = 1.0;
+  } else if (mode == 2) {
+    S[kOmega] = (b != 0.0) ? a / b : 0.0;
+  } else {   // mode 3 (also used for initialisation)
+    const double rho_old = S[kRhoNew];
+    const double omega = S[kOmega];
+    const double alpha = S[kAlpha];
+    S[kRho] = rho_old;
+    S[kRhoNew] = a;
+    S[kRes2] = b;
+    S[kBeta] = (rho_old != 0.0 && omega != 0.0) ? (a / rho_old) * (alpha / omega)
+                                                : 0.0;
+  }
+}
+
+// p = r + beta (p - omega v) ; y = dinv p
+__global__ void bicg_p_kernel(int n, const double* __restrict__ S,
+                              const double* __restrict__ dinv,
+                              const double* __restrict__ r,
+                              const double* __restrict__ v,
+                              double* __restrict__ p, double* __restrict__ y) {
+  const double beta = S[kBeta];
+  const double omega = S[kOmega];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    const double pi = r[i] + beta * (p[i] - omega * v[i]);
+    p[i] = pi;
+    y[i] = dinv ? dinv[i] * pi : pi;
+  }
+}
+
+// s = r - alpha v (in place in r) ; z = dinv s
+__global__ void bicg_s_kernel(int n, const double* __restrict__ S,
+                              const double* __restrict__ dinv,
+                              const double* __restrict__ v,
+                              double* __restrict__ r, double* __restrict__ z) {
+  const double alpha = S[kAlpha];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    const double si = r[i] - alpha * v[i];
+    r[i] = si;
+    z[i] = dinv ? dinv[i] * si : si;
+  }
+}
+
+// x += alpha y + omega z ; r = s - omega t
+__global__ void bicg_x_kernel(int n, const double* __restrict__ S,
+                              const double* __restrict__ y,
+                              const double* __restrict__ z,
+                              const double* __restrict__ t,
+                              double* __restrict__ x, double* __restrict__ r) {
+  const double alpha = S[kAlpha];
+  const double omega = S[kOmega];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    x[i] += alpha * y[i] + omega * z[i];
+    r[i] -= omega * t[i];
+  }
+}
+
+static int bicgstab(const flow_operator* A, const double* dinv, const double* b,
+                    double* x, double rtol, double atol, int maxit,
+                    int check_every, double* work, int* iters_host,
+                    double* resid_host, hipStream_t st) {
+  const int N = op_size(A);
+  double* partial = work;
+  double* S = work + 3 * kRedBlocks;
+  double* r = work + FLOW_REDUCE_WORK;
+  double* rhat = r + N;
+  double* p = rhat + N;
+  double* v = p + N;
+  double* y = v + N;
+  double* z = y + N;
+  double* t = z + N;
+  const int gv = grid_for(N);
+  int np = 0, rc;
+
+  FLOW_CHECK_HIP(hipMemsetAsync(S, 0, kNumSlots * sizeof(double), st));
+  FLOW_CHECK_HIP(hipMemsetAsync(p, 0, 2 * sizeof(double) * N, st));   // p, v
+  if ((rc = dots(N, 1, b, b, b, b, b, b, partial, &np, st))) return rc;
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 1, 0,
+                     partial, S + kB2);
+  if ((rc = apply(A, x, t, st))) return rc;
+  hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(kBlock), 0, st, N, b, t,
+                     static_cast<const double*>(nullptr), r,
+                     static_cast<double*>(nullptr));
+  FLOW_CHECK_HIP(hipMemcpyAsync(rhat, r, sizeof(double) * N,
+                                hipMemcpyDeviceToDevice, st));
+  // rho_new = rhat.r, res2 = r.r ; beta = 0 because rho_old = omega = 0
+  if ((rc = dots(N, 2, rhat, r, r, r, r, r, partial, &np, st))) return rc;
+  hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, 3,
+                     partial, S);
+  FLOW_CHECK_LAUNCH();
+
+  double b2 = 0.0, res2 = 0.0;
+  if ((rc = read_slot(S, kB2, &b2, st))) return rc;
+  if ((rc = read_slot(S, kRes2, &res2, st))) return rc;
+  const double target = fmax(rtol * sqrt(b2), atol);
+  int it = 0;
+  while (true) {
+    if (!(res2 == res2)) {
+      *iters_host = it;
+      *resid_host = res2;
+      set_error("BiCGStab broke down (NaN residual) at iteration %d", it);
+      return FLOW_NOT_CONVERGED;
+    }
+    if (sqrt(res2) <= target) break;
+    if (it >= maxit) {
+      *iters_host = it;
+      *resid_host = sqrt(res2);
+      set_error("BiCGStab did not converge in %d iterations: |r| = %.3e > %.3e",
+                it, sqrt(res2), target);
+      return FLOW_NOT_CONVERGED;
+    }
+    const int todo = (maxit - it < check_every) ? maxit - it : check_every;
+    for (int k = 0; k < todo; ++k) {
+      hipLaunchKernelGGL(bicg_p_kernel, dim3(gv), dim3(kBlock), 0, st, N, S,
+                         dinv, r, v, p, y);
+      if ((rc = apply(A, y, v, st))) return rc;
+      if ((rc = dots(N, 1, rhat, v, v, v, v, v, partial, &np, st))) return rc;
+      hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np,
+                         1, partial, S);
+      hipLaunchKernelGGL(bicg_s_kernel, dim3(gv), dim3(kBlock), 0, st, N, S,
+                         dinv, v, r, z);
+      if ((rc = apply(A, z, t, st))) return rc;
+      if ((rc = dots(N, 2, t, r, t, t, t, t, partial, &np, st))) return rc;
+      hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np,
+                         2, partial, S);
+      hipLaunchKernelGGL(bicg_x_kernel, dim3(gv), dim3(kBlock), 0, st, N, S, y,
+                         z, t, x, r);
+      if ((rc = dots(N, 2, rhat, r, r, r, r, r, partial, &np, st))) return rc;
+      hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np,
+                         3, partial, S);
+    }
+    FLOW_CHECK_LAUNCH();
+    it += todo;
+    if ((rc = read_slot(S, kRes2, &res2, st))) return rc;
+  }
+  *iters_host = it;
+  *resid_host = sqrt(res2);
+  return FLOW_OK;
+}
+
+}  // namespace flow
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+using namespace flow;
+
+extern "C" const char* flow_last_error(void) { return g_error; }
+extern "C" int flow_abi_version(void) { return 1; }
+
+extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
+                                   double* y, void* stream) {
+  int rc = check_operator(A);
+  if (rc) return rc;
+  FLOW_REQUIRE(x && y && x != y, "x, y");
+  return apply(A, x, y, as_stream(stream));
+}
+
+extern "C" int flow_operator_diag_inv(const flow_operator* A,
+                                      const int* diag_idx, double* dinv,
+                                      void* stream) {
+  int rc = check_operator(A);
+  if (rc) return rc;
+  FLOW_REQUIRE(diag_idx && dinv, "diag_idx, dinv");
+  const double* v1 = A->kind == 0 ? A->vals[0]
+                                  : (A->kind == 1 ? A->vals[1] : A->vals[3]);
+  hipLaunchKernelGGL(diag_inv_kernel, dim3(grid_for(A->n)), dim3(kBlock), 0,
+                     as_stream(stream), A->n, A->kind, diag_idx, A->vals[0], v1,
+                     dinv);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_dot_host(int n, const double* x, const double* y,
+                             double* work, double* result_host, void* stream) {
+  FLOW_REQUIRE(n > 0 && x && y && work && result_host, "dot arguments");
+  hipStream_t st = as_stream(stream);
+  int np = 0;
+  int rc = dots(n, 1, x, y, x, y, x, y, work, &np, st);
+  if (rc) return rc;
+  double* S = work + 3 * kRedBlocks;
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 1, 0, work,
+                     S);
+  FLOW_CHECK_LAUNCH();
+  return read_slot(S, 0, result_host, st);
+}
+
+extern "C" int flow_norm_host(int n, const double* x, int kind, double* work,
+                              double* result_host, void* stream) {
+  FLOW_REQUIRE(n > 0 && x && work && result_host, "norm arguments");
+  FLOW_REQUIRE(kind == 0 || kind == 1, "norm kind");
+  hipStream_t st = as_stream(stream);
+  double* S = work + 3 * kRedBlocks;
+  if (kind == 0) {
+    int rc = flow_dot_host(n, x, x, work, result_host, stream);
+    if (rc) return rc;
+    *result_host = sqrt(*result_host);
+    return FLOW_OK;
+  }
+  const int g = grid_for(n, kBlock * 4, kRedBlocks);
+  hipLaunchKernelGGL(absmax_kernel, dim3(g), dim3(kBlock), 0, st, n, x, work);
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, g, 1, 1, work,
+                     S);
+  FLOW_CHECK_LAUNCH();
+  return read_slot(S, 0, result_host, st);
+}
+
+extern "C" int flow_axpby(int n, double a, const double* x, double b, double* y,
+                          void* stream) {
+  FLOW_REQUIRE(n > 0 && x && y, "axpby arguments");
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
+                     as_stream(stream), n, a, x, b, y);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+static int check_solver_args(const flow_operator* A, const double* b,
+                             const double* x, double rtol, double atol,
+                             int maxit, int check_every, const double* work,
+                             size_t work_len, size_t nvec, const int* iters_host,
+                             const double* resid_host) {
+  int rc = check_operator(A);
+  if (rc) return rc;
+  FLOW_REQUIRE(b && x && work && iters_host && resid_host, "solver pointers");
+  FLOW_REQUIRE(rtol >= 0.0 && atol >= 0.0 && maxit >= 0 && check_every > 0,
+               "solver tolerances");
+  FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK + nvec * (size_t)op_size(A),
+               "solver workspace too small");
+  return FLOW_OK;
+}
+
+extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
+                             const double* b, double* x, double rtol,
+                             double atol, int maxit, int check_every,
+                             double* work, size_t work_len, int* iters_host,
+                             double* resid_host, void* stream) {
+  int rc = check_solver_args(A, b, x, rtol, atol, maxit, check_every, work,
+                             work_len, 5, iters_host, resid_host);
+  if (rc) return rc;
+  return cg(A, dinv, b, x, rtol, atol, maxit, check_every, work, iters_host,
+            resid_host, as_stream(stream));
+}
+
+extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
+                                   const double* b, double* x, double rtol,
+                                   double atol, int maxit, int check_every,
+                                   double* work, size_t work_len,
+                                   int* iters_host, double* resid_host,
+                                   void* stream) {
+  int rc = check_solver_args(A, b, x, rtol, atol, maxit, check_every, work,
+                             work_len, 7, iters_host, resid_host);
+  if (rc) return rc;
+  return bicgstab(A, dinv, b, x, rtol, atol, maxit, check_every, work,
+                  iters_host, resid_host, as_stream(stream));
+}

@@ -1,0 +1,381 @@
+# -*- coding: utf-8 -*-
+'''
+Host-side operations that run on the HIP path: matrices over a space's CSR
+pattern, Krylov solves, norms, and the callers' utilities `project`,
+`interpolate`, `errornorm`, `norm` (tests/test_navier_stokes.py:296-308, 333;
+tests/test_karman_vortex_street.py:262-268; tests/test_boussinesq.py:85).
+
+Everything numerical is a call into libflow_hip.so (flow_amd/_hip.py); torch
+only owns the HBM buffers.
+'''
+import ctypes
+
+import numpy
+import torch
+
+from . import reference
+from .function import (
+    Function, Expression, Constant, as_cell_coefficient, cell_lattice_points,
+    )
+from .space import FunctionSpace, mesh_geometry_dev
+from .. import _hip
+from .. import device
+
+
+# -- C structs ----------------------------------------------------------------
+def mesh_struct(mesh):
+    if 'mesh_struct' not in mesh._cache:
+        xy = mesh_geometry_dev(mesh)
+        s = _hip.MeshS(mesh.num_cells(), _hip.f64(xy, 6 * mesh.num_cells(), 'xy'))
+        mesh._cache['mesh_struct'] = (s, xy)
+    return mesh._cache['mesh_struct'][0]
+
+
+def space_struct(layout):
+    if 'struct' not in layout._dev:
+        nc = layout.mesh.num_cells()
+        cd = layout.dev('cell_dofs')
+        s = _hip.SpaceS(
+            layout.degree, layout.N, layout.nnz,
+            _hip.i32(cd, layout.nloc * nc, 'cell_dofs'),
+            _hip.i32(layout.dev('cptr'), layout.nnz + 1, 'cptr'),
+            _hip.i32(layout.dev('csrc'), layout.nloc**2 * nc, 'csrc'),
+            _hip.i32(layout.dev('vptr'), layout.N + 1, 'vptr'),
+            _hip.i32(layout.dev('vsrc'), layout.nloc * nc, 'vsrc'),
+            )
+        layout._dev['struct'] = s
+    return layout._dev['struct']
+
+
+_G_CACHE = {}
+
+
+def coef_struct(coef, mesh, test_degree):
+    '''flow_coef of a CellCoefficient for test functions of `test_degree`.
+    Returns (struct, keepalive).'''
+    key = (coef.k, test_degree, str(device.get()))
+    if key not in _G_CACHE:
+        _G_CACHE[key] = device.to_device(
+            reference.source_matrix(coef.k, test_degree)
+            )
+    G = _G_CACHE[key]
+    nce = mesh.num_cells() if coef.cell_stride else 1
+    s = _hip.CoefS(
+        coef.nl, coef.cell_stride,
+        _hip.f64(coef.values, coef.dim * coef.nl * nce, 'coefficient values'),
+        _hip.f64(G, coef.nl * reference.nloc(test_degree), 'G'),
+        )
+    return s, (coef.values, G)
+
+
+def scratch(mesh, ndoubles):
+    '''Per-mesh scratch buffer for the cell kernels (grown on demand).'''
+    buf = mesh._cache.get('scratch')
+    if buf is None or buf.numel() < ndoubles:
+        mesh._cache['scratch'] = None
+        buf = device.empty(ndoubles)
+        mesh._cache['scratch'] = buf
+    return buf
+
+
+_WORK = {}
+
+
+def work(ndoubles):
+    key = str(device.get())
+    buf = _WORK.get(key)
+    if buf is None or buf.numel() < ndoubles:
+        _WORK[key] = None
+        buf = device.empty(ndoubles)
+        _WORK[key] = buf
+    return buf
+
+
+# -- matrices -----------------------------------------------------------------
+class Matrix(object):
+    '''Value planes over the CSR pattern of a scalar layout.
+    kind 0: scalar (1 plane), 1: block-diagonal (2 planes), 2: 2x2 (4 planes);
+    `vals` is one tensor of nplanes*nnz doubles (planes contiguous).'''
+    NPLANES = {0: 1, 1: 2, 2: 4}
+
+    def __init__(self, layout, kind, vals=None):
+        self.layout = layout
+        self.kind = kind
+        self.nplanes = self.NPLANES[kind]
+        nnz = layout.nnz
+        self.vals = vals if vals is not None else \
+            device.zeros(self.nplanes * nnz)
+        assert self.vals.numel() == self.nplanes * nnz
+        self._op = None
+        return
+
+    @property
+    def size(self):
+        return self.layout.N * (1 if self.kind == 0 else 2)
+
+    def plane(self, p):
+        nnz = self.layout.nnz
+        return self.vals[p * nnz:(p + 1) * nnz]
+
+    def operator(self):
+        if self._op is None:
+            lay = self.layout
+            op = _hip.Operator()
+            op.kind = self.kind
+            op.n = lay.N
+            op.nnz = lay.nnz
+            rb = lay.dev('rowblocks')
+            op.nblocks = rb.numel() - 1
+            op.rowptr = _hip.i32(lay.dev('rowptr'), lay.N + 1, 'rowptr')
+            op.cols = _hip.i32(lay.dev('cols'), lay.nnz, 'cols')
+            op.rowblocks = _hip.i32(rb, None, 'rowblocks')
+            base = _hip.f64(self.vals, self.nplanes * lay.nnz, 'vals').value
+            for p in range(self.nplanes):
+                op.vals[p] = base + 8 * p * lay.nnz
+            self._op = op
+        return self._op
+
+    def apply(self, x, y):
+        lib = _hip.lib()
+        assert x.data_ptr() != y.data_ptr()
+        _hip.check(lib.flow_operator_apply(
+            ctypes.byref(self.operator()), _hip.f64(x, self.size, 'x'),
+            _hip.f64(y, self.size, 'y'), _hip.stream()
+            ))
+        return y
+
+    def diag_inv(self):
+        lib = _hip.lib()
+        out = device.empty(self.size)
+        _hip.check(lib.flow_operator_diag_inv(
+            ctypes.byref(self.operator()),
+            _hip.i32(self.layout.dev('diag_idx'), self.layout.N, 'diag_idx'),
+            _hip.f64(out), _hip.stream()
+            ))
+        return out
+
+    def to_scipy(self):
+        '''Host copy (tests / debugging only).'''
+        import scipy.sparse as sp
+        lay = self.layout
+        rp = lay.pattern('rowptr')
+        cols = lay.pattern('cols')
+        v = self.vals.cpu().numpy()
+        nnz = lay.nnz
+        P = [sp.csr_matrix((v[p * nnz:(p + 1) * nnz], cols, rp),
+                           shape=(lay.N, lay.N)) for p in range(self.nplanes)]
+        if self.kind == 0:
+            return P[0]
+        if self.kind == 1:
+            return sp.block_diag(P, format='csr')
+        return sp.bmat([[P[0], P[1]], [P[2], P[3]]], format='csr')
+
+
+STIFFNESS, MASS, LUMPED_MASS = 0, 1, 2
+
+
+def assemble_scalar_matrix(layout, kind):
+    '''Step-invariant scalar matrices, cached per layout (K1, K3).'''
+    key = ('matrix', kind)
+    if key not in layout._dev:
+        lib = _hip.lib()
+        mesh = layout.mesh
+        A = Matrix(layout, 0)
+        buf = scratch(mesh, layout.nloc**2 * mesh.num_cells())
+        _hip.check(lib.flow_assemble_scalar_matrix(
+            kind, ctypes.byref(mesh_struct(mesh)),
+            ctypes.byref(space_struct(layout)), _hip.f64(buf),
+            _hip.f64(A.vals), _hip.stream()
+            ))
+        layout._dev[key] = A
+    return layout._dev[key]
+
+
+def assemble_mass(V):
+    return assemble_scalar_matrix(V.layout, MASS)
+
+
+def assemble_stiffness(V):
+    return assemble_scalar_matrix(V.layout, STIFFNESS)
+
+
+def symmetric_bc_matrix(A, isbc):
+    '''assemble_system-style symmetric elimination of one scalar plane.'''
+    lib = _hip.lib()
+    lay = A.layout
+    out = Matrix(lay, 0)
+    _hip.check(lib.flow_bc_symmetric_matrix(
+        lay.N, _hip.i32(lay.dev('rowptr')), _hip.i32(lay.dev('cols')),
+        _hip.f64(A.vals, lay.nnz), _hip.u8(isbc, lay.N, 'isbc'),
+        _hip.f64(out.vals, lay.nnz), _hip.stream()
+        ))
+    return out
+
+
+# -- BLAS-1 / norms -----------------------------------------------------------
+def vector_norm(x, kind='l2'):
+    lib = _hip.lib()
+    code = {'l2': 0, 'linf': 1}[kind]
+    res = ctypes.c_double(0.0)
+    _hip.check(lib.flow_norm_host(
+        x.numel(), _hip.f64(x), code, _hip.f64(work(_hip.REDUCE_WORK)),
+        ctypes.byref(res), _hip.stream()
+        ))
+    return res.value
+
+
+def dot(x, y):
+    lib = _hip.lib()
+    assert x.numel() == y.numel()
+    res = ctypes.c_double(0.0)
+    _hip.check(lib.flow_dot_host(
+        x.numel(), _hip.f64(x), _hip.f64(y), _hip.f64(work(_hip.REDUCE_WORK)),
+        ctypes.byref(res), _hip.stream()
+        ))
+    return res.value
+
+
+def axpby(a, x, b, y):
+    '''y = a x + b y'''
+    lib = _hip.lib()
+    assert x.numel() == y.numel()
+    _hip.check(lib.flow_axpby(
+        x.numel(), float(a), _hip.f64(x), float(b), _hip.f64(y), _hip.stream()
+        ))
+    return y
+
+
+# -- Krylov -------------------------------------------------------------------
+class SolveInfo(object):
+    def __init__(self, iterations, residual, method):
+        self.iterations = iterations
+        self.residual = residual
+        self.method = method
+
+    def __repr__(self):
+        return '%s: %d iterations, |r| = %.3e' % (
+            self.method, self.iterations, self.residual
+            )
+
+
+def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
+                 check_every=None):
+    '''Solve A x = b on the device; x holds the initial guess.  Raises
+    _hip.NotConverged (a RuntimeError) like dolfin's
+    'error_on_nonconvergence'.'''
+    lib = _hip.lib()
+    n = A.size
+    if isinstance(dinv, str):
+        assert dinv == 'jacobi'
+        dinv = A.diag_inv()
+    nvec = 5 if method == 'cg' else 7
+    wk = work(_hip.REDUCE_WORK + nvec * n)
+    if check_every is None:
+        check_every = 10 if method == 'bicgstab' else 50
+    its = ctypes.c_int(0)
+    res = ctypes.c_double(0.0)
+    fn = lib.flow_cg_solve if method == 'cg' else lib.flow_bicgstab_solve
+    rc = fn(
+        ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
+        _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
+        int(maxit), int(check_every), _hip.f64(wk), wk.numel(),
+        ctypes.byref(its), ctypes.byref(res), _hip.stream()
+        )
+    _hip.check(rc)
+    return SolveInfo(its.value, res.value, method)
+
+
+# -- load vectors, projection, norms -----------------------------------------
+def assemble_source(V, f):
+    '''(f, v) for v in V (scalar or vector space).'''
+    lib = _hip.lib()
+    mesh = V.mesh()
+    lay = V.layout
+    coef = as_cell_coefficient(f, mesh, V.dim)
+    cs, keep = coef_struct(coef, mesh, lay.degree)
+    b = device.empty(V.size())
+    buf = scratch(mesh, V.dim * lay.nloc * mesh.num_cells())
+    _hip.check(lib.flow_assemble_source(
+        ctypes.byref(mesh_struct(mesh)), ctypes.byref(space_struct(lay)), V.dim,
+        ctypes.byref(cs), _hip.f64(buf), _hip.f64(b), _hip.stream()
+        ))
+    del keep
+    return b
+
+
+def project(f, V, tol=1.0e-14):
+    '''L2 projection (dolfin.project): mass solve per component, CG + Jacobi on
+    the device.'''
+    b = assemble_source(V, f)
+    M = assemble_mass(V)
+    dinv = M.diag_inv()
+    out = Function(V)
+    n = V.N
+    for c in range(V.dim):
+        x = out.data[c * n:(c + 1) * n]
+        krylov_solve('cg', M, b[c * n:(c + 1) * n].contiguous(), x, tol,
+                     maxit=1000, dinv=dinv, check_every=10)
+    return out
+
+
+def interpolate(f, V):
+    out = Function(V)
+    if isinstance(f, Constant):
+        out.assign(f)
+        return out
+    assert isinstance(f, Expression)
+    vals = f.eval(V.layout.dof_coords.T)
+    assert vals.shape[0] == V.dim
+    out.set_array(vals.reshape(-1))
+    return out
+
+
+def norm(u, kind='L2'):
+    '''norm(Function, 'L2') = sqrt(u^T M u) (tests/test_boussinesq.py:85);
+    norm(vector, 'linf'|'l2').'''
+    if isinstance(u, Function):
+        assert kind == 'L2'
+        V = u.function_space()
+        M = assemble_mass(V)
+        n = V.N
+        tmp = device.empty(n)
+        total = 0.0
+        for c in range(V.dim):
+            x = u.data[c * n:(c + 1) * n]
+            M.apply(x, tmp)
+            total += dot(x, tmp)
+        return numpy.sqrt(total)
+    data = u.data if hasattr(u, 'data') else u
+    return vector_norm(data, kind.lower())
+
+
+def integral(u):
+    '''assemble(u*dx) for a scalar Function: 1^T M u.'''
+    V = u.function_space()
+    assert V.dim == 1
+    M = assemble_mass(V)
+    tmp = device.empty(V.N)
+    M.apply(u.data, tmp)
+    one = torch.ones(V.N, dtype=torch.float64, device=device.get())
+    return dot(one, tmp)
+
+
+def errornorm(exact, uh, degree_rise=3):
+    '''L2 error between an Expression and a discrete Function, both
+    interpolated per cell into P_(k+degree_rise) as dolfin.errornorm does
+    (tests/test_navier_stokes.py:333, 360).  A measurement for the harness:
+    evaluated on the host with numpy.'''
+    V = uh.function_space()
+    mesh = V.mesh()
+    k = min(V.degree + degree_rise, 5)
+    lat = reference.lattice(k)
+    X = cell_lattice_points(mesh, k)                        # (Nc, nl, 2)
+    nc, nl = X.shape[:2]
+    ue = exact.eval(X.reshape(-1, 2).T).reshape(V.dim, nc, nl)
+    tab = reference.tabulate(V.degree, lat)                 # (nl, nloc)
+    U = uh.array().reshape(V.dim, V.N)
+    uhl = numpy.einsum('acj,lj->acl', U[:, V.layout.cell_dofs], tab)
+    e = ue - uhl
+    Mk = reference.mass_matrix(k)
+    detj = 2.0 * mesh.cell_areas()
+    return float(numpy.sqrt(numpy.einsum('acl,lm,acm,c->', e, Mk, e, detj)))

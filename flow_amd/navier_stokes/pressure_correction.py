@@ -1,1 +1,467 @@
-__all__ = []
+# -*- coding: utf-8 -*-
+#
+'''
+Incremental pressure-correction schemes for the incompressible Navier--Stokes
+equations
+
+        rho (u' + u.nabla(u)) = - nabla(p) + mu Delta(u) + f,
+        div(u) = 0,
+
+on MI355X.  Same interface and the same three sub-steps as the reference
+(flow/navier_stokes/pressure_correction.py): `Chorin`, `IPCS`, `Rotational`
+with `.step(dt, u, p0, u_bcs, p_bcs, rho, mu, f, verbose, tol)` and the class
+attribute `.order` (reference :521-617).  Where the reference hands UFL forms
+to dolfin/PETSc, this module calls the HIP kernels of libflow_hip.so:
+
+  tentative velocity   Newton on F1 (reference :147-255): residual + exact
+                       Jacobian assembled on the GPU (K5/K6), Dirichlet rows
+                       (K7), BiCGStab + Jacobi instead of sparse LU;
+  pressure             P1 Poisson (reference :258-433): cached stiffness matrix
+                       (K1), right-hand side kernel (K2), CG + Jacobi instead
+                       of CG + BoomerAMG; Dirichlet branch with symmetric
+                       elimination, Neumann branch from x0 = 0 without
+                       null-space handling, as in the reference;
+  velocity correction  vector mass system (reference :436-465): cached mass
+                       matrix (K3), right-hand side kernel (K4), CG + Jacobi.
+
+The Krylov solvers differ from the reference's (north star: CG/BiCGStab +
+Jacobi), so parity means "same converged discrete solution"; iteration counts
+are reported in `last_step_info`.
+'''
+from __future__ import print_function
+
+import ctypes
+
+import numpy
+import torch
+
+from ..fem import ops
+from ..fem.bcs import collect
+from ..fem.function import Function, as_cell_coefficient, scalar_value
+from ..message import Message, info
+from .. import _hip
+from .. import device
+
+__all__ = ['Chorin', 'IPCS', 'Rotational', 'solver_parameters',
+           'last_step_info']
+
+# Jacobi-preconditioned Krylov needs more iterations than the reference's AMG
+# (maxit 100/1000, reference :335,422,460): limits are scaled up, everything
+# else (rtol = tol, atol = 0, error on non-convergence) is kept.
+solver_parameters = {
+    'newton': {'maximum_iterations': 10, 'linear_maxit': 5000,
+               'linear_rtol': 1.0e-13, 'linear_atol_factor': 0.05},
+    'pressure': {'maxit': 200000, 'check_every': 50},
+    'correction': {'maxit': 10000, 'check_every': 10},
+    }
+
+# iteration counts / residuals of the most recent step()
+last_step_info = {}
+
+_THETA = {
+    'forward euler': (0.0, 1.0),
+    'backward euler': (1.0, 0.0),
+    'crank-nicolson': (0.5, 0.5),
+    }
+
+
+def _bc_arrays(bcs, size):
+    '''Sorted unique (dofs, values) on the device.'''
+    dofs, vals = collect(bcs, size)
+    return (
+        dofs, device.to_device(dofs.astype(numpy.int32)),
+        device.to_device(vals.astype(numpy.float64)),
+        )
+
+
+def _bc_mask(dofs, n, comp=None):
+    '''uint8 mask of length n for the dofs of component `comp`.'''
+    mask = numpy.zeros(n, dtype=numpy.uint8)
+    if comp is None:
+        mask[dofs] = 1
+    else:
+        sel = dofs[(dofs >= comp * n) & (dofs < (comp + 1) * n)] - comp * n
+        mask[sel] = 1
+    return mask
+
+
+def _compute_tentative_velocity(
+        u, p0, f, u_bcs, time_step_method, rho, mu, dt, v=None,
+        tol=1.0e-10
+        ):
+    '''Solve F1(ui) = 0 (reference :147-255): F1 scaled with dt/rho,
+    time_step_method in {forward euler, backward euler, crank-nicolson},
+    Newton from ui = u[0] with the exact Jacobian, at most 10 iterations,
+    converged when ||F||_2 < tol (absolute; relative_tolerance 0),
+    RuntimeError otherwise.'''
+    lib = _hip.lib()
+    assert time_step_method in _THETA, time_step_method
+    theta_i, theta_e = _THETA[time_step_method]
+    alpha = 1.0
+    W = u[0].function_space()
+    P = p0.function_space()
+    mesh = W.mesh()
+    lay = W.layout
+    nc = mesh.num_cells()
+    n2 = W.size()
+
+    ui = Function(W)
+    # initial guess: previous velocity (reference :204-220)
+    ui.assign(u[0])
+
+    f0 = as_cell_coefficient(f[0], mesh, 2)
+    f1 = as_cell_coefficient(f[1], mesh, 2)
+    f0s, keep0 = ops.coef_struct(f0, mesh, lay.degree)
+    f1s, keep1 = ops.coef_struct(f1, mesh, lay.degree)
+    prm = _hip.NsParams(dt, rho, mu, theta_i, theta_e)
+    _, bc_dofs, bc_vals = _bc_arrays(u_bcs, n2)
+    nbc = bc_dofs.numel()
+    bfmask = mesh._cache.get('bfmask_dev')
+    if bfmask is None:
+        bfmask = device.to_device(mesh.cell_bfacet_mask())
+        mesh._cache['bfmask_dev'] = bfmask
+
+    J = lay._dev.get('jacobian')
+    if J is None:
+        J = ops.Matrix(lay, 2)
+        lay._dev['jacobian'] = J
+    F = device.empty(n2)
+    dx = device.empty(n2)
+    buf = ops.scratch(mesh, max(2 * lay.nloc, 4 * lay.nloc**2) * nc)
+    ms = ops.mesh_struct(mesh)
+    ws = ops.space_struct(lay)
+    ps = ops.space_struct(P.layout)
+    st = _hip.stream()
+    npar = solver_parameters['newton']
+
+    def assemble(want_f, want_j):
+        _hip.check(lib.flow_assemble_momentum(
+            ctypes.byref(ms), ctypes.byref(ws), ctypes.byref(ps),
+            _hip.i32(bfmask, nc, 'bfmask'), _hip.f64(ui.data, n2),
+            _hip.f64(u[0].data, n2), _hip.f64(p0.data, P.size()),
+            ctypes.byref(f0s), ctypes.byref(f1s), ctypes.byref(prm),
+            _hip.f64(buf), _hip.f64(F, n2) if want_f else None,
+            _hip.f64(J.vals, 4 * lay.nnz) if want_j else None, st
+            ))
+
+    history = []
+    linear_its = []
+    it = 0
+    while True:
+        assemble(True, False)
+        _hip.check(lib.flow_bc_residual(
+            nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(ui.data),
+            _hip.f64(F), st
+            ))
+        nrm = ops.vector_norm(F)
+        history.append(nrm)
+        info('Newton iteration %d: r (abs) = %.3e (tol = %.3e)' % (it, nrm, tol))
+        if nrm < tol:
+            break
+        if it >= npar['maximum_iterations'] or not numpy.isfinite(nrm):
+            raise RuntimeError(
+                'Newton solver did not converge after %d iterations '
+                '(residual history %r)' % (it, history)
+                )
+        assemble(False, True)
+        _hip.check(lib.flow_bc_identity_rows(
+            ctypes.byref(J.operator()), _hip.f64(J.vals),
+            _hip.i32(lay.dev('diag_idx')), nbc, _hip.i32(bc_dofs), st
+            ))
+        dx.zero_()
+        sol = ops.krylov_solve(
+            'bicgstab', J, F, dx, rtol=npar['linear_rtol'],
+            atol=npar['linear_atol_factor'] * tol,
+            maxit=npar['linear_maxit'], check_every=5
+            )
+        linear_its.append(sol.iterations)
+        ops.axpby(-1.0, dx, 1.0, ui.data)
+        it += 1
+    del keep0, keep1
+    last_step_info['newton_residuals'] = history
+    last_step_info['newton_linear_iterations'] = linear_its
+    return ui, alpha
+
+
+def _compute_pressure(
+        p0,
+        alpha, rho, dt, mu,
+        ui,
+        p_bcs=None,
+        rotational_form=False,
+        tol=1.0e-10,
+        verbose=True
+        ):
+    '''Solve the pressure Poisson equation (reference :258-433)
+
+        (grad p1, grad q) = -alpha rho/dt (div ui, q) + (grad p0, grad q)
+                            [- mu (grad div ui, grad q)].
+    '''
+    lib = _hip.lib()
+    P = p0.function_space()
+    W = ui.function_space()
+    mesh = P.mesh()
+    lay = P.layout
+    nc = mesh.num_cells()
+    st = _hip.stream()
+
+    p1 = Function(P)
+    K = ops.assemble_stiffness(P)
+    b = device.empty(P.N)
+    buf = ops.scratch(mesh, 3 * nc)
+    _hip.check(lib.flow_assemble_pressure_rhs(
+        ctypes.byref(ops.mesh_struct(mesh)),
+        ctypes.byref(ops.space_struct(W.layout)),
+        ctypes.byref(ops.space_struct(lay)), _hip.f64(ui.data, W.size()),
+        _hip.f64(p0.data, P.N), alpha * rho / dt, mu, int(rotational_form),
+        _hip.f64(buf), _hip.f64(b, P.N), st
+        ))
+    par = solver_parameters['pressure']
+    if p_bcs:
+        # 'symmetric': True  =>  assemble_system-style elimination
+        # (reference :325-339)
+        dofs, bc_dofs, bc_vals = _bc_arrays(p_bcs, P.N)
+        key = ('K_bc', dofs.tobytes())
+        if key not in lay._dev:
+            Kbc = ops.symmetric_bc_matrix(
+                K, device.to_device(_bc_mask(dofs, P.N))
+                )
+            lay._dev[key] = (Kbc, Kbc.diag_inv())
+        Kbc, dinv = lay._dev[key]
+        xg = device.zeros(P.N)
+        nbc = bc_dofs.numel()
+        _hip.check(lib.flow_bc_set_values(
+            nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(xg), st
+            ))
+        tmp = device.empty(P.N)
+        K.apply(xg, tmp)
+        ops.axpby(-1.0, tmp, 1.0, b)
+        _hip.check(lib.flow_bc_set_values(
+            nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(b), st
+            ))
+        sol = ops.krylov_solve(
+            'cg', Kbc, b, p1.data, rtol=tol, atol=0.0, maxit=par['maxit'],
+            dinv=dinv, check_every=par['check_every']
+            )
+    else:
+        # pure Neumann problem: singular but consistent, CG from x0 = 0, no
+        # null-space handling (reference :340-432)
+        key = ('K_dinv',)
+        if key not in lay._dev:
+            lay._dev[key] = K.diag_inv()
+        sol = ops.krylov_solve(
+            'cg', K, b, p1.data, rtol=tol, atol=0.0, maxit=par['maxit'],
+            dinv=lay._dev[key], check_every=par['check_every']
+            )
+    if verbose:
+        info('pressure: %r' % sol)
+    last_step_info['pressure'] = sol
+    return p1
+
+
+def _compute_velocity_correction(
+        ui, u, u_bcs, p1, p0, v, mu, rho, dt, rotational_form, tol, verbose
+        ):
+    '''Velocity correction  (u1, v) = (ui, v) - dt/rho (grad phi, v),
+    phi = p1 - p0 [+ mu div ui]  (reference :436-465).'''
+    lib = _hip.lib()
+    W = u[0].function_space()
+    P = p0.function_space()
+    mesh = W.mesh()
+    lay = W.layout
+    nc = mesh.num_cells()
+    n = W.N
+    n2 = W.size()
+    st = _hip.stream()
+
+    b = device.empty(n2)
+    buf = ops.scratch(mesh, 2 * lay.nloc * nc)
+    _hip.check(lib.flow_assemble_correction_rhs(
+        ctypes.byref(ops.mesh_struct(mesh)), ctypes.byref(ops.space_struct(lay)),
+        ctypes.byref(ops.space_struct(P.layout)), _hip.f64(ui.data, n2),
+        _hip.f64(p1.data, P.N), _hip.f64(p0.data, P.N), dt / rho, mu,
+        int(rotational_form), _hip.f64(buf), _hip.f64(b, n2), st
+        ))
+    M = ops.assemble_mass(W)
+    if ('M2',) not in lay._dev:
+        lay._dev[('M2',)] = ops.Matrix(lay, 1, torch.cat([M.vals, M.vals]))
+    M2 = lay._dev[('M2',)]
+    dofs, bc_dofs, bc_vals = _bc_arrays(u_bcs, n2)
+    key = ('M_bc', dofs.tobytes())
+    if key not in lay._dev:
+        planes = [
+            ops.symmetric_bc_matrix(
+                M, device.to_device(_bc_mask(dofs, n, comp))
+                ).vals
+            for comp in range(2)
+            ]
+        Mbc = ops.Matrix(lay, 1, torch.cat(planes))
+        lay._dev[key] = (Mbc, Mbc.diag_inv())
+    Mbc, dinv = lay._dev[key]
+    nbc = bc_dofs.numel()
+    if nbc > 0:
+        xg = device.zeros(n2)
+        _hip.check(lib.flow_bc_set_values(
+            nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(xg), st
+            ))
+        tmp = device.empty(n2)
+        M2.apply(xg, tmp)
+        ops.axpby(-1.0, tmp, 1.0, b)
+        _hip.check(lib.flow_bc_set_values(
+            nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(b), st
+            ))
+    u1 = Function(W)
+    par = solver_parameters['correction']
+    sol = ops.krylov_solve(
+        'cg', Mbc, b, u1.data, rtol=tol, atol=0.0, maxit=par['maxit'],
+        dinv=dinv, check_every=par['check_every']
+        )
+    if verbose:
+        info('velocity correction: %r' % sol)
+    last_step_info['correction'] = sol
+    return u1
+
+
+def _step(
+        dt,
+        u, p0,
+        u_bcs, p_bcs,
+        rho, mu,
+        time_step_method,
+        f,
+        rotational_form=False,
+        verbose=True,
+        tol=1.0e-10,
+        ):
+    '''Incremental pressure correction scheme as described in section 3.4 of
+    Guermond, Minev, Shen (2006); reference :468-518.'''
+    # dt, mu are Constant()s; rho may be a Constant or a plain float
+    dt_ = scalar_value(dt)
+    mu_ = scalar_value(mu)
+    rho_ = scalar_value(rho)
+    assert dt_ > 0.0
+    assert mu_ > 0.0
+
+    with Message('Computing tentative velocity'):
+        ui, alpha = _compute_tentative_velocity(
+                u, p0, f, u_bcs, time_step_method, rho_, mu_, dt_, None,
+                tol=1.0e-10
+                )
+
+    with Message('Computing pressure'):
+        p1 = _compute_pressure(
+                p0,
+                alpha, rho_, dt_, mu_,
+                ui,
+                p_bcs=p_bcs,
+                rotational_form=rotational_form,
+                tol=tol,
+                verbose=verbose
+                )
+
+    with Message('Computing velocity correction'):
+        u1 = _compute_velocity_correction(
+            ui, u, u_bcs, p1, p0, None, mu_, rho_, dt_, rotational_form, tol,
+            verbose
+            )
+    last_step_info['tentative_velocity'] = ui
+    return u1, p1
+
+
+class Chorin(object):
+    order = {
+        'velocity': 1.0,
+        'pressure': 0.5,
+        }
+
+    def __init__(self):
+        return
+
+    # p0 is zeroed here, f0 is unused: interface equality with IPCS
+    # (reference :530-552).
+    # pylint: disable=no-self-use
+    def step(
+            self,
+            dt,
+            u, p0,
+            u_bcs, p_bcs,
+            rho, mu,
+            f,
+            verbose=True,
+            tol=1.0e-10
+            ):
+        return _step(
+            dt,
+            u, Function(p0.function_space()),
+            u_bcs, p_bcs,
+            rho, mu,
+            'backward euler',
+            f,
+            verbose=verbose,
+            tol=tol,
+            )
+
+
+class IPCS(object):
+    order = {
+        'velocity': 2.0,
+        'pressure': 1.0,
+        }
+
+    def __init__(self, time_step_method='backward euler'):
+        self.time_step_method = time_step_method
+        return
+
+    def step(
+            self,
+            dt,
+            u, p0,
+            u_bcs, p_bcs,
+            rho, mu,
+            f,
+            verbose=True,
+            tol=1.0e-10
+            ):
+        return _step(
+            dt,
+            u, p0,
+            u_bcs, p_bcs,
+            rho, mu,
+            self.time_step_method,
+            f,
+            verbose=verbose,
+            tol=tol
+            )
+
+
+class Rotational(object):
+    order = {
+        'velocity': 2.0,
+        'pressure': 1.5,
+        }
+
+    def __init__(self, time_step_method='backward euler'):
+        self.time_step_method = time_step_method
+        return
+
+    def step(
+            self,
+            dt,
+            u, p0,
+            u_bcs, p_bcs,
+            rho, mu,
+            f,
+            verbose=True,
+            tol=1.0e-10
+            ):
+        return _step(
+            dt,
+            u, p0,
+            u_bcs, p_bcs,
+            rho, mu,
+            self.time_step_method,
+            f,
+            rotational_form=True,
+            verbose=verbose,
+            tol=tol
+            )

@@ -1,0 +1,217 @@
+/*
+ * flow_hip.h -- C ABI of libflow_hip.so, the MI355X (gfx950) implementation of
+ * the Navier-Stokes pressure-correction / heat hot path of nschloe/flow.
+ *
+ * The reference has no FFI: its boundary is the Python API of
+ * flow/navier_stokes/pressure_correction.py (Chorin/IPCS/Rotational.step) and
+ * flow/heat.py (Heat).  Every numerical operation the reference delegates to
+ * FFC-generated tabulate_tensor + DOLFIN Assembler + PETSc is exported here as
+ * a plain-C entry point; each declaration cites the reference lines whose work
+ * it replaces (paths relative to the reference root).  The Python host code in
+ * flow_amd/ binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *     the library never allocates or frees memory and keeps no state;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued on it; only the *_solve entry points and the *_host
+ *     readbacks synchronise it;
+ *   - fp64 values, int32 indices; vector fields are component-blocked
+ *     (dof (a, i) -> a*n + i);
+ *   - per-cell arrays are SoA with the cell index fastest ([k][cell]);
+ *   - return codes: 0 ok, 1 not converged, 2 invalid argument, 3 HIP error;
+ *     flow_last_error() returns the message of the last failure on the
+ *     calling thread.
+ */
+#ifndef FLOW_HIP_H
+#define FLOW_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLOW_OK 0
+#define FLOW_NOT_CONVERGED 1
+#define FLOW_INVALID 2
+#define FLOW_HIP_ERROR 3
+
+/* CSR-stream tiling of flow_spmv (row blocks are built on the host). */
+#define FLOW_SPMV_ROWS_PER_BLOCK 256
+#define FLOW_SPMV_NNZ_PER_BLOCK 2048
+
+const char* flow_last_error(void);
+int flow_abi_version(void);
+
+/* A linear operator over ONE scalar CSR pattern (n rows, nnz entries).
+ *   kind 0: scalar              y = A0 x                      (size n)
+ *   kind 1: block diagonal      y_a = A_a x_a, a = 0,1        (size 2n)
+ *   kind 2: full 2x2 blocks     y_a = sum_c A_{2a+c} x_c      (size 2n)
+ * Replaces the PETSc AIJ matrices behind `solve`/`assemble`
+ * (pressure_correction.py:224-254, 326-339, 419-432, 451-464; heat.py:88,106). */
+typedef struct {
+  int kind;
+  int n;
+  int nnz;
+  int nblocks;             /* number of CSR-stream row blocks */
+  const int* rowptr;       /* n+1 */
+  const int* cols;         /* nnz */
+  const int* rowblocks;    /* nblocks+1 */
+  const double* vals[4];   /* value planes, nnz each */
+} flow_operator;
+
+/* ---- K8: SpMV (PETSc MatMult inside every Krylov solve; heat.py:101) ---- */
+int flow_operator_apply(const flow_operator* A, const double* x, double* y,
+                        void* stream);
+/* dinv[a*n+i] = 1 / A_aa[i,i]  (K10 Jacobi; replaces 'hypre_amg',
+ * pressure_correction.py:331,414,456). diag_idx[i] = position of (i,i). */
+int flow_operator_diag_inv(const flow_operator* A, const int* diag_idx,
+                           double* dinv, void* stream);
+
+/* ---- K9: BLAS-1 (PETSc VecDot/VecAXPY/VecNorm) -------------------------- */
+int flow_dot_host(int n, const double* x, const double* y, double* work,
+                  double* result_host, void* stream);
+/* kind 0: l2, 1: linf (norm(vec,'linf'), tests/test_karman_vortex_street.py:268) */
+int flow_norm_host(int n, const double* x, int kind, double* work,
+                   double* result_host, void* stream);
+int flow_axpby(int n, double a, const double* x, double b, double* y,
+               void* stream);                       /* y = a x + b y */
+#define FLOW_REDUCE_WORK 4096   /* doubles of `work` the reductions need */
+
+/* ---- K12: Krylov drivers -------------------------------------------------
+ * Device-resident loops; the host reads the residual norm every check_every
+ * iterations.  Stop when ||r||_2 <= max(rtol*||b||_2, atol); return
+ * FLOW_NOT_CONVERGED after maxit iterations (dolfin raises RuntimeError:
+ * 'error_on_nonconvergence', pressure_correction.py:337,424,462).
+ * dinv may be NULL (no preconditioner).  x holds the initial guess.
+ * work: FLOW_REDUCE_WORK + 5*N doubles (cg), FLOW_REDUCE_WORK + 8*N (bicgstab),
+ * N = operator size. */
+int flow_cg_solve(const flow_operator* A, const double* dinv, const double* b,
+                  double* x, double rtol, double atol, int maxit,
+                  int check_every, double* work, size_t work_len,
+                  int* iters_host, double* resid_host, void* stream);
+int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
+                        const double* b, double* x, double rtol, double atol,
+                        int maxit, int check_every, double* work,
+                        size_t work_len, int* iters_host, double* resid_host,
+                        void* stream);
+
+/* ---- assembly ------------------------------------------------------------
+ * Two-phase, atomic-free: a cell kernel writes local tensors to `scratch`
+ * ([entry][cell]); a gather kernel sums, per CSR nonzero / per dof, the
+ * contributions listed in the contribution maps built once per mesh on the
+ * host (flow_amd/fem/space.py). */
+typedef struct {
+  int nc;                  /* cells */
+  const double* xy;        /* (2,3,nc): vertex coordinates */
+} flow_mesh;
+
+typedef struct {
+  int deg;                 /* 1 | 2 */
+  int n;                   /* scalar dofs */
+  int nnz;
+  const int* cell_dofs;    /* (nloc, nc) */
+  const int* cptr;         /* nnz+1  matrix contribution map */
+  const int* csrc;
+  const int* vptr;         /* n+1    vector contribution map */
+  const int* vsrc;
+} flow_space;
+
+/* per-cell P_k lattice values of a coefficient (Constant / Expression(degree=k)
+ * / Function), `dim` components: values[(a*nl + l)*nc_eff + c*cell_stride];
+ * G = (nl x nloc_test) reference matrix int psi_l phi_i. */
+typedef struct {
+  int nl;
+  int cell_stride;         /* 0: spatially constant, 1: per cell */
+  const double* values;
+  const double* G;
+} flow_coef;
+
+/* K1: a2 = dot(grad(p), grad(q))*dx            (pressure_correction.py:317)
+ * K3: a3 = inner(u2, v)*dx per component       (pressure_correction.py:442)
+ * kind 0: stiffness, 1: mass, 2: vertex-quadrature lumped mass (heat.py:39-45).
+ * scratch: nloc^2 * nc doubles. */
+int flow_assemble_scalar_matrix(int kind, const flow_mesh* mesh,
+                                const flow_space* V, double* scratch,
+                                double* vals, void* stream);
+
+/* K2: L2 (pressure_correction.py:318-323):
+ *   b_i = -alpha*rho/dt (div u, q_i) + (grad p0, grad q_i)
+ *         [- mu (grad div u, grad q_i)  if rotational].
+ * W: velocity scalar space (deg 1|2), P: P1.  scratch: 3*nc. */
+int flow_assemble_pressure_rhs(const flow_mesh* mesh, const flow_space* W,
+                               const flow_space* P, const double* u,
+                               const double* p0, double alpha_rho_dt, double mu,
+                               int rotational, double* scratch, double* b,
+                               void* stream);
+
+/* K4: L3 (pressure_correction.py:444-449):
+ *   b_(a,i) = (u_a, v_i) - dt/rho (d_a phi, v_i),
+ *   phi = p1 - p0 [+ mu div u  if rotational].   scratch: 2*nloc*nc. */
+int flow_assemble_correction_rhs(const flow_mesh* mesh, const flow_space* W,
+                                 const flow_space* P, const double* u,
+                                 const double* p1, const double* p0,
+                                 double dt_rho, double mu, int rotational,
+                                 double* scratch, double* b, void* stream);
+
+/* K5+K6: F1 and J = derivative(F1, ui) (pressure_correction.py:169-202) with
+ * the integrand of _rhs_weak (:135-144), exterior-facet terms included:
+ *   F = (ui - u0, v) - dt/rho [theta_i R(ui; f1) + theta_e R(u0; f0)],
+ *   J = dF/dui.
+ * bfmask[c]: bit i set iff local facet i of cell c is a boundary facet.
+ * F (2n) and/or Jvals (4 planes x nnz) may be NULL to skip.
+ * scratch: max(2*nloc, 4*nloc^2) * nc doubles. */
+typedef struct {
+  double dt, rho, mu, theta_i, theta_e;
+} flow_ns_params;
+int flow_assemble_momentum(const flow_mesh* mesh, const flow_space* W,
+                           const flow_space* P, const int* bfmask,
+                           const double* ui, const double* u0,
+                           const double* p0, const flow_coef* f0,
+                           const flow_coef* f1, const flow_ns_params* prm,
+                           double* scratch, double* F, double* Jvals,
+                           void* stream);
+
+/* (f, v) for a `dim`-component coefficient: the load vector behind
+ * dolfin.project (tests/test_navier_stokes.py:296-308).  scratch: dim*nloc*nc. */
+int flow_assemble_source(const flow_mesh* mesh, const flow_space* V, int dim,
+                         const flow_coef* f, double* scratch, double* b,
+                         void* stream);
+
+/* ---- K7: Dirichlet conditions (bcs= in solve, pressure_correction.py:226,
+ * 327,452; bc.apply(A, b), heat.py:113-114).  dofs sorted, in operator
+ * numbering (a*n + i). ------------------------------------------------------ */
+/* Newton form: rows -> identity (all planes), F[d] = u[d] - g[d]. */
+int flow_bc_identity_rows(const flow_operator* A, double* vals_planes,
+                          const int* diag_idx, int nbc, const int* dofs,
+                          void* stream);
+int flow_bc_residual(int nbc, const int* dofs, const double* g, const double* u,
+                     double* F, void* stream);
+int flow_bc_set_values(int nbc, const int* dofs, const double* g, double* x,
+                       void* stream);
+/* symmetric elimination (assemble_system semantics, 'symmetric': True):
+ * vals_out = vals_in with rows AND columns of marked dofs replaced by identity;
+ * isbc: byte mask of length n for the plane's component. */
+int flow_bc_symmetric_matrix(int n, const int* rowptr, const int* cols,
+                             const double* vals_in, const unsigned char* isbc,
+                             double* vals_out, void* stream);
+
+/* ---- K13/K14: heat operator (heat.py:20-89) and SUPG tau
+ * (stabilization.py:50-143) -------------------------------------------------
+ * A = matrix of  -kappa/(rho cp) (grad u, grad v) - (conv . grad u, v)
+ *     [+ SUPG terms], Msupg = (u, tau conv . grad v) (added to the lumped M).
+ * Q: temperature space (deg 1|2), W: scalar space of `conv` (2 comps).
+ * tau_out (3*nc, optional): tau at the three vertices of every cell.
+ * status_dev: int, set to 1 on device if any tau > 1e3 (the reference throws).
+ * scratch: 2*nloc^2*nc. */
+int flow_assemble_heat(const flow_mesh* mesh, const flow_space* Q,
+                       const flow_space* W, const double* conv, double kappa,
+                       double rho_cp, int supg, double* scratch, double* Avals,
+                       double* Msupg_vals, double* tau_out, int* status_dev,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOW_HIP_H */

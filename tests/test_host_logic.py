@@ -1,0 +1,213 @@
+# -*- coding: utf-8 -*-
+'''
+CPU tests of the host logic (meshes, dof maps, sparsity pattern, contribution
+maps, Dirichlet dof search, coefficients) and of the C-ABI library's symbol
+table.  No compute call is made: that needs a GPU.
+'''
+import os
+import re
+
+import numpy
+import pytest
+import scipy.sparse as sp
+
+from flow_amd import fem, _hip, message
+from flow_amd.fem import reference
+from flow_amd.fem.bcs import collect
+from flow_amd.fem.space import csr_stream_rowblocks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _meshes():
+    return [
+        fem.UnitSquareMesh(5, 4, 'crossed'),
+        fem.UnitSquareMesh(3, 3, 'left/right'),
+        fem.RectangleMesh(fem.Point(-1, -1), fem.Point(1, 1), 4, 6, 'right'),
+        fem.karman_channel(30, 8),
+        fem.heater_box(5),
+        ]
+
+
+def test_mesh_topology():
+    m = fem.UnitSquareMesh(5, 4, 'crossed')
+    assert m.num_vertices() == 6 * 5 + 20 and m.num_cells() == 80
+    # Euler: V - E + F = 1 for a simply connected planar mesh
+    assert m.num_vertices() - m.num_edges() + m.num_cells() == 1
+    assert len(m.bfacets) == 2 * (5 + 4)
+    assert m.cell_areas().sum() == pytest.approx(1.0)
+    k = fem.karman_channel(30, 8)
+    # one hole
+    assert k.num_vertices() - k.num_edges() + k.num_cells() == 0
+    for mesh in _meshes():
+        # every boundary facet is the stated local facet of its owner cell
+        for e, c, lf in zip(mesh.bfacets, mesh.bfacet_cell, mesh.bfacet_local):
+            assert mesh.cell_edges[c, lf] == e
+            verts = set(mesh.cell_vertices[c]) - {mesh.cell_vertices[c, lf]}
+            assert verts == set(mesh.edges[e])
+        mask = mesh.cell_bfacet_mask()
+        assert numpy.count_nonzero(mask) == len(set(mesh.bfacet_cell))
+        assert mesh.hmin() <= mesh.hmax()
+
+
+def test_karman_geometry_constants():
+    # tests/test_karman_vortex_street.py:18-23, 35-38 of the reference
+    m = fem.karman_channel(120, 28)
+    p = m.points
+    assert p[:, 0].min() == 0.0 and p[:, 0].max() == pytest.approx(0.6)
+    assert p[:, 1].min() == pytest.approx(-0.07)
+    assert p[:, 1].max() == pytest.approx(0.07)
+    area = m.cell_areas().sum()
+    assert area == pytest.approx(0.6 * 0.14 - numpy.pi * 0.02**2, rel=2e-3)
+    # x-major numbering: x never decreases with the vertex id
+    assert (numpy.diff(p[:, 0]) >= -1e-15).all()
+
+
+@pytest.mark.parametrize('deg', [1, 2])
+def test_dofmap_and_pattern(deg):
+    rng = numpy.random.RandomState(0)
+    for mesh in _meshes():
+        V = fem.FunctionSpace(mesh, 'CG', deg)
+        lay = V.layout
+        nloc = reference.nloc(deg)
+        assert lay.cell_dofs.shape == (mesh.num_cells(), nloc)
+        assert sorted(set(lay.cell_dofs.ravel())) == list(range(lay.N))
+        # dof coordinates agree with the per-cell lattice
+        X = fem.cell_lattice_points(mesh, deg)
+        assert numpy.allclose(lay.dof_coords[lay.cell_dofs], X, atol=1e-14)
+        # contribution maps reproduce a COO assembly of random local tensors
+        nc = mesh.num_cells()
+        Ke = rng.standard_normal((nc, nloc, nloc))
+        rows = numpy.repeat(lay.cell_dofs[:, :, None], nloc, axis=2)
+        cols = numpy.repeat(lay.cell_dofs[:, None, :], nloc, axis=1)
+        ref = sp.coo_matrix((Ke.ravel(), (rows.ravel(), cols.ravel())),
+                            shape=(lay.N, lay.N)).tocsr()
+        ref.sort_indices()
+        rowptr, colidx = lay.pattern('rowptr'), lay.pattern('cols')
+        assert numpy.array_equal(rowptr, ref.indptr)
+        assert numpy.array_equal(colidx, ref.indices)
+        scratch = Ke.transpose(1, 2, 0).reshape(-1)      # [ij][cell]
+        cptr, csrc = lay.pattern('cptr'), lay.pattern('csrc')
+        vals = numpy.add.reduceat(scratch[csrc], cptr[:-1])
+        assert numpy.allclose(vals, ref.data, rtol=1e-13, atol=1e-13)
+        assert numpy.array_equal(
+            colidx[lay.pattern('diag_idx')], numpy.arange(lay.N))
+        Fe = rng.standard_normal((nc, nloc))
+        vref = numpy.zeros(lay.N)
+        numpy.add.at(vref, lay.cell_dofs.ravel(), Fe.ravel())
+        vptr, vsrc = lay.vmap('vptr'), lay.vmap('vsrc')
+        vec = numpy.add.reduceat(Fe.T.reshape(-1)[vsrc], vptr[:-1])
+        assert numpy.allclose(vec, vref, rtol=1e-13, atol=1e-13)
+
+
+def test_rowblocks():
+    rng = numpy.random.RandomState(1)
+    lens = rng.randint(1, 40, size=5000)
+    rowptr = numpy.concatenate([[0], numpy.cumsum(lens)])
+    rb = csr_stream_rowblocks(rowptr)
+    assert rb[0] == 0 and rb[-1] == 5000 and (numpy.diff(rb) > 0).all()
+    assert (numpy.diff(rb) <= _hip.SPMV_ROWS_PER_BLOCK).all()
+    assert (numpy.diff(rowptr[rb]) <= _hip.SPMV_NNZ_PER_BLOCK).all()
+    with pytest.raises(AssertionError):
+        csr_stream_rowblocks(numpy.array([0, 5000]))
+
+
+def test_dirichlet_search_and_override():
+    mesh = fem.UnitSquareMesh(4, 4, 'crossed')
+    W = fem.VectorFunctionSpace(mesh, 'CG', 2)
+    lay = W.layout
+    on_b = numpy.zeros(lay.N, dtype=bool)
+    c = lay.dof_coords
+    on_b[(abs(c[:, 0]) < 1e-12) | (abs(c[:, 0] - 1) < 1e-12)
+         | (abs(c[:, 1]) < 1e-12) | (abs(c[:, 1] - 1) < 1e-12)] = True
+    d, v = collect([fem.DirichletBC(W, (1.0, 2.0), 'on_boundary')], W.size())
+    assert numpy.array_equal(d[:len(d) // 2], numpy.nonzero(on_b)[0])
+    assert numpy.array_equal(d[len(d) // 2:], numpy.nonzero(on_b)[0] + lay.N)
+    assert set(v[:len(d) // 2]) == {1.0} and set(v[len(d) // 2:]) == {2.0}
+
+    class Left(fem.SubDomain):
+        def inside(self, x, on_boundary):
+            return on_boundary and x[0] < 1e-12      # scalar-style condition
+
+    # component-wise condition, later condition overrides on shared dofs
+    expr = fem.Expression('3.0 + x[1]', degree=1)
+    d2, v2 = collect([
+        fem.DirichletBC(W, (1.0, 2.0), 'on_boundary'),
+        fem.DirichletBC(W.sub(0), expr, Left()),
+        ], W.size())
+    assert numpy.array_equal(d2, d)
+    left = numpy.nonzero(abs(c[:, 0]) < 1e-12)[0]
+    pos = numpy.searchsorted(d2, left)
+    assert numpy.allclose(v2[pos], 3.0 + c[left, 1])
+    # corner dofs belong to the left facets too, the y-component is untouched
+    assert set(v2[numpy.searchsorted(d2, left + lay.N)]) == {2.0}
+    # chained comparison forces the point-by-point fallback
+    class Inner(fem.SubDomain):
+        def inside(self, x, on_boundary):
+            return on_boundary and 0.2 < x[1] < 0.8 and x[0] < 1e-12
+    d3, _ = collect([fem.DirichletBC(W.sub(1), 0.0, Inner())], W.size())
+    assert len(d3) > 0 and (d3 >= lay.N).all()
+    assert (c[d3 - lay.N, 1] > 0.2 - 1e-12).all()
+
+
+def test_expression_and_coefficients():
+    e = fem.Expression(('sin(x[0] + t)*pow(x[1], 2)', 'cos(pi*x[0])'),
+                       degree=3, t=0.5)
+    x = numpy.array([[0.1, 0.7], [0.2, 0.3]])
+    assert numpy.allclose(e.eval(x)[0], numpy.sin(x[0] + 0.5) * x[1]**2)
+    e.t = 1.5
+    assert numpy.allclose(e.eval(x)[0], numpy.sin(x[0] + 1.5) * x[1]**2)
+    assert numpy.allclose(e.eval(x)[1], numpy.cos(numpy.pi * x[0]))
+    assert e.value_dim() == 2
+    c = fem.Constant(2.5)
+    assert c.values()[0] == 2.5 and fem.scalar_value(c) == 2.5
+    assert fem.scalar_value(3.0) == 3.0
+    # reference matrices: rows of G sum to the integral of the test basis
+    for k in range(6):
+        G = reference.source_matrix(k, 2)
+        assert numpy.allclose(G.sum(axis=0), [0, 0, 0, 1 / 6., 1 / 6., 1 / 6.],
+                              atol=1e-14)
+        assert numpy.allclose(reference.tabulate(k, reference.lattice(k)),
+                              numpy.eye(reference.nloc(k)), atol=1e-10)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'flow_hip.h')).read()
+    declared = set(re.findall(r'^\s*(?:int|const char\*)\s+(flow_\w+)\s*\(',
+                              header, flags=re.M))
+    assert declared, 'no declarations parsed'
+    lib = _hip.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared - {'flow_last_error'} == set(_hip.SYMBOLS), \
+        declared ^ set(_hip.SYMBOLS)
+    assert lib.flow_abi_version() == 1
+    assert _hip.SPMV_ROWS_PER_BLOCK == int(
+        re.search(r'FLOW_SPMV_ROWS_PER_BLOCK (\d+)', header).group(1))
+    assert _hip.SPMV_NNZ_PER_BLOCK == int(
+        re.search(r'FLOW_SPMV_NNZ_PER_BLOCK (\d+)', header).group(1))
+    assert _hip.REDUCE_WORK == int(
+        re.search(r'FLOW_REDUCE_WORK (\d+)', header).group(1))
+
+
+def test_no_cpu_fallback():
+    from flow_amd import device
+    if device.on_gpu():
+        pytest.skip('GPU present')
+    with pytest.raises(_hip.HipError):
+        _hip.lib()
+    mesh = fem.UnitSquareMesh(2, 2)
+    V = fem.FunctionSpace(mesh, 'CG', 1)
+    with pytest.raises(_hip.HipError):
+        fem.project(fem.Constant(1.0), V)
+
+
+def test_message(capsys):
+    message.set_log_active(True)
+    try:
+        with message.Message('outer'):
+            message.info('inner')
+    finally:
+        message.set_log_active(False)
+    out = capsys.readouterr().out.splitlines()
+    assert out == ['outer', '  inner']

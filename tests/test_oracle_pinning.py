@@ -1,0 +1,108 @@
+# -*- coding: utf-8 -*-
+'''
+Pins the CPU oracle (oracle/fem_oracle.py) with the reference's own
+known-answer tests -- the reference itself cannot run offline (no dolfin):
+
+  * temporal convergence orders of Chorin / IPCS / Rotational on the
+    manufactured solutions, thresholds `order - 0.1`
+    (reference tests/test_navier_stokes.py:379-446,
+    flow/navier_stokes/pressure_correction.py:522-525, 556-559, 588-591);
+  * hydrostatic rest state stays at rest, |u|_inf < 1e-13 after two IPCS steps
+    (reference tests/test_sealed_box.py:84-141);
+  * SUPG tau closed form incl. the small-Pe Taylor branch
+    (reference flow/stabilization.py:116-140);
+  * the order-of-convergence formula (reference tests/helpers.py:10-14).
+CPU only.
+'''
+import numpy
+import pytest
+
+from flow_amd import fem
+from flow_amd.fem.bcs import collect
+from oracle import fem_oracle as orc
+
+import mms
+import oracle_harness as H
+
+
+def test_order_formula():
+    Dt = [1.0, 0.5, 0.25]
+    err = [3.0 * dt**2 for dt in Dt]
+    assert numpy.allclose(orc.order_of_convergence(Dt, err), 2.0)
+
+
+def _assert_time_order(problem, scheme, order, mesh_sizes, Dt):
+    errors = H.oracle_time_errors(problem, scheme, 'backward euler',
+                                  mesh_sizes, Dt)
+    o = H.orders(Dt, errors)
+    assert (o['u'][:, 0] > order['velocity'] - 0.1).all(), o
+    assert (o['p'][:, 0] > order['pressure'] - 0.1).all(), o
+
+
+@pytest.mark.parametrize('problem', [mms.flat, mms.guermond1, mms.guermond2])
+def test_chorin_order(problem):
+    # reference: Dt = [1e-3, 5e-4], n = [16, 32]; the n = 16 column pins it
+    _assert_time_order(problem(), 'chorin',
+                       {'velocity': 1.0, 'pressure': 0.5}, [16],
+                       [1.0e-3, 0.5e-3])
+
+
+def test_ipcs_order():
+    # reference: guermond2, n = [8, 16, 32], Dt = [1, 0.5]
+    _assert_time_order(mms.guermond2(), 'ipcs',
+                       {'velocity': 2.0, 'pressure': 1.0}, [8, 16], [1.0, 0.5])
+
+
+def test_rotational_order():
+    # reference: guermond1, n = [32, 64], Dt = [1e-2, 5e-3]
+    _assert_time_order(mms.guermond1(), 'rotational',
+                       {'velocity': 2.0, 'pressure': 1.5}, [32],
+                       [1.0e-2, 0.5e-2])
+
+
+def test_sealed_box_stays_at_rest():
+    mesh = fem.heater_box(6)
+    W = H.oracle_space(mesh, 2)
+    P = H.oracle_space(mesh, 1)
+    g = -9.81
+    rho, mu = 998.2, 1.0e-3          # nominal water at 293 K
+    Wv = fem.VectorFunctionSpace(mesh, 'CG', 2)
+    u_bc = collect([fem.DirichletBC(Wv, (0.0, 0.0), 'on_boundary')], Wv.size())
+    u0 = numpy.zeros(2 * W.N)
+    p0 = g * mesh.points[:, 1]        # project(g*y) is exact for a P1 field
+    f = H.lattice_values(mesh, 0, lambda x: numpy.array(
+        [numpy.zeros(x.shape[1]), numpy.full(x.shape[1], g)]))
+    for _ in range(2):
+        u0, p0, _ = orc.step(W, P, u0, p0, f, f, u_bc, None, rho, mu, 1.0e-2,
+                             scheme='ipcs')
+    assert abs(u0).max() < 1.0e-13
+
+
+@pytest.mark.parametrize('speed', [1e-7, 1e-3, 1.0, 50.0])
+def test_supg_tau_closed_form(speed):
+    pts = numpy.array([[0.0, 0.0], [0.2, 0.0], [0.05, 0.1]])
+    eps, p = 0.01, 2
+    b = speed * numpy.array([0.6, 0.8])
+    tau = orc.supg_tau(pts, b, eps, p)
+    # independent restatement of the formula
+    nb = speed
+    area = 0.5 * 0.2 * 0.1
+    s = sum(abs((pts[i][1] - pts[j][1]) * b[0] - (pts[i][0] - pts[j][0]) * b[1])
+            for i in range(3) for j in range(i + 1, 3))
+    h = 4.0 * nb * area / s
+    Pe = 0.5 * nb * h / (p * eps)
+    if Pe > 1e-5:
+        xi = (1.0 / numpy.tanh(Pe) - 1.0 / Pe) / Pe
+    else:
+        xi = 1.0 / 3.0 - Pe**2 / 45.0 + 2.0 / 945.0 * Pe**4
+    assert tau == pytest.approx(h * h / 4.0 / eps / p * xi, rel=1e-14)
+    # tau -> h^2/(12 eps p) for small Pe
+    if Pe < 1e-3:
+        assert tau == pytest.approx(h * h / 12.0 / eps / p, rel=1e-5)
+
+
+def test_supg_tau_edge_cases():
+    pts = numpy.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
+    assert orc.supg_tau(pts, numpy.array([1e-11, 0.0]), 0.01, 1) == 0.0
+    with pytest.raises(RuntimeError):
+        orc.supg_tau(1e3 * pts, numpy.array([1e-6, 0.0]), 1e-6, 1)
