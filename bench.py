@@ -1,0 +1,253 @@
+# -*- coding: utf-8 -*-
+'''
+bench.py -- headline benchmark of the hot path (BASELINE.json):
+  IPCS (rotational pressure-correction) time-steps/s on the Karman-vortex-street
+  channel, P2-P1 Taylor-Hood, ~10 M DoF, plus the pressure-Poisson SpMV GB/s
+  against the MI355X HBM roofline.
+
+A "step" is one pass of the reference driver's loop body
+(tests/test_karman_vortex_street.py:219-286 of the reference): Rotational.step()
+(tentative velocity -> pressure Poisson -> velocity correction) followed by the
+CFL step-size controller, on synthetic data (structured channel mesh with a
+staircase obstacle; inflow profile as the initial state).
+
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the pressure
+Poisson solve is row-block sharded over the ranks (flow_amd/parallel.py); the
+other sub-steps are replicated.  Strong scaling: the mesh is fixed.
+
+Prints ONE JSON line on rank 0.
+'''
+from __future__ import print_function
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def spmv_bytes(n, nnz):
+    '''Algorithmic bytes of one CSR SpMV.'''
+    return 12 * nnz + 4 * (n + 1) + 8 * n + 8 * n
+
+
+def measure_spmv(A, reps=100, warmup=10):
+    '''Average launch duration (s) of the SpMV kernel, timed with HIP events on
+    the stream the kernel is launched on (torch's current stream).'''
+    import torch
+    from flow_amd import device
+    n = A.size
+    x = torch.sin(torch.arange(n, dtype=torch.float64, device=device.get()))
+    y = device.empty(n)
+    for _ in range(warmup):
+        A.apply(x, y)
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(reps):
+        A.apply(x, y)
+    stop.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(stop) * 1.0e-3 / reps
+
+
+def cpu_baseline(A_scipy, b, gpu_pressure_its_per_step, budget_s=15.0):
+    '''CPU port (oracle/cpu_cg.c, OpenMP) of the dominant loop on the SAME
+    pressure matrix, on this box's host cores: Jacobi-CG iterations/s on a
+    bounded sample, converted to time-steps/s with the GPU-measured pressure
+    iterations per step (pressure solve only: an upper bound for the CPU).'''
+    import numpy
+    from oracle import cpu_lib
+    try:
+        lib = cpu_lib.load(cpu_lib.build(native=True, out_dir='/tmp'))
+    except Exception:                                  # noqa: BLE001
+        lib = cpu_lib.load()
+    cores = lib.oracle_num_threads()
+    n = A_scipy.shape[0]
+    nnz = A_scipy.nnz
+    t0 = time.perf_counter()
+    _, its, _, _ = cpu_lib.jacobi_cg(lib, A_scipy, b, 1e-30, maxit=20)
+    per_it = (time.perf_counter() - t0) / max(its, 1)
+    sample = int(max(20, min(20000, budget_s / max(per_it, 1e-6))))
+    t0 = time.perf_counter()
+    _, its, _, _ = cpu_lib.jacobi_cg(lib, A_scipy, b, 1e-30, maxit=sample)
+    wall = time.perf_counter() - t0
+    it_rate = its / wall
+    # SpMV alone
+    x = numpy.sin(numpy.arange(n, dtype=float))
+    y = numpy.empty(n)
+    rp = A_scipy.indptr.astype(numpy.int32)
+    ci = A_scipy.indices.astype(numpy.int32)
+    reps = int(max(5, min(500, 3.0 / max(per_it, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lib.oracle_spmv_csr(n, rp, ci, A_scipy.data, x, y)
+    spmv_s = (time.perf_counter() - t0) / reps
+    steps_per_s = it_rate / max(gpu_pressure_its_per_step, 1.0)
+    return {
+        'value': steps_per_s,
+        'unit': 'time-steps/s',
+        'cores': cores,
+        'kind': 'port',
+        'sample': '%d Jacobi-CG iterations (%.1f s) of the %d-row pressure-'
+                  'Poisson system in C/OpenMP (oracle/cpu_cg.c); steps/s = '
+                  'CG-iterations/s / %.0f pressure iterations per step measured '
+                  'on the GPU run (pressure solve only, other sub-steps free)'
+                  % (its, wall, n, gpu_pressure_its_per_step),
+        'cg_iterations_per_s': it_rate,
+        'spmv_GBps': spmv_bytes(n, nnz) / spmv_s / 1e9,
+        }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--nx', type=int, default=2182,
+                    help='cells along the channel (2182 x 509: ~10 M DoF)')
+    ap.add_argument('--ny', type=int, default=None)
+    ap.add_argument('--scheme', default='rotational',
+                    choices=['chorin', 'ipcs', 'rotational'])
+    ap.add_argument('--tol', type=float, default=1.0e-10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--spmv-reps', type=int, default=100)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(
+                'launch N > 1 with: python -m torch.distributed.run --nnodes=1 '
+                '--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N'
+                )
+    import torch
+    import torch.distributed as dist
+    from flow_amd import device, _hip, karman, parallel
+    from flow_amd.fem import ops
+    import flow_amd.navier_stokes as navsto
+
+    _hip.lib()          # fail loudly without the HIP library / a GPU
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device.get())
+        parallel.enable(dist.group.WORLD)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_setup = time.perf_counter()
+    ny = args.ny if args.ny else max(2, int(round(args.nx * 509.0 / 2182.0)))
+    prob = karman.KarmanProblem(args.nx, ny, velocity_degree=2,
+                                scheme=args.scheme)
+    prob.set_initial_profile()
+    setup_s = time.perf_counter() - t_setup
+
+    for _ in range(args.warmup):
+        prob.step(tol=args.tol)
+    barrier()
+    t0 = time.perf_counter()
+    infos = [prob.step(tol=args.tol) for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device.get())
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # --- pressure-Poisson SpMV against the HBM roofline (dominant kernel) ---
+    P = prob.P
+    lay = P.layout
+    Kbc = [v for k, v in lay._dev.items()
+           if isinstance(k, tuple) and k[0] == 'K_bc'][0][0]
+    n, nnz = lay.N, lay.nnz
+    t_spmv = measure_spmv(Kbc, reps=args.spmv_reps)
+    bytes_alg = spmv_bytes(n, nnz)
+    achieved = bytes_alg / t_spmv / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'spmv_traffic.json')
+    if os.path.isfile(tpath):
+        try:
+            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        except Exception:                              # noqa: BLE001
+            traffic = None
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    p_its = [i['pressure'].iterations for i in infos]
+    c_its = [i['correction'].iterations for i in infos]
+    n_its = [sum(i['newton_linear_iterations']) for i in infos]
+    tim = {}
+    for key in ('tentative_s', 'pressure_s', 'correction_s'):
+        tim[key] = sum(i.get('timings', {}).get(key, 0.0) for i in infos) \
+            / len(infos)
+    out = {
+        'metric': 'ipcs_time_steps_per_sec',
+        'value': args.steps / elapsed,
+        'unit': 'time-steps/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': 1.0e3 * elapsed / args.steps,
+        'higher_is_better': True,
+        'scaling': 'strong',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {
+            'workload': 'Karman vortex street P2-P1 Taylor-Hood, %d DoF '
+                        '(%d x %d structured channel, staircase obstacle), '
+                        '%s scheme, backward Euler, tol %.0e, mu 0.002, '
+                        'rho 998.2, dt0 1e-5 + CFL controller'
+                        % (prob.num_dofs(), args.nx, ny, args.scheme, args.tol),
+            'dofs': prob.num_dofs(),
+            'cells': prob.mesh.num_cells(),
+            'pressure_rows': n,
+            'pressure_nnz': nnz,
+            'parallelism': 'pressure-poisson row-block x%d' % world,
+            'setup_s': setup_s,
+            'dt': [i['dt'] for i in infos],
+            'pressure_cg_iterations': p_its,
+            'correction_cg_iterations': c_its,
+            'newton_iterations': [len(i['newton_residuals']) - 1 for i in infos],
+            'newton_bicgstab_iterations': n_its,
+            'substep_s': tim,
+            },
+        'roofline': {
+            'kernel': 'spmv_stream_kernel (pressure-Poisson CSR SpMV, fp64)',
+            'bound': 'hbm',
+            'achieved': achieved,
+            'peak': HBM_PEAK_GBPS,
+            'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBPS,
+            'traffic': traffic,
+            'bytes_per_launch': bytes_alg,
+            'us_per_launch': t_spmv * 1e6,
+            },
+        }
+    if world == 1 and not args.no_cpu_baseline:
+        A = Kbc.to_scipy()
+        import numpy
+        b = numpy.sin(numpy.arange(n, dtype=float))
+        out['cpu_baseline'] = cpu_baseline(A, b, sum(p_its) / len(p_its))
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

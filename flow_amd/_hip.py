@@ -88,6 +88,10 @@ SYMBOLS = {
                       ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_bicgstab_solve': [_P(Operator), _VP, _VP, _VP, _D, _D, _I, _I, _VP,
                             ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_dot3_dev': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
+    'flow_cg_scalars_dev': [_I, _VP, _VP, _VP],
+    'flow_cg_update_dev': [_I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
+    'flow_residual_dev': [_I, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_assemble_scalar_matrix': [_I, _P(MeshS), _P(SpaceS), _VP, _VP, _VP],
     'flow_assemble_pressure_rhs': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _VP,
                                    _D, _D, _I, _VP, _VP, _VP],
@@ -98,6 +102,7 @@ SYMBOLS = {
                                _VP, _VP, _VP],
     'flow_assemble_source': [_P(MeshS), _P(SpaceS), _I, _P(CoefS), _VP, _VP,
                              _VP],
+    'flow_assemble_magnitude': [_P(MeshS), _P(SpaceS), _I, _VP, _VP, _VP, _VP],
     'flow_bc_identity_rows': [_P(Operator), _VP, _VP, _I, _VP, _VP],
     'flow_bc_residual': [_I, _VP, _VP, _VP, _VP, _VP],
     'flow_bc_set_values': [_I, _VP, _VP, _VP, _VP],

@@ -708,6 +708,44 @@ __global__ __launch_bounds__(kBlock) void heat_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// K16: load vector of |u| for the callers' step-size control
+// ---------------------------------------------------------------------------
+// b_i = int m(u) phi_i, m = sqrt(ux^2+uy^2) (mode 0) or |ux|+|uy| (mode 1)
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void magnitude_kernel(
+    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    const double* __restrict__ u, int mode, double* __restrict__ scratch) {
+  constexpr int NL = Elem<DEG>::NL;
+  constexpr int NQ = 7;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const Geom g = load_geom(xy, nc, c);
+  double U[2][NL];
+  load_local<NL>(u, nu, cdu, nc, c, 2, U);
+  double acc[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double L[3] = {kQ7L[q][0], kQ7L[q][1], kQ7L[q][2]};
+    const double w = 0.5 * kQ7W[q] * g.adet;
+    double phi[NL], dphi[NL][3];
+    basis<DEG>(L, phi, dphi);
+    double ux = 0.0, uy = 0.0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      ux += U[0][j] * phi[j];
+      uy += U[1][j] * phi[j];
+    }
+    const double m = mode == 0 ? sqrt(ux * ux + uy * uy) : fabs(ux) + fabs(uy);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc[i] += w * m * phi[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NL; ++i) scratch[static_cast<size_t>(i) * nc + c] = acc[i];
+}
+
 static int check_mesh_space(const flow_mesh* mesh, const flow_space* V) {
   FLOW_REQUIRE(mesh && mesh->nc > 0 && mesh->xy, "mesh");
   FLOW_REQUIRE(V && (V->deg == 1 || V->deg == 2) && V->n > 0 && V->cell_dofs,
@@ -836,6 +874,20 @@ extern "C" int flow_assemble_momentum(
       return rc;
   }
   return FLOW_OK;
+}
+
+extern "C" int flow_assemble_magnitude(const flow_mesh* mesh, const flow_space* W,
+                                       int mode, const double* u,
+                                       double* scratch, double* b,
+                                       void* stream) {
+  int rc = check_mesh_space(mesh, W);
+  if (rc) return rc;
+  FLOW_REQUIRE(mode == 0 || mode == 1, "mode");
+  FLOW_REQUIRE(u && scratch && b && W->vptr && W->vsrc, "pointers");
+  hipStream_t st = as_stream(stream);
+  FLOW_DISPATCH_DEG(W->deg, magnitude_kernel, cell_grid(mesh->nc), st, mesh->nc,
+                    mesh->xy, W->cell_dofs, W->n, u, mode, scratch);
+  return gather(W->n, 1, W->vptr, W->vsrc, scratch, 0, b, st);
 }
 
 extern "C" int flow_bc_identity_rows(const flow_operator* A, double* vals_planes,

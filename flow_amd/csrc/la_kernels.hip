@@ -644,3 +644,79 @@ extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
   return bicgstab(A, dinv, b, x, rtol, atol, maxit, check_every, work,
                   iters_host, resid_host, as_stream(stream));
 }
+
+// ---------------------------------------------------------------------------
+// building blocks of the row-sharded (multi-GPU) CG: the same kernels, driven
+// by flow_amd/parallel.py with one all-reduce + one halo exchange per iteration
+// ---------------------------------------------------------------------------
+extern "C" int flow_dot3_dev(int n, int nd, const double* a0, const double* b0,
+                             const double* a1, const double* b1,
+                             const double* a2, const double* b2, double* work,
+                             double* out, void* stream) {
+  FLOW_REQUIRE(n > 0 && nd >= 1 && nd <= 3 && a0 && b0 && work && out, "dot3");
+  FLOW_REQUIRE(nd < 2 || (a1 && b1), "dot3 pair 1");
+  FLOW_REQUIRE(nd < 3 || (a2 && b2), "dot3 pair 2");
+  hipStream_t st = as_stream(stream);
+  int np = 0;
+  int rc = dots(n, nd, a0, b0, nd > 1 ? a1 : a0, nd > 1 ? b1 : b0,
+                nd > 2 ? a2 : a0, nd > 2 ? b2 : b0, work, &np, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, nd, 0, work,
+                     out);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+// S <- Chronopoulos-Gear scalars from the (all-reduced) sums in3 =
+// (r.z, z.w, r.r)
+__global__ void cg_scalar_from_sums_kernel(int first,
+                                           const double* __restrict__ in3,
+                                           double* __restrict__ S) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double g = in3[0], d = in3[1], rr = in3[2];
+  double alpha, beta;
+  if (first) {
+    beta = 0.0;
+    alpha = (d != 0.0) ? g / d : 0.0;
+  } else {
+    const double g_old = S[kGamma];
+    const double a_old = S[kAlpha];
+    beta = (g_old != 0.0) ? g / g_old : 0.0;
+    const double den = (a_old != 0.0) ? d - beta * g / a_old : 0.0;
+    alpha = (den != 0.0) ? g / den : 0.0;
+  }
+  S[kGamma] = g;
+  S[kAlpha] = alpha;
+  S[kBeta] = beta;
+  S[kRes2] = rr;
+}
+
+extern "C" int flow_cg_scalars_dev(int first, const double* in3, double* S,
+                                   void* stream) {
+  FLOW_REQUIRE(in3 && S, "cg scalars");
+  hipLaunchKernelGGL(cg_scalar_from_sums_kernel, dim3(1), dim3(64), 0,
+                     as_stream(stream), first, in3, S);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_cg_update_dev(int n, const double* S, const double* dinv,
+                                  const double* w, double* z, double* p,
+                                  double* s, double* x, double* r,
+                                  void* stream) {
+  FLOW_REQUIRE(n > 0 && S && w && z && p && s && x && r, "cg update");
+  hipLaunchKernelGGL(cg_update_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
+                     as_stream(stream), n, S, dinv, w, z, p, s, x, r);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_residual_dev(int n, const double* b, const double* q,
+                                 const double* dinv, double* r, double* z,
+                                 void* stream) {
+  FLOW_REQUIRE(n > 0 && b && q && r, "residual");
+  hipLaunchKernelGGL(residual_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
+                     as_stream(stream), n, b, q, dinv, r, z);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}

@@ -28,7 +28,7 @@ def __getattr__(name):
     # the operations below run on the HIP path; import them lazily so that the
     # host-only parts (meshes, spaces, BC search) work without the library
     if name in ('project', 'interpolate', 'errornorm', 'norm', 'assemble_mass',
-                'assemble_stiffness', 'integral', 'ops'):
+                'assemble_stiffness', 'integral', 'project_magnitude', 'ops'):
         import importlib
         ops = importlib.import_module('.ops', __name__)
         return ops if name == 'ops' else getattr(ops, name)

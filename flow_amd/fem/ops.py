@@ -318,6 +318,34 @@ def project(f, V, tol=1.0e-14):
     return out
 
 
+def project_magnitude(u, mode=0, tol=1.0e-12):
+    '''`project(sqrt(ux**2 + uy**2), FunctionSpace(mesh, 'Lagrange', k))`
+    (mode 0; tests/test_karman_vortex_street.py:262-267) or
+    `project(abs(ux) + abs(uy), Q)` (mode 1; tests/test_boussinesq.py:268-272)
+    for a vector field u of degree k.'''
+    lib = _hip.lib()
+    W = u.function_space()
+    assert W.dim == 2
+    mesh = W.mesh()
+    lay = W.layout
+    S = W.collapse()
+    b = device.empty(lay.N)
+    buf = scratch(mesh, lay.nloc * mesh.num_cells())
+    _hip.check(lib.flow_assemble_magnitude(
+        ctypes.byref(mesh_struct(mesh)), ctypes.byref(space_struct(lay)),
+        int(mode), _hip.f64(u.data, 2 * lay.N), _hip.f64(buf), _hip.f64(b),
+        _hip.stream()
+        ))
+    M = assemble_mass(S)
+    key = ('M_dinv',)
+    if key not in lay._dev:
+        lay._dev[key] = M.diag_inv()
+    out = Function(S)
+    krylov_solve('cg', M, b, out.data, tol, maxit=1000, dinv=lay._dev[key],
+                 check_every=10)
+    return out
+
+
 def interpolate(f, V):
     out = Function(V)
     if isinstance(f, Constant):

@@ -1,0 +1,136 @@
+# -*- coding: utf-8 -*-
+'''
+Karman-vortex-street channel problem: the caller of the hot path used by
+bench.py and the tests.  Counterpart of the reference driver
+tests/test_karman_vortex_street.py:56-289 with the same geometry (:18-23,
+:35-38), boundary conditions (:128-145, :190-203), parameters (mu = 0.002 :167,
+dt0 = 1e-5 :210, dt_max = 1 :211, tol = 1e-10 :239) and step-size controller
+(:262-286).  gmsh and the Stokes bootstrap (flow.stokes.solve)
+are not available: the mesh is the structured channel of fem.karman_channel and
+the run starts from the inflow profile.
+'''
+from __future__ import print_function
+
+from . import fem
+from . import navier_stokes
+
+X0, X1 = 0.0, 0.6
+Y0, Y1 = -0.07, 0.07
+ENTRANCE_VELOCITY = 0.01
+MESH_EPS = 1.0e-12
+RHO_WATER_293K = 998.2     # materials.water.density(T=293.0) is not available
+
+
+class LeftBoundary(fem.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary & (x[0] < X0 + MESH_EPS)
+
+
+class RightBoundary(fem.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary & (x[0] > X1 - MESH_EPS)
+
+
+class LowerBoundary(fem.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary & (x[1] < Y0 + MESH_EPS)
+
+
+class UpperBoundary(fem.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary & (x[1] > Y1 - MESH_EPS)
+
+
+class ObstacleBoundary(fem.SubDomain):
+    def inside(self, x, on_boundary):
+        return (
+            on_boundary
+            & (X0 + MESH_EPS < x[0]) & (x[0] < X1 - MESH_EPS)
+            & (Y0 + MESH_EPS < x[1]) & (x[1] < Y1 - MESH_EPS)
+            )
+
+
+class KarmanProblem(object):
+    def __init__(self, nx, ny=None, velocity_degree=2, mu=0.002,
+                 rho=RHO_WATER_293K, scheme='rotational'):
+        self.mesh = fem.karman_channel(nx, ny)
+        self.W = fem.VectorFunctionSpace(self.mesh, 'Lagrange', velocity_degree)
+        self.P = fem.FunctionSpace(self.mesh, 'Lagrange', 1)
+        self.mu = mu
+        self.rho = rho
+        profile = '%e * (%e - x[1]) * (x[1] - %e) / %e' % (
+            ENTRANCE_VELOCITY, Y1, Y0, (0.5 * (Y1 - Y0))**2
+            )
+        self.inflow = fem.Expression(profile, degree=2)
+        self.outflow = fem.Expression(profile, degree=2)
+        W, P = self.W, self.P
+        self.u_bcs = [
+            fem.DirichletBC(W, (0.0, 0.0), UpperBoundary()),
+            fem.DirichletBC(W, (0.0, 0.0), LowerBoundary()),
+            fem.DirichletBC(W, (0.0, 0.0), ObstacleBoundary()),
+            fem.DirichletBC(W.sub(0), self.inflow, LeftBoundary()),
+            fem.DirichletBC(W.sub(0), self.outflow, RightBoundary()),
+            ]
+        self.p_bcs = [fem.DirichletBC(P, 0.0, RightBoundary())]
+        self.stepper = {
+            'chorin': navier_stokes.Chorin,
+            'ipcs': navier_stokes.IPCS,
+            'rotational': navier_stokes.Rotational,
+            }[scheme]()
+        self.u0 = fem.Function(W)
+        self.p0 = fem.Function(P)
+        self.u0.rename('velocity', 'velocity')
+        self.p0.rename('pressure', 'pressure')
+        self.dt = 1.0e-5
+        self.dt_max = 1.0
+        self.t = 0.0
+        self.hmax = self.mesh.hmax()
+        self.history = []
+        return
+
+    def num_dofs(self):
+        return self.W.size() + self.P.size()
+
+    def set_initial_profile(self):
+        '''Start from the inflow profile (x-velocity), zero pressure.'''
+        prof = fem.Expression(
+            (self.inflow.cppcode, '0.0'), degree=2
+            )
+        self.u0.assign(fem.interpolate(prof, self.W))
+        return
+
+    def reynolds(self):
+        return ENTRANCE_VELOCITY * 0.04 * self.rho / self.mu
+
+    def step(self, tol=1.0e-10, adapt=True):
+        '''One pass of the reference's time loop body (:219-286).'''
+        u1, p1 = self.stepper.step(
+            fem.Constant(self.dt),
+            {0: self.u0}, self.p0,
+            self.u_bcs, self.p_bcs,
+            fem.Constant(self.rho), fem.Constant(self.mu),
+            f={0: fem.Constant((0.0, 0.0)), 1: fem.Constant((0.0, 0.0))},
+            verbose=False,
+            tol=tol
+            )
+        self.u0.assign(u1)
+        self.p0.assign(p1)
+        info = dict(navier_stokes.last_step_info)
+        info.pop('tentative_velocity', None)
+        info['dt'] = self.dt
+        info['t'] = self.t
+        if adapt:
+            # CFL-like step-size control on ||project(|u|)||_inf (:262-286)
+            unorm = fem.project_magnitude(self.u0).vector().norm('linf')
+            target_dt = 1.0 * self.hmax / unorm
+            alpha = 0.5
+            self.dt = min(
+                self.dt_max,
+                # at most double the step size from step to step
+                self.dt * min(2.0, 1.0 + alpha * (target_dt - self.dt) / self.dt)
+                )
+            info['unorm'] = unorm
+            info['target_dt'] = target_dt
+        self.t += self.dt
+        self.history.append(info)
+        return info

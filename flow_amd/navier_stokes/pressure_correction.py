@@ -31,6 +31,7 @@ are reported in `last_step_info`.
 from __future__ import print_function
 
 import ctypes
+import time
 
 import numpy
 import torch
@@ -41,6 +42,7 @@ from ..fem.function import Function, as_cell_coefficient, scalar_value
 from ..message import Message, info
 from .. import _hip
 from .. import device
+from .. import parallel
 
 __all__ = ['Chorin', 'IPCS', 'Rotational', 'solver_parameters',
            'last_step_info']
@@ -183,6 +185,20 @@ def _compute_tentative_velocity(
     return ui, alpha
 
 
+def _pressure_cg(A, dinv, b, x, tol, par):
+    '''CG + Jacobi for the pressure system: rtol = tol, atol = 0 (reference
+    :332-335, :420-422); row-sharded over the GPUs of the node when
+    flow_amd.parallel is enabled.'''
+    if parallel.active():
+        return parallel.pressure_cg(
+            A, dinv, b, x, tol, 0.0, par['maxit'], par['check_every']
+            )
+    return ops.krylov_solve(
+        'cg', A, b, x, rtol=tol, atol=0.0, maxit=par['maxit'], dinv=dinv,
+        check_every=par['check_every']
+        )
+
+
 def _compute_pressure(
         p0,
         alpha, rho, dt, mu,
@@ -239,20 +255,14 @@ def _compute_pressure(
         _hip.check(lib.flow_bc_set_values(
             nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(b), st
             ))
-        sol = ops.krylov_solve(
-            'cg', Kbc, b, p1.data, rtol=tol, atol=0.0, maxit=par['maxit'],
-            dinv=dinv, check_every=par['check_every']
-            )
+        sol = _pressure_cg(Kbc, dinv, b, p1.data, tol, par)
     else:
         # pure Neumann problem: singular but consistent, CG from x0 = 0, no
         # null-space handling (reference :340-432)
         key = ('K_dinv',)
         if key not in lay._dev:
             lay._dev[key] = K.diag_inv()
-        sol = ops.krylov_solve(
-            'cg', K, b, p1.data, rtol=tol, atol=0.0, maxit=par['maxit'],
-            dinv=lay._dev[key], check_every=par['check_every']
-            )
+        sol = _pressure_cg(K, lay._dev[key], b, p1.data, tol, par)
     if verbose:
         info('pressure: %r' % sol)
     last_step_info['pressure'] = sol
@@ -342,12 +352,14 @@ def _step(
     assert dt_ > 0.0
     assert mu_ > 0.0
 
+    t_0 = time.perf_counter()
     with Message('Computing tentative velocity'):
         ui, alpha = _compute_tentative_velocity(
                 u, p0, f, u_bcs, time_step_method, rho_, mu_, dt_, None,
                 tol=1.0e-10
                 )
 
+    t_1 = time.perf_counter()
     with Message('Computing pressure'):
         p1 = _compute_pressure(
                 p0,
@@ -359,11 +371,19 @@ def _step(
                 verbose=verbose
                 )
 
+    t_2 = time.perf_counter()
     with Message('Computing velocity correction'):
         u1 = _compute_velocity_correction(
             ui, u, u_bcs, p1, p0, None, mu_, rho_, dt_, rotational_form, tol,
             verbose
             )
+    t_3 = time.perf_counter()
+    # every sub-step ends with a host read-back of a residual norm, so the host
+    # clock brackets the device work
+    last_step_info['timings'] = {
+        'tentative_s': t_1 - t_0, 'pressure_s': t_2 - t_1,
+        'correction_s': t_3 - t_2,
+        }
     last_step_info['tentative_velocity'] = ui
     return u1, p1
 

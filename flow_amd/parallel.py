@@ -1,0 +1,306 @@
+# -*- coding: utf-8 -*-
+'''
+Row-block sharding of the pressure-Poisson solve over the GPUs of one node
+(nothing in the reference: DOLFIN/PETSc would do this
+implicitly under mpirun).
+
+One process per GPU, torch.distributed over RCCL ('nccl' backend) on xGMI.
+Rank g owns the contiguous rows [r_g, r_{g+1}) of the P1 stiffness matrix,
+balanced by nonzeros.  With the x-major vertex numbering of the channel mesh
+the matrix is banded (bandwidth ~ ny), so a rank only needs `halo` entries from
+its left and right neighbour.  Per CG iteration (Chronopoulos-Gear single
+reduction form) there is ONE neighbour halo exchange of z and ONE all-reduce of
+the three scalars (r.z, z.w, r.r); both are latency bound (a few KB / 24 B).
+The local pieces are the same HIP kernels as the single-GPU solver, launched on
+the owned row range through the C ABI (flow_cg_update_dev, flow_operator_apply
+with the rank's row blocks, flow_dot3_dev, flow_cg_scalars_dev).
+
+Every rank keeps full-length vectors (the pressure space is small: 9 MB at
+10 M DoF); only the owned slice and the halos are kept current during the
+iteration, and the solution is all-gathered at the end because the other
+sub-steps are replicated.
+'''
+import ctypes
+
+import numpy
+import torch
+import torch.distributed as dist
+
+from . import _hip
+from . import device
+from .fem.space import csr_stream_rowblocks
+
+_STATE = {'group': None}
+
+
+def enable(group):
+    '''Shard subsequent pressure solves over `group`.'''
+    _STATE['group'] = group
+
+
+def disable():
+    _STATE['group'] = None
+
+
+def active():
+    return _STATE['group'] is not None and \
+        dist.get_world_size(_STATE['group']) > 1
+
+
+# -- partition (pure host logic, CPU-testable) --------------------------------
+class Partition(object):
+    '''Row-block partition of a CSR pattern, balanced by nonzeros.'''
+
+    def __init__(self, rowptr, cols, world):
+        rowptr = numpy.asarray(rowptr, dtype=numpy.int64)
+        n = len(rowptr) - 1
+        nnz = int(rowptr[-1])
+        assert 1 <= world <= n
+        targets = (numpy.arange(1, world) * nnz) // world
+        cuts = numpy.searchsorted(rowptr, targets, side='left')
+        bounds = numpy.concatenate([[0], cuts, [n]]).astype(numpy.int64)
+        # strictly increasing (tiny problems)
+        for g in range(1, world + 1):
+            bounds[g] = max(bounds[g], bounds[g - 1] + 1)
+        bounds[world] = n
+        assert (numpy.diff(bounds) > 0).all(), 'more ranks than rows'
+        self.n = n
+        self.world = world
+        self.bounds = bounds
+        # columns referenced by each rank's rows
+        self.lo = numpy.empty(world, dtype=numpy.int64)
+        self.hi = numpy.empty(world, dtype=numpy.int64)
+        cols = numpy.asarray(cols)
+        for g in range(world):
+            seg = cols[rowptr[bounds[g]]:rowptr[bounds[g + 1]]]
+            self.lo[g] = seg.min()
+            self.hi[g] = seg.max() + 1
+        for g in range(world):
+            # halos must come from the immediate neighbours only
+            left = bounds[g - 1] if g > 0 else 0
+            right = bounds[g + 2] if g + 2 <= world else n
+            assert self.lo[g] >= left and self.hi[g] <= right, \
+                'matrix bandwidth exceeds the neighbour row blocks'
+
+    def rows(self, g):
+        return int(self.bounds[g]), int(self.bounds[g + 1])
+
+    def exchanges(self, g):
+        '''[(peer, send_slice, recv_slice)] of rank g: what it must send to and
+        receive from each neighbour before a local SpMV.'''
+        r0, r1 = self.rows(g)
+        out = []
+        if g > 0:
+            # left neighbour needs my first rows up to its hi; I need [lo, r0)
+            send = (r0, int(max(r0, min(self.hi[g - 1], r1))))
+            recv = (int(min(self.lo[g], r0)), r0)
+            out.append((g - 1, send, recv))
+        if g + 1 < self.world:
+            send = (int(min(r1, max(self.lo[g + 1], r0))), r1)
+            recv = (r1, int(max(self.hi[g], r1)))
+            out.append((g + 1, send, recv))
+        return out
+
+
+class Comm(object):
+    '''The two collectives of the solver on a torch.distributed group.
+    The gloo backend cannot move device tensors point-to-point, so with gloo
+    (CPU tests, single-GPU rehearsals) buffers are staged through the host.'''
+
+    def __init__(self, group):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.staged = dist.get_backend(group) == 'gloo'
+
+    def global_rank(self, r):
+        return dist.get_global_rank(self.group, r) \
+            if self.group is not dist.group.WORLD else r
+
+    def allreduce_sum(self, t):
+        if self.staged and t.is_cuda:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+    def halo_exchange(self, vec, plan):
+        '''plan: [(peer, (s0, s1), (r0, r1))] slices of the full-length vec.'''
+        ops_ = []
+        staged = []
+        for peer, (s0, s1), (r0, r1) in plan:
+            gp = self.global_rank(peer)
+            if s1 > s0:
+                buf = vec[s0:s1]
+                if self.staged and vec.is_cuda:
+                    buf = buf.cpu()
+                ops_.append(dist.P2POp(dist.isend, buf, gp, self.group))
+            if r1 > r0:
+                buf = vec[r0:r1]
+                if self.staged and vec.is_cuda:
+                    buf = torch.empty(r1 - r0, dtype=vec.dtype)
+                    staged.append((buf, r0, r1))
+                ops_.append(dist.P2POp(dist.irecv, buf, gp, self.group))
+        if ops_:
+            for req in dist.batch_isend_irecv(ops_):
+                req.wait()
+        for buf, r0, r1 in staged:
+            vec[r0:r1].copy_(buf)
+
+    def allgather_rows(self, vec, bounds):
+        '''Make the full vector current on every rank (owned slices -> all).'''
+        for g in range(self.world):
+            r0, r1 = int(bounds[g]), int(bounds[g + 1])
+            seg = vec[r0:r1]
+            if self.staged and vec.is_cuda:
+                h = seg.cpu()
+                dist.broadcast(h, self.global_rank(g), group=self.group)
+                seg.copy_(h)
+            else:
+                dist.broadcast(seg, self.global_rank(g), group=self.group)
+
+
+# -- local kernels ------------------------------------------------------------
+class HipLocal(object):
+    '''Local pieces of the sharded CG on the HIP path.'''
+
+    def __init__(self, A, r0, r1):
+        self.lib = _hip.lib()
+        lay = A.layout
+        self.A = A
+        self.r0, self.r1 = r0, r1
+        rowptr = lay.pattern('rowptr').astype(numpy.int64)
+        rb = csr_stream_rowblocks(rowptr[r0:r1 + 1] - rowptr[r0]) + r0
+        self.rowblocks = device.to_device(rb.astype(numpy.int32))
+        base = A.operator()
+        op = _hip.Operator()
+        ctypes.memmove(ctypes.byref(op), ctypes.byref(base),
+                       ctypes.sizeof(_hip.Operator))
+        op.rowblocks = _hip.i32(self.rowblocks)
+        op.nblocks = len(rb) - 1
+        self.op = op
+        self.work = device.empty(_hip.REDUCE_WORK)
+
+    def zeros(self, n):
+        return device.zeros(n)
+
+    def spmv_rows(self, x, y):
+        _hip.check(self.lib.flow_operator_apply(
+            ctypes.byref(self.op), _hip.f64(x, self.A.size),
+            _hip.f64(y, self.A.size), _hip.stream()
+            ))
+
+    def residual(self, b, q, dinv, r, z):
+        s = slice(self.r0, self.r1)
+        _hip.check(self.lib.flow_residual_dev(
+            self.r1 - self.r0, _hip.f64(b[s]), _hip.f64(q[s]), _hip.f64(dinv[s]),
+            _hip.f64(r[s]), _hip.f64(z[s]), _hip.stream()
+            ))
+
+    def dots(self, r, z, w, b, out):
+        '''out[0:3] = local (r.z, z.w, r.r); out[3] = b.b if b is given.'''
+        s = slice(self.r0, self.r1)
+        n = self.r1 - self.r0
+        _hip.check(self.lib.flow_dot3_dev(
+            n, 3, _hip.f64(r[s]), _hip.f64(z[s]), _hip.f64(z[s]), _hip.f64(w[s]),
+            _hip.f64(r[s]), _hip.f64(r[s]), _hip.f64(self.work),
+            _hip.f64(out[0:3]), _hip.stream()
+            ))
+        if b is not None:
+            _hip.check(self.lib.flow_dot3_dev(
+                n, 1, _hip.f64(b[s]), _hip.f64(b[s]), None, None, None, None,
+                _hip.f64(self.work), _hip.f64(out[3:4]), _hip.stream()
+                ))
+
+    def scalars(self, first, sums, S):
+        _hip.check(self.lib.flow_cg_scalars_dev(
+            int(first), _hip.f64(sums), _hip.f64(S), _hip.stream()
+            ))
+
+    def update(self, S, dinv, w, z, p, s_, x, r):
+        s = slice(self.r0, self.r1)
+        _hip.check(self.lib.flow_cg_update_dev(
+            self.r1 - self.r0, _hip.f64(S), _hip.f64(dinv[s]), _hip.f64(w[s]),
+            _hip.f64(z[s]), _hip.f64(p[s]), _hip.f64(s_[s]), _hip.f64(x[s]),
+            _hip.f64(r[s]), _hip.stream()
+            ))
+
+
+def sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit, check_every):
+    '''Chronopoulos-Gear CG on the row partition `part`.  `local` provides the
+    kernels (HipLocal in the product; the CPU tests inject a numpy stand-in to
+    exercise the partition + communication logic under gloo).  Returns
+    (iterations, residual norm); raises _hip.NotConverged.'''
+    g = comm.rank
+    plan = part.exchanges(g)
+    n = part.n
+    r = local.zeros(n)
+    z = local.zeros(n)
+    w = local.zeros(n)
+    p = local.zeros(n)
+    s = local.zeros(n)
+    S = local.zeros(16)
+    sums = local.zeros(4)
+
+    comm.halo_exchange(x, plan)
+    local.spmv_rows(x, w)
+    local.residual(b, w, dinv, r, z)
+    comm.halo_exchange(z, plan)
+    local.spmv_rows(z, w)
+    local.dots(r, z, w, b, sums)
+    comm.allreduce_sum(sums)
+    local.scalars(True, sums, S)
+    host = sums.cpu()
+    b2 = float(host[3])
+    res2 = float(host[2])
+    target = max(rtol * numpy.sqrt(b2), atol)
+    it = 0
+    while True:
+        if res2 != res2:
+            raise _hip.NotConverged('sharded CG broke down (NaN residual)')
+        if numpy.sqrt(res2) <= target:
+            break
+        if it >= maxit:
+            raise _hip.NotConverged(
+                'sharded CG did not converge in %d iterations: |r| = %.3e > %.3e'
+                % (it, numpy.sqrt(res2), target)
+                )
+        todo = min(check_every, maxit - it)
+        for _ in range(todo):
+            local.update(S, dinv, w, z, p, s, x, r)
+            comm.halo_exchange(z, plan)
+            local.spmv_rows(z, w)
+            local.dots(r, z, w, None, sums)
+            comm.allreduce_sum(sums[0:3])
+            local.scalars(False, sums, S)
+        it += todo
+        res2 = float(sums[2].item())
+    comm.allgather_rows(x, part.bounds)
+    return it, float(numpy.sqrt(res2))
+
+
+_PART_CACHE = {}
+
+
+def pressure_cg(A, dinv, b, x, rtol, atol, maxit, check_every):
+    '''Sharded replacement of ops.krylov_solve('cg', ...) for the pressure
+    system (called from navier_stokes._compute_pressure when enabled).'''
+    from .fem.ops import SolveInfo
+    comm = Comm(_STATE['group'])
+    lay = A.layout
+    key = (id(lay), comm.world)
+    if key not in _PART_CACHE:
+        _PART_CACHE[key] = Partition(
+            lay.pattern('rowptr'), lay.pattern('cols'), comm.world
+            )
+    part = _PART_CACHE[key]
+    r0, r1 = part.rows(comm.rank)
+    lkey = (id(A), comm.world, comm.rank)
+    if lkey not in _PART_CACHE:
+        _PART_CACHE[lkey] = HipLocal(A, r0, r1)
+    local = _PART_CACHE[lkey]
+    its, res = sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit,
+                          check_every)
+    return SolveInfo(its, res, 'cg[row-sharded x%d]' % comm.world)

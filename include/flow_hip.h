@@ -85,7 +85,7 @@ int flow_axpby(int n, double a, const double* x, double b, double* y,
  * FLOW_NOT_CONVERGED after maxit iterations (dolfin raises RuntimeError:
  * 'error_on_nonconvergence', pressure_correction.py:337,424,462).
  * dinv may be NULL (no preconditioner).  x holds the initial guess.
- * work: FLOW_REDUCE_WORK + 5*N doubles (cg), FLOW_REDUCE_WORK + 8*N (bicgstab),
+ * work: FLOW_REDUCE_WORK + 5*N doubles (cg), FLOW_REDUCE_WORK + 7*N (bicgstab),
  * N = operator size. */
 int flow_cg_solve(const flow_operator* A, const double* dinv, const double* b,
                   double* x, double rtol, double atol, int maxit,
@@ -96,6 +96,22 @@ int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
                         int maxit, int check_every, double* work,
                         size_t work_len, int* iters_host, double* resid_host,
                         void* stream);
+
+/* ---- K15: building blocks of the row-sharded multi-GPU CG ----------------
+ * (nothing in the reference: DOLFIN/PETSc would do this implicitly under
+ * mpirun).  The loop lives in flow_amd/parallel.py: per iteration one halo
+ * exchange of z and ONE all-reduce of (r.z, z.w, r.r) over RCCL; these entry
+ * points run the local pieces on pre-offset pointers of the owned row range.
+ * S: 16 doubles of solver scalars (alpha, beta, ...; slot 3 = r.r). */
+int flow_dot3_dev(int n, int nd, const double* a0, const double* b0,
+                  const double* a1, const double* b1, const double* a2,
+                  const double* b2, double* work, double* out, void* stream);
+int flow_cg_scalars_dev(int first, const double* in3, double* S, void* stream);
+int flow_cg_update_dev(int n, const double* S, const double* dinv,
+                       const double* w, double* z, double* p, double* s,
+                       double* x, double* r, void* stream);
+int flow_residual_dev(int n, const double* b, const double* q,
+                      const double* dinv, double* r, double* z, void* stream);
 
 /* ---- assembly ------------------------------------------------------------
  * Two-phase, atomic-free: a cell kernel writes local tensors to `scratch`
@@ -178,6 +194,14 @@ int flow_assemble_momentum(const flow_mesh* mesh, const flow_space* W,
 int flow_assemble_source(const flow_mesh* mesh, const flow_space* V, int dim,
                          const flow_coef* f, double* scratch, double* b,
                          void* stream);
+
+/* K16: b_i = int m(u) phi_i with m = sqrt(ux^2+uy^2) (mode 0) or |ux|+|uy|
+ * (mode 1): the load vector of the callers' `project(sqrt(ux**2 + uy**2), ...)`
+ * step-size control (tests/test_karman_vortex_street.py:262-268,
+ * tests/test_boussinesq.py:268-273).  scratch: nloc*nc. */
+int flow_assemble_magnitude(const flow_mesh* mesh, const flow_space* W, int mode,
+                            const double* u, double* scratch, double* b,
+                            void* stream);
 
 /* ---- K7: Dirichlet conditions (bcs= in solve, pressure_correction.py:226,
  * 327,452; bc.apply(A, b), heat.py:113-114).  dofs sorted, in operator
