@@ -1,0 +1,23 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun) from the repo root:
+#   bash profiles/run_profiles.sh rNN
+# Three separate rocprofv3 runs of the SAME bench command: kernel trace (+stats),
+# FETCH_SIZE pass, WRITE_SIZE pass.  Summaries land in gpurun_out/ and are then
+# copied into profiles/ (tracked).
+set -e
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --spmv-reps 50"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
+echo trace done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
+echo fetch done
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
+echo write done
+python3 $R/profiles/summarize.py stats $OUT/trace $R/gpurun_out/kernel_stats_$TAG.md
+python3 $R/profiles/summarize.py pmc $OUT/fetch $OUT/write $R/gpurun_out/spmv_traffic_$TAG.json
+# keep the merge-back small: drop the raw traces
+rm -rf $OUT/trace $OUT/fetch $OUT/write

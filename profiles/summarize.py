@@ -1,0 +1,95 @@
+# -*- coding: utf-8 -*-
+'''
+Summarise rocprofv3 CSV output into the small files committed under profiles/.
+
+  python profiles/summarize.py stats  <dir> <out.md>     kernel-trace summary
+  python profiles/summarize.py pmc    <fetch_dir> <write_dir> <out.json>
+
+The PMC summary follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
+FETCH_SIZE and WRITE_SIZE come from separate passes, are in KiB, and on gfx950
+FETCH_SIZE reports half of the bytes of a coalesced streaming read, so
+hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch.  (The x2 is
+calibrated for 16-B-per-lane loads; the SpMV issues 8-B and 4-B loads, so the
+absolute figure is indicative -- Infinity-Cache hits are also counted.)
+'''
+from __future__ import print_function
+
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def _find(directory, suffix):
+    hits = glob.glob(os.path.join(directory, '**', '*' + suffix), recursive=True)
+    if not hits:
+        raise SystemExit('no *%s under %s' % (suffix, directory))
+    return hits
+
+
+def stats(directory, out):
+    rows = defaultdict(lambda: [0, 0.0])
+    for path in _find(directory, 'kernel_trace.csv'):
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                name = r['Kernel_Name'].split('(')[0]
+                dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3
+                rows[name][0] += 1
+                rows[name][1] += dur
+    total = sum(v[1] for v in rows.values())
+    lines = [
+        '| kernel | calls | total ms | avg us | % |',
+        '|---|---|---|---|---|',
+        ]
+    for name, (cnt, us) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+        lines.append('| %s | %d | %.3f | %.2f | %.1f |' % (
+            name, cnt, us * 1e-3, us / cnt, 100.0 * us / max(total, 1e-30)))
+    with open(out, 'w') as fh:
+        fh.write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[:14]))
+
+
+def _counter(directory, counter, kernel):
+    vals = []
+    for path in _find(directory, 'counter_collection.csv'):
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                if r['Counter_Name'] == counter and \
+                        r['Kernel_Name'].startswith(kernel):
+                    vals.append(float(r['Counter_Value']))
+    return vals
+
+
+def pmc(fetch_dir, write_dir, out, kernel='flow::spmv_stream_kernel'):
+    # group by dispatch size: keep the dispatches of the pressure matrix
+    # (the most frequent value set is the CG loop + the timed roofline launches)
+    f = _counter(fetch_dir, 'FETCH_SIZE', kernel)
+    w = _counter(write_dir, 'WRITE_SIZE', kernel)
+    if not f or not w:
+        raise SystemExit('no counter rows for %s' % kernel)
+    f.sort()
+    w.sort()
+    fmed = f[len(f) // 2]
+    wmed = w[len(w) // 2]
+    res = {
+        'kernel': kernel,
+        'dispatches_fetch_pass': len(f),
+        'dispatches_write_pass': len(w),
+        'FETCH_SIZE_KiB_median': fmed,
+        'WRITE_SIZE_KiB_median': wmed,
+        'hbm_bytes_per_launch': (2.0 * fmed + wmed) * 1024.0,
+        'note': 'hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 '
+                'correction of MI355X_MICROARCH.md; median over dispatches',
+        }
+    with open(out, 'w') as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'stats':
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
