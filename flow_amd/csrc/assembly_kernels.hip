@@ -613,15 +613,17 @@ __device__ __forceinline__ double supg_tau(const double px[3], const double py[3
   return tau;
 }
 
-template <int DEGQ, int DEGW>
+template <int DEGQ, int DEGW, bool SUPG>
 __global__ __launch_bounds__(kBlock) void heat_kernel(
     int nc, const double* __restrict__ xy, const int* __restrict__ cdw, int nw,
-    const double* __restrict__ conv, double kappa, double rho_cp, int supg,
+    const double* __restrict__ conv, double kappa, double rho_cp,
     double* __restrict__ scratch, double* __restrict__ tau_out,
     int* __restrict__ status) {
   constexpr int NL = Elem<DEGQ>::NL;
   constexpr int NW = Elem<DEGW>::NL;
-  constexpr int NQ = 7;
+  // plain operator: conv(2) grad u(1) v(2) = degree 5 -> 7-point rule;
+  // SUPG terms reach degree 7 -> 16-point rule (FFC picks the exact degree)
+  constexpr int NQ = SUPG ? 16 : 7;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const Geom g = load_geom(xy, nc, c);
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(kBlock) void heat_kernel(
   double lap[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) lap[i] = 0.0;
-  if (supg) {
+  if constexpr (SUPG) {
     const double px[3] = {xy[0 * nc + c], xy[1 * nc + c], xy[2 * nc + c]};
     const double py[3] = {xy[3 * nc + c], xy[4 * nc + c], xy[5 * nc + c]};
     // tau is Expression(degree=1): evaluated at the cell vertices
@@ -662,10 +664,11 @@ __global__ __launch_bounds__(kBlock) void heat_kernel(
     double Ka[NL], Ma[NL];
 #pragma unroll
     for (int j = 0; j < NL; ++j) Ka[j] = Ma[j] = 0.0;
-#pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const double L[3] = {kQ7L[q][0], kQ7L[q][1], kQ7L[q][2]};
-      const double w = 0.5 * kQ7W[q] * g.adet;
+      const double L[3] = {SUPG ? kQ16L[q][0] : kQ7L[q][0],
+                           SUPG ? kQ16L[q][1] : kQ7L[q][1],
+                           SUPG ? kQ16L[q][2] : kQ7L[q][2]};
+      const double w = 0.5 * (SUPG ? kQ16W[q] : kQ7W[q]) * g.adet;
       double phi[NL], dphi[NL][3], gphi[NL][2];
       basis<DEGQ>(L, phi, dphi);
       phys_grad<NL>(g, dphi, gphi);
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(kBlock) void heat_kernel(
         const double cgj = b[0] * gphi[j][0] + b[1] * gphi[j][1];
         double k = -kappa / rho_cp * (gphi[j][0] * gi0 + gphi[j][1] * gi1) -
                    cgj * pi;
-        if (supg) {
+        if constexpr (SUPG) {
           k += (kappa / rho_cp * lap[j] - cgj) * tq * cgi;
           Ma[j] += w * phi[j] * tq * cgi;
         }
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void heat_kernel(
     for (int j = 0; j < NL; ++j) {
       const size_t idx = static_cast<size_t>(i * NL + j) * nc + c;
       scratch[idx] = Ka[j];
-      if (supg) scratch[plane + idx] = Ma[j];
+      if constexpr (SUPG) scratch[plane + idx] = Ma[j];
     }
   }
 }
@@ -955,9 +958,16 @@ extern "C" int flow_assemble_heat(const flow_mesh* mesh, const flow_space* Q,
   hipStream_t st = as_stream(stream);
   const dim3 grid = cell_grid(mesh->nc);
 #define FLOW_HEAT(DQ, DW)                                                      \
-  hipLaunchKernelGGL((heat_kernel<DQ, DW>), grid, dim3(kBlock), 0, st, mesh->nc, \
-                     mesh->xy, W->cell_dofs, W->n, conv, kappa, rho_cp, supg,  \
-                     scratch, tau_out, status_dev)
+  do {                                                                         \
+    if (supg)                                                                  \
+      hipLaunchKernelGGL((heat_kernel<DQ, DW, true>), grid, dim3(kBlock), 0, st, \
+                         mesh->nc, mesh->xy, W->cell_dofs, W->n, conv, kappa,  \
+                         rho_cp, scratch, tau_out, status_dev);                \
+    else                                                                       \
+      hipLaunchKernelGGL((heat_kernel<DQ, DW, false>), grid, dim3(kBlock), 0,  \
+                         st, mesh->nc, mesh->xy, W->cell_dofs, W->n, conv,     \
+                         kappa, rho_cp, scratch, tau_out, status_dev);         \
+  } while (0)
   if (Q->deg == 1 && W->deg == 1) FLOW_HEAT(1, 1);
   else if (Q->deg == 1 && W->deg == 2) FLOW_HEAT(1, 2);
   else if (Q->deg == 2 && W->deg == 1) FLOW_HEAT(2, 1);

@@ -43,6 +43,33 @@ __device__ constexpr double kQ7L[7][3] = {
 __device__ constexpr double kQ7W[7] = {0.225,   FLOW_WA, FLOW_WA, FLOW_WA,
                                        FLOW_WB, FLOW_WB, FLOW_WB};
 
+// 16-point collapsed Gauss-Jacobi rule, exact for degree 7 (SUPG terms:
+// conv(2) * grad u(1) * tau(1) * conv(2) * grad v(1)); generated from
+// flow_amd/fem/reference.py triangle_rule(7); weights sum to 1
+__device__ constexpr double kQ16L[16][3] = {
+    {0.87742880933046774, 0.057104196114517725, 0.065466994555014452},
+    {0.6317312516411252, 0.057104196114517725, 0.31116455224435702},
+    {0.31116455224435702, 0.057104196114517725, 0.6317312516411252},
+    {0.065466994555014479, 0.057104196114517725, 0.87742880933046774},
+    {0.67294686315050645, 0.2768430136381238, 0.050210123211369778},
+    {0.48450832663043331, 0.2768430136381238, 0.23864865973144292},
+    {0.23864865973144295, 0.2768430136381238, 0.48450832663043325},
+    {0.050210123211369861, 0.2768430136381238, 0.67294686315050634},
+    {0.38749748340669415, 0.58359043236891683, 0.028912084224389012},
+    {0.2789904634965088, 0.58359043236891683, 0.13741910413457437},
+    {0.13741910413457437, 0.58359043236891683, 0.2789904634965088},
+    {0.028912084224389012, 0.58359043236891683, 0.38749748340669415},
+    {0.1300560792168344, 0.86024013565621948, 0.0097037851269461094},
+    {0.093637784437328481, 0.86024013565621948, 0.046122079906452035},
+    {0.046122079906452035, 0.86024013565621948, 0.093637784437328481},
+    {0.0097037851269461128, 0.86024013565621948, 0.1300560792168344},
+};
+__device__ constexpr double kQ16W[16] = {
+    0.047136736386764778, 0.088370177044723719, 0.088370177044723719, 0.047136736386764778,
+    0.070776135796171771, 0.13268843221409932, 0.13268843221409932, 0.070776135796171771,
+    0.0451680985647398, 0.084679449043492519, 0.084679449043492519, 0.0451680985647398,
+    0.010846451821050504, 0.020334519128957576, 0.020334519128957576, 0.010846451821050504};
+
 template <int DEG>
 __device__ __forceinline__ double qpoint(int q, int k) {
   if constexpr (DEG == 1) return kQ3L[q][k];

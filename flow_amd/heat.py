@@ -1,0 +1,160 @@
+# -*- coding: utf-8 -*-
+#
+'''
+Convection-diffusion (heat) operator in the "alpha M + beta F" form an external
+ODE stepper drives; same interface as the reference's flow/heat.py:
+
+    Heat(V, conv, kappa, rho, cp, bcs, source, supg_stabilization=False)
+        .V .bcs .M .A .b
+        .eval_alpha_M_beta_F(alpha, beta, u, t)
+        .solve_alpha_M_beta_F(alpha, beta, b, t)
+
+All operators are assembled by the HIP kernels of libflow_hip.so (K13/K14):
+  M  u*v*dx with the 'vertex' quadrature scheme (reference :39-45): a lumped,
+     diagonal matrix; for P2 the edge rows are zero (the vertex rule only sees
+     the vertex basis functions) -- reproduced on purpose;
+  A  matrix of f = -kappa grad(u).grad(v/(rho cp)) - (conv.grad u) v
+     (reference :54-58) [+ SUPG terms, :60-86];
+  b  rhs(f) = -int source v (UFL's rhs() negates; reference :88).
+The reference solves with sparse LU (:117-121); here BiCGStab + Jacobi.
+'''
+import ctypes
+
+import torch
+
+from .fem import ops
+from .fem.bcs import collect
+from .fem.function import Constant, Function, Vector
+from . import _hip
+from . import device
+from . import stabilization
+
+solver_parameters = {'rtol': 1.0e-13, 'maxit': 20000, 'check_every': 10}
+last_solve_info = {}
+
+
+def _data(v):
+    if isinstance(v, Function):
+        return v.data
+    if isinstance(v, Vector):
+        return v.data
+    if hasattr(v, 'vec'):            # vec[:]
+        return v.vec.data
+    return v
+
+
+class Heat(object):
+    '''
+    Provides methods for computing
+
+        u' = F(t, u).
+    '''
+    def __init__(
+            self, V, conv, kappa, rho, cp, bcs, source,
+            supg_stabilization=False
+            ):
+        lib = _hip.lib()
+        self.V = V
+        self.bcs = bcs
+        assert V.dim == 1
+        mesh = V.mesh()
+        lay = V.layout
+        nc = mesh.num_cells()
+        rho_cp = float(rho) * float(cp)
+        kappa = float(kappa)
+
+        lumped = ops.assemble_scalar_matrix(lay, ops.LUMPED_MASS)
+        self.A = ops.Matrix(lay, 0)
+        msupg = device.empty(lay.nnz) if supg_stabilization else None
+        status = device.zeros(1, dtype=torch.int32)
+        if supg_stabilization:
+            assert conv is not None
+            # kept for interface parity with the reference (:75-77)
+            self.tau = stabilization.supg(
+                mesh, conv, kappa, V.ufl_element().degree()
+                )
+        W = conv.function_space()
+        assert W.dim == 2 and W.mesh() is mesh
+        buf = ops.scratch(mesh, 2 * lay.nloc**2 * nc)
+        _hip.check(lib.flow_assemble_heat(
+            ctypes.byref(ops.mesh_struct(mesh)),
+            ctypes.byref(ops.space_struct(lay)),
+            ctypes.byref(ops.space_struct(W.layout)),
+            _hip.f64(conv.data, W.size()), kappa, rho_cp,
+            int(bool(supg_stabilization)), _hip.f64(buf),
+            _hip.f64(self.A.vals), _hip.f64(msupg), None, _hip.i32(status),
+            _hip.stream()
+            ))
+        if supg_stabilization:
+            if int(status.item()) != 0:
+                # the reference's C++ Expression throws (stabilization.py:132-140)
+                raise RuntimeError('SUPG stabilization: tau > 1e3')
+            self.M = ops.Matrix(lay, 0, lumped.vals + msupg)
+        else:
+            self.M = lumped
+
+        # b = rhs(f) = - int source v  [SUPG source term only for source = 0]
+        if isinstance(source, (int, float)):
+            source = Constant(source)
+        zero_source = isinstance(source, Constant) and \
+            float(source.values()[0]) == 0.0
+        if zero_source:
+            self.b = Vector(device.zeros(V.N))
+        else:
+            if supg_stabilization:
+                raise NotImplementedError(
+                    'SUPG with a non-zero source is outside the hot path'
+                    )
+            self.b = Vector(-ops.assemble_source(V, source))
+        return
+
+    # pylint: disable=unused-argument
+    def eval_alpha_M_beta_F(self, alpha, beta, u, t):
+        '''Evaluate  alpha * M * u + beta * F(u, t).
+        '''
+        uvec = _data(u)
+        alpha = float(alpha)
+        beta = float(beta)
+        n = self.V.N
+        out = device.empty(n)
+        tmp = device.empty(n)
+        self.M.apply(uvec, out)                 # M u
+        self.A.apply(uvec, tmp)                 # A u
+        ops.axpby(1.0, self.b.data, 1.0, tmp)   # A u + b
+        ops.axpby(beta, tmp, alpha, out)        # alpha M u + beta (A u + b)
+        return Vector(out)
+
+    def solve_alpha_M_beta_F(self, alpha, beta, b, t):
+        '''Solve  alpha * M * u + beta * F(u, t) = b  for u.
+        '''
+        lib = _hip.lib()
+        lay = self.V.layout
+        st = _hip.stream()
+        A = ops.Matrix(lay, 0, float(alpha) * self.M.vals
+                       + float(beta) * self.A.vals)
+        # The reference computes right_hand_side = -beta*self.b + b but then
+        # solves with the raw `b` (reference :109-121); identical when
+        # self.b = 0.  Kept.
+        bvec = _data(b)
+        dofs, vals = collect(self.bcs, self.V.size())
+        nbc = len(dofs)
+        if nbc > 0:
+            bc_dofs = device.to_device(dofs)
+            bc_vals = device.to_device(vals)
+            # bc.apply(A, b): identity rows, b[d] = g (in place, as dolfin)
+            _hip.check(lib.flow_bc_identity_rows(
+                ctypes.byref(A.operator()), _hip.f64(A.vals),
+                _hip.i32(lay.dev('diag_idx')), nbc, _hip.i32(bc_dofs), st
+                ))
+            _hip.check(lib.flow_bc_set_values(
+                nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(bvec), st
+                ))
+        u = Function(self.V)
+        # warm start is not used: x0 = 0 like a direct solve has no history
+        par = solver_parameters
+        info = ops.krylov_solve(
+            'bicgstab', A, bvec, u.data, rtol=par['rtol'], atol=0.0,
+            maxit=par['maxit'], check_every=par['check_every']
+            )
+        last_solve_info['heat'] = info
+        return u
