@@ -131,3 +131,20 @@ def collect(bcs, size):
     v = v[last]
     assert len(d) == 0 or (d[0] >= 0 and d[-1] < size)
     return d.astype(numpy.int32), v
+
+
+class FixedDofsBC(object):
+    '''Dirichlet data given directly as (dofs, values) in the numbering of the
+    space (replays of recorded cases, golden fixtures).'''
+
+    def __init__(self, V, dofs, values):
+        self.V = V
+        self._dofs = numpy.asarray(dofs, dtype=numpy.int64)
+        self._values = numpy.asarray(values, dtype=float)
+        assert self._dofs.shape == self._values.shape
+
+    def function_space(self):
+        return self.V
+
+    def dofs_and_values(self):
+        return self._dofs, self._values

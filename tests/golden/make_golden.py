@@ -1,0 +1,108 @@
+# -*- coding: utf-8 -*-
+'''
+Generates the golden fixtures under tests/golden/ with the CPU oracle
+(oracle/fem_oracle.py).  The reference itself cannot run offline (no dolfin),
+so these vectors come from the oracle, which is pinned by the reference's
+analytic known-answer tests (tests/test_oracle_pinning.py).
+
+    python tests/golden/make_golden.py
+
+Fixtures are plain data (inputs and expected outputs):
+  ns_step_<name>.npz   one pressure-correction step per scheme
+  heat_ops.npz         heat operators M, A (CSR data) with and without SUPG,
+                       SUPG tau per cell vertex, one implicit-Euler solve
+'''
+import os
+import sys
+
+import numpy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from flow_amd import fem                                   # noqa: E402
+from flow_amd.fem.bcs import collect                       # noqa: E402
+from oracle import fem_oracle as orc                       # noqa: E402
+import cases                                               # noqa: E402
+import mms                                                 # noqa: E402
+
+
+def ns_fixture(name, mesh, vdeg, bc_kind, dt, rho, mu, seed):
+    case = cases.Case(mesh, vdeg=vdeg, dt=dt, bc_kind=bc_kind, rho=rho, mu=mu,
+                      f_degree=2, seed=seed)
+    u_bc, p_bc = case.bc_data()
+    data = {
+        'points': mesh.points, 'cells': mesh.cell_vertices,
+        'w_cell_dofs': case.W.layout.cell_dofs,
+        'p_cell_dofs': case.P.layout.cell_dofs,
+        'vdeg': vdeg, 'dt': dt, 'rho': rho, 'mu': mu,
+        'u0': case.u0, 'p0': case.p0,
+        'u_bc_dofs': u_bc[0], 'u_bc_vals': u_bc[1],
+        'p_bc_dofs': p_bc[0] if p_bc else numpy.zeros(0, dtype=numpy.int32),
+        'p_bc_vals': p_bc[1] if p_bc else numpy.zeros(0),
+        'f_degree': 2,
+        'f0': case.lattice(case.f0)[1], 'f1': case.lattice(case.f1)[1],
+        }
+    for scheme, method in (('chorin', 'backward euler'),
+                           ('ipcs', 'backward euler'),
+                           ('rotational', 'backward euler'),
+                           ('ipcs', 'crank-nicolson')):
+        u1, p1, ui = case.oracle_step(scheme, method)
+        key = scheme + '_' + method.replace(' ', '_').replace('-', '_')
+        data[key + '_u1'] = u1
+        data[key + '_p1'] = p1
+        data[key + '_ui'] = ui
+    numpy.savez_compressed(os.path.join(HERE, 'ns_step_%s.npz' % name), **data)
+
+
+def heat_fixture():
+    sys.path.insert(0, os.path.dirname(HERE))
+    mesh = fem.heater_box(5)
+    Q = fem.FunctionSpace(mesh, 'Lagrange', 2)
+    W = fem.VectorFunctionSpace(mesh, 'Lagrange', 2)
+    x = W.layout.dof_coords
+    conv = 2.0e-5 * numpy.concatenate([
+        -(x[:, 1] - 0.1) * (1.0 + x[:, 0]), (x[:, 0] - 0.05) * (1.0 + x[:, 1]**2)
+        ])
+    Qo = orc.Space(mesh.points, mesh.cell_vertices, Q.layout.cell_dofs, 2, Q.N)
+    Wo = orc.Space(mesh.points, mesh.cell_vertices, W.layout.cell_dofs, 2, W.N)
+    kappa, rho, cp = 0.6, 998.0, 4182.0
+    data = {'points': mesh.points, 'cells': mesh.cell_vertices,
+            'q_cell_dofs': Q.layout.cell_dofs, 'conv': conv,
+            'kappa': kappa, 'rho': rho, 'cp': cp}
+    rng = numpy.random.RandomState(3)
+    u0 = 293.0 + rng.standard_normal(Q.N)
+    data['u0'] = u0
+    bc_dofs = numpy.nonzero(Q.layout.dof_coords[:, 1] < 1e-12)[0]
+    data['bc_dofs'] = bc_dofs
+    data['bc_vals'] = numpy.full(len(bc_dofs), 320.0)
+    for supg in (False, True):
+        M, A, b = orc.heat_operators(Qo, Wo, conv, kappa, rho, cp, 0.0, supg)
+        M = M.tocsr()
+        A = A.tocsr()
+        tag = 'supg' if supg else 'plain'
+        data['M_dense_' + tag] = M.toarray()
+        data['A_dense_' + tag] = A.toarray()
+        data['solve_' + tag] = orc.heat_solve(
+            M, A, 1.0, -0.01, M.dot(u0), bc_dofs, data['bc_vals'])
+    Cc = numpy.stack([conv[W.layout.cell_dofs],
+                      conv[W.N + W.layout.cell_dofs]], axis=1)
+    pc = mesh.points[mesh.cell_vertices]
+    data['tau'] = numpy.array([
+        [orc.supg_tau(pc[k], Cc[k, :, v], kappa, 2) for v in range(3)]
+        for k in range(mesh.num_cells())])
+    numpy.savez_compressed(os.path.join(HERE, 'heat_ops.npz'), **data)
+
+
+if __name__ == '__main__':
+    # C1: the reference's plumbing configuration (tests/test_navier_stokes.py:
+    # 403-410): UnitSquareMesh(8, 8, 'crossed'), P2-P1, guermond2
+    ns_fixture('c1_unit_square', fem.UnitSquareMesh(8, 8, 'crossed'), 2, 'all',
+               0.5, 1.0, 1.0, 21)
+    ns_fixture('channel_p2', fem.karman_channel(24, 8), 2, 'channel', 0.02, 1.5,
+               0.05, 22)
+    ns_fixture('channel_p1', fem.karman_channel(24, 8), 1, 'channel', 0.02, 1.5,
+               0.05, 23)
+    heat_fixture()
+    print('fixtures written to', HERE)
