@@ -38,6 +38,17 @@ class Operator(ctypes.Structure):
         ]
 
 
+class CoarseS(ctypes.Structure):
+    _fields_ = [
+        ('n', ctypes.c_int),
+        ('nc', ctypes.c_int),
+        ('agg_ptr', ctypes.c_void_p),
+        ('agg_dofs', ctypes.c_void_p),
+        ('agg_of', ctypes.c_void_p),
+        ('Ainv', ctypes.c_void_p),
+        ]
+
+
 class MeshS(ctypes.Structure):
     _fields_ = [('nc', ctypes.c_int), ('xy', ctypes.c_void_p)]
 
@@ -84,13 +95,16 @@ SYMBOLS = {
     'flow_dot_host': [_I, _VP, _VP, _VP, _P(_D), _VP],
     'flow_norm_host': [_I, _VP, _I, _VP, _P(_D), _VP],
     'flow_axpby': [_I, _D, _VP, _D, _VP, _VP],
-    'flow_cg_solve': [_P(Operator), _VP, _VP, _VP, _D, _D, _I, _I, _VP,
-                      ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_cg_solve': [_P(Operator), _VP, _P(CoarseS), _VP, _VP, _D, _D, _I, _I,
+                      _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_bicgstab_solve': [_P(Operator), _VP, _VP, _VP, _D, _D, _I, _I, _VP,
                             ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_dot3_dev': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_cg_scalars_dev': [_I, _VP, _VP, _VP],
-    'flow_cg_update_dev': [_I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
+    'flow_cg_update_dev': [_I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP],
+    'flow_coarse_restrict_dev': [_P(CoarseS), _VP, _I, _I, _VP, _VP],
+    'flow_coarse_solve_dev': [_P(CoarseS), _VP, _VP, _VP],
+    'flow_coarse_prolong_dev': [_P(CoarseS), _VP, _VP, _VP, _VP, _I, _I, _VP],
     'flow_residual_dev': [_I, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_assemble_scalar_matrix': [_I, _P(MeshS), _P(SpaceS), _VP, _VP, _VP],
     'flow_assemble_pressure_rhs': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _VP,

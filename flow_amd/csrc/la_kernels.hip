@@ -256,12 +256,13 @@ __global__ __launch_bounds__(kBlock) void cg_scalar_kernel(
 }
 
 // p = z + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; z = dinv r
+// (want_z = 0: z is produced afterwards by the two-level preconditioner)
 __global__ void cg_update_kernel(int n, const double* __restrict__ S,
                                  const double* __restrict__ dinv,
                                  const double* __restrict__ w,
                                  double* __restrict__ z, double* __restrict__ p,
                                  double* __restrict__ s, double* __restrict__ x,
-                                 double* __restrict__ r) {
+                                 double* __restrict__ r, int want_z) {
   const double alpha = S[kAlpha];
   const double beta = S[kBeta];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -273,8 +274,86 @@ __global__ void cg_update_kernel(int n, const double* __restrict__ S,
     x[i] += alpha * pi;
     const double ri = r[i] - alpha * si;
     r[i] = ri;
-    z[i] = dinv ? dinv[i] * ri : ri;
+    if (want_z) z[i] = dinv ? dinv[i] * ri : ri;
   }
+}
+
+// ---------------------------------------------------------------------------
+// two-level additive preconditioner  z = D^-1 r + P Ac^-1 P^T r
+// (Jacobi + piecewise-constant aggregate coarse space, dense coarse inverse)
+// ---------------------------------------------------------------------------
+// rc[a] = sum of r over the dofs of aggregate a that lie in [r0, r1): one
+// wavefront per aggregate, fixed order => reproducible
+__global__ __launch_bounds__(kBlock) void coarse_restrict_kernel(
+    int nc, const int* __restrict__ agg_ptr, const int* __restrict__ agg_dofs,
+    const double* __restrict__ r, int r0, int r1, double* __restrict__ rc) {
+  const int lane = threadIdx.x & 63;
+  for (int a = blockIdx.x * 4 + (threadIdx.x >> 6); a < nc; a += gridDim.x * 4) {
+    double sum = 0.0;
+    for (int k = agg_ptr[a] + lane; k < agg_ptr[a + 1]; k += 64) {
+      const int d = agg_dofs[k];
+      if (d >= r0 && d < r1) sum += r[d];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if (lane == 0) rc[a] = sum;
+  }
+}
+
+// zc = Ainv rc (dense, row-major, symmetric): one wavefront per row
+__global__ __launch_bounds__(kBlock) void coarse_gemv_kernel(
+    int nc, const double* __restrict__ Ainv, const double* __restrict__ rc,
+    double* __restrict__ zc) {
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nc;
+       row += gridDim.x * 4) {
+    const double* __restrict__ a = Ainv + static_cast<size_t>(row) * nc;
+    double s0 = 0.0, s1 = 0.0;
+    int j = lane;
+    for (; j + 64 < nc; j += 128) {
+      s0 += a[j] * rc[j];
+      s1 += a[j + 64] * rc[j + 64];
+    }
+    if (j < nc) s0 += a[j] * rc[j];
+    double sum = s0 + s1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if (lane == 0) zc[row] = sum;
+  }
+}
+
+// z = dinv r + zc[agg_of]  on dofs [0, n) of pre-offset arrays
+__global__ void coarse_prolong_kernel(int n, const int* __restrict__ agg_of,
+                                      const double* __restrict__ dinv,
+                                      const double* __restrict__ r,
+                                      const double* __restrict__ zc,
+                                      double* __restrict__ z) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    const int a = agg_of[i];
+    z[i] = dinv[i] * r[i] + (a >= 0 ? zc[a] : 0.0);
+  }
+}
+
+static int check_coarse(const flow_coarse* C, int n) {
+  FLOW_REQUIRE(C->nc > 0 && C->n == n, "coarse space size");
+  FLOW_REQUIRE(C->agg_ptr && C->agg_dofs && C->agg_of && C->Ainv,
+               "coarse space pointers");
+  return FLOW_OK;
+}
+
+// z = M^-1 r with the two-level preconditioner; rc, zc: nc doubles each
+static int two_level(const flow_coarse* C, const double* dinv, const double* r,
+                     double* z, double* rc, double* zc, hipStream_t st) {
+  const int g = grid_for(C->nc, 4, kMaxGrid);
+  hipLaunchKernelGGL(coarse_restrict_kernel, dim3(g), dim3(kBlock), 0, st, C->nc,
+                     C->agg_ptr, C->agg_dofs, r, 0, C->n, rc);
+  hipLaunchKernelGGL(coarse_gemv_kernel, dim3(g), dim3(kBlock), 0, st, C->nc,
+                     C->Ainv, rc, zc);
+  hipLaunchKernelGGL(coarse_prolong_kernel, dim3(grid_for(C->n)), dim3(kBlock),
+                     0, st, C->n, C->agg_of, dinv, r, zc, z);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
 }
 
 static int dots(int n, int nd, const double* a0, const double* b0,
@@ -296,7 +375,8 @@ static int read_slot(const double* S, int slot, double* host, hipStream_t st) {
   return FLOW_OK;
 }
 
-static int cg(const flow_operator* A, const double* dinv, const double* b,
+static int cg(const flow_operator* A, const double* dinv,
+              const flow_coarse* C, const double* b,
               double* x, double rtol, double atol, int maxit, int check_every,
               double* work, int* iters_host, double* resid_host,
               hipStream_t st) {
@@ -308,6 +388,8 @@ static int cg(const flow_operator* A, const double* dinv, const double* b,
   double* w = z + N;
   double* p = w + N;
   double* s = p + N;
+  double* crc = s + N;                    // coarse vectors (two-level only)
+  double* czc = crc + (C ? C->nc : 0);
   const int gv = grid_for(N);
   int np = 0, rc;
 
@@ -317,10 +399,11 @@ static int cg(const flow_operator* A, const double* dinv, const double* b,
   if ((rc = dots(N, 1, b, b, b, b, b, b, partial, &np, st))) return rc;
   hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 1, 0,
                      partial, S + kB2);
-  // r = b - A x ; z = dinv r ; w = A z
+  // r = b - A x ; z = M^-1 r ; w = A z
   if ((rc = apply(A, x, w, st))) return rc;
   hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(kBlock), 0, st, N, b, w,
                      dinv, r, z);
+  if (C && (rc = two_level(C, dinv, r, z, crc, czc, st))) return rc;
   if ((rc = apply(A, z, w, st))) return rc;
   if ((rc = dots(N, 3, r, z, z, w, r, r, partial, &np, st))) return rc;
   hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, 1,
@@ -350,7 +433,8 @@ static int cg(const flow_operator* A, const double* dinv, const double* b,
     const int todo = (maxit - it < check_every) ? maxit - it : check_every;
     for (int k = 0; k < todo; ++k) {
       hipLaunchKernelGGL(cg_update_kernel, dim3(gv), dim3(kBlock), 0, st, N, S,
-                         dinv, w, z, p, s, x, r);
+                         dinv, w, z, p, s, x, r, C ? 0 : 1);
+      if (C && (rc = two_level(C, dinv, r, z, crc, czc, st))) return rc;
       if ((rc = apply(A, z, w, st))) return rc;
       if ((rc = dots(N, 3, r, z, z, w, r, r, partial, &np, st))) return rc;
       hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, 0,
@@ -537,7 +621,7 @@ static int bicgstab(const flow_operator* A, const double* dinv, const double* b,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 1; }
+extern "C" int flow_abi_version(void) { return 2; }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {
@@ -621,15 +705,59 @@ static int check_solver_args(const flow_operator* A, const double* b,
 }
 
 extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
-                             const double* b, double* x, double rtol,
-                             double atol, int maxit, int check_every,
-                             double* work, size_t work_len, int* iters_host,
-                             double* resid_host, void* stream) {
+                             const flow_coarse* coarse, const double* b,
+                             double* x, double rtol, double atol, int maxit,
+                             int check_every, double* work, size_t work_len,
+                             int* iters_host, double* resid_host,
+                             void* stream) {
   int rc = check_solver_args(A, b, x, rtol, atol, maxit, check_every, work,
                              work_len, 5, iters_host, resid_host);
   if (rc) return rc;
-  return cg(A, dinv, b, x, rtol, atol, maxit, check_every, work, iters_host,
-            resid_host, as_stream(stream));
+  if (coarse) {
+    FLOW_REQUIRE(dinv != nullptr, "two-level preconditioner needs dinv");
+    FLOW_REQUIRE(A->kind == 0, "two-level preconditioner: scalar operators");
+    if ((rc = check_coarse(coarse, A->n))) return rc;
+    FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK + 5 * (size_t)A->n +
+                                 2 * (size_t)coarse->nc,
+                 "solver workspace too small for the coarse vectors");
+  }
+  return cg(A, dinv, coarse, b, x, rtol, atol, maxit, check_every, work,
+            iters_host, resid_host, as_stream(stream));
+}
+
+// pieces of the two-level preconditioner for the row-sharded loop
+extern "C" int flow_coarse_restrict_dev(const flow_coarse* C, const double* r,
+                                        int r0, int r1, double* rc_out,
+                                        void* stream) {
+  FLOW_REQUIRE(C && r && rc_out && r0 >= 0 && r1 <= C->n && r0 < r1, "restrict");
+  hipLaunchKernelGGL(coarse_restrict_kernel, dim3(grid_for(C->nc, 4, kMaxGrid)),
+                     dim3(kBlock), 0, as_stream(stream), C->nc, C->agg_ptr,
+                     C->agg_dofs, r, r0, r1, rc_out);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_coarse_solve_dev(const flow_coarse* C, const double* rc_in,
+                                     double* zc, void* stream) {
+  FLOW_REQUIRE(C && rc_in && zc && rc_in != zc, "coarse solve");
+  hipLaunchKernelGGL(coarse_gemv_kernel, dim3(grid_for(C->nc, 4, kMaxGrid)),
+                     dim3(kBlock), 0, as_stream(stream), C->nc, C->Ainv, rc_in,
+                     zc);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
+                                       const double* r, const double* zc,
+                                       double* z, int r0, int r1,
+                                       void* stream) {
+  FLOW_REQUIRE(C && dinv && r && zc && z && r0 >= 0 && r1 <= C->n && r0 < r1,
+               "prolong");
+  hipLaunchKernelGGL(coarse_prolong_kernel, dim3(grid_for(r1 - r0)), dim3(kBlock),
+                     0, as_stream(stream), r1 - r0, C->agg_of + r0, dinv + r0,
+                     r + r0, zc, z + r0);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
 }
 
 extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
@@ -702,11 +830,11 @@ extern "C" int flow_cg_scalars_dev(int first, const double* in3, double* S,
 
 extern "C" int flow_cg_update_dev(int n, const double* S, const double* dinv,
                                   const double* w, double* z, double* p,
-                                  double* s, double* x, double* r,
+                                  double* s, double* x, double* r, int want_z,
                                   void* stream) {
   FLOW_REQUIRE(n > 0 && S && w && z && p && s && x && r, "cg update");
   hipLaunchKernelGGL(cg_update_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
-                     as_stream(stream), n, S, dinv, w, z, p, s, x, r);
+                     as_stream(stream), n, S, dinv, w, z, p, s, x, r, want_z);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }

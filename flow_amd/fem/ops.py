@@ -212,6 +212,76 @@ def symmetric_bc_matrix(A, isbc):
     return out
 
 
+class CoarseSpace(object):
+    '''Piecewise-constant aggregate coarse space of a scalar SPD operator for
+    the two-level additive preconditioner of flow_cg_solve (include/flow_hip.h,
+    `flow_coarse`): dofs are binned into square patches of `s` mesh widths,
+    Dirichlet dofs are left out, Ac = P^T A P is inverted densely on the host
+    once per (operator, BC set).  `singular`: pure Neumann operator (constants
+    in the kernel) -> pseudo-inverse via the rank-one shift.  Setup only; the
+    per-iteration work runs in the HIP kernels.'''
+
+    def __init__(self, A, isbc=None, singular=False, target_nc=4096):
+        import scipy.sparse as sp
+        lay = A.layout
+        n = lay.N
+        assert A.kind == 0
+        isbc = numpy.zeros(n, dtype=bool) if isbc is None else \
+            numpy.asarray(isbc, dtype=bool)
+        x = lay.dof_coords
+        h = numpy.sqrt(2.0 * lay.mesh.cell_areas().mean())
+        nfree = int(n - isbc.sum())
+        s = max(2.0, numpy.sqrt(max(nfree, 1) / float(target_nc)))
+        while True:
+            ix = numpy.floor((x[:, 0] - x[:, 0].min()) / (s * h) + 1e-9)
+            iy = numpy.floor((x[:, 1] - x[:, 1].min()) / (s * h) + 1e-9)
+            key = (ix * 2000003 + iy).astype(numpy.int64)
+            key[isbc] = -1
+            ukey, agg = numpy.unique(key, return_inverse=True)
+            if len(ukey) and ukey[0] == -1:
+                agg = agg - 1          # excluded dofs -> -1
+                nc = len(ukey) - 1
+            else:
+                nc = len(ukey)
+            if nc <= 1.25 * target_nc or s > 1.0e6:
+                break
+            s *= 1.1
+        assert nc >= 1
+        self.s = s
+        self.nc = nc
+        self.n = n
+        free = numpy.nonzero(agg >= 0)[0]
+        Pm = sp.csr_matrix(
+            (numpy.ones(len(free)), (free, agg[free])), shape=(n, nc)
+            )
+        Ah = A.to_scipy()
+        Ac = (Pm.T.dot(Ah).dot(Pm)).toarray()
+        if singular:
+            e = numpy.ones(nc)
+            beta = numpy.trace(Ac) / nc
+            Ainv = numpy.linalg.inv(Ac + beta * numpy.outer(e, e) / nc) \
+                - numpy.outer(e, e) / (beta * nc)
+        else:
+            Ainv = numpy.linalg.inv(Ac)
+        Ainv = 0.5 * (Ainv + Ainv.T)
+        order = numpy.argsort(agg[free], kind='stable')
+        agg_dofs = free[order].astype(numpy.int32)
+        agg_ptr = numpy.zeros(nc + 1, dtype=numpy.int64)
+        numpy.cumsum(numpy.bincount(agg[free], minlength=nc), out=agg_ptr[1:])
+        self.agg_of_host = agg.astype(numpy.int32)
+        self._keep = (
+            device.to_device(agg_ptr.astype(numpy.int32)),
+            device.to_device(agg_dofs),
+            device.to_device(self.agg_of_host),
+            device.to_device(numpy.ascontiguousarray(Ainv)),
+            )
+        k = self._keep
+        self.struct = _hip.CoarseS(
+            n, nc, _hip.i32(k[0], nc + 1), _hip.i32(k[1], len(agg_dofs)),
+            _hip.i32(k[2], n), _hip.f64(k[3], nc * nc)
+            )
+
+
 # -- BLAS-1 / norms -----------------------------------------------------------
 def vector_norm(x, kind='l2'):
     lib = _hip.lib()
@@ -259,7 +329,7 @@ class SolveInfo(object):
 
 
 def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
-                 check_every=None):
+                 check_every=None, coarse=None):
     '''Solve A x = b on the device; x holds the initial guess.  Raises
     _hip.NotConverged (a RuntimeError) like dolfin's
     'error_on_nonconvergence'.'''
@@ -269,20 +339,30 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
         assert dinv == 'jacobi'
         dinv = A.diag_inv()
     nvec = 5 if method == 'cg' else 7
-    wk = work(_hip.REDUCE_WORK + nvec * n)
+    wk = work(_hip.REDUCE_WORK + nvec * n + (2 * coarse.nc if coarse else 0))
     if check_every is None:
         check_every = 10 if method == 'bicgstab' else 50
     its = ctypes.c_int(0)
     res = ctypes.c_double(0.0)
-    fn = lib.flow_cg_solve if method == 'cg' else lib.flow_bicgstab_solve
-    rc = fn(
-        ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
-        _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
-        int(maxit), int(check_every), _hip.f64(wk), wk.numel(),
-        ctypes.byref(its), ctypes.byref(res), _hip.stream()
-        )
+    if method == 'cg':
+        rc = lib.flow_cg_solve(
+            ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
+            ctypes.byref(coarse.struct) if coarse is not None else None,
+            _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
+            int(maxit), int(check_every), _hip.f64(wk), wk.numel(),
+            ctypes.byref(its), ctypes.byref(res), _hip.stream()
+            )
+    else:
+        assert coarse is None
+        rc = lib.flow_bicgstab_solve(
+            ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
+            _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
+            int(maxit), int(check_every), _hip.f64(wk), wk.numel(),
+            ctypes.byref(its), ctypes.byref(res), _hip.stream()
+            )
     _hip.check(rc)
-    return SolveInfo(its.value, res.value, method)
+    return SolveInfo(its.value, res.value,
+                     method + ('+2level' if coarse is not None else ''))
 
 
 # -- load vectors, projection, norms -----------------------------------------

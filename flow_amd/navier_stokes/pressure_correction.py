@@ -53,7 +53,10 @@ __all__ = ['Chorin', 'IPCS', 'Rotational', 'solver_parameters',
 solver_parameters = {
     'newton': {'maximum_iterations': 10, 'linear_maxit': 5000,
                'linear_rtol': 1.0e-13, 'linear_atol_factor': 0.05},
-    'pressure': {'maxit': 200000, 'check_every': 50},
+    # 'two_level': Jacobi + aggregate coarse space (stands in for the
+    # reference's hypre_amg, :331, :414); False = plain Jacobi
+    'pressure': {'maxit': 200000, 'check_every': 10, 'two_level': True,
+                 'coarse_size': 4096},
     'correction': {'maxit': 10000, 'check_every': 10},
     }
 
@@ -185,18 +188,29 @@ def _compute_tentative_velocity(
     return ui, alpha
 
 
-def _pressure_cg(A, dinv, b, x, tol, par):
-    '''CG + Jacobi for the pressure system: rtol = tol, atol = 0 (reference
-    :332-335, :420-422); row-sharded over the GPUs of the node when
-    flow_amd.parallel is enabled.'''
+def _pressure_cg(A, dinv, coarse, b, x, tol, par):
+    '''CG for the pressure system: rtol = tol, atol = 0 (reference :332-335,
+    :420-422), preconditioned with Jacobi [+ the aggregate coarse space];
+    row-sharded over the GPUs of the node when flow_amd.parallel is enabled.'''
     if parallel.active():
         return parallel.pressure_cg(
-            A, dinv, b, x, tol, 0.0, par['maxit'], par['check_every']
+            A, dinv, coarse, b, x, tol, 0.0, par['maxit'], par['check_every']
             )
     return ops.krylov_solve(
         'cg', A, b, x, rtol=tol, atol=0.0, maxit=par['maxit'], dinv=dinv,
-        check_every=par['check_every']
+        check_every=par['check_every'], coarse=coarse
         )
+
+
+def _coarse_space(lay, key, A, isbc, singular, par):
+    if not par.get('two_level', False):
+        return None
+    ckey = ('coarse', key, par['coarse_size'])
+    if ckey not in lay._dev:
+        lay._dev[ckey] = ops.CoarseSpace(
+            A, isbc, singular=singular, target_nc=par['coarse_size']
+            )
+    return lay._dev[ckey]
 
 
 def _compute_pressure(
@@ -221,7 +235,14 @@ def _compute_pressure(
     nc = mesh.num_cells()
     st = _hip.stream()
 
+    par = solver_parameters['pressure']
     p1 = Function(P)
+    if par.get('initial_guess', 'previous') == 'previous':
+        # The reference starts its Krylov solve from a fresh (zero) Function
+        # (:313).  Starting from p0 is the natural choice for an incremental
+        # scheme, converges to the same discrete solution (same stopping test
+        # ||r|| <= tol ||b||) and keeps a state of rest exactly at rest.
+        p1.assign(p0)
     K = ops.assemble_stiffness(P)
     b = device.empty(P.N)
     buf = ops.scratch(mesh, 3 * nc)
@@ -232,7 +253,6 @@ def _compute_pressure(
         _hip.f64(p0.data, P.N), alpha * rho / dt, mu, int(rotational_form),
         _hip.f64(buf), _hip.f64(b, P.N), st
         ))
-    par = solver_parameters['pressure']
     if p_bcs:
         # 'symmetric': True  =>  assemble_system-style elimination
         # (reference :325-339)
@@ -255,14 +275,21 @@ def _compute_pressure(
         _hip.check(lib.flow_bc_set_values(
             nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(b), st
             ))
-        sol = _pressure_cg(Kbc, dinv, b, p1.data, tol, par)
+        coarse = _coarse_space(lay, key, Kbc, _bc_mask(dofs, P.N) != 0, False,
+                               par)
+        # the initial guess satisfies the Dirichlet data
+        _hip.check(lib.flow_bc_set_values(
+            nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(p1.data), st
+            ))
+        sol = _pressure_cg(Kbc, dinv, coarse, b, p1.data, tol, par)
     else:
         # pure Neumann problem: singular but consistent, CG from x0 = 0, no
         # null-space handling (reference :340-432)
         key = ('K_dinv',)
         if key not in lay._dev:
             lay._dev[key] = K.diag_inv()
-        sol = _pressure_cg(K, lay._dev[key], b, p1.data, tol, par)
+        coarse = _coarse_space(lay, key, K, None, True, par)
+        sol = _pressure_cg(K, lay._dev[key], coarse, b, p1.data, tol, par)
     if verbose:
         info('pressure: %r' % sol)
     last_step_info['pressure'] = sol

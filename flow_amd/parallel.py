@@ -219,16 +219,37 @@ class HipLocal(object):
             int(first), _hip.f64(sums), _hip.f64(S), _hip.stream()
             ))
 
-    def update(self, S, dinv, w, z, p, s_, x, r):
+    def update(self, S, dinv, w, z, p, s_, x, r, want_z=True):
         s = slice(self.r0, self.r1)
         _hip.check(self.lib.flow_cg_update_dev(
             self.r1 - self.r0, _hip.f64(S), _hip.f64(dinv[s]), _hip.f64(w[s]),
             _hip.f64(z[s]), _hip.f64(p[s]), _hip.f64(s_[s]), _hip.f64(x[s]),
-            _hip.f64(r[s]), _hip.stream()
+            _hip.f64(r[s]), int(want_z), _hip.stream()
+            ))
+
+    # two-level preconditioner: partial restriction / coarse solve / prolongation
+    def coarse_restrict(self, coarse, r, rc):
+        _hip.check(self.lib.flow_coarse_restrict_dev(
+            ctypes.byref(coarse.struct), _hip.f64(r, coarse.n), self.r0, self.r1,
+            _hip.f64(rc, coarse.nc), _hip.stream()
+            ))
+
+    def coarse_solve(self, coarse, rc, zc):
+        _hip.check(self.lib.flow_coarse_solve_dev(
+            ctypes.byref(coarse.struct), _hip.f64(rc, coarse.nc),
+            _hip.f64(zc, coarse.nc), _hip.stream()
+            ))
+
+    def coarse_prolong(self, coarse, dinv, r, zc, z):
+        _hip.check(self.lib.flow_coarse_prolong_dev(
+            ctypes.byref(coarse.struct), _hip.f64(dinv, coarse.n),
+            _hip.f64(r, coarse.n), _hip.f64(zc, coarse.nc), _hip.f64(z, coarse.n),
+            self.r0, self.r1, _hip.stream()
             ))
 
 
-def sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit, check_every):
+def sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit, check_every,
+               coarse=None):
     '''Chronopoulos-Gear CG on the row partition `part`.  `local` provides the
     kernels (HipLocal in the product; the CPU tests inject a numpy stand-in to
     exercise the partition + communication logic under gloo).  Returns
@@ -243,10 +264,23 @@ def sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit, check_every):
     s = local.zeros(n)
     S = local.zeros(16)
     sums = local.zeros(4)
+    if coarse is not None:
+        rc = local.zeros(coarse.nc)
+        zc = local.zeros(coarse.nc)
+
+    def two_level():
+        # z = D^-1 r + P Ac^-1 P^T r: the restriction is summed over the ranks
+        # (one extra small all-reduce), the dense coarse solve is replicated
+        local.coarse_restrict(coarse, r, rc)
+        comm.allreduce_sum(rc)
+        local.coarse_solve(coarse, rc, zc)
+        local.coarse_prolong(coarse, dinv, r, zc, z)
 
     comm.halo_exchange(x, plan)
     local.spmv_rows(x, w)
     local.residual(b, w, dinv, r, z)
+    if coarse is not None:
+        two_level()
     comm.halo_exchange(z, plan)
     local.spmv_rows(z, w)
     local.dots(r, z, w, b, sums)
@@ -269,7 +303,9 @@ def sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit, check_every):
                 )
         todo = min(check_every, maxit - it)
         for _ in range(todo):
-            local.update(S, dinv, w, z, p, s, x, r)
+            local.update(S, dinv, w, z, p, s, x, r, coarse is None)
+            if coarse is not None:
+                two_level()
             comm.halo_exchange(z, plan)
             local.spmv_rows(z, w)
             local.dots(r, z, w, None, sums)
@@ -284,7 +320,7 @@ def sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit, check_every):
 _PART_CACHE = {}
 
 
-def pressure_cg(A, dinv, b, x, rtol, atol, maxit, check_every):
+def pressure_cg(A, dinv, coarse, b, x, rtol, atol, maxit, check_every):
     '''Sharded replacement of ops.krylov_solve('cg', ...) for the pressure
     system (called from navier_stokes._compute_pressure when enabled).'''
     from .fem.ops import SolveInfo
@@ -302,5 +338,6 @@ def pressure_cg(A, dinv, b, x, rtol, atol, maxit, check_every):
         _PART_CACHE[lkey] = HipLocal(A, r0, r1)
     local = _PART_CACHE[lkey]
     its, res = sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit,
-                          check_every)
-    return SolveInfo(its, res, 'cg[row-sharded x%d]' % comm.world)
+                          check_every, coarse)
+    return SolveInfo(its, res, 'cg%s[row-sharded x%d]' % (
+        '+2level' if coarse is not None else '', comm.world))

@@ -79,18 +79,35 @@ int flow_axpby(int n, double a, const double* x, double b, double* y,
                void* stream);                       /* y = a x + b y */
 #define FLOW_REDUCE_WORK 4096   /* doubles of `work` the reductions need */
 
+/* Two-level additive preconditioner  z = D^-1 r + P Ac^-1 P^T r  for scalar
+ * SPD systems (stands in for the reference's 'hypre_amg', pressure_correction.py
+ * :331,414-418): Jacobi plus a piecewise-constant aggregate coarse space whose
+ * Galerkin operator Ac = P^T A P is inverted once on the host (dense; for the
+ * singular Neumann operator the pseudo-inverse).  Aggregates: agg_of[i] in
+ * [0,nc) or -1 (Dirichlet dofs); agg_ptr/agg_dofs list the dofs per aggregate. */
+typedef struct {
+  int n;                   /* fine dofs */
+  int nc;                  /* aggregates */
+  const int* agg_ptr;      /* nc+1 */
+  const int* agg_dofs;     /* fine dofs sorted by aggregate */
+  const int* agg_of;       /* n */
+  const double* Ainv;      /* nc*nc, row-major */
+} flow_coarse;
+
 /* ---- K12: Krylov drivers -------------------------------------------------
  * Device-resident loops; the host reads the residual norm every check_every
  * iterations.  Stop when ||r||_2 <= max(rtol*||b||_2, atol); return
  * FLOW_NOT_CONVERGED after maxit iterations (dolfin raises RuntimeError:
  * 'error_on_nonconvergence', pressure_correction.py:337,424,462).
  * dinv may be NULL (no preconditioner).  x holds the initial guess.
- * work: FLOW_REDUCE_WORK + 5*N doubles (cg), FLOW_REDUCE_WORK + 7*N (bicgstab),
- * N = operator size. */
-int flow_cg_solve(const flow_operator* A, const double* dinv, const double* b,
-                  double* x, double rtol, double atol, int maxit,
-                  int check_every, double* work, size_t work_len,
-                  int* iters_host, double* resid_host, void* stream);
+ * coarse may be NULL (Jacobi only).
+ * work: FLOW_REDUCE_WORK + 5*N [+ 2*nc] doubles (cg), FLOW_REDUCE_WORK + 7*N
+ * (bicgstab), N = operator size. */
+int flow_cg_solve(const flow_operator* A, const double* dinv,
+                  const flow_coarse* coarse, const double* b, double* x,
+                  double rtol, double atol, int maxit, int check_every,
+                  double* work, size_t work_len, int* iters_host,
+                  double* resid_host, void* stream);
 int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
                         const double* b, double* x, double rtol, double atol,
                         int maxit, int check_every, double* work,
@@ -109,7 +126,16 @@ int flow_dot3_dev(int n, int nd, const double* a0, const double* b0,
 int flow_cg_scalars_dev(int first, const double* in3, double* S, void* stream);
 int flow_cg_update_dev(int n, const double* S, const double* dinv,
                        const double* w, double* z, double* p, double* s,
-                       double* x, double* r, void* stream);
+                       double* x, double* r, int want_z, void* stream);
+/* two-level preconditioner on the owned rows [r0, r1): partial restriction
+ * (all-reduced by the caller), replicated dense coarse solve, prolongation */
+int flow_coarse_restrict_dev(const flow_coarse* C, const double* r, int r0,
+                             int r1, double* rc_out, void* stream);
+int flow_coarse_solve_dev(const flow_coarse* C, const double* rc_in, double* zc,
+                          void* stream);
+int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
+                            const double* r, const double* zc, double* z, int r0,
+                            int r1, void* stream);
 int flow_residual_dev(int n, const double* b, const double* q,
                       const double* dinv, double* r, double* z, void* stream);
 

@@ -111,6 +111,44 @@ def test_cg_matches_direct_solve(hip):
                          maxit=3, check_every=2)
 
 
+@pytest.mark.parametrize('neumann', [False, True])
+def test_two_level_cg(hip, neumann):
+    '''Jacobi + aggregate coarse space: same solution, far fewer iterations.'''
+    rng = numpy.random.RandomState(14)
+    mesh = fem.karman_channel(160, 37)
+    V = fem.FunctionSpace(mesh, 'CG', 1)
+    K = ops.assemble_stiffness(V)
+    n = V.N
+    if neumann:
+        A = K
+        isbc = None
+        xs = rng.standard_normal(n)
+        b = A.to_scipy().dot(xs)            # consistent right-hand side
+    else:
+        isbc = mesh.points[:, 0] > 0.6 - 1e-12
+        A = ops.symmetric_bc_matrix(K, _dev(isbc.astype(numpy.uint8)))
+        b = rng.standard_normal(n)
+        b[isbc] = 0.0
+    coarse = ops.CoarseSpace(A, isbc, singular=neumann, target_nc=256)
+    assert coarse.nc <= 320
+    assert (coarse.agg_of_host[isbc] == -1).all() if isbc is not None else True
+    x1 = _dev(numpy.zeros(n))
+    x2 = _dev(numpy.zeros(n))
+    i1 = ops.krylov_solve('cg', A, _dev(b), x1, rtol=1e-12, maxit=20000)
+    i2 = ops.krylov_solve('cg', A, _dev(b), x2, rtol=1e-12, maxit=20000,
+                          coarse=coarse, check_every=5)
+    assert i2.iterations * 4 < i1.iterations, (i1, i2)
+    a1, a2 = x1.cpu().numpy(), x2.cpu().numpy()
+    if neumann:
+        a1 -= a1.mean()
+        a2 -= a2.mean()
+        ref = xs - xs.mean()
+    else:
+        ref = spla.splu(A.to_scipy().tocsc()).solve(b)
+    assert cases.rel_l2(a2, ref) < 1e-7, i2
+    assert cases.rel_l2(a1, ref) < 1e-7, i1
+
+
 def test_bicgstab_matches_direct_solve(hip):
     rng = numpy.random.RandomState(4)
     mesh = fem.UnitSquareMesh(10, 10, 'crossed')

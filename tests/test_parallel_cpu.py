@@ -61,7 +61,7 @@ class NumpyLocal(object):
             alpha = g / den if den != 0.0 else 0.0
         S[0], S[1], S[2], S[3] = g, alpha, beta, rr
 
-    def update(self, S, dinv, w, z, p, s_, x, r):
+    def update(self, S, dinv, w, z, p, s_, x, r, want_z=True):
         s = slice(self.r0, self.r1)
         alpha, beta = float(S[1]), float(S[2])
         pn, sn = p.numpy(), s_.numpy()
