@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libflow_hip.so')
 
 REDUCE_WORK = 4096
 SPMV_ROWS_PER_BLOCK = 256
-SPMV_NNZ_PER_BLOCK = 2048
+SPMV_NNZ_PER_BLOCK = 2046
 
 c_double_p = ctypes.c_void_p
 c_int_p = ctypes.c_void_p
@@ -113,7 +113,7 @@ SYMBOLS = {
                                      _VP, _VP, _D, _D, _I, _VP, _VP, _VP],
     'flow_assemble_momentum': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _VP, _VP,
                                _VP, _P(CoefS), _P(CoefS), _P(NsParams), _VP,
-                               _VP, _VP, _VP],
+                               _VP, _VP, ctypes.c_size_t, _VP],
     'flow_assemble_source': [_P(MeshS), _P(SpaceS), _I, _P(CoefS), _VP, _VP,
                              _VP],
     'flow_assemble_magnitude': [_P(MeshS), _P(SpaceS), _I, _VP, _VP, _VP, _VP],

@@ -24,7 +24,8 @@ namespace flow {
 __global__ void gather_kernel(int nout, int nplanes, const int* __restrict__ ptr,
                               const int* __restrict__ src,
                               const double* __restrict__ scratch,
-                              size_t plane_stride, double* __restrict__ out) {
+                              size_t plane_stride, size_t out_stride,
+                              double* __restrict__ out) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nout;
        k += gridDim.x * blockDim.x) {
     const int a = ptr[k];
@@ -33,17 +34,17 @@ __global__ void gather_kernel(int nout, int nplanes, const int* __restrict__ ptr
       const double* __restrict__ sp = scratch + p * plane_stride;
       double s = 0.0;
       for (int t = a; t < b; ++t) s += sp[src[t]];
-      out[static_cast<size_t>(p) * nout + k] = s;
+      out[static_cast<size_t>(p) * out_stride + k] = s;
     }
   }
 }
 
 static int gather(int nout, int nplanes, const int* ptr, const int* src,
                   const double* scratch, size_t plane_stride, double* out,
-                  hipStream_t st) {
+                  hipStream_t st, size_t out_stride = 0) {
   hipLaunchKernelGGL(gather_kernel, dim3(grid_for(nout, kBlock, 1 << 20)),
                      dim3(kBlock), 0, st, nout, nplanes, ptr, src, scratch,
-                     plane_stride, out);
+                     plane_stride, out_stride ? out_stride : (size_t)nout, out);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(kBlock) void momentum_jacobian_kernel(
 // ---------------------------------------------------------------------------
 // K7: Dirichlet conditions
 // ---------------------------------------------------------------------------
-__global__ void bc_identity_rows_kernel(int kind, int n, int nnz,
+__global__ void bc_identity_rows_kernel(int kind, int n, size_t nnz,
                                         const int* __restrict__ rowptr,
                                         const int* __restrict__ diag_idx,
                                         int nbc, const int* __restrict__ dofs,
@@ -847,7 +848,8 @@ extern "C" int flow_assemble_momentum(
     const flow_mesh* mesh, const flow_space* W, const flow_space* P,
     const int* bfmask, const double* ui, const double* u0, const double* p0,
     const flow_coef* f0, const flow_coef* f1, const flow_ns_params* prm,
-    double* scratch, double* F, double* Jvals, void* stream) {
+    double* scratch, double* F, double* Jvals, size_t j_plane_stride,
+    void* stream) {
   int rc = check_mesh_space(mesh, W);
   if (rc) return rc;
   if ((rc = check_mesh_space(mesh, P))) return rc;
@@ -869,11 +871,13 @@ extern "C" int flow_assemble_momentum(
   }
   if (Jvals) {
     FLOW_REQUIRE(W->cptr && W->csrc && W->nnz > 0, "matrix map");
+    FLOW_REQUIRE(j_plane_stride >= (size_t)W->nnz, "Jacobian plane stride");
     FLOW_DISPATCH_DEG(W->deg, momentum_jacobian_kernel,
                       dim3((mesh->nc + 63) / 64), st, mesh->nc, mesh->xy,
                       W->cell_dofs, W->n, bfmask, ui, *prm, scratch);
     if ((rc = gather(W->nnz, 4, W->cptr, W->csrc, scratch,
-                     static_cast<size_t>(nl) * nl * mesh->nc, Jvals, st)))
+                     static_cast<size_t>(nl) * nl * mesh->nc, Jvals, st,
+                     j_plane_stride)))
       return rc;
   }
   return FLOW_OK;
@@ -901,9 +905,19 @@ extern "C" int flow_bc_identity_rows(const flow_operator* A, double* vals_planes
   FLOW_REQUIRE(vals_planes && diag_idx && nbc >= 0, "pointers");
   if (nbc == 0) return FLOW_OK;
   FLOW_REQUIRE(dofs != nullptr, "dofs");
+  FLOW_REQUIRE(vals_planes == A->vals[0], "vals_planes must be A->vals[0]");
+  // planes are equally spaced (stride >= nnz, even: 16-B aligned planes)
+  const long long stride =
+      A->kind == 0 ? A->nnz : static_cast<long long>(A->vals[1] - A->vals[0]);
+  FLOW_REQUIRE(stride >= A->nnz, "plane stride");
+  if (A->kind == 2)
+    FLOW_REQUIRE(A->vals[2] - A->vals[0] == 2 * stride &&
+                     A->vals[3] - A->vals[0] == 3 * stride,
+                 "equally spaced planes");
   hipLaunchKernelGGL(bc_identity_rows_kernel, dim3(grid_for(nbc)), dim3(kBlock),
-                     0, as_stream(stream), A->kind, A->n, A->nnz, A->rowptr,
-                     diag_idx, nbc, dofs, vals_planes);
+                     0, as_stream(stream), A->kind, A->n,
+                     static_cast<size_t>(stride), A->rowptr, diag_idx, nbc, dofs,
+                     vals_planes);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }

@@ -32,8 +32,10 @@ void set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 // SpMV
 // ---------------------------------------------------------------------------
-constexpr int kRowsPerBlock = FLOW_SPMV_ROWS_PER_BLOCK;
-constexpr int kNnzPerBlock = FLOW_SPMV_NNZ_PER_BLOCK;
+constexpr int kPairs = 4;                       // nonzero pairs per lane
+constexpr int kTile = 2 * kBlock * kPairs;      // LDS products per workgroup
+static_assert(FLOW_SPMV_ROWS_PER_BLOCK == kBlock, "one lane per row");
+static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTile - 2, "tile minus alignment slack");
 
 // scalar plane(s): blockIdx.y selects the component of a block-diagonal operator
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
     const double* __restrict__ vals0, const double* __restrict__ vals1,
     const int* __restrict__ rowblocks, const double* __restrict__ x,
     double* __restrict__ y) {
-  __shared__ double prod[kNnzPerBlock];
+  __shared__ double prod[kTile];
   const double* __restrict__ vals = blockIdx.y == 0 ? vals0 : vals1;
   x += static_cast<size_t>(blockIdx.y) * n;
   y += static_cast<size_t>(blockIdx.y) * n;
@@ -49,13 +51,45 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
   const int r1 = rowblocks[blockIdx.x + 1];
   const int k0 = rowptr[r0];
   const int k1 = rowptr[r1];
-  for (int k = k0 + threadIdx.x; k < k1; k += kBlock)
-    prod[k - k0] = vals[k] * x[cols[k]];
-  __syncthreads();
+  // 16-byte value loads / 8-byte index loads: every lane owns PAIRS pairs of
+  // consecutive nonzeros; the tile base is aligned down to an even index (value
+  // planes start 16-B aligned and the host caps a block at kTile-2 nonzeros).
+  const int ka = k0 & ~1;
   const int r = r0 + threadIdx.x;
+  int a = 0, b = 0;
   if (r < r1) {
-    const int a = rowptr[r] - k0;
-    const int b = rowptr[r + 1] - k0;
+    a = rowptr[r] - ka;
+    b = rowptr[r + 1] - ka;
+  }
+  const double2* __restrict__ v2p = reinterpret_cast<const double2*>(vals + ka);
+  const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
+  const int npair = (k1 - ka + 1) >> 1;   // a trailing odd element reads one
+                                          // entry of the next tile (unused)
+  double2 v[kPairs];
+  int2 c[kPairs];
+#pragma unroll
+  for (int j = 0; j < kPairs; ++j) {
+    const int p = threadIdx.x + j * kBlock;
+    const bool ok = p < npair;
+    v[j] = ok ? v2p[p] : make_double2(0.0, 0.0);
+    c[j] = ok ? c2p[p] : make_int2(0, 0);
+  }
+  double x0[kPairs], x1[kPairs];
+#pragma unroll
+  for (int j = 0; j < kPairs; ++j) {   // all gathers in flight before any use
+    x0[j] = x[c[j].x];
+    x1[j] = x[c[j].y];
+  }
+#pragma unroll
+  for (int j = 0; j < kPairs; ++j) {
+    const int p = threadIdx.x + j * kBlock;
+    if (p < npair) {
+      prod[2 * p] = v[j].x * x0[j];
+      prod[2 * p + 1] = v[j].y * x1[j];
+    }
+  }
+  __syncthreads();
+  if (r < r1) {
     double s = 0.0;
     for (int k = a; k < b; ++k) s += prod[k];
     y[r] = s;
@@ -69,24 +103,41 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
     const double* __restrict__ vyx, const double* __restrict__ vyy,
     const int* __restrict__ rowblocks, const double* __restrict__ x,
     double* __restrict__ y) {
-  __shared__ double prod0[kNnzPerBlock];
-  __shared__ double prod1[kNnzPerBlock];
+  __shared__ double prod0[kTile];
+  __shared__ double prod1[kTile];
   const int r0 = rowblocks[blockIdx.x];
   const int r1 = rowblocks[blockIdx.x + 1];
   const int k0 = rowptr[r0];
   const int k1 = rowptr[r1];
-  for (int k = k0 + threadIdx.x; k < k1; k += kBlock) {
-    const int c = cols[k];
-    const double x0 = x[c];
-    const double x1 = x[n + c];
-    prod0[k - k0] = vxx[k] * x0 + vxy[k] * x1;
-    prod1[k - k0] = vyx[k] * x0 + vyy[k] * x1;
+  const int ka = k0 & ~1;
+  const int r = r0 + threadIdx.x;
+  int a = 0, b = 0;
+  if (r < r1) {
+    a = rowptr[r] - ka;
+    b = rowptr[r + 1] - ka;
+  }
+  const int npair = (k1 - ka + 1) >> 1;
+  const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
+  const double2* __restrict__ pxx = reinterpret_cast<const double2*>(vxx + ka);
+  const double2* __restrict__ pxy = reinterpret_cast<const double2*>(vxy + ka);
+  const double2* __restrict__ pyx = reinterpret_cast<const double2*>(vyx + ka);
+  const double2* __restrict__ pyy = reinterpret_cast<const double2*>(vyy + ka);
+#pragma unroll
+  for (int j = 0; j < kPairs; ++j) {
+    const int p = threadIdx.x + j * kBlock;
+    if (p < npair) {
+      const int2 c = c2p[p];
+      const double2 axx = pxx[p], axy = pxy[p], ayx = pyx[p], ayy = pyy[p];
+      const double u0 = x[c.x], u1 = x[n + c.x];
+      const double w0 = x[c.y], w1 = x[n + c.y];
+      prod0[2 * p] = axx.x * u0 + axy.x * u1;
+      prod1[2 * p] = ayx.x * u0 + ayy.x * u1;
+      prod0[2 * p + 1] = axx.y * w0 + axy.y * w1;
+      prod1[2 * p + 1] = ayx.y * w0 + ayy.y * w1;
+    }
   }
   __syncthreads();
-  const int r = r0 + threadIdx.x;
   if (r < r1) {
-    const int a = rowptr[r] - k0;
-    const int b = rowptr[r + 1] - k0;
     double s0 = 0.0, s1 = 0.0;
     for (int k = a; k < b; ++k) {
       s0 += prod0[k];
@@ -103,8 +154,13 @@ static int check_operator(const flow_operator* A) {
   FLOW_REQUIRE(A->n > 0 && A->nnz > 0 && A->nblocks > 0, "operator sizes");
   FLOW_REQUIRE(A->rowptr && A->cols && A->rowblocks, "operator pattern");
   const int planes = A->kind == 0 ? 1 : (A->kind == 1 ? 2 : 4);
-  for (int p = 0; p < planes; ++p)
+  for (int p = 0; p < planes; ++p) {
     FLOW_REQUIRE(A->vals[p] != nullptr, "operator value plane");
+    FLOW_REQUIRE((reinterpret_cast<size_t>(A->vals[p]) & 15) == 0,
+                 "value planes must be 16-byte aligned");
+  }
+  FLOW_REQUIRE((reinterpret_cast<size_t>(A->cols) & 7) == 0,
+               "cols must be 8-byte aligned");
   return FLOW_OK;
 }
 
@@ -621,7 +677,7 @@ static int bicgstab(const flow_operator* A, const double* dinv, const double* b,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 2; }
+extern "C" int flow_abi_version(void) { return 3; }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {

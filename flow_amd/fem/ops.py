@@ -92,10 +92,21 @@ def work(ndoubles):
 
 
 # -- matrices -----------------------------------------------------------------
+def plane_stride(layout):
+    '''Distance between value planes: nnz rounded up to even, so that every
+    plane is 16-byte aligned and readable one entry past nnz (the SpMV loads
+    value pairs; include/flow_hip.h, flow_operator).'''
+    return layout.nnz + (layout.nnz & 1)
+
+
+def value_plane(layout):
+    return device.zeros(plane_stride(layout))
+
+
 class Matrix(object):
     '''Value planes over the CSR pattern of a scalar layout.
     kind 0: scalar (1 plane), 1: block-diagonal (2 planes), 2: 2x2 (4 planes);
-    `vals` is one tensor of nplanes*nnz doubles (planes contiguous).'''
+    `vals` is one tensor of nplanes*stride doubles, stride = plane_stride().'''
     NPLANES = {0: 1, 1: 2, 2: 4}
 
     def __init__(self, layout, kind, vals=None):
@@ -103,9 +114,19 @@ class Matrix(object):
         self.kind = kind
         self.nplanes = self.NPLANES[kind]
         nnz = layout.nnz
-        self.vals = vals if vals is not None else \
-            device.zeros(self.nplanes * nnz)
-        assert self.vals.numel() == self.nplanes * nnz
+        self.stride = plane_stride(layout)
+        if vals is None:
+            vals = device.zeros(self.nplanes * self.stride)
+        elif vals.numel() == self.nplanes * nnz and self.stride != nnz:
+            # compact planes -> aligned planes
+            packed = device.zeros(self.nplanes * self.stride)
+            for p in range(self.nplanes):
+                packed[p * self.stride:p * self.stride + nnz] = \
+                    vals[p * nnz:(p + 1) * nnz]
+            vals = packed
+        assert vals.numel() == self.nplanes * self.stride
+        assert vals.data_ptr() % 16 == 0
+        self.vals = vals
         self._op = None
         return
 
@@ -114,8 +135,7 @@ class Matrix(object):
         return self.layout.N * (1 if self.kind == 0 else 2)
 
     def plane(self, p):
-        nnz = self.layout.nnz
-        return self.vals[p * nnz:(p + 1) * nnz]
+        return self.vals[p * self.stride:p * self.stride + self.layout.nnz]
 
     def operator(self):
         if self._op is None:
@@ -129,9 +149,9 @@ class Matrix(object):
             op.rowptr = _hip.i32(lay.dev('rowptr'), lay.N + 1, 'rowptr')
             op.cols = _hip.i32(lay.dev('cols'), lay.nnz, 'cols')
             op.rowblocks = _hip.i32(rb, None, 'rowblocks')
-            base = _hip.f64(self.vals, self.nplanes * lay.nnz, 'vals').value
+            base = _hip.f64(self.vals, self.nplanes * self.stride, 'vals').value
             for p in range(self.nplanes):
-                op.vals[p] = base + 8 * p * lay.nnz
+                op.vals[p] = base + 8 * p * self.stride
             self._op = op
         return self._op
 
@@ -162,7 +182,8 @@ class Matrix(object):
         cols = lay.pattern('cols')
         v = self.vals.cpu().numpy()
         nnz = lay.nnz
-        P = [sp.csr_matrix((v[p * nnz:(p + 1) * nnz], cols, rp),
+        st = self.stride
+        P = [sp.csr_matrix((v[p * st:p * st + nnz], cols, rp),
                            shape=(lay.N, lay.N)) for p in range(self.nplanes)]
         if self.kind == 0:
             return P[0]

@@ -24,7 +24,7 @@ from . import reference
 
 # CSR-stream tiling (must match flow_amd/csrc/la_kernels.hip)
 SPMV_ROWS_PER_BLOCK = 256
-SPMV_NNZ_PER_BLOCK = 2048
+SPMV_NNZ_PER_BLOCK = 2046     # LDS tile (2048) minus the alignment slack
 
 
 class ScalarLayout(object):
@@ -148,26 +148,30 @@ class ScalarLayout(object):
                 arr = self.vmap(name)
             else:
                 arr = self.pattern(name)
+            if name == 'cols':
+                # the SpMV loads index PAIRS: readable one entry past nnz
+                arr = numpy.concatenate([arr, numpy.zeros(1, dtype=arr.dtype)])
             self._dev[name] = device.to_device(arr)
         return self._dev[name]
 
 
-def csr_stream_rowblocks(rowptr):
+def csr_stream_rowblocks(rowptr, rows_per_block=SPMV_ROWS_PER_BLOCK,
+                         nnz_per_block=SPMV_NNZ_PER_BLOCK):
     '''Row-block boundaries for the CSR-stream SpMV: consecutive rows are
-    grouped so that a block has at most SPMV_ROWS_PER_BLOCK rows and at most
-    SPMV_NNZ_PER_BLOCK nonzeros (the LDS tile of products).'''
+    grouped so that a block has at most `rows_per_block` rows and at most
+    `nnz_per_block` nonzeros (the LDS tile of products).'''
     n = len(rowptr) - 1
     rowptr = numpy.asarray(rowptr, dtype=numpy.int64)
     if n > 0:
-        assert (rowptr[1:] - rowptr[:-1]).max() <= SPMV_NNZ_PER_BLOCK, \
+        assert (rowptr[1:] - rowptr[:-1]).max() <= nnz_per_block, \
             'row longer than the CSR-stream LDS tile'
     blocks = [0]
     r = 0
     while r < n:
         r_nnz = int(numpy.searchsorted(
-            rowptr, rowptr[r] + SPMV_NNZ_PER_BLOCK, side='right'
+            rowptr, rowptr[r] + nnz_per_block, side='right'
             )) - 1
-        r_next = min(r + SPMV_ROWS_PER_BLOCK, r_nnz, n)
+        r_next = min(r + rows_per_block, r_nnz, n)
         assert r_next > r
         blocks.append(r_next)
         r = r_next

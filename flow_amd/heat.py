@@ -65,7 +65,7 @@ class Heat(object):
 
         lumped = ops.assemble_scalar_matrix(lay, ops.LUMPED_MASS)
         self.A = ops.Matrix(lay, 0)
-        msupg = device.empty(lay.nnz) if supg_stabilization else None
+        msupg = ops.value_plane(lay) if supg_stabilization else None
         status = device.zeros(1, dtype=torch.int32)
         if supg_stabilization:
             assert conv is not None

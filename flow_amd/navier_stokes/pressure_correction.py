@@ -146,7 +146,7 @@ def _compute_tentative_velocity(
             _hip.f64(u[0].data, n2), _hip.f64(p0.data, P.size()),
             ctypes.byref(f0s), ctypes.byref(f1s), ctypes.byref(prm),
             _hip.f64(buf), _hip.f64(F, n2) if want_f else None,
-            _hip.f64(J.vals, 4 * lay.nnz) if want_j else None, st
+            _hip.f64(J.vals, 4 * J.stride) if want_j else None, J.stride, st
             ))
 
     history = []

@@ -39,7 +39,7 @@ extern "C" {
 
 /* CSR-stream tiling of flow_spmv (row blocks are built on the host). */
 #define FLOW_SPMV_ROWS_PER_BLOCK 256
-#define FLOW_SPMV_NNZ_PER_BLOCK 2048
+#define FLOW_SPMV_NNZ_PER_BLOCK 2046
 
 const char* flow_last_error(void);
 int flow_abi_version(void);
@@ -58,7 +58,9 @@ typedef struct {
   const int* rowptr;       /* n+1 */
   const int* cols;         /* nnz */
   const int* rowblocks;    /* nblocks+1 */
-  const double* vals[4];   /* value planes, nnz each */
+  const double* vals[4];   /* value planes, nnz each; every plane 16-B aligned
+                              and readable up to index nnz (the SpMV loads
+                              value PAIRS); cols likewise readable at nnz */
 } flow_operator;
 
 /* ---- K8: SpMV (PETSc MatMult inside every Krylov solve; heat.py:101) ---- */
@@ -202,7 +204,8 @@ int flow_assemble_correction_rhs(const flow_mesh* mesh, const flow_space* W,
  *   F = (ui - u0, v) - dt/rho [theta_i R(ui; f1) + theta_e R(u0; f0)],
  *   J = dF/dui.
  * bfmask[c]: bit i set iff local facet i of cell c is a boundary facet.
- * F (2n) and/or Jvals (4 planes x nnz) may be NULL to skip.
+ * F (2n) and/or Jvals (4 planes, j_plane_stride >= nnz apart) may be NULL to
+ * skip.
  * scratch: max(2*nloc, 4*nloc^2) * nc doubles. */
 typedef struct {
   double dt, rho, mu, theta_i, theta_e;
@@ -213,7 +216,7 @@ int flow_assemble_momentum(const flow_mesh* mesh, const flow_space* W,
                            const double* p0, const flow_coef* f0,
                            const flow_coef* f1, const flow_ns_params* prm,
                            double* scratch, double* F, double* Jvals,
-                           void* stream);
+                           size_t j_plane_stride, void* stream);
 
 /* (f, v) for a `dim`-component coefficient: the load vector behind
  * dolfin.project (tests/test_navier_stokes.py:296-308).  scratch: dim*nloc*nc. */

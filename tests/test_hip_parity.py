@@ -156,8 +156,8 @@ def test_bicgstab_matches_direct_solve(hip):
     lay = V.layout
     M = ops.assemble_mass(V).vals
     K = ops.assemble_stiffness(V).vals
-    pert = _dev(0.02 * rng.standard_normal(4 * lay.nnz) * float(M.abs().max()))
     import torch
+    pert = _dev(0.02 * rng.standard_normal(4 * M.numel()) * float(M.abs().max()))
     base = torch.cat([M + 0.01 * K, torch.zeros_like(M), torch.zeros_like(M),
                       M + 0.01 * K])
     A = ops.Matrix(lay, 2, (base + pert).contiguous())
@@ -212,7 +212,7 @@ def test_momentum_residual_and_jacobian(hip, vdeg, method):
             ctypes.byref(ops.space_struct(case.P.layout)), _hip.i32(bfm),
             _hip.f64(uid), _hip.f64(u0d), _hip.f64(p0d), ctypes.byref(f0s),
             ctypes.byref(f1s), ctypes.byref(prm), _hip.f64(buf), _hip.f64(F),
-            _hip.f64(J.vals), _hip.stream()
+            _hip.f64(J.vals), J.stride, _hip.stream()
             ))
         Fh = F.cpu().numpy()
         errF = abs(Fh - F_ref).max() / abs(F_ref).max()
