@@ -120,6 +120,9 @@ def main():
     ap.add_argument('--scheme', default='rotational',
                     choices=['chorin', 'ipcs', 'rotational'])
     ap.add_argument('--tol', type=float, default=1.0e-10)
+    ap.add_argument('--velocity-degree', type=int, default=2, choices=[1, 2],
+                    help='2: P2-P1 Taylor-Hood (headline); 1: P1-P1 '
+                         '(BASELINE config 1M DoF: --nx 1196 --velocity-degree 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--spmv-reps', type=int, default=100)
     args = ap.parse_args()
@@ -151,7 +154,8 @@ def main():
 
     t_setup = time.perf_counter()
     ny = args.ny if args.ny else max(2, int(round(args.nx * 509.0 / 2182.0)))
-    prob = karman.KarmanProblem(args.nx, ny, velocity_degree=2,
+    prob = karman.KarmanProblem(args.nx, ny,
+                                velocity_degree=args.velocity_degree,
                                 scheme=args.scheme)
     prob.set_initial_profile()
     setup_s = time.perf_counter() - t_setup
@@ -211,11 +215,14 @@ def main():
         'dtype': 'f64',
         'data': 'synthetic',
         'config': {
-            'workload': 'Karman vortex street P2-P1 Taylor-Hood, %d DoF '
+            'workload': 'Karman vortex street %s, %d DoF '
                         '(%d x %d structured channel, staircase obstacle), '
                         '%s scheme, backward Euler, tol %.0e, mu 0.002, '
                         'rho 998.2, dt0 1e-5 + CFL controller'
-                        % (prob.num_dofs(), args.nx, ny, args.scheme, args.tol),
+                        % ('P2-P1 Taylor-Hood' if args.velocity_degree == 2
+                           else 'P1-P1', prob.num_dofs(), args.nx, ny,
+                           args.scheme, args.tol),
+            'newton_residuals': [i['newton_residuals'] for i in infos],
             'dofs': prob.num_dofs(),
             'cells': prob.mesh.num_cells(),
             'pressure_rows': n,

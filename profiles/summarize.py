@@ -35,6 +35,11 @@ def stats(directory, out):
         with open(path) as fh:
             for r in csv.DictReader(fh):
                 name = r['Kernel_Name'].split('(')[0]
+                if 'spmv_stream' in name and 'Grid_Size_X' in r:
+                    # one row per matrix: the same kernel serves the pressure
+                    # matrix, the P2 mass matrices and the Jacobian
+                    name += ' [grid %sx%s]' % (
+                        r['Grid_Size_X'], r.get('Grid_Size_Y', '1'))
                 dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3
                 rows[name][0] += 1
                 rows[name][1] += dur
