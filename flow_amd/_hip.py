@@ -49,6 +49,24 @@ class CoarseS(ctypes.Structure):
         ]
 
 
+class IluPlanS(ctypes.Structure):
+    _fields_ = [
+        ('n', ctypes.c_int), ('nnz', ctypes.c_int), ('ncolors', ctypes.c_int),
+        ('color_ptr_host', ctypes.c_void_p),
+        ('rowptr', ctypes.c_void_p), ('cols', ctypes.c_void_p),
+        ('diag', ctypes.c_void_p), ('src_pos', ctypes.c_void_p),
+        ('old_of_new', ctypes.c_void_p),
+        ]
+
+
+class IluS(ctypes.Structure):
+    _fields_ = [
+        ('plan', ctypes.POINTER(IluPlanS)),
+        ('nblocks', ctypes.c_int),
+        ('lu', ctypes.c_void_p),
+        ]
+
+
 class MeshS(ctypes.Structure):
     _fields_ = [('nc', ctypes.c_int), ('xy', ctypes.c_void_p)]
 
@@ -97,8 +115,10 @@ SYMBOLS = {
     'flow_axpby': [_I, _D, _VP, _D, _VP, _VP],
     'flow_cg_solve': [_P(Operator), _VP, _P(CoarseS), _VP, _VP, _D, _D, _I, _I,
                       _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
-    'flow_bicgstab_solve': [_P(Operator), _VP, _VP, _VP, _D, _D, _I, _I, _VP,
-                            ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
+                            _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_ilu0_factor': [_P(IluPlanS), _VP, _VP, _VP],
+    'flow_ilu0_solve': [_P(IluPlanS), _VP, _VP, _VP, _VP, _VP],
     'flow_dot3_dev': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_cg_scalars_dev': [_I, _VP, _VP, _VP],
     'flow_cg_update_dev': [_I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP],

@@ -13,6 +13,11 @@ void set_error(const char* fmt, ...);
 
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
+// ilu_kernels.hip
+int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
+              hipStream_t st);
+int ilu_check(const flow_ilu* ilu, int op_size);
+
 #define FLOW_CHECK_HIP(expr)                                                 \
   do {                                                                       \
     hipError_t err_ = (expr);                                                \

@@ -586,7 +586,8 @@ __global__ void bicg_x_kernel(int n, const double* __restrict__ S,
   }
 }
 
-static int bicgstab(const flow_operator* A, const double* dinv, const double* b,
+static int bicgstab(const flow_operator* A, const double* dinv,
+                    const flow_ilu* ilu, const double* b,
                     double* x, double rtol, double atol, int maxit,
                     int check_every, double* work, int* iters_host,
                     double* resid_host, hipStream_t st) {
@@ -600,6 +601,8 @@ static int bicgstab(const flow_operator* A, const double* dinv, const double* b,
   double* y = v + N;
   double* z = y + N;
   double* t = z + N;
+  double* iwork = t + N;                  // ILU sweep buffer (ilu only)
+  if (ilu) dinv = nullptr;                // y = ILU(p), z = ILU(s) below
   const int gv = grid_for(N);
   int np = 0, rc;
 
@@ -644,12 +647,14 @@ static int bicgstab(const flow_operator* A, const double* dinv, const double* b,
     for (int k = 0; k < todo; ++k) {
       hipLaunchKernelGGL(bicg_p_kernel, dim3(gv), dim3(kBlock), 0, st, N, S,
                          dinv, r, v, p, y);
+      if (ilu && (rc = ilu_apply(ilu, p, y, iwork, st))) return rc;
       if ((rc = apply(A, y, v, st))) return rc;
       if ((rc = dots(N, 1, rhat, v, v, v, v, v, partial, &np, st))) return rc;
       hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np,
                          1, partial, S);
       hipLaunchKernelGGL(bicg_s_kernel, dim3(gv), dim3(kBlock), 0, st, N, S,
                          dinv, v, r, z);
+      if (ilu && (rc = ilu_apply(ilu, r, z, iwork, st))) return rc;
       if ((rc = apply(A, z, t, st))) return rc;
       if ((rc = dots(N, 2, t, r, t, t, t, t, partial, &np, st))) return rc;
       hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np,
@@ -677,7 +682,7 @@ static int bicgstab(const flow_operator* A, const double* dinv, const double* b,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 3; }
+extern "C" int flow_abi_version(void) { return 4; }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {
@@ -817,15 +822,21 @@ extern "C" int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
 }
 
 extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
-                                   const double* b, double* x, double rtol,
-                                   double atol, int maxit, int check_every,
-                                   double* work, size_t work_len,
-                                   int* iters_host, double* resid_host,
-                                   void* stream) {
+                                   const flow_ilu* ilu, const double* b,
+                                   double* x, double rtol, double atol,
+                                   int maxit, int check_every, double* work,
+                                   size_t work_len, int* iters_host,
+                                   double* resid_host, void* stream) {
   int rc = check_solver_args(A, b, x, rtol, atol, maxit, check_every, work,
                              work_len, 7, iters_host, resid_host);
   if (rc) return rc;
-  return bicgstab(A, dinv, b, x, rtol, atol, maxit, check_every, work,
+  if (ilu) {
+    if ((rc = ilu_check(ilu, op_size(A)))) return rc;
+    FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK + 7 * (size_t)op_size(A) +
+                                 (size_t)A->n,
+                 "solver workspace too small for the ILU sweep buffer");
+  }
+  return bicgstab(A, dinv, ilu, b, x, rtol, atol, maxit, check_every, work,
                   iters_host, resid_host, as_stream(stream));
 }
 

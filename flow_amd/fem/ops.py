@@ -350,7 +350,7 @@ class SolveInfo(object):
 
 
 def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
-                 check_every=None, coarse=None):
+                 check_every=None, coarse=None, ilu=None):
     '''Solve A x = b on the device; x holds the initial guess.  Raises
     _hip.NotConverged (a RuntimeError) like dolfin's
     'error_on_nonconvergence'.'''
@@ -358,9 +358,10 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     n = A.size
     if isinstance(dinv, str):
         assert dinv == 'jacobi'
-        dinv = A.diag_inv()
+        dinv = A.diag_inv() if ilu is None else None
     nvec = 5 if method == 'cg' else 7
-    wk = work(_hip.REDUCE_WORK + nvec * n + (2 * coarse.nc if coarse else 0))
+    wk = work(_hip.REDUCE_WORK + nvec * n + (2 * coarse.nc if coarse else 0)
+              + (A.layout.N if ilu is not None else 0))
     if check_every is None:
         check_every = 10 if method == 'bicgstab' else 50
     its = ctypes.c_int(0)
@@ -377,13 +378,15 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
         assert coarse is None
         rc = lib.flow_bicgstab_solve(
             ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
+            ctypes.byref(ilu.struct) if ilu is not None else None,
             _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
             int(maxit), int(check_every), _hip.f64(wk), wk.numel(),
             ctypes.byref(its), ctypes.byref(res), _hip.stream()
             )
     _hip.check(rc)
     return SolveInfo(its.value, res.value,
-                     method + ('+2level' if coarse is not None else ''))
+                     method + ('+2level' if coarse is not None else '')
+                     + ('+ilu0' if ilu is not None else ''))
 
 
 # -- load vectors, projection, norms -----------------------------------------

@@ -29,7 +29,8 @@ from . import _hip
 from . import device
 from . import stabilization
 
-solver_parameters = {'rtol': 1.0e-13, 'maxit': 20000, 'check_every': 10}
+solver_parameters = {'rtol': 1.0e-13, 'maxit': 20000, 'check_every': 10,
+                     'preconditioner': 'ilu0'}     # 'ilu0' | 'jacobi'
 last_solve_info = {}
 
 
@@ -152,9 +153,15 @@ class Heat(object):
         u = Function(self.V)
         # warm start is not used: x0 = 0 like a direct solve has no history
         par = solver_parameters
+        pre = None
+        if par.get('preconditioner', 'ilu0') == 'ilu0':
+            # The zero-mass edge rows and the skew convection make the diagonal
+            # a poor preconditioner; the reference solves with LU (:116-121).
+            from .fem import ilu
+            pre = ilu.Ilu0(A)
         info = ops.krylov_solve(
             'bicgstab', A, bvec, u.data, rtol=par['rtol'], atol=0.0,
-            maxit=par['maxit'], check_every=par['check_every']
+            maxit=par['maxit'], check_every=par['check_every'], ilu=pre
             )
         last_solve_info['heat'] = info
         return u

@@ -51,8 +51,12 @@ __all__ = ['Chorin', 'IPCS', 'Rotational', 'solver_parameters',
 # (maxit 100/1000, reference :335,422,460): limits are scaled up, everything
 # else (rtol = tol, atol = 0, error on non-convergence) is kept.
 solver_parameters = {
+    # BiCGStab preconditioner of the Newton systems: 'jacobi' (default: the
+    # velocity systems are mass dominated) or 'ilu0' (multicolour ILU(0) of the
+    # two diagonal blocks)
     'newton': {'maximum_iterations': 10, 'linear_maxit': 5000,
-               'linear_rtol': 1.0e-13, 'linear_atol_factor': 0.05},
+               'linear_rtol': 1.0e-13, 'linear_atol_factor': 0.05,
+               'preconditioner': 'jacobi'},
     # 'two_level': Jacobi + aggregate coarse space (stands in for the
     # reference's hypre_amg, :331, :414); False = plain Jacobi
     'pressure': {'maxit': 200000, 'check_every': 10, 'two_level': True,
@@ -174,10 +178,14 @@ def _compute_tentative_velocity(
             _hip.i32(lay.dev('diag_idx')), nbc, _hip.i32(bc_dofs), st
             ))
         dx.zero_()
+        pre = None
+        if npar.get('preconditioner', 'jacobi') == 'ilu0':
+            from ..fem import ilu
+            pre = ilu.Ilu0(J)
         sol = ops.krylov_solve(
             'bicgstab', J, F, dx, rtol=npar['linear_rtol'],
             atol=npar['linear_atol_factor'] * tol,
-            maxit=npar['linear_maxit'], check_every=5
+            maxit=npar['linear_maxit'], check_every=5, ilu=pre
             )
         linear_its.append(sol.iterations)
         ops.axpby(-1.0, dx, 1.0, ui.data)

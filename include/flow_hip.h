@@ -96,25 +96,53 @@ typedef struct {
   const double* Ainv;      /* nc*nc, row-major */
 } flow_coarse;
 
+/* ---- K11: multicolour ILU(0) ----------------------------------------------
+ * (replaces the sparse LU of the Newton solve, pressure_correction.py:224-254,
+ * and `LUSolver`, heat.py:117-121, as a BiCGStab preconditioner).  The plan is
+ * built once per pattern on the host (flow_amd/fem/ilu.py): rows are ordered by
+ * colour (independent sets), so factorisation and both triangular sweeps are
+ * one launch per colour.  color_ptr_host is a HOST array; everything else is
+ * device memory.  lu: nnz doubles per factored block. */
+typedef struct {
+  int n, nnz, ncolors;
+  const int* color_ptr_host; /* ncolors+1 (host): row range of every colour */
+  const int* rowptr;         /* n+1, permuted (colour-major) numbering */
+  const int* cols;           /* nnz, ascending per row, permuted numbering */
+  const int* diag;           /* n: position of the diagonal entry */
+  const int* src_pos;        /* nnz: entry -> position in the operator plane */
+  const int* old_of_new;     /* n: permuted row -> original dof */
+} flow_ilu_plan;
+typedef struct {
+  const flow_ilu_plan* plan;
+  int nblocks;               /* 1 (scalar) or 2 (diagonal blocks of a 2-field op) */
+  const double* lu;          /* nblocks * nnz */
+} flow_ilu;
+int flow_ilu0_factor(const flow_ilu_plan* plan, const double* avals, double* lu,
+                     void* stream);
+/* z = (LU)^-1 r in the ORIGINAL numbering; work: n doubles */
+int flow_ilu0_solve(const flow_ilu_plan* plan, const double* lu, const double* r,
+                    double* z, double* work, void* stream);
+
 /* ---- K12: Krylov drivers -------------------------------------------------
  * Device-resident loops; the host reads the residual norm every check_every
  * iterations.  Stop when ||r||_2 <= max(rtol*||b||_2, atol); return
  * FLOW_NOT_CONVERGED after maxit iterations (dolfin raises RuntimeError:
  * 'error_on_nonconvergence', pressure_correction.py:337,424,462).
  * dinv may be NULL (no preconditioner).  x holds the initial guess.
- * coarse may be NULL (Jacobi only).
+ * coarse may be NULL (Jacobi only); ilu may be NULL (Jacobi), else it replaces
+ * dinv as the (right) preconditioner of BiCGStab.
  * work: FLOW_REDUCE_WORK + 5*N [+ 2*nc] doubles (cg), FLOW_REDUCE_WORK + 7*N
- * (bicgstab), N = operator size. */
+ * [+ n] (bicgstab), N = operator size. */
 int flow_cg_solve(const flow_operator* A, const double* dinv,
                   const flow_coarse* coarse, const double* b, double* x,
                   double rtol, double atol, int maxit, int check_every,
                   double* work, size_t work_len, int* iters_host,
                   double* resid_host, void* stream);
 int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
-                        const double* b, double* x, double rtol, double atol,
-                        int maxit, int check_every, double* work,
-                        size_t work_len, int* iters_host, double* resid_host,
-                        void* stream);
+                        const flow_ilu* ilu, const double* b, double* x,
+                        double rtol, double atol, int maxit, int check_every,
+                        double* work, size_t work_len, int* iters_host,
+                        double* resid_host, void* stream);
 
 /* ---- K15: building blocks of the row-sharded multi-GPU CG ----------------
  * (nothing in the reference: DOLFIN/PETSc would do this implicitly under

@@ -1,0 +1,139 @@
+# -*- coding: utf-8 -*-
+'''
+K11: multicolour ILU(0) (flow_amd/fem/ilu.py + flow_amd/csrc/ilu_kernels.hip).
+GPU tests: the factor equals a textbook IKJ ILU(0) of the colour-permuted
+matrix computed on the host, the sweeps equal host triangular solves, and
+BiCGStab + ILU(0) solves a convection-dominated heat system on which
+BiCGStab + Jacobi does not converge (the reference uses LU there:
+"The Krylov solver doesn't converge", flow/heat.py:116).  CPU test: colouring.
+'''
+import numpy
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from flow_amd import fem
+from flow_amd.fem import ilu
+
+import cases
+
+
+def _ilu0_reference(A):
+    '''IKJ ILU(0) on a scipy CSR with sorted indices (host, loops).'''
+    A = A.tocsr().copy()
+    A.sort_indices()
+    ip, ix, v = A.indptr, A.indices, A.data.copy()
+    n = A.shape[0]
+    diag = numpy.array([ip[i] + numpy.searchsorted(ix[ip[i]:ip[i + 1]], i)
+                        for i in range(n)])
+    for i in range(n):
+        for p in range(ip[i], diag[i]):
+            k = ix[p]
+            v[p] /= v[diag[k]]
+            pos = {ix[q]: q for q in range(diag[k] + 1, ip[k + 1])}
+            for t in range(p + 1, ip[i + 1]):
+                q = pos.get(ix[t])
+                if q is not None:
+                    v[t] -= v[p] * v[q]
+    return sp.csr_matrix((v, ix, ip), shape=A.shape), diag
+
+
+def test_colouring_is_proper():
+    for mesh in (fem.UnitSquareMesh(7, 5, 'crossed'), fem.karman_channel(30, 8)):
+        for deg in (1, 2):
+            lay = fem.FunctionSpace(mesh, 'CG', deg).layout
+            rp, ci = lay.pattern('rowptr'), lay.pattern('cols')
+            colour, nc = ilu.colour_graph(rp, ci)
+            assert colour.min() == 0 and colour.max() == nc - 1
+            rows = numpy.repeat(numpy.arange(lay.N), numpy.diff(rp))
+            off = rows != ci
+            assert (colour[rows[off]] != colour[ci[off]]).all()
+            assert nc <= 40
+
+
+@pytest.mark.gpu
+def test_factor_and_sweeps_match_host_ilu0(hip):
+    from flow_amd import device
+    from flow_amd.fem import ops
+    rng = numpy.random.RandomState(0)
+    mesh = fem.karman_channel(20, 6)
+    V = fem.FunctionSpace(mesh, 'CG', 2)
+    lay = V.layout
+    M = ops.assemble_mass(V)
+    K = ops.assemble_stiffness(V)
+    pert = device.to_device(0.1 * rng.standard_normal(M.vals.numel())) \
+        * float(M.vals.abs().max())
+    A = ops.Matrix(lay, 0, (M.vals + 0.002 * K.vals + pert * (M.vals != 0)))
+    pre = ilu.Ilu0(A)
+    plan = pre.plan
+    # host reference on the permuted matrix
+    P = sp.csr_matrix(
+        (numpy.ones(lay.N), (numpy.arange(lay.N), plan.host['old_of_new'])),
+        shape=(lay.N, lay.N))
+    Ap = (P @ A.to_scipy() @ P.T).tocsr()
+    Ap.sort_indices()
+    assert numpy.array_equal(Ap.indices, plan.host['cols'])
+    LUref, diag = _ilu0_reference(Ap)
+    lu = pre.lu.cpu().numpy()
+    assert abs(lu - LUref.data).max() < 1e-12 * abs(LUref.data).max()
+    # sweeps
+    r = rng.standard_normal(lay.N)
+    z = device.zeros(lay.N)
+    pre.solve(device.to_device(r), z)
+    L = sp.tril(LUref, -1) + sp.identity(lay.N)
+    U = sp.triu(LUref)
+    rp = r[plan.host['old_of_new']]
+    zp = spla.spsolve_triangular(
+        U.tocsr(), spla.spsolve_triangular(L.tocsr(), rp, lower=True),
+        lower=False)
+    zref = numpy.empty(lay.N)
+    zref[plan.host['old_of_new']] = zp
+    assert cases.rel_l2(z.cpu().numpy(), zref) < 1e-12
+
+
+@pytest.mark.gpu
+def test_bicgstab_ilu0_on_convection_dominated_heat(hip):
+    '''The regime where Jacobi fails (tests/test_hip_heat.py keeps to the
+    diffusion-resolved one): cell Peclet number ~ 600.'''
+    from flow_amd import heat, time_steppers
+    from flow_amd.fem.bcs import collect
+    from oracle import fem_oracle as orc
+    import test_hip_heat as th
+    kappa, rho, cp = 0.6, 998.0, 4182.0
+    mesh, Q, W, conv, Qo, Wo, bcs = th._setup(2, 2, 1.0e-2)
+    H = heat.Heat(Q, conv, kappa, rho, cp, bcs, fem.Constant(0.0))
+    Mo, Ao, bo = orc.heat_operators(Qo, Wo, conv.array(), kappa, rho, cp, 0.0,
+                                    False)
+    rng = numpy.random.RandomState(0)
+    u = fem.Function(Q)
+    u.set_array(293.0 + rng.standard_normal(Q.N))
+    dt = 0.5
+    u1 = time_steppers.ImplicitEuler(H).step(u, 0.0, dt)
+    info = heat.last_solve_info['heat']
+    assert 'ilu0' in info.method and info.iterations < 2000, info
+    dofs, vals = collect(bcs, Q.N)
+    ref1 = orc.heat_solve(Mo, Ao, 1.0, -dt, Mo.dot(u.array()), dofs, vals)
+    assert cases.rel_l2(u1.array(), ref1) < 1e-6
+
+
+@pytest.mark.gpu
+def test_newton_with_ilu0_preconditioner(hip):
+    '''ILU(0) of the two diagonal Jacobian blocks as the BiCGStab
+    preconditioner of the tentative-velocity Newton solve: same converged
+    step as with Jacobi.'''
+    import flow_amd.navier_stokes as navsto
+    mesh = fem.karman_channel(30, 10)
+    case = cases.Case(mesh, vdeg=2, dt=0.05, bc_kind='channel', rho=1.5,
+                      mu=0.05, seed=3)
+    u1j, p1j, uij = case.product_step('rotational')
+    its_j = sum(navsto.last_step_info['newton_linear_iterations'])
+    navsto.solver_parameters['newton']['preconditioner'] = 'ilu0'
+    try:
+        u1i, p1i, uii = case.product_step('rotational')
+        its_i = sum(navsto.last_step_info['newton_linear_iterations'])
+    finally:
+        navsto.solver_parameters['newton']['preconditioner'] = 'jacobi'
+    # both runs stop at the same Newton tolerance: agreement to solver accuracy
+    assert cases.rel_l2(uii, uij) < 1e-8
+    assert cases.rel_l2(u1i, u1j) < 1e-8
+    assert its_i < its_j, (its_i, its_j)

@@ -64,7 +64,10 @@ def test_sharded_pressure_solve_matches_single_gpu(hip, world, two_level):
         assert ('2level' in method) == two_level
         # different summation order across ranks: agreement to solver accuracy
         # (tol 1e-12 on a kappa ~ 1e5 system; bar: 1e-6)
-        assert numpy.linalg.norm(p - p_ref) <= 1e-7 * numpy.linalg.norm(p_ref)
-        assert numpy.linalg.norm(u - u_ref) <= 1e-7 * numpy.linalg.norm(u_ref)
+        ep = numpy.linalg.norm(p - p_ref) / numpy.linalg.norm(p_ref)
+        eu = numpy.linalg.norm(u - u_ref) / numpy.linalg.norm(u_ref)
+        assert ep <= 5e-7, ep
+        assert eu <= 5e-7, eu
         for a, b in zip(its, its_ref):
-            assert abs(a - b) <= 20, (its, its_ref)
+            # the stopping test is evaluated every check_every iterations
+            assert abs(a - b) <= 60, (its, its_ref)
