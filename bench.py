@@ -123,6 +123,12 @@ def main():
     ap.add_argument('--velocity-degree', type=int, default=2, choices=[1, 2],
                     help='2: P2-P1 Taylor-Hood (headline); 1: P1-P1 '
                          '(BASELINE config 1M DoF: --nx 1196 --velocity-degree 1)')
+    ap.add_argument('--newton-preconditioner', default=None,
+                    choices=['jacobi', 'ilu0'],
+                    help='BiCGStab preconditioner of the tentative-velocity '
+                         'Newton systems (default: the library default)')
+    ap.add_argument('--dt0', type=float, default=1.0e-5,
+                    help='initial step size (reference driver: 1e-5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--spmv-reps', type=int, default=100)
     args = ap.parse_args()
@@ -158,6 +164,10 @@ def main():
                                 velocity_degree=args.velocity_degree,
                                 scheme=args.scheme)
     prob.set_initial_profile()
+    prob.dt = args.dt0
+    if args.newton_preconditioner:
+        navsto.solver_parameters['newton']['preconditioner'] = \
+            args.newton_preconditioner
     setup_s = time.perf_counter() - t_setup
 
     for _ in range(args.warmup):

@@ -1,18 +1,29 @@
-// K11: multicolour ILU(0) on gfx950 -- factorisation and the two triangular
-// sweeps, one kernel launch per colour (rows of one colour are an independent
-// set, so a launch has no internal dependencies).  The plan (colouring, permuted
-// colour-major CSR, map back to the operator's value plane) is built once per
-// pattern on the host: flow_amd/fem/ilu.py.
+// K11: multicolour ILU(0) on gfx950.  The plan (colouring, colour-major permuted
+// CSR, strictly-lower / strictly-upper streams with CSR-stream row blocks per
+// colour, map back to the operator's value plane) is built once per pattern on
+// the host: flow_amd/fem/ilu.py.
 //
 // Stands in for the sparse LU behind the reference's Newton and heat solves
 // (flow/navier_stokes/pressure_correction.py:224-254, flow/heat.py:117-121) as
-// the preconditioner of BiCGStab.  HBM-bound: every L/U entry (12 B) is read
-// once per application; lanes own rows (rows are short: 7..23 entries).
+// the preconditioner of BiCGStab.
+//
+//  * factorisation: one launch per colour, a lane per row (IKJ with a sorted
+//    merge); runs once per (re)factorisation;
+//  * sweeps: one launch per colour and sweep; rows of a colour are contiguous in
+//    the permuted numbering, so each launch streams its slice of the L (or U)
+//    triangle exactly once with the SpMV's LDS-tiled structure (16-B value
+//    loads, products parked in LDS, one lane per row for the segmented sum) and
+//    applies the sweep update in the epilogue.  Both diagonal blocks of a
+//    two-field operator go through the same launch (blockIdx.y).
+// HBM-bound: 12 B per factor entry and application.
 #include "common.h"
 
 namespace flow {
 
-// LU <- A in the permuted numbering, rows [a, b)
+constexpr int kPairsI = 4;
+constexpr int kTileI = 2 * kBlock * kPairsI;
+static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTileI - 2, "ILU sweeps reuse the SpMV tiling");
+
 __global__ void ilu_copy_kernel(int nnz, const int* __restrict__ src_pos,
                                 const double* __restrict__ avals,
                                 double* __restrict__ lu) {
@@ -36,12 +47,12 @@ __global__ void ilu_factor_colour_kernel(int a, int b,
     const int k = cols[p];
     const double lik = lu[p] / lu[diag[k]];
     lu[p] = lik;
-    // a_ij -= l_ik * u_kj for j > k present in both rows
+    // a_ij -= l_ik * u_kj for j > k present in both rows (both lists ascend)
     int q = diag[k] + 1;
     const int qe = rowptr[k + 1];
     for (int t = p + 1; t < p1 && q < qe; ++t) {
       const int j = cols[t];
-      while (q < qe && cols[q] < j) ++q;     // both lists ascend: merge
+      while (q < qe && cols[q] < j) ++q;
       if (q < qe && cols[q] == j) lu[t] -= lik * lu[q];
     }
   }
@@ -50,56 +61,103 @@ __global__ void ilu_factor_colour_kernel(int a, int b,
   if (!(fabs(d) > 1.0e-12 * fabs(d_orig))) lu[pd] = d_orig != 0.0 ? d_orig : 1.0;
 }
 
-// forward sweep: y_i = r_old(i) - sum_{k<i} L_ik y_k   (unit lower)
-__global__ void ilu_forward_colour_kernel(int a, int b,
-                                          const int* __restrict__ rowptr,
-                                          const int* __restrict__ cols,
-                                          const int* __restrict__ diag,
-                                          const int* __restrict__ old_of_new,
-                                          const double* __restrict__ lu,
-                                          const double* __restrict__ r,
-                                          double* __restrict__ y) {
-  const int i = a + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b) return;
-  double s = r[old_of_new[i]];
-  const int pd = diag[i];
-  for (int p = rowptr[i]; p < pd; ++p) s -= lu[p] * y[cols[p]];
-  y[i] = s;
+// split the combined factor into the two streams and the inverse pivots
+__global__ void ilu_split_kernel(int n, int nnz_l, int nnz_u,
+                                 const int* __restrict__ l_pos,
+                                 const int* __restrict__ u_pos,
+                                 const int* __restrict__ diag,
+                                 const double* __restrict__ lu,
+                                 double* __restrict__ lvals,
+                                 double* __restrict__ uvals,
+                                 double* __restrict__ dinv) {
+  const int total = nnz_l + nnz_u + n;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < total;
+       k += gridDim.x * blockDim.x) {
+    if (k < nnz_l) lvals[k] = lu[l_pos[k]];
+    else if (k < nnz_l + nnz_u) uvals[k - nnz_l] = lu[u_pos[k - nnz_l]];
+    else dinv[k - nnz_l - nnz_u] = 1.0 / lu[diag[k - nnz_l - nnz_u]];
+  }
 }
 
-// backward sweep (in place in y): y_i = (y_i - sum_{j>i} U_ij y_j) / U_ii,
-// result scattered back to the original numbering
-__global__ void ilu_backward_colour_kernel(int a, int b,
-                                           const int* __restrict__ rowptr,
-                                           const int* __restrict__ cols,
-                                           const int* __restrict__ diag,
-                                           const int* __restrict__ old_of_new,
-                                           const double* __restrict__ lu,
-                                           double* __restrict__ y,
-                                           double* __restrict__ z) {
-  const int i = a + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b) return;
-  double s = y[i];
-  const int pd = diag[i];
-  const int p1 = rowptr[i + 1];
-  for (int p = pd + 1; p < p1; ++p) s -= lu[p] * y[cols[p]];
-  s /= lu[pd];
-  y[i] = s;
-  z[old_of_new[i]] = s;
+// One colour of one sweep, CSR-stream style.
+//   FWD:  y_i = r[old(i)] - sum_k L_ik y_k
+//   BWD:  y_i = (y_i - sum_j U_ij y_j) / U_ii ;  z[old(i)] = y_i
+// blockIdx.y selects the diagonal block: values at vals + blk*lu_size, vectors
+// at + blk*n.
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void ilu_sweep_kernel(
+    int n, size_t lu_size, const int* __restrict__ rowptr,
+    const int* __restrict__ cols, const double* __restrict__ vals,
+    const double* __restrict__ dinv, const int* __restrict__ rowblocks,
+    const int* __restrict__ old_of_new, const double* __restrict__ r,
+    double* __restrict__ y, double* __restrict__ z) {
+  __shared__ double prod[kTileI];
+  const size_t blk = blockIdx.y;
+  vals += blk * lu_size;
+  if (BWD) dinv += blk * lu_size;
+  y += blk * n;
+  const int r0 = rowblocks[blockIdx.x];
+  const int r1 = rowblocks[blockIdx.x + 1];
+  const int k0 = rowptr[r0];
+  const int k1 = rowptr[r1];
+  const int ka = k0 & ~1;
+  const int row = r0 + threadIdx.x;
+  int a = 0, b = 0;
+  if (row < r1) {
+    a = rowptr[row] - ka;
+    b = rowptr[row + 1] - ka;
+  }
+  const double2* __restrict__ v2p = reinterpret_cast<const double2*>(vals + ka);
+  const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
+  const int npair = (k1 - ka + 1) >> 1;
+#pragma unroll
+  for (int j = 0; j < kPairsI; ++j) {
+    const int p = threadIdx.x + j * kBlock;
+    if (p < npair) {
+      const double2 v = v2p[p];
+      const int2 c = c2p[p];
+      // the possible extra element past k1 belongs to a later row / the pad
+      // (column 0): its product is never summed
+      prod[2 * p] = v.x * y[c.x];
+      prod[2 * p + 1] = v.y * y[c.y];
+    }
+  }
+  __syncthreads();
+  if (row < r1) {
+    double s = 0.0;
+    for (int k = a; k < b; ++k) s += prod[k];
+    const int o = old_of_new[row];
+    if (!BWD) {
+      y[row] = r[blk * n + o] - s;
+    } else {
+      const double yi = (y[row] - s) * dinv[row];
+      y[row] = yi;
+      z[blk * n + o] = yi;
+    }
+  }
 }
 
 static int check_plan(const flow_ilu_plan* P) {
   FLOW_REQUIRE(P && P->n > 0 && P->nnz > 0 && P->ncolors > 0, "ilu plan sizes");
-  FLOW_REQUIRE(P->color_ptr_host && P->rowptr && P->cols && P->diag &&
-                   P->src_pos && P->old_of_new,
+  FLOW_REQUIRE(P->color_ptr_host && P->l_rbptr_host && P->u_rbptr_host,
+               "ilu plan host arrays");
+  FLOW_REQUIRE(P->rowptr && P->cols && P->diag && P->src_pos && P->old_of_new &&
+                   P->l_rowptr && P->l_cols && P->l_pos && P->l_rowblocks &&
+                   P->u_rowptr && P->u_cols && P->u_pos && P->u_rowblocks,
                "ilu plan pointers");
   FLOW_REQUIRE(P->color_ptr_host[0] == 0 && P->color_ptr_host[P->ncolors] == P->n,
                "ilu colour ranges");
+  FLOW_REQUIRE((P->off_l & 1) == 0 && (P->off_u & 1) == 0 && (P->off_d & 1) == 0 &&
+                   (P->lu_size & 1) == 0 && P->off_l >= P->nnz &&
+                   P->off_u >= P->off_l + P->nnz_l && P->off_d >= P->off_u + P->nnz_u &&
+                   P->lu_size >= P->off_d + P->n,
+               "ilu buffer layout");
   return FLOW_OK;
 }
 
 static int factor(const flow_ilu_plan* P, const double* avals, double* lu,
                   hipStream_t st) {
+  FLOW_REQUIRE((reinterpret_cast<size_t>(lu) & 15) == 0, "lu must be 16-B aligned");
   hipLaunchKernelGGL(ilu_copy_kernel, dim3(grid_for(P->nnz)), dim3(kBlock), 0, st,
                      P->nnz, P->src_pos, avals, lu);
   for (int c = 1; c < P->ncolors; ++c) {   // colour 0 has no lower neighbours
@@ -108,40 +166,38 @@ static int factor(const flow_ilu_plan* P, const double* avals, double* lu,
     hipLaunchKernelGGL(ilu_factor_colour_kernel, dim3((b - a + kBlock - 1) / kBlock),
                        dim3(kBlock), 0, st, a, b, P->rowptr, P->cols, P->diag, lu);
   }
+  hipLaunchKernelGGL(ilu_split_kernel,
+                     dim3(grid_for(P->nnz_l + P->nnz_u + P->n)), dim3(kBlock), 0,
+                     st, P->n, P->nnz_l, P->nnz_u, P->l_pos, P->u_pos, P->diag, lu,
+                     lu + P->off_l, lu + P->off_u, lu + P->off_d);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
 
-static int solve(const flow_ilu_plan* P, const double* lu, const double* r,
-                 double* z, double* work, hipStream_t st) {
-  for (int c = 0; c < P->ncolors; ++c) {
-    const int a = P->color_ptr_host[c], b = P->color_ptr_host[c + 1];
-    if (b <= a) continue;
-    hipLaunchKernelGGL(ilu_forward_colour_kernel,
-                       dim3((b - a + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a,
-                       b, P->rowptr, P->cols, P->diag, P->old_of_new, lu, r, work);
-  }
-  for (int c = P->ncolors - 1; c >= 0; --c) {
-    const int a = P->color_ptr_host[c], b = P->color_ptr_host[c + 1];
-    if (b <= a) continue;
-    hipLaunchKernelGGL(ilu_backward_colour_kernel,
-                       dim3((b - a + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a,
-                       b, P->rowptr, P->cols, P->diag, P->old_of_new, lu, work, z);
-  }
-  FLOW_CHECK_LAUNCH();
-  return FLOW_OK;
-}
-
-// out = blockdiag(LU_0, LU_1)^-1 in ; used by the BiCGStab driver
+// out = blockdiag(LU_0[, LU_1])^-1 in ; work: nblocks * n doubles
 int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
               hipStream_t st) {
   const flow_ilu_plan* P = ilu->plan;
-  for (int k = 0; k < ilu->nblocks; ++k) {
-    int rc = solve(P, ilu->lu + static_cast<size_t>(k) * P->nnz,
-                   in + static_cast<size_t>(k) * P->n,
-                   out + static_cast<size_t>(k) * P->n, work, st);
-    if (rc) return rc;
+  const size_t lus = static_cast<size_t>(P->lu_size);
+  for (int c = 0; c < P->ncolors; ++c) {
+    const int nb = P->l_rbptr_host[c + 1] - P->l_rbptr_host[c];
+    if (nb <= 0) continue;
+    hipLaunchKernelGGL((ilu_sweep_kernel<false>), dim3(nb, ilu->nblocks),
+                       dim3(kBlock), 0, st, P->n, lus, P->l_rowptr, P->l_cols,
+                       ilu->lu + P->off_l, static_cast<const double*>(nullptr),
+                       P->l_rowblocks + P->l_rbptr_host[c], P->old_of_new, in, work,
+                       static_cast<double*>(nullptr));
   }
+  for (int c = P->ncolors - 1; c >= 0; --c) {
+    const int nb = P->u_rbptr_host[c + 1] - P->u_rbptr_host[c];
+    if (nb <= 0) continue;
+    hipLaunchKernelGGL((ilu_sweep_kernel<true>), dim3(nb, ilu->nblocks),
+                       dim3(kBlock), 0, st, P->n, lus, P->u_rowptr, P->u_cols,
+                       ilu->lu + P->off_u, ilu->lu + P->off_d,
+                       P->u_rowblocks + P->u_rbptr_host[c], P->old_of_new, in, work,
+                       out);
+  }
+  FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
 
@@ -151,6 +207,7 @@ int ilu_check(const flow_ilu* ilu, int op_size) {
   if (rc) return rc;
   FLOW_REQUIRE(ilu->nblocks == 1 || ilu->nblocks == 2, "ilu blocks");
   FLOW_REQUIRE(ilu->nblocks * ilu->plan->n == op_size, "ilu size");
+  FLOW_REQUIRE((reinterpret_cast<size_t>(ilu->lu) & 15) == 0, "lu alignment");
   return FLOW_OK;
 }
 
@@ -166,11 +223,11 @@ extern "C" int flow_ilu0_factor(const flow_ilu_plan* plan, const double* avals,
   return factor(plan, avals, lu, as_stream(stream));
 }
 
-extern "C" int flow_ilu0_solve(const flow_ilu_plan* plan, const double* lu,
-                               const double* r, double* z, double* work,
-                               void* stream) {
-  int rc = check_plan(plan);
+extern "C" int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
+                               double* work, void* stream) {
+  FLOW_REQUIRE(ilu && ilu->plan, "ilu");
+  int rc = ilu_check(ilu, ilu->nblocks * ilu->plan->n);
   if (rc) return rc;
-  FLOW_REQUIRE(lu && r && z && work && r != work && z != work, "ilu solve pointers");
-  return solve(plan, lu, r, z, work, as_stream(stream));
+  FLOW_REQUIRE(r && z && work && r != work && z != work, "ilu solve pointers");
+  return ilu_apply(ilu, r, z, work, as_stream(stream));
 }

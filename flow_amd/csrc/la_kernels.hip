@@ -832,8 +832,7 @@ extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
   if (rc) return rc;
   if (ilu) {
     if ((rc = ilu_check(ilu, op_size(A)))) return rc;
-    FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK + 7 * (size_t)op_size(A) +
-                                 (size_t)A->n,
+    FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK + 8 * (size_t)op_size(A),
                  "solver workspace too small for the ILU sweep buffer");
   }
   return bicgstab(A, dinv, ilu, b, x, rtol, atol, maxit, check_every, work,

@@ -361,7 +361,7 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
         dinv = A.diag_inv() if ilu is None else None
     nvec = 5 if method == 'cg' else 7
     wk = work(_hip.REDUCE_WORK + nvec * n + (2 * coarse.nc if coarse else 0)
-              + (A.layout.N if ilu is not None else 0))
+              + (n if ilu is not None else 0))
     if check_every is None:
         check_every = 10 if method == 'bicgstab' else 50
     its = ctypes.c_int(0)

@@ -51,12 +51,14 @@ __all__ = ['Chorin', 'IPCS', 'Rotational', 'solver_parameters',
 # (maxit 100/1000, reference :335,422,460): limits are scaled up, everything
 # else (rtol = tol, atol = 0, error on non-convergence) is kept.
 solver_parameters = {
-    # BiCGStab preconditioner of the Newton systems: 'jacobi' (default: the
-    # velocity systems are mass dominated) or 'ilu0' (multicolour ILU(0) of the
-    # two diagonal blocks)
+    # BiCGStab preconditioner of the Newton systems: 'ilu0' (default:
+    # multicolour ILU(0) of the two diagonal blocks, refactored when dt has
+    # moved by more than `ilu_lag`; 3-4x fewer and far more regular iterations
+    # than Jacobi at CFL-sized steps) or 'jacobi'
     'newton': {'maximum_iterations': 10, 'linear_maxit': 5000,
                'linear_rtol': 1.0e-13, 'linear_atol_factor': 0.05,
-               'preconditioner': 'jacobi'},
+               'forcing': 1.0e-4, 'check_every': 2, 'restart': 400,
+               'preconditioner': 'ilu0', 'ilu_lag': 3.0},
     # 'two_level': Jacobi + aggregate coarse space (stands in for the
     # reference's hypre_amg, :331, :414); False = plain Jacobi
     'pressure': {'maxit': 200000, 'check_every': 10, 'two_level': True,
@@ -123,7 +125,7 @@ def _compute_tentative_velocity(
     f0s, keep0 = ops.coef_struct(f0, mesh, lay.degree)
     f1s, keep1 = ops.coef_struct(f1, mesh, lay.degree)
     prm = _hip.NsParams(dt, rho, mu, theta_i, theta_e)
-    _, bc_dofs, bc_vals = _bc_arrays(u_bcs, n2)
+    bc_dofs_host, bc_dofs, bc_vals = _bc_arrays(u_bcs, n2)
     nbc = bc_dofs.numel()
     bfmask = mesh._cache.get('bfmask_dev')
     if bfmask is None:
@@ -180,14 +182,48 @@ def _compute_tentative_velocity(
         dx.zero_()
         pre = None
         if npar.get('preconditioner', 'jacobi') == 'ilu0':
+            # factor once per step (first Newton iteration); later iterations
+            # of the step reuse it as a lagged preconditioner
             from ..fem import ilu
-            pre = ilu.Ilu0(J)
-        sol = ops.krylov_solve(
-            'bicgstab', J, F, dx, rtol=npar['linear_rtol'],
-            atol=npar['linear_atol_factor'] * tol,
-            maxit=npar['linear_maxit'], check_every=5, ilu=pre
-            )
-        linear_its.append(sol.iterations)
+            pre = lay._dev.get('jacobian_ilu')
+            key = (rho, mu, theta_i, nbc, hash(bc_dofs_host.tobytes()))
+            if pre is None:
+                pre = ilu.Ilu0(J)
+                pre.dt, pre.key = dt, key
+                lay._dev['jacobian_ilu'] = pre
+            elif pre.key != key or (
+                    it == 0 and not (1.0 / npar['ilu_lag'] <= dt / pre.dt
+                                     <= npar['ilu_lag'])):
+                # lagged preconditioner: J = M + dt (...) changes slowly from
+                # step to step; refactor when dt has moved by more than
+                # `ilu_lag` since the last factorisation (or the problem
+                # itself changed)
+                pre.refactor(J)
+                pre.dt, pre.key = dt, key
+        # Inexact Newton: the linear residual only has to get below what the
+        # quadratic term leaves anyway (forcing term 1e-4 ||F||), and below a
+        # fraction of the Newton tolerance so that one more step is never
+        # needed because of the linear solve.
+        lin_atol = max(npar['linear_atol_factor'] * tol, npar['forcing'] * nrm)
+        lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
+        # BiCGStab can stagnate when its bi-orthogonality degrades: restart
+        # from the current iterate every `restart` iterations (x is updated in
+        # place also when the solver reports non-convergence).
+        its = 0
+        while True:
+            chunk = min(npar['restart'], npar['linear_maxit'] - its)
+            try:
+                sol = ops.krylov_solve(
+                    'bicgstab', J, F, dx, rtol=lin_rtol, atol=0.0,
+                    maxit=chunk, check_every=npar['check_every'], ilu=pre
+                    )
+                its += sol.iterations
+                break
+            except _hip.NotConverged:
+                its += chunk
+                if its >= npar['linear_maxit']:
+                    raise
+        linear_its.append(its)
         ops.axpby(-1.0, dx, 1.0, ui.data)
         it += 1
     del keep0, keep1

@@ -101,27 +101,42 @@ typedef struct {
  * and `LUSolver`, heat.py:117-121, as a BiCGStab preconditioner).  The plan is
  * built once per pattern on the host (flow_amd/fem/ilu.py): rows are ordered by
  * colour (independent sets), so factorisation and both triangular sweeps are
- * one launch per colour.  color_ptr_host is a HOST array; everything else is
- * device memory.  lu: nnz doubles per factored block. */
+ * one launch per colour; each sweep streams its triangle once with the SpMV's
+ * LDS-tiled structure.  The *_host members are HOST arrays; everything else is
+ * device memory.  Factor buffer of one block (lu_size doubles, 16-B aligned):
+ *   [0, nnz) combined L\U in the permuted CSR | [off_l, +nnz_l) L stream |
+ *   [off_u, +nnz_u) U stream | [off_d, +n) inverse pivots. */
 typedef struct {
   int n, nnz, ncolors;
+  int nnz_l, nnz_u;
+  int off_l, off_u, off_d, lu_size;
   const int* color_ptr_host; /* ncolors+1 (host): row range of every colour */
+  const int* l_rbptr_host;   /* ncolors+1 (host): first L row block per colour */
+  const int* u_rbptr_host;   /* ncolors+1 (host): first U row block per colour */
   const int* rowptr;         /* n+1, permuted (colour-major) numbering */
   const int* cols;           /* nnz, ascending per row, permuted numbering */
   const int* diag;           /* n: position of the diagonal entry */
   const int* src_pos;        /* nnz: entry -> position in the operator plane */
   const int* old_of_new;     /* n: permuted row -> original dof */
+  const int* l_rowptr;       /* n+1: strictly lower stream */
+  const int* l_cols;         /* nnz_l (+2 readable) */
+  const int* l_pos;          /* nnz_l: position in the combined factor */
+  const int* l_rowblocks;    /* CSR-stream row blocks, colour by colour */
+  const int* u_rowptr;       /* n+1: strictly upper stream */
+  const int* u_cols;         /* nnz_u (+2 readable) */
+  const int* u_pos;
+  const int* u_rowblocks;
 } flow_ilu_plan;
 typedef struct {
   const flow_ilu_plan* plan;
   int nblocks;               /* 1 (scalar) or 2 (diagonal blocks of a 2-field op) */
-  const double* lu;          /* nblocks * nnz */
+  const double* lu;          /* nblocks * lu_size */
 } flow_ilu;
 int flow_ilu0_factor(const flow_ilu_plan* plan, const double* avals, double* lu,
                      void* stream);
-/* z = (LU)^-1 r in the ORIGINAL numbering; work: n doubles */
-int flow_ilu0_solve(const flow_ilu_plan* plan, const double* lu, const double* r,
-                    double* z, double* work, void* stream);
+/* z = blockdiag(LU)^-1 r in the ORIGINAL numbering; r, z, work: nblocks*n */
+int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
+                    double* work, void* stream);
 
 /* ---- K12: Krylov drivers -------------------------------------------------
  * Device-resident loops; the host reads the residual norm every check_every

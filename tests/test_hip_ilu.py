@@ -74,7 +74,7 @@ def test_factor_and_sweeps_match_host_ilu0(hip):
     Ap.sort_indices()
     assert numpy.array_equal(Ap.indices, plan.host['cols'])
     LUref, diag = _ilu0_reference(Ap)
-    lu = pre.lu.cpu().numpy()
+    lu = pre.factor_values()
     assert abs(lu - LUref.data).max() < 1e-12 * abs(LUref.data).max()
     # sweeps
     r = rng.standard_normal(lay.N)
@@ -125,15 +125,17 @@ def test_newton_with_ilu0_preconditioner(hip):
     mesh = fem.karman_channel(30, 10)
     case = cases.Case(mesh, vdeg=2, dt=0.05, bc_kind='channel', rho=1.5,
                       mu=0.05, seed=3)
-    u1j, p1j, uij = case.product_step('rotational')
-    its_j = sum(navsto.last_step_info['newton_linear_iterations'])
-    navsto.solver_parameters['newton']['preconditioner'] = 'ilu0'
+    default = navsto.solver_parameters['newton']['preconditioner']
     try:
+        navsto.solver_parameters['newton']['preconditioner'] = 'jacobi'
+        u1j, p1j, uij = case.product_step('rotational')
+        its_j = sum(navsto.last_step_info['newton_linear_iterations'])
+        navsto.solver_parameters['newton']['preconditioner'] = 'ilu0'
         u1i, p1i, uii = case.product_step('rotational')
         its_i = sum(navsto.last_step_info['newton_linear_iterations'])
     finally:
-        navsto.solver_parameters['newton']['preconditioner'] = 'jacobi'
+        navsto.solver_parameters['newton']['preconditioner'] = default
     # both runs stop at the same Newton tolerance: agreement to solver accuracy
-    assert cases.rel_l2(uii, uij) < 1e-8
-    assert cases.rel_l2(u1i, u1j) < 1e-8
+    assert cases.rel_l2(uii, uij) < 1e-7
+    assert cases.rel_l2(u1i, u1j) < 1e-7
     assert its_i < its_j, (its_i, its_j)
