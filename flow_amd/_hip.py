@@ -121,6 +121,7 @@ SYMBOLS = {
     'flow_dot_host': [_I, _VP, _VP, _VP, _P(_D), _VP],
     'flow_norm_host': [_I, _VP, _I, _VP, _P(_D), _VP],
     'flow_axpby': [_I, _D, _VP, _D, _VP, _VP],
+    'flow_vmul': [_I, _D, _VP, _VP, _VP, _VP],
     'flow_cg_solve': [_P(Operator), _VP, _P(CoarseS), _VP, _VP, _D, _D, _I, _I,
                       _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
@@ -145,6 +146,8 @@ SYMBOLS = {
     'flow_assemble_source': [_P(MeshS), _P(SpaceS), _I, _P(CoefS), _VP, _VP,
                              _VP],
     'flow_assemble_magnitude': [_P(MeshS), _P(SpaceS), _I, _VP, _VP, _VP, _VP],
+    'flow_assemble_div_adjoint': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _VP,
+                                  _VP, _VP],
     'flow_bc_identity_rows': [_P(Operator), _VP, _VP, _I, _VP, _VP],
     'flow_bc_residual': [_I, _VP, _VP, _VP, _VP, _VP],
     'flow_bc_set_values': [_I, _VP, _VP, _VP, _VP],

@@ -713,6 +713,48 @@ __global__ __launch_bounds__(kBlock) void heat_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Stokes (flow/stokes.py:40-42): adjoint of the divergence coupling,
+// out_(a,i) = - int p d_a phi_i   (the term  - p * div(v) * dx)
+// ---------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void div_adjoint_kernel(
+    int nc, const double* __restrict__ xy, const int* __restrict__ cdp,
+    const double* __restrict__ p, double* __restrict__ scratch) {
+  constexpr int NL = Elem<DEG>::NL;
+  constexpr int NQ = 7;   // p (1) * grad phi (1): degree 2, the 7-pt rule is exact
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const Geom g = load_geom(xy, nc, c);
+  double P[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) P[k] = p[cdp[k * nc + c]];
+  double acc[2][NL];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc[a][i] = 0.0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double L[3] = {kQ7L[q][0], kQ7L[q][1], kQ7L[q][2]};
+    const double w = 0.5 * kQ7W[q] * g.adet;
+    double phi[NL], dphi[NL][3], gphi[NL][2];
+    basis<DEG>(L, phi, dphi);
+    phys_grad<NL>(g, dphi, gphi);
+    const double pq = P[0] * L[0] + P[1] * L[1] + P[2] * L[2];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      acc[0][i] -= w * pq * gphi[i][0];
+      acc[1][i] -= w * pq * gphi[i][1];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      scratch[static_cast<size_t>(a * NL + i) * nc + c] = acc[a][i];
+}
+
+// ---------------------------------------------------------------------------
 // K16: load vector of |u| for the callers' step-size control
 // ---------------------------------------------------------------------------
 // b_i = int m(u) phi_i, m = sqrt(ux^2+uy^2) (mode 0) or |ux|+|uy| (mode 1)
@@ -895,6 +937,23 @@ extern "C" int flow_assemble_magnitude(const flow_mesh* mesh, const flow_space* 
   FLOW_DISPATCH_DEG(W->deg, magnitude_kernel, cell_grid(mesh->nc), st, mesh->nc,
                     mesh->xy, W->cell_dofs, W->n, u, mode, scratch);
   return gather(W->n, 1, W->vptr, W->vsrc, scratch, 0, b, st);
+}
+
+extern "C" int flow_assemble_div_adjoint(const flow_mesh* mesh,
+                                         const flow_space* W, const flow_space* P,
+                                         const double* p, double* scratch,
+                                         double* out, void* stream) {
+  int rc = check_mesh_space(mesh, W);
+  if (rc) return rc;
+  if ((rc = check_mesh_space(mesh, P))) return rc;
+  FLOW_REQUIRE(P->deg == 1, "pressure space must be P1");
+  FLOW_REQUIRE(p && scratch && out && W->vptr && W->vsrc, "pointers");
+  hipStream_t st = as_stream(stream);
+  FLOW_DISPATCH_DEG(W->deg, div_adjoint_kernel, cell_grid(mesh->nc), st, mesh->nc,
+                    mesh->xy, P->cell_dofs, p, scratch);
+  const int nl = W->deg == 1 ? 3 : 6;
+  return gather(W->n, 2, W->vptr, W->vsrc, scratch,
+                static_cast<size_t>(nl) * mesh->nc, out, st);
 }
 
 extern "C" int flow_bc_identity_rows(const flow_operator* A, double* vals_planes,

@@ -256,6 +256,14 @@ __global__ void axpby_kernel(int n, double a, const double* __restrict__ x,
     y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
 }
 
+// out = a * x .* y  (masks, diagonal scalings; out may alias x or y)
+__global__ void vmul_kernel(int n, double a, const double* x, const double* y,
+                            double* out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x)
+    out[i] = a * x[i] * y[i];
+}
+
 // ---------------------------------------------------------------------------
 // Krylov: scalar slots in HBM
 // ---------------------------------------------------------------------------
@@ -746,6 +754,15 @@ extern "C" int flow_axpby(int n, double a, const double* x, double b, double* y,
   FLOW_REQUIRE(n > 0 && x && y, "axpby arguments");
   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
                      as_stream(stream), n, a, x, b, y);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_vmul(int n, double a, const double* x, const double* y,
+                         double* out, void* stream) {
+  FLOW_REQUIRE(n > 0 && x && y && out, "vmul arguments");
+  hipLaunchKernelGGL(vmul_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
+                     as_stream(stream), n, a, x, y, out);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }

@@ -336,6 +336,19 @@ def axpby(a, x, b, y):
     return y
 
 
+def vmul(x, y, out=None, a=1.0):
+    '''out = a * x .* y (out may alias x or y)'''
+    lib = _hip.lib()
+    assert x.numel() == y.numel()
+    if out is None:
+        out = device.empty(x.numel())
+    _hip.check(lib.flow_vmul(
+        x.numel(), float(a), _hip.f64(x), _hip.f64(y), _hip.f64(out),
+        _hip.stream()
+        ))
+    return out
+
+
 # -- Krylov -------------------------------------------------------------------
 class SolveInfo(object):
     def __init__(self, iterations, residual, method):

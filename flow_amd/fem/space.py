@@ -202,6 +202,13 @@ class FunctionSpace(object):
     component-wise Dirichlet conditions
     (tests/test_karman_vortex_street.py:194-196).'''
 
+    def __new__(cls, mesh, family='CG', *args, **kwargs):
+        # FunctionSpace(mesh, W_element * P_element) -> Taylor-Hood pair
+        # (tests/test_karman_vortex_street.py:59-61)
+        if isinstance(family, MixedElement):
+            return MixedFunctionSpace(mesh, family)
+        return super(FunctionSpace, cls).__new__(cls)
+
     def __init__(self, mesh, family='CG', degree=1, dim=1, _component=None,
                  _parent=None):
         if isinstance(family, FiniteElement):
@@ -266,6 +273,36 @@ class FiniteElement(object):
 
     def degree(self):
         return self._degree
+
+    def __mul__(self, other):
+        return MixedElement([self, other])
+
+
+class MixedElement(object):
+    def __init__(self, elements):
+        self.elements = list(elements)
+
+
+class MixedFunctionSpace(object):
+    '''The velocity-pressure pair `W_element * P_element`: only what the
+    reference's drivers use -- `.sub(0)` / `.sub(1)` to pose Dirichlet
+    conditions and to hand the pair to `flow.stokes.solve`
+    (tests/test_karman_vortex_street.py:59-63, 171-179; tests/test_stokes.py:
+    137-153).  The sub-spaces are ordinary (collapsed) spaces; there is no
+    monolithic mixed dof vector.'''
+
+    def __init__(self, mesh, element):
+        self._mesh = mesh
+        self.spaces = [FunctionSpace(mesh, e) for e in element.elements]
+
+    def mesh(self):
+        return self._mesh
+
+    def sub(self, i):
+        return self.spaces[i]
+
+    def num_sub_spaces(self):
+        return len(self.spaces)
 
 
 # pylint: disable=invalid-name

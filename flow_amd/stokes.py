@@ -1,0 +1,226 @@
+# -*- coding: utf-8 -*-
+#
+'''
+Steady Stokes solve used to bootstrap the Karman run; same interface as the
+reference's `flow.stokes.solve(WP, bcs, mu, f, verbose=True, tol=1e-13,
+max_iter=500)` (flow/stokes.py:13-148), which returns deep-copied `(u, p)`.
+
+The reference assembles the mixed Taylor-Hood system
+    a = mu (grad u, grad v) - (p, div v) - (q, div u),   L = (f, v)
+with `assemble_system(a, L, bcs)` and hands it to GMRES preconditioned with
+BoomerAMG on  mu (grad u, grad v) - p q  (:40-60).  Here the same discrete
+system is solved by CG on its pressure Schur complement
+    S = B K^-1 B^T        (K = mu * vector Laplacian with the Dirichlet rows
+                           eliminated, B = -(q, div u) on the free dofs)
+preconditioned with the scaled lumped pressure mass matrix (S is spectrally
+equivalent to M_p / mu -- the same fact the reference's `- p*q` preconditioner
+block uses).  Every application of S is a velocity solve: CG with the Jacobi +
+aggregate-coarse-space preconditioner of the pressure-Poisson solver.  All
+pieces run on the HIP path: stiffness / mass assembly, the two coupling kernels
+(flow_assemble_pressure_rhs with p0 = 0 for B, flow_assemble_div_adjoint for
+B^T), SpMV, CG.  Non-convergence raises RuntimeError as
+'error_on_nonconvergence' does (:139).
+'''
+import ctypes
+
+import numpy
+import torch
+
+from .fem import ops
+from .fem.bcs import collect
+from .fem.function import Function, scalar_value
+from .fem.space import MixedFunctionSpace
+from .message import info
+from . import _hip
+from . import device
+
+last_solve_info = {}
+
+
+def solve(
+        WP,
+        bcs,
+        mu,
+        f,
+        verbose=True,
+        tol=1.0e-13,
+        max_iter=500
+        ):
+    lib = _hip.lib()
+    mu = scalar_value(mu)
+    assert mu > 0.0
+    assert isinstance(WP, MixedFunctionSpace)
+    W, P = WP.sub(0), WP.sub(1)
+    assert W.dim == 2 and P.dim == 1 and P.degree == 1
+    mesh = W.mesh()
+    lay, play = W.layout, P.layout
+    nc = mesh.num_cells()
+    n, n2, npr = W.N, W.size(), P.N
+    st = _hip.stream()
+    ms = ops.mesh_struct(mesh)
+    ws = ops.space_struct(lay)
+    ps = ops.space_struct(play)
+    buf = ops.scratch(mesh, 2 * lay.nloc * nc)
+
+    # Dirichlet data, split into velocity and pressure conditions
+    def target(bc):
+        # a component condition (W.sub(0)) lives on its parent vector space
+        return getattr(bc, 'space', None) or bc.function_space()
+    u_bcs = [bc for bc in bcs if target(bc).dim == 2]
+    p_bcs = [bc for bc in bcs if target(bc).dim == 1]
+    ud, uv = collect(u_bcs, n2)
+    pd, pv = collect(p_bcs, npr) if p_bcs else (numpy.zeros(0, numpy.int32),
+                                                numpy.zeros(0))
+    umask = numpy.ones(n2)
+    umask[ud] = 0.0
+    pmask = numpy.ones(npr)
+    pmask[pd] = 0.0
+    umask_d = device.to_device(umask)
+    pmask_d = device.to_device(pmask)
+    ug = numpy.zeros(n2)
+    ug[ud] = uv
+    pg = numpy.zeros(npr)
+    pg[pd] = pv
+    ug_d = device.to_device(ug)
+    pg_d = device.to_device(pg)
+
+    # K = mu * stiffness per component, Dirichlet rows/columns eliminated
+    K = ops.assemble_scalar_matrix(lay, ops.STIFFNESS)
+    planes = []
+    coarse = []
+    for comp in range(2):
+        isbc = (umask[comp * n:(comp + 1) * n] == 0.0)
+        Kc = ops.symmetric_bc_matrix(
+            K, device.to_device(isbc.astype(numpy.uint8))
+            )
+        # scale the free part by mu (identity rows stay 1)
+        ops.axpby(mu, Kc.vals, 0.0, Kc.vals)
+        Kc.vals[lay.dev('diag_idx').long()[device.to_device(isbc)]] = 1.0
+        planes.append(Kc)
+        coarse.append(ops.CoarseSpace(
+            Kc, isbc, singular=not isbc.any(), target_nc=2048
+            ))
+    dinvs = [Kc.diag_inv() for Kc in planes]
+    Kfull = ops.Matrix(lay, 1, torch.cat([K.vals, K.vals]))
+
+    inner = {'its': 0, 'solves': 0}
+    inner_tol = min(1.0e-12, 1.0e-2 * tol)
+
+    def solve_K(rhs, out):
+        '''out = K_bc^-1 rhs, component by component (rhs holds the Dirichlet
+        values on the eliminated rows).'''
+        for comp in range(2):
+            sl = slice(comp * n, (comp + 1) * n)
+            x = out[sl]
+            sol = ops.krylov_solve(
+                'cg', planes[comp], rhs[sl], x, rtol=inner_tol, atol=1.0e-300,
+                maxit=20000, dinv=dinvs[comp], check_every=10,
+                coarse=coarse[comp]
+                )
+            inner['its'] += sol.iterations
+            inner['solves'] += 1
+        return out
+
+    def apply_B(u, out):
+        '''out = -(q, div u), rows of pressure Dirichlet dofs zeroed.'''
+        zero_p = device.zeros(npr)
+        _hip.check(lib.flow_assemble_pressure_rhs(
+            ctypes.byref(ms), ctypes.byref(ws), ctypes.byref(ps),
+            _hip.f64(u, n2), _hip.f64(zero_p, npr), 1.0, 0.0, 0,
+            _hip.f64(buf), _hip.f64(out, npr), st
+            ))
+        ops.vmul(out, pmask_d, out)
+        return out
+
+    def apply_Bt(p, out):
+        '''out = -(p, div v), rows of velocity Dirichlet dofs zeroed.'''
+        _hip.check(lib.flow_assemble_div_adjoint(
+            ctypes.byref(ms), ctypes.byref(ws), ctypes.byref(ps),
+            _hip.f64(p, npr), _hip.f64(buf), _hip.f64(out, n2), st
+            ))
+        ops.vmul(out, umask_d, out)
+        return out
+
+    # right-hand side of the velocity block: (f, v) - K u_g - B^T p_g on the
+    # free rows, the Dirichlet values on the eliminated rows
+    F = ops.assemble_source(W, f)
+    tmp_u = device.empty(n2)
+    Kfull.apply(ug_d, tmp_u)
+    ops.axpby(-mu, tmp_u, 1.0, F)
+    apply_Bt_raw = device.empty(n2)
+    _hip.check(lib.flow_assemble_div_adjoint(
+        ctypes.byref(ms), ctypes.byref(ws), ctypes.byref(ps),
+        _hip.f64(pg_d, npr), _hip.f64(buf), _hip.f64(apply_Bt_raw, n2), st
+        ))
+    ops.axpby(-1.0, apply_Bt_raw, 1.0, F)
+    ops.vmul(F, umask_d, F)
+    ops.axpby(1.0, ug_d, 1.0, F)
+
+    # u(p_f) = K^-1 (F - B^T p_f);  continuity on the free pressure rows:
+    #   B u(p_f) = 0   <=>   S p_f = B u(0)
+    u_hat = device.zeros(n2)
+    solve_K(F, u_hat)
+    rhs = device.empty(npr)
+    apply_B(u_hat, rhs)
+
+    # preconditioner: mu / lumped pressure mass (S ~ M_p / mu)
+    Mp = ops.assemble_scalar_matrix(play, ops.MASS)
+    one = torch.ones(npr, dtype=torch.float64, device=device.get())
+    lumped = device.empty(npr)
+    Mp.apply(one, lumped)
+    # minv = mu / lumped, zero on the pressure Dirichlet rows
+    minv = device.to_device(mu * pmask / lumped.cpu().numpy())
+
+    def apply_S(p, out):
+        t = device.empty(n2)
+        apply_Bt(p, t)
+        y = device.zeros(n2)
+        solve_K(t, y)
+        return apply_B(y, out)
+
+    # preconditioned CG on S p_f = rhs (host loop; every operation is a
+    # library call)
+    pf = device.zeros(npr)
+    r = device.empty(npr)
+    r.copy_(rhs)
+    z = ops.vmul(r, minv)
+    d = device.empty(npr)
+    d.copy_(z)
+    rz = ops.dot(r, z)
+    bnorm = numpy.sqrt(ops.dot(rhs, rhs))
+    Sd = device.empty(npr)
+    its = 0
+    res = bnorm
+    while bnorm > 0.0 and res > tol * bnorm:
+        if its >= max_iter:
+            raise _hip.NotConverged(
+                'Stokes Schur-complement CG did not converge in %d iterations '
+                '(|r|/|b| = %.3e > %.3e)' % (its, res / bnorm, tol)
+                )
+        apply_S(d, Sd)
+        alpha = rz / ops.dot(d, Sd)
+        ops.axpby(alpha, d, 1.0, pf)
+        ops.axpby(-alpha, Sd, 1.0, r)
+        res = numpy.sqrt(ops.dot(r, r))
+        ops.vmul(r, minv, z)
+        rz_new = ops.dot(r, z)
+        ops.axpby(1.0, z, rz_new / rz, d)
+        rz = rz_new
+        its += 1
+        if verbose:
+            info('Stokes CG %d: |r|/|b| = %.3e' % (its, res / bnorm))
+
+    # velocity of the converged pressure, assemble the outputs
+    t = device.empty(n2)
+    apply_Bt(pf, t)
+    ops.axpby(-1.0, t, 1.0, F)          # F - B^T p_f (Dirichlet rows keep u_g)
+    u = Function(W)
+    solve_K(F, u.data)
+    p = Function(P)
+    ops.vmul(pf, pmask_d, p.data)
+    ops.axpby(1.0, pg_d, 1.0, p.data)
+    last_solve_info.update(
+        outer_iterations=its, inner_iterations=inner['its'],
+        inner_solves=inner['solves'], residual=res / max(bnorm, 1e-300)
+        )
+    return u, p

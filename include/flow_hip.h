@@ -79,6 +79,8 @@ int flow_norm_host(int n, const double* x, int kind, double* work,
                    double* result_host, void* stream);
 int flow_axpby(int n, double a, const double* x, double b, double* y,
                void* stream);                       /* y = a x + b y */
+int flow_vmul(int n, double a, const double* x, const double* y, double* out,
+              void* stream);                        /* out = a x .* y */
 #define FLOW_REDUCE_WORK 4096   /* doubles of `work` the reductions need */
 
 /* Two-level additive preconditioner  z = D^-1 r + P Ac^-1 P^T r  for scalar
@@ -266,6 +268,14 @@ int flow_assemble_momentum(const flow_mesh* mesh, const flow_space* W,
 int flow_assemble_source(const flow_mesh* mesh, const flow_space* V, int dim,
                          const flow_coef* f, double* scratch, double* b,
                          void* stream);
+
+/* Stokes bootstrap (flow/stokes.py:40-42): adjoint of the
+ * divergence coupling, out_(a,i) = - int p d_a phi_i  (`- p*div(v)*dx`); the
+ * coupling itself, - int q div u, is flow_assemble_pressure_rhs with p0 = 0,
+ * alpha_rho_dt = 1.  scratch: 2*nloc*nc. */
+int flow_assemble_div_adjoint(const flow_mesh* mesh, const flow_space* W,
+                              const flow_space* P, const double* p,
+                              double* scratch, double* out, void* stream);
 
 /* K16: b_i = int m(u) phi_i with m = sqrt(ux^2+uy^2) (mode 0) or |ux|+|uy|
  * (mode 1): the load vector of the callers' `project(sqrt(ux**2 + uy**2), ...)`

@@ -577,6 +577,37 @@ def l2_error(S, U, lattice_pts, exact_values, dim=1):
     return numpy.sqrt(err)
 
 
+def stokes_solve(W, P, f, mu, u_bc, p_bc=None):
+    '''`flow.stokes.solve` (flow/stokes.py:13-148): mixed Taylor-Hood system
+        a = mu (grad u, grad v) - (p, div v) - (q, div u),  L = (f, v),
+    `assemble_system(a, L, bcs)` (symmetric elimination of velocity AND pressure
+    Dirichlet dofs), solved here with a sparse direct factorisation (the
+    reference: GMRES + AMG to rtol tol).  f: (lattice_pts, cell_values
+    (Nc, nl, 2)); u_bc / p_bc: (dofs, values).  Returns (u, p).'''
+    pts, w = duffy_rule(4)
+    _, gref = basis(W.deg, pts)
+    gphi = W.phys_grad(gref)                      # (Nc, nq, nl, 2)
+    psi, _ = basis(1, pts)
+    wd = w[None, :] * numpy.abs(W.detJ)[:, None]
+    # B[q_i, (a, j)] = - int q_i d_a phi_j
+    Be = -numpy.einsum('cq,qi,cqja->ciaj', wd, psi, gphi)
+    B = _coo(P, W, Be[:, None, :, :, :], 1, 2)
+    K = stiffness_matrix(W)
+    A = sp.bmat([[sp.block_diag([mu * K, mu * K]), B.T], [B, None]],
+                format='csr')
+    nw = 2 * W.N
+    b = numpy.concatenate([load_vector(W, f[0], f[1], dim=2),
+                           numpy.zeros(P.N)])
+    dofs = [numpy.asarray(u_bc[0], dtype=numpy.int64)]
+    vals = [numpy.asarray(u_bc[1], dtype=float)]
+    if p_bc is not None and len(p_bc[0]) > 0:
+        dofs.append(nw + numpy.asarray(p_bc[0], dtype=numpy.int64))
+        vals.append(numpy.asarray(p_bc[1], dtype=float))
+    A, b = symmetric_bc(A, b, numpy.concatenate(dofs), numpy.concatenate(vals))
+    x = spla.splu(A.tocsc()).solve(b)
+    return x[:nw], x[nw:]
+
+
 def order_of_convergence(Dt, errors):
     '''tests/helpers.py:10-14.'''
     return numpy.array([
