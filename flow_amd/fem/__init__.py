@@ -18,6 +18,8 @@ from .function import (                                         # noqa: F401
     as_cell_coefficient, cell_lattice_points, scalar_value,
     )
 from .bcs import DirichletBC, SubDomain                         # noqa: F401
+from .io import XDMFFile, mpi_comm_world, read_mesh             # noqa: F401
+from .space import MixedFunctionSpace                           # noqa: F401
 
 DOLFIN_EPS = 3.0e-16
 triangle = 'triangle'

@@ -1,0 +1,204 @@
+# -*- coding: utf-8 -*-
+'''
+On-disk formats either side of the path: the meshes the
+reference's drivers read -- gmsh `.msh` (the pygmsh cache file,
+tests/test_karman_vortex_street.py:29-33) and DOLFIN XML (`Mesh('test.xml')`,
+:52-53) -- and the XDMF time series they write (`XDMFFile(...).write(u0, t)`,
+:214-227; tests/test_boussinesq.py:164-166, 307-309).
+
+Plain-text implementations (MSH 2.2 ASCII, DOLFIN XML, XDMF with inline XML
+data items): no meshio / h5py offline.  Host-side I/O only.
+'''
+from __future__ import print_function
+
+import os
+import xml.etree.ElementTree as ET
+
+import numpy
+
+from .mesh import Mesh
+
+
+def mpi_comm_world():
+    '''Placeholder for dolfin's communicator argument of XDMFFile.'''
+    return None
+
+
+# -- meshes -------------------------------------------------------------------
+def read_msh(path):
+    '''gmsh MSH 2.2 ASCII: triangles (element type 2) of a planar mesh.'''
+    with open(path) as fh:
+        lines = [ln.strip() for ln in fh]
+    i = lines.index('$MeshFormat')
+    version = lines[i + 1].split()
+    if not version[0].startswith('2') or version[1] != '0':
+        raise ValueError('only MSH 2.x ASCII is supported (got %r)' % version)
+    i = lines.index('$Nodes')
+    n = int(lines[i + 1])
+    nodes = numpy.array([ln.split() for ln in lines[i + 2:i + 2 + n]],
+                        dtype=float)
+    ids = nodes[:, 0].astype(numpy.int64)
+    i = lines.index('$Elements')
+    m = int(lines[i + 1])
+    tris = []
+    for ln in lines[i + 2:i + 2 + m]:
+        t = ln.split()
+        if int(t[1]) == 2:                   # 3-node triangle
+            ntags = int(t[2])
+            tris.append([int(v) for v in t[3 + ntags:3 + ntags + 3]])
+    tris = numpy.array(tris, dtype=numpy.int64)
+    # compress node ids to the vertices actually used, keep file order
+    used = numpy.unique(tris)
+    lookup = -numpy.ones(ids.max() + 1, dtype=numpy.int64)
+    pos = {int(v): k for k, v in enumerate(ids)}
+    rows = numpy.array([pos[int(v)] for v in used])
+    lookup[used] = numpy.arange(len(used))
+    return Mesh(nodes[rows][:, 1:3], lookup[tris])
+
+
+def write_msh(path, mesh):
+    with open(path, 'w') as fh:
+        fh.write('$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n%d\n'
+                 % mesh.num_vertices())
+        for k, (x, y) in enumerate(mesh.points):
+            fh.write('%d %.17g %.17g 0\n' % (k + 1, x, y))
+        fh.write('$EndNodes\n$Elements\n%d\n' % mesh.num_cells())
+        for k, c in enumerate(mesh.cell_vertices):
+            fh.write('%d 2 2 0 1 %d %d %d\n' % (k + 1, c[0] + 1, c[1] + 1,
+                                                 c[2] + 1))
+        fh.write('$EndElements\n')
+
+
+def read_dolfin_xml(path):
+    root = ET.parse(path).getroot()
+    m = root.find('mesh')
+    assert m.get('celltype') == 'triangle'
+    verts = m.find('vertices')
+    pts = numpy.zeros((int(verts.get('size')), 2))
+    for v in verts:
+        pts[int(v.get('index'))] = (float(v.get('x')), float(v.get('y')))
+    cells_el = m.find('cells')
+    cells = numpy.zeros((int(cells_el.get('size')), 3), dtype=numpy.int64)
+    for c in cells_el:
+        cells[int(c.get('index'))] = (int(c.get('v0')), int(c.get('v1')),
+                                      int(c.get('v2')))
+    return Mesh(pts, cells)
+
+
+def write_dolfin_xml(path, mesh):
+    with open(path, 'w') as fh:
+        fh.write('<?xml version="1.0"?>\n<dolfin xmlns:dolfin='
+                 '"http://fenicsproject.org">\n  <mesh celltype="triangle" '
+                 'dim="2">\n    <vertices size="%d">\n' % mesh.num_vertices())
+        for k, (x, y) in enumerate(mesh.points):
+            fh.write('      <vertex index="%d" x="%.17g" y="%.17g"/>\n'
+                     % (k, x, y))
+        fh.write('    </vertices>\n    <cells size="%d">\n' % mesh.num_cells())
+        for k, c in enumerate(mesh.cell_vertices):
+            fh.write('      <triangle index="%d" v0="%d" v1="%d" v2="%d"/>\n'
+                     % (k, c[0], c[1], c[2]))
+        fh.write('    </cells>\n  </mesh>\n</dolfin>\n')
+
+
+def read_mesh(path):
+    '''`Mesh('test.xml')` / the `.msh` cache of the reference drivers.'''
+    ext = os.path.splitext(path)[1].lower()
+    if ext == '.msh':
+        return read_msh(path)
+    if ext == '.xml':
+        return read_dolfin_xml(path)
+    raise ValueError('unknown mesh format %r' % ext)
+
+
+# -- XDMF time series ---------------------------------------------------------
+class XDMFFile(object):
+    '''`with XDMFFile(mpi_comm_world(), 'karman.xdmf') as f: f.write(u, t)`.
+    Vertex values of the field are written (what dolfin's XDMFFile.write does
+    for a P2 function as well); data items are inline XML.'''
+
+    def __init__(self, comm_or_path, path=None):
+        self.path = path if path is not None else comm_or_path
+        self.parameters = {'flush_output': False,
+                           'rewrite_function_mesh': True}
+        self._steps = []          # (t, name, ncomp, values (Nv, ncomp))
+        self._mesh = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, tpe, value, traceback):
+        self.close()
+        return False
+
+    def write(self, u, t=0.0):
+        V = u.function_space()
+        mesh = V.mesh()
+        assert self._mesh is None or self._mesh is mesh
+        self._mesh = mesh
+        arr = u.array().reshape(V.dim, V.N)
+        vals = arr[:, V.layout.vertex_dofs].T.copy()
+        self._steps.append((float(t), u.name(), V.dim, vals))
+        if self.parameters.get('flush_output'):
+            self.close()
+
+    def close(self):
+        if self._mesh is None:
+            return
+        mesh = self._mesh
+        nv, nc = mesh.num_vertices(), mesh.num_cells()
+        out = ['<?xml version="1.0"?>', '<Xdmf Version="3.0">', ' <Domain>',
+               '  <Grid Name="TimeSeries" GridType="Collection" '
+               'CollectionType="Temporal">']
+        topo = '\n'.join(' '.join(str(v) for v in c)
+                         for c in mesh.cell_vertices)
+        geom = '\n'.join('%.17g %.17g' % (x, y) for x, y in mesh.points)
+        times = sorted(set(s[0] for s in self._steps))
+        for t in times:
+            out.append('   <Grid Name="mesh" GridType="Uniform">')
+            out.append('    <Time Value="%.17g"/>' % t)
+            out.append('    <Topology TopologyType="Triangle" '
+                       'NumberOfElements="%d"><DataItem Format="XML" '
+                       'Dimensions="%d 3" NumberType="Int">' % (nc, nc))
+            out.append(topo)
+            out.append('    </DataItem></Topology>')
+            out.append('    <Geometry GeometryType="XY"><DataItem Format="XML" '
+                       'Dimensions="%d 2">' % nv)
+            out.append(geom)
+            out.append('    </DataItem></Geometry>')
+            for (ts, name, ncomp, vals) in self._steps:
+                if ts != t:
+                    continue
+                if ncomp == 1:
+                    atype, dims, rows = 'Scalar', '%d' % nv, vals[:, 0:1]
+                else:
+                    atype, dims = 'Vector', '%d 3' % nv
+                    rows = numpy.concatenate(
+                        [vals, numpy.zeros((nv, 1))], axis=1)
+                out.append('    <Attribute Name="%s" AttributeType="%s" '
+                           'Center="Node"><DataItem Format="XML" '
+                           'Dimensions="%s">' % (name, atype, dims))
+                out.append('\n'.join(' '.join('%.17g' % v for v in r)
+                                     for r in rows))
+                out.append('    </DataItem></Attribute>')
+            out.append('   </Grid>')
+        out += ['  </Grid>', ' </Domain>', '</Xdmf>']
+        with open(self.path, 'w') as fh:
+            fh.write('\n'.join(out) + '\n')
+
+
+def read_xdmf_series(path):
+    '''[(t, {name: values})] of a file written by XDMFFile (tests).'''
+    root = ET.parse(path).getroot()
+    series = []
+    for grid in root.iter('Grid'):
+        if grid.get('GridType') != 'Uniform':
+            continue
+        t = float(grid.find('Time').get('Value'))
+        fields = {}
+        for att in grid.findall('Attribute'):
+            item = att.find('DataItem')
+            dims = [int(d) for d in item.get('Dimensions').split()]
+            fields[att.get('Name')] = numpy.array(
+                item.text.split(), dtype=float).reshape(dims)
+        series.append((t, fields))
+    return series

@@ -28,7 +28,13 @@ class Mesh(object):
       bfacets      (Nb,)    ids of edges with exactly one incident cell
       bfacet_cell  (Nb,), bfacet_local (Nb,)  the cell and its local facet index
     '''
-    def __init__(self, points, cells):
+    def __init__(self, points, cells=None):
+        if isinstance(points, str):
+            # Mesh('test.xml') / Mesh('karman.msh') as the reference drivers do
+            # (tests/test_karman_vortex_street.py:52-53)
+            from . import io
+            loaded = io.read_mesh(points)
+            points, cells = loaded.points, loaded.cell_vertices
         self.points = numpy.ascontiguousarray(points, dtype=numpy.float64)
         self.cell_vertices = numpy.ascontiguousarray(cells, dtype=numpy.int32)
         assert self.points.ndim == 2 and self.points.shape[1] == 2

@@ -1,0 +1,78 @@
+# -*- coding: utf-8 -*-
+'''
+Mesh readers/writers (gmsh MSH 2.2 ASCII, DOLFIN XML) and the XDMF time-series
+writer the reference's drivers use (tests/test_karman_vortex_street.py:29-53,
+214-227).  CPU only.
+'''
+import numpy
+import pytest
+
+from flow_amd import fem
+from flow_amd.fem import io
+
+
+@pytest.mark.parametrize('ext', ['msh', 'xml'])
+def test_mesh_round_trip(tmp_path, ext):
+    mesh = fem.karman_channel(20, 6)
+    path = str(tmp_path / ('mesh.' + ext))
+    (io.write_msh if ext == 'msh' else io.write_dolfin_xml)(path, mesh)
+    back = fem.Mesh(path)
+    assert numpy.array_equal(back.points, mesh.points)
+    assert numpy.array_equal(back.cell_vertices, mesh.cell_vertices)
+    assert back.num_edges() == mesh.num_edges()
+
+
+def test_msh_with_other_element_types(tmp_path):
+    # a gmsh file as pygmsh writes it: points, lines and triangles mixed,
+    # 1-based node ids, unused nodes (the circle centre)
+    text = '''$MeshFormat
+2.2 0 8
+$EndMeshFormat
+$Nodes
+5
+1 0 0 0
+2 1 0 0
+3 0 1 0
+4 1 1 0
+5 0.5 0.5 0
+$EndNodes
+$Elements
+4
+1 15 2 0 1 1
+2 1 2 0 1 1 2
+3 2 2 0 6 1 2 3
+4 2 2 0 6 2 4 3
+$EndElements
+'''
+    path = tmp_path / 'g.msh'
+    path.write_text(text)
+    mesh = io.read_mesh(str(path))
+    assert mesh.num_vertices() == 4 and mesh.num_cells() == 2
+    assert mesh.cell_areas().sum() == pytest.approx(1.0)
+
+
+def test_xdmf_time_series(tmp_path):
+    mesh = fem.UnitSquareMesh(3, 3)
+    W = fem.VectorFunctionSpace(mesh, 'CG', 2)
+    P = fem.FunctionSpace(mesh, 'CG', 1)
+    u = fem.Function(W)
+    p = fem.Function(P)
+    u.rename('velocity', 'velocity')
+    p.rename('pressure', 'pressure')
+    path = str(tmp_path / 'out.xdmf')
+    with io.XDMFFile(io.mpi_comm_world(), path) as xf:
+        xf.parameters['flush_output'] = True
+        xf.parameters['rewrite_function_mesh'] = False
+        for k, t in enumerate((0.0, 0.5)):
+            x = W.layout.dof_coords
+            u.set_array(numpy.concatenate([x[:, 0] + t, x[:, 1] * (k + 1)]))
+            p.set_array(mesh.points[:, 0] * t)
+            xf.write(u, t)
+            xf.write(p, t)
+    series = io.read_xdmf_series(path)
+    assert [s[0] for s in series] == [0.0, 0.5]
+    vel = series[1][1]['velocity']
+    assert vel.shape == (mesh.num_vertices(), 3)
+    assert numpy.allclose(vel[:, 0], mesh.points[:, 0] + 0.5)
+    assert numpy.allclose(vel[:, 1], mesh.points[:, 1] * 2)
+    assert numpy.allclose(series[1][1]['pressure'], mesh.points[:, 0] * 0.5)
