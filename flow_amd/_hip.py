@@ -133,6 +133,7 @@ SYMBOLS = {
     'flow_cg_update_dev': [_I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP],
     'flow_coarse_restrict_dev': [_P(CoarseS), _VP, _I, _I, _VP, _VP],
     'flow_coarse_solve_dev': [_P(CoarseS), _VP, _VP, _VP],
+    'flow_coarse_recur_dev': [_I, _VP, _VP, _VP, _VP, _VP],
     'flow_coarse_prolong_dev': [_P(CoarseS), _VP, _VP, _VP, _VP, _I, _I, _VP],
     'flow_residual_dev': [_I, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_assemble_scalar_matrix': [_I, _P(MeshS), _P(SpaceS), _VP, _VP, _VP],

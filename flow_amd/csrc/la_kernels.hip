@@ -825,6 +825,32 @@ extern "C" int flow_coarse_solve_dev(const flow_coarse* C, const double* rc_in,
   return FLOW_OK;
 }
 
+// sigma = omega + beta sigma ; rc -= alpha sigma   (alpha, beta from S):
+// keeps rc = P^T r current by recurrence, so that the restriction travels in
+// the same all-reduce as the dot products (omega = P^T w, w = A z)
+__global__ void coarse_recur_kernel(int nc, const double* __restrict__ S,
+                                    const double* __restrict__ omega,
+                                    double* __restrict__ sigma,
+                                    double* __restrict__ rc) {
+  const double alpha = S[kAlpha];
+  const double beta = S[kBeta];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc;
+       i += gridDim.x * blockDim.x) {
+    const double s = omega[i] + beta * sigma[i];
+    sigma[i] = s;
+    rc[i] -= alpha * s;
+  }
+}
+
+extern "C" int flow_coarse_recur_dev(int nc, const double* S, const double* omega,
+                                     double* sigma, double* rc, void* stream) {
+  FLOW_REQUIRE(nc > 0 && S && omega && sigma && rc, "coarse recurrence");
+  hipLaunchKernelGGL(coarse_recur_kernel, dim3(grid_for(nc)), dim3(kBlock), 0,
+                     as_stream(stream), nc, S, omega, sigma, rc);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
 extern "C" int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
                                        const double* r, const double* zc,
                                        double* z, int r0, int r1,

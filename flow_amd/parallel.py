@@ -9,8 +9,11 @@ Rank g owns the contiguous rows [r_g, r_{g+1}) of the P1 stiffness matrix,
 balanced by nonzeros.  With the x-major vertex numbering of the channel mesh
 the matrix is banded (bandwidth ~ ny), so a rank only needs `halo` entries from
 its left and right neighbour.  Per CG iteration (Chronopoulos-Gear single
-reduction form) there is ONE neighbour halo exchange of z and ONE all-reduce of
-the three scalars (r.z, z.w, r.r); both are latency bound (a few KB / 24 B).
+reduction form) there is ONE neighbour halo exchange of z and ONE all-reduce
+carrying the three scalars (r.z, z.w, r.r) and, with the two-level
+preconditioner, the partial coarse restriction omega = P^T w of the same
+iteration (P^T r is then advanced by the recurrence that mirrors r -= alpha s);
+both are latency bound (a few KB / <= 32 KB).
 The local pieces are the same HIP kernels as the single-GPU solver, launched on
 the owned row range through the C ABI (flow_cg_update_dev, flow_operator_apply
 with the rank's row blocks, flow_dot3_dev, flow_cg_scalars_dev).
@@ -34,8 +37,14 @@ _STATE = {'group': None}
 
 
 def enable(group):
-    '''Shard subsequent pressure solves over `group`.'''
+    '''Shard subsequent pressure solves over `group`.  Collective: every rank
+    of the group must call it (the first NCCL operation on a group has to
+    involve all of its ranks before point-to-point traffic may start).'''
     _STATE['group'] = group
+    if dist.get_world_size(group) > 1:
+        t = torch.zeros(1, dtype=torch.float64, device=device.get()
+                        if dist.get_backend(group) != 'gloo' else 'cpu')
+        dist.all_reduce(t, group=group)
 
 
 def disable():
@@ -240,6 +249,12 @@ class HipLocal(object):
             _hip.f64(zc, coarse.nc), _hip.stream()
             ))
 
+    def coarse_recur(self, coarse, S, omega, sigma, rc):
+        _hip.check(self.lib.flow_coarse_recur_dev(
+            coarse.nc, _hip.f64(S), _hip.f64(omega, coarse.nc),
+            _hip.f64(sigma, coarse.nc), _hip.f64(rc, coarse.nc), _hip.stream()
+            ))
+
     def coarse_prolong(self, coarse, dinv, r, zc, z):
         _hip.check(self.lib.flow_coarse_prolong_dev(
             ctypes.byref(coarse.struct), _hip.f64(dinv, coarse.n),
@@ -263,32 +278,47 @@ def sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit, check_every,
     p = local.zeros(n)
     s = local.zeros(n)
     S = local.zeros(16)
-    sums = local.zeros(4)
+    # ONE all-reduce per iteration: [r.z, z.w, r.r, b.b | omega = P^T w]
+    nc = coarse.nc if coarse is not None else 0
+    buf = local.zeros(4 + nc)
+    sums = buf[0:4]
     if coarse is not None:
-        rc = local.zeros(coarse.nc)
-        zc = local.zeros(coarse.nc)
+        omega = buf[4:4 + nc]
+        rc = local.zeros(nc)
+        zc = local.zeros(nc)
+        sigma = local.zeros(nc)
 
-    def two_level():
-        # z = D^-1 r + P Ac^-1 P^T r: the restriction is summed over the ranks
-        # (one extra small all-reduce), the dense coarse solve is replicated
-        local.coarse_restrict(coarse, r, rc)
-        comm.allreduce_sum(rc)
+    def precondition():
+        # z = D^-1 r + P Ac^-1 rc with rc = P^T r kept current by recurrence
+        # (rc -= alpha (omega + beta sigma), mirroring r -= alpha s); the dense
+        # coarse solve is replicated on every rank
         local.coarse_solve(coarse, rc, zc)
         local.coarse_prolong(coarse, dinv, r, zc, z)
+
+    def reduce_and_scalars(first, with_b):
+        local.dots(r, z, w, b if with_b else None, sums)
+        if coarse is not None:
+            local.coarse_restrict(coarse, w, omega)
+        comm.allreduce_sum(buf)
+        local.scalars(first, sums, S)
+        if coarse is not None:
+            local.coarse_recur(coarse, S, omega, sigma, rc)
 
     comm.halo_exchange(x, plan)
     local.spmv_rows(x, w)
     local.residual(b, w, dinv, r, z)
     if coarse is not None:
-        two_level()
+        # the only separate coarse all-reduce: rc_0 = P^T r_0
+        local.coarse_restrict(coarse, r, rc)
+        comm.allreduce_sum(rc)
+        precondition()
     comm.halo_exchange(z, plan)
     local.spmv_rows(z, w)
-    local.dots(r, z, w, b, sums)
-    comm.allreduce_sum(sums)
-    local.scalars(True, sums, S)
+    reduce_and_scalars(True, True)
     host = sums.cpu()
     b2 = float(host[3])
     res2 = float(host[2])
+    sums[3:4].zero_()       # the slot rides along in every later all-reduce
     target = max(rtol * numpy.sqrt(b2), atol)
     it = 0
     while True:
@@ -305,12 +335,10 @@ def sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit, check_every,
         for _ in range(todo):
             local.update(S, dinv, w, z, p, s, x, r, coarse is None)
             if coarse is not None:
-                two_level()
+                precondition()
             comm.halo_exchange(z, plan)
             local.spmv_rows(z, w)
-            local.dots(r, z, w, None, sums)
-            comm.allreduce_sum(sums[0:3])
-            local.scalars(False, sums, S)
+            reduce_and_scalars(False, False)
         it += todo
         res2 = float(sums[2].item())
     comm.allgather_rows(x, part.bounds)

@@ -180,6 +180,11 @@ int flow_coarse_restrict_dev(const flow_coarse* C, const double* r, int r0,
                              int r1, double* rc_out, void* stream);
 int flow_coarse_solve_dev(const flow_coarse* C, const double* rc_in, double* zc,
                           void* stream);
+/* sigma = omega + beta sigma; rc -= alpha sigma (alpha, beta from S): keeps
+ * rc = P^T r current by recurrence so that omega = P^T w rides in the same
+ * all-reduce as the dot products */
+int flow_coarse_recur_dev(int nc, const double* S, const double* omega,
+                          double* sigma, double* rc, void* stream);
 int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
                             const double* r, const double* zc, double* z, int r0,
                             int r1, void* stream);

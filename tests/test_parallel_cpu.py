@@ -71,6 +71,46 @@ class NumpyLocal(object):
         r.numpy()[s] -= alpha * sn[s]
         z.numpy()[s] = dinv.numpy()[s] * r.numpy()[s]
 
+    # two-level preconditioner pieces (numpy coarse object: see NumpyCoarse)
+    def coarse_restrict(self, coarse, vec, out):
+        v = numpy.zeros(coarse.n)
+        v[self.r0:self.r1] = vec.numpy()[self.r0:self.r1]
+        out.numpy()[:] = coarse.P.T.dot(v)
+
+    def coarse_solve(self, coarse, rc, zc):
+        zc.numpy()[:] = coarse.Ainv.dot(rc.numpy())
+
+    def coarse_prolong(self, coarse, dinv, r, zc, z):
+        s = slice(self.r0, self.r1)
+        z.numpy()[s] = dinv.numpy()[s] * r.numpy()[s] \
+            + coarse.P.dot(zc.numpy())[s]
+
+    def coarse_recur(self, coarse, S, omega, sigma, rc):
+        alpha, beta = float(S[1]), float(S[2])
+        sg = sigma.numpy()
+        sg[:] = omega.numpy() + beta * sg
+        rc.numpy()[:] -= alpha * sg
+
+
+class NumpyCoarse(object):
+    '''Aggregates of 6 x 6 vertices, dense inverse of P^T A P (tests only).'''
+
+    def __init__(self, A, points, isbc):
+        import scipy.sparse as sp
+        n = A.shape[0]
+        h = 0.6 / 36
+        ix = numpy.floor(points[:, 0] / (6 * h) + 1e-9).astype(int)
+        iy = numpy.floor((points[:, 1] + 0.07) / (6 * h) + 1e-9).astype(int)
+        _, agg = numpy.unique(ix * 1000 + iy, return_inverse=True)
+        free = numpy.nonzero(~isbc)[0]
+        P = sp.csr_matrix((numpy.ones(len(free)), (free, agg[free])),
+                          shape=(n, agg.max() + 1))
+        keep = numpy.nonzero(numpy.asarray(P.sum(axis=0)).ravel() > 0)[0]
+        self.P = P[:, keep].tocsr()
+        self.Ainv = numpy.linalg.inv(self.P.T.dot(A).dot(self.P).toarray())
+        self.n = n
+        self.nc = self.P.shape[1]
+
 
 def _system():
     mesh = fem.karman_channel(36, 9)
@@ -82,6 +122,9 @@ def _system():
     b = rng.standard_normal(P.N)
     A, b = orc.symmetric_bc(A, b, bc, numpy.zeros(len(bc)))
     A.sort_indices()
+    isbc = numpy.zeros(P.N, dtype=bool)
+    isbc[bc] = True
+    _system.extra = (mesh.points, isbc)
     return A, b
 
 
@@ -93,12 +136,13 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, two_level, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         A, b = _system()
+        coarse = NumpyCoarse(A, *_system.extra) if two_level else None
         part = parallel.Partition(A.indptr, A.indices, world)
         comm = parallel.Comm(dist.group.WORLD)
         r0, r1 = part.rows(rank)
@@ -106,7 +150,8 @@ def _worker(rank, world, port, out):
         x = torch.zeros(A.shape[0], dtype=torch.float64)
         dinv = torch.from_numpy(1.0 / A.diagonal())
         its, res = parallel.sharded_cg(
-            local, comm, part, torch.from_numpy(b), x, dinv, 1e-12, 0.0, 5000, 7
+            local, comm, part, torch.from_numpy(b), x, dinv, 1e-12, 0.0, 5000, 7,
+            coarse
             )
         out[rank] = (its, res, x.numpy().copy())
     finally:
@@ -137,13 +182,14 @@ def test_partition_and_halo_plans():
         parallel.Partition(A.indptr, A.indices, 200)    # blocks thinner than band
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_sharded_cg_gloo(world):
+@pytest.mark.parametrize('world,two_level', [(2, False), (3, False), (2, True)])
+def test_sharded_cg_gloo(world, two_level):
     A, b = _system()
     ref = spla.splu(A.tocsc()).solve(b)
     manager = mp.get_context('spawn').Manager()
     out = manager.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), two_level, out), nprocs=world,
+             join=True)
     its = {out[r][0] for r in range(world)}
     assert len(its) == 1
     for r in range(world):
@@ -165,8 +211,18 @@ def test_sharded_cg_gloo(world):
         def allgather_rows(self, vec, bounds):
             pass
     x = torch.zeros(A.shape[0], dtype=torch.float64)
+    coarse = NumpyCoarse(A, *_system.extra) if two_level else None
     it1, _ = parallel.sharded_cg(
         NumpyLocal(A, 0, A.shape[0]), Solo(), part, torch.from_numpy(b), x,
-        torch.from_numpy(1.0 / A.diagonal()), 1e-12, 0.0, 5000, 7
+        torch.from_numpy(1.0 / A.diagonal()), 1e-12, 0.0, 5000, 7, coarse
         )
-    assert abs(it1 - its.pop()) <= 7
+    n_its = its.pop()
+    assert abs(it1 - n_its) <= 7
+    if two_level:
+        # the coarse space pays off also through the recurrence form
+        x0 = torch.zeros(A.shape[0], dtype=torch.float64)
+        it0, _ = parallel.sharded_cg(
+            NumpyLocal(A, 0, A.shape[0]), Solo(), part, torch.from_numpy(b), x0,
+            torch.from_numpy(1.0 / A.diagonal()), 1e-12, 0.0, 5000, 7, None
+            )
+        assert n_its < 0.75 * it0, (n_its, it0)
