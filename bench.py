@@ -129,6 +129,10 @@ def main():
                          'Newton systems (default: the library default)')
     ap.add_argument('--dt0', type=float, default=1.0e-5,
                     help='initial step size (reference driver: 1e-5)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="torch.distributed backend for N > 1: 'nccl' (= RCCL, "
+                         "one GPU per rank); 'gloo' only to rehearse several "
+                         "ranks on one GPU")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--spmv-reps', type=int, default=100)
     args = ap.parse_args()
@@ -150,7 +154,10 @@ def main():
     _hip.lib()          # fail loudly without the HIP library / a GPU
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device.get())
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device.get())
+        else:
+            dist.init_process_group('gloo')
         parallel.enable(dist.group.WORLD)
 
     def barrier():
@@ -193,7 +200,8 @@ def main():
     achieved = bytes_alg / t_spmv / 1e9
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'spmv_traffic.json')
-    if os.path.isfile(tpath):
+    # the committed PMC summary belongs to the headline workload only
+    if os.path.isfile(tpath) and args.nx == 2182 and args.ny is None:
         try:
             traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
         except Exception:                              # noqa: BLE001

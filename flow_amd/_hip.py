@@ -126,7 +126,7 @@ SYMBOLS = {
                       _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
                             _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
-    'flow_ilu0_factor': [_P(IluPlanS), _VP, _VP, _VP],
+    'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],
     'flow_ilu0_solve': [_P(IluS), _VP, _VP, _VP, _VP],
     'flow_dot3_dev': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_cg_scalars_dev': [_I, _VP, _VP, _VP],

@@ -34,31 +34,50 @@ __global__ void ilu_copy_kernel(int nnz, const int* __restrict__ src_pos,
 
 // IKJ ILU(0) of the rows [a, b) of one colour.  Every row k < i referenced here
 // has a lower colour and is final.
+// NB blocks (the two velocity blocks share the pattern) are factored by the
+// same lane: the index traffic of the sorted merge is paid once.
+template <int NB>
 __global__ void ilu_factor_colour_kernel(int a, int b,
                                          const int* __restrict__ rowptr,
                                          const int* __restrict__ cols,
                                          const int* __restrict__ diag,
-                                         double* __restrict__ lu) {
+                                         double* __restrict__ lu,
+                                         size_t lu_size) {
   const int i = a + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b) return;
   const int p0 = rowptr[i], pd = diag[i], p1 = rowptr[i + 1];
-  const double d_orig = lu[pd];
+  double d_orig[NB];
+#pragma unroll
+  for (int m = 0; m < NB; ++m) d_orig[m] = lu[m * lu_size + pd];
   for (int p = p0; p < pd; ++p) {
     const int k = cols[p];
-    const double lik = lu[p] / lu[diag[k]];
-    lu[p] = lik;
+    const int dk = diag[k];
+    double lik[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+      lik[m] = lu[m * lu_size + p] / lu[m * lu_size + dk];
+      lu[m * lu_size + p] = lik[m];
+    }
     // a_ij -= l_ik * u_kj for j > k present in both rows (both lists ascend)
-    int q = diag[k] + 1;
+    int q = dk + 1;
     const int qe = rowptr[k + 1];
     for (int t = p + 1; t < p1 && q < qe; ++t) {
       const int j = cols[t];
       while (q < qe && cols[q] < j) ++q;
-      if (q < qe && cols[q] == j) lu[t] -= lik * lu[q];
+      if (q < qe && cols[q] == j) {
+#pragma unroll
+        for (int m = 0; m < NB; ++m)
+          lu[m * lu_size + t] -= lik[m] * lu[m * lu_size + q];
+      }
     }
   }
   // pivot guard: keep the factor usable if a pivot collapses
-  const double d = lu[pd];
-  if (!(fabs(d) > 1.0e-12 * fabs(d_orig))) lu[pd] = d_orig != 0.0 ? d_orig : 1.0;
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+    const double d = lu[m * lu_size + pd];
+    if (!(fabs(d) > 1.0e-12 * fabs(d_orig[m])))
+      lu[m * lu_size + pd] = d_orig[m] != 0.0 ? d_orig[m] : 1.0;
+  }
 }
 
 // split the combined factor into the two streams and the inverse pivots
@@ -155,21 +174,33 @@ static int check_plan(const flow_ilu_plan* P) {
   return FLOW_OK;
 }
 
-static int factor(const flow_ilu_plan* P, const double* avals, double* lu,
-                  hipStream_t st) {
+static int factor(const flow_ilu_plan* P, int nblocks, const double* avals0,
+                  const double* avals1, double* lu, hipStream_t st) {
   FLOW_REQUIRE((reinterpret_cast<size_t>(lu) & 15) == 0, "lu must be 16-B aligned");
-  hipLaunchKernelGGL(ilu_copy_kernel, dim3(grid_for(P->nnz)), dim3(kBlock), 0, st,
-                     P->nnz, P->src_pos, avals, lu);
+  const size_t lus = static_cast<size_t>(P->lu_size);
+  for (int m = 0; m < nblocks; ++m)
+    hipLaunchKernelGGL(ilu_copy_kernel, dim3(grid_for(P->nnz)), dim3(kBlock), 0,
+                       st, P->nnz, P->src_pos, m == 0 ? avals0 : avals1,
+                       lu + m * lus);
   for (int c = 1; c < P->ncolors; ++c) {   // colour 0 has no lower neighbours
     const int a = P->color_ptr_host[c], b = P->color_ptr_host[c + 1];
     if (b <= a) continue;
-    hipLaunchKernelGGL(ilu_factor_colour_kernel, dim3((b - a + kBlock - 1) / kBlock),
-                       dim3(kBlock), 0, st, a, b, P->rowptr, P->cols, P->diag, lu);
+    const dim3 grid((b - a + kBlock - 1) / kBlock);
+    if (nblocks == 1)
+      hipLaunchKernelGGL((ilu_factor_colour_kernel<1>), grid, dim3(kBlock), 0, st,
+                         a, b, P->rowptr, P->cols, P->diag, lu, lus);
+    else
+      hipLaunchKernelGGL((ilu_factor_colour_kernel<2>), grid, dim3(kBlock), 0, st,
+                         a, b, P->rowptr, P->cols, P->diag, lu, lus);
   }
-  hipLaunchKernelGGL(ilu_split_kernel,
-                     dim3(grid_for(P->nnz_l + P->nnz_u + P->n)), dim3(kBlock), 0,
-                     st, P->n, P->nnz_l, P->nnz_u, P->l_pos, P->u_pos, P->diag, lu,
-                     lu + P->off_l, lu + P->off_u, lu + P->off_d);
+  for (int m = 0; m < nblocks; ++m) {
+    double* base = lu + m * lus;
+    hipLaunchKernelGGL(ilu_split_kernel,
+                       dim3(grid_for(P->nnz_l + P->nnz_u + P->n)), dim3(kBlock),
+                       0, st, P->n, P->nnz_l, P->nnz_u, P->l_pos, P->u_pos,
+                       P->diag, base, base + P->off_l, base + P->off_u,
+                       base + P->off_d);
+  }
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -215,12 +246,14 @@ int ilu_check(const flow_ilu* ilu, int op_size) {
 
 using namespace flow;
 
-extern "C" int flow_ilu0_factor(const flow_ilu_plan* plan, const double* avals,
+extern "C" int flow_ilu0_factor(const flow_ilu_plan* plan, int nblocks,
+                                const double* avals0, const double* avals1,
                                 double* lu, void* stream) {
   int rc = check_plan(plan);
   if (rc) return rc;
-  FLOW_REQUIRE(avals && lu && avals != lu, "ilu factor pointers");
-  return factor(plan, avals, lu, as_stream(stream));
+  FLOW_REQUIRE(nblocks == 1 || nblocks == 2, "ilu blocks");
+  FLOW_REQUIRE(avals0 && lu && (nblocks == 1 || avals1), "ilu factor pointers");
+  return factor(plan, nblocks, avals0, avals1, lu, as_stream(stream));
 }
 
 extern "C" int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,

@@ -188,14 +188,13 @@ class Ilu0(object):
     def refactor(self, A):
         lib = _hip.lib()
         assert plan_for(A.layout) is self.plan
-        size = self.plan.lu_size
-        for k, p in enumerate(self.planes):
-            _hip.check(lib.flow_ilu0_factor(
-                ctypes.byref(self.plan.struct),
-                _hip.f64(A.plane(p), self.plan.nnz),
-                _hip.f64(self.lu[k * size:(k + 1) * size], size),
-                _hip.stream()
-                ))
+        nb = len(self.planes)
+        _hip.check(lib.flow_ilu0_factor(
+            ctypes.byref(self.plan.struct), nb,
+            _hip.f64(A.plane(self.planes[0]), self.plan.nnz),
+            _hip.f64(A.plane(self.planes[-1]), self.plan.nnz),
+            _hip.f64(self.lu, nb * self.plan.lu_size), _hip.stream()
+            ))
         return self
 
     def factor_values(self, k=0):

@@ -435,11 +435,12 @@ def project(f, V, tol=1.0e-14):
     return out
 
 
-def project_magnitude(u, mode=0, tol=1.0e-12):
+def project_magnitude(u, mode=0, tol=1.0e-12, initial_guess=None):
     '''`project(sqrt(ux**2 + uy**2), FunctionSpace(mesh, 'Lagrange', k))`
     (mode 0; tests/test_karman_vortex_street.py:262-267) or
     `project(abs(ux) + abs(uy), Q)` (mode 1; tests/test_boussinesq.py:268-272)
-    for a vector field u of degree k.'''
+    for a vector field u of degree k.  `initial_guess`: a previous projection
+    to start the mass solve from (step-size controllers call this every step).'''
     lib = _hip.lib()
     W = u.function_space()
     assert W.dim == 2
@@ -458,8 +459,10 @@ def project_magnitude(u, mode=0, tol=1.0e-12):
     if key not in lay._dev:
         lay._dev[key] = M.diag_inv()
     out = Function(S)
+    if initial_guess is not None:
+        out.assign(initial_guess)
     krylov_solve('cg', M, b, out.data, tol, maxit=1000, dinv=lay._dev[key],
-                 check_every=10)
+                 check_every=4)
     return out
 
 

@@ -134,7 +134,10 @@ typedef struct {
   int nblocks;               /* 1 (scalar) or 2 (diagonal blocks of a 2-field op) */
   const double* lu;          /* nblocks * lu_size */
 } flow_ilu;
-int flow_ilu0_factor(const flow_ilu_plan* plan, const double* avals, double* lu,
+/* factor nblocks (1|2) value planes over the plan's pattern into lu
+ * (nblocks * lu_size); the blocks share one pass over the index structure */
+int flow_ilu0_factor(const flow_ilu_plan* plan, int nblocks,
+                     const double* avals0, const double* avals1, double* lu,
                      void* stream);
 /* z = blockdiag(LU)^-1 r in the ORIGINAL numbering; r, z, work: nblocks*n */
 int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
