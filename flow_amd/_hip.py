@@ -55,6 +55,7 @@ class IluPlanS(ctypes.Structure):
         ('nnz_l', ctypes.c_int), ('nnz_u', ctypes.c_int),
         ('off_l', ctypes.c_int), ('off_u', ctypes.c_int),
         ('off_d', ctypes.c_int), ('lu_size', ctypes.c_int),
+        ('max_row', ctypes.c_int),
         ('color_ptr_host', ctypes.c_void_p),
         ('l_rbptr_host', ctypes.c_void_p), ('u_rbptr_host', ctypes.c_void_p),
         ('rowptr', ctypes.c_void_p), ('cols', ctypes.c_void_p),

@@ -152,7 +152,8 @@ def compute_boussinesq(target_time, nx=16, supg=False, verbose=False,
                 break
 
             du = fem.Function(W)
-            du.data.copy_(u1.data - u_prev.data)
+            du.assign(u1)
+            fem.ops.axpby(-1.0, u_prev.data, 1.0, du.data)
             u_diff_norm = fem.project_magnitude(du, mode=1).vector().norm('linf')
             theta_diff = fem.Function(Q)
             theta_diff.vector()[:] = theta1.vector() - theta_prev.vector()

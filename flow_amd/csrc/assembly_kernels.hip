@@ -451,7 +451,6 @@ __global__ __launch_bounds__(kBlock) void momentum_jacobian_kernel(
   const double c1 = -prm.dt / prm.rho * prm.theta_i;
   const double hr = 0.5 * prm.rho;
   const double mu = prm.mu;
-  const size_t plane = static_cast<size_t>(NP) * nc;
 
   for (int pr = grp; pr < NP; pr += 4) {
     const int i = pr / NL, j = pr % NL;       // row local dof i, column j
@@ -520,12 +519,47 @@ __global__ __launch_bounds__(kBlock) void momentum_jacobian_kernel(
       }
     }
     if (active) {
-      const size_t base = static_cast<size_t>(pr) * nc + c;
-      scratch[0 * plane + base] = B[0][0];
-      scratch[1 * plane + base] = B[0][1];
-      scratch[2 * plane + base] = B[1][0];
-      scratch[3 * plane + base] = B[1][1];
+      // cell-major scratch [cell][ij][plane]: the 2x2 block of one (cell, ij)
+      // is one aligned 32-byte sector, and the gather below finds all entries
+      // of the few cells around a row close together
+      double2* out = reinterpret_cast<double2*>(
+          scratch + (static_cast<size_t>(c) * NP + pr) * 4);
+      out[0] = make_double2(B[0][0], B[0][1]);
+      out[1] = make_double2(B[1][0], B[1][1]);
     }
+  }
+}
+
+// phase 2 for the Jacobian: per CSR nonzero, sum the 32-byte 2x2 blocks of its
+// contributions (src[t] = ij*nc + cell, the shared contribution map) and write
+// the four value planes
+__global__ void gather_blocks_kernel(int nnz, int nc, int np,
+                                     const int* __restrict__ ptr,
+                                     const int* __restrict__ src,
+                                     const double* __restrict__ scratch,
+                                     size_t out_stride,
+                                     double* __restrict__ out) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nnz;
+       k += gridDim.x * blockDim.x) {
+    const int a = ptr[k];
+    const int b = ptr[k + 1];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int t = a; t < b; ++t) {
+      const int s = src[t];
+      const int ij = s / nc;
+      const int cell = s - ij * nc;
+      const double2* blk = reinterpret_cast<const double2*>(
+          scratch + (static_cast<size_t>(cell) * np + ij) * 4);
+      const double2 v0 = blk[0], v1 = blk[1];
+      s0 += v0.x;
+      s1 += v0.y;
+      s2 += v1.x;
+      s3 += v1.y;
+    }
+    out[k] = s0;
+    out[out_stride + k] = s1;
+    out[2 * out_stride + k] = s2;
+    out[3 * out_stride + k] = s3;
   }
 }
 
@@ -917,10 +951,11 @@ extern "C" int flow_assemble_momentum(
     FLOW_DISPATCH_DEG(W->deg, momentum_jacobian_kernel,
                       dim3((mesh->nc + 63) / 64), st, mesh->nc, mesh->xy,
                       W->cell_dofs, W->n, bfmask, ui, *prm, scratch);
-    if ((rc = gather(W->nnz, 4, W->cptr, W->csrc, scratch,
-                     static_cast<size_t>(nl) * nl * mesh->nc, Jvals, st,
-                     j_plane_stride)))
-      return rc;
+    hipLaunchKernelGGL(gather_blocks_kernel,
+                       dim3(grid_for(W->nnz, kBlock, 1 << 20)), dim3(kBlock), 0,
+                       st, W->nnz, mesh->nc, nl * nl, W->cptr, W->csrc, scratch,
+                       j_plane_stride, Jvals);
+    FLOW_CHECK_LAUNCH();
   }
   return FLOW_OK;
 }

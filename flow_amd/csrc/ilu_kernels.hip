@@ -80,6 +80,91 @@ __global__ void ilu_factor_colour_kernel(int a, int b,
   }
 }
 
+// Same factorisation with 8 lanes per row: every lane keeps up to kSlots of the
+// row's entries (column + NB values) in registers, the L entries are
+// eliminated one after the other (wave-uniform within the 8-lane group), the
+// multiplier is broadcast with a shuffle, and each lane locates its own
+// columns in row k's U part by bisection -- ~4 dependent loads per L entry
+// instead of a ~13-step sequential merge, and 8x more loads in flight.
+constexpr int kSub = 8;
+constexpr int kSlots = 6;     // rows up to 48 entries; longer rows: scalar kernel
+
+template <int NB>
+__global__ __launch_bounds__(kBlock) void ilu_factor_colour_sub_kernel(
+    int a, int b, const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const int* __restrict__ diag, double* __restrict__ lu, size_t lu_size) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = a + gid / kSub;
+  const int sub = threadIdx.x % kSub;
+  const bool live = i < b;
+  const int ii = live ? i : b - 1;
+  const int p0 = rowptr[ii], pd = diag[ii], p1 = rowptr[ii + 1];
+  int col[kSlots];
+  double val[kSlots][NB];
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    const int t = p0 + sub + s * kSub;
+    col[s] = t < p1 ? cols[t] : -1;
+#pragma unroll
+    for (int m = 0; m < NB; ++m) val[s][m] = t < p1 ? lu[m * lu_size + t] : 0.0;
+  }
+  double d_orig[NB];
+#pragma unroll
+  for (int m = 0; m < NB; ++m) d_orig[m] = lu[m * lu_size + pd];
+
+  for (int p = p0; p < pd; ++p) {            // uniform over the 8 lanes of a row
+    const int k = cols[p];
+    const int dk = diag[k];
+    const int qb = dk + 1, qe = rowptr[k + 1];
+    const int owner = (p - p0) % kSub, slot = (p - p0) / kSub;
+    double lik[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+      double mine = 0.0;
+#pragma unroll
+      for (int s = 0; s < kSlots; ++s)
+        if (s == slot) mine = val[s][m];
+      mine /= lu[m * lu_size + dk];
+      lik[m] = __shfl(mine, owner, kSub);
+    }
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+      if (s == slot && sub == owner) {
+#pragma unroll
+        for (int m = 0; m < NB; ++m) val[s][m] = lik[m];
+      }
+      const int j = col[s];
+      if (j > k) {
+        // bisection for j in cols[qb, qe)
+        int lo = qb, hi = qe;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (cols[mid] < j) lo = mid + 1; else hi = mid;
+        }
+        if (lo < qe && cols[lo] == j) {
+#pragma unroll
+          for (int m = 0; m < NB; ++m) val[s][m] -= lik[m] * lu[m * lu_size + lo];
+        }
+      }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    const int t = p0 + sub + s * kSub;
+    if (t < p1) {
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        double v = val[s][m];
+        // pivot guard: keep the factor usable if a pivot collapses
+        if (t == pd && !(fabs(v) > 1.0e-12 * fabs(d_orig[m])))
+          v = d_orig[m] != 0.0 ? d_orig[m] : 1.0;
+        lu[m * lu_size + t] = v;
+      }
+    }
+  }
+}
+
 // split the combined factor into the two streams and the inverse pivots
 __global__ void ilu_split_kernel(int n, int nnz_l, int nnz_u,
                                  const int* __restrict__ l_pos,
@@ -185,6 +270,17 @@ static int factor(const flow_ilu_plan* P, int nblocks, const double* avals0,
   for (int c = 1; c < P->ncolors; ++c) {   // colour 0 has no lower neighbours
     const int a = P->color_ptr_host[c], b = P->color_ptr_host[c + 1];
     if (b <= a) continue;
+    if (P->max_row <= kSub * kSlots) {
+      // 8 lanes per row
+      const dim3 grid(((b - a) * kSub + kBlock - 1) / kBlock);
+      if (nblocks == 1)
+        hipLaunchKernelGGL((ilu_factor_colour_sub_kernel<1>), grid, dim3(kBlock),
+                           0, st, a, b, P->rowptr, P->cols, P->diag, lu, lus);
+      else
+        hipLaunchKernelGGL((ilu_factor_colour_sub_kernel<2>), grid, dim3(kBlock),
+                           0, st, a, b, P->rowptr, P->cols, P->diag, lu, lus);
+      continue;
+    }
     const dim3 grid((b - a + kBlock - 1) / kBlock);
     if (nblocks == 1)
       hipLaunchKernelGGL((ilu_factor_colour_kernel<1>), grid, dim3(kBlock), 0, st,

@@ -150,6 +150,7 @@ class IluPlan(object):
         self.struct = _hip.IluPlanS(
             n, nnz, nc, self.nnz_l, self.nnz_u,
             self.off_l, self.off_u, self.off_d, self.lu_size,
+            int(numpy.diff(rowptr).max()),
             self.colour_ptr.ctypes.data_as(ctypes.c_void_p),
             self.l_rbptr.ctypes.data_as(ctypes.c_void_p),
             self.u_rbptr.ctypes.data_as(ctypes.c_void_p),

@@ -90,7 +90,8 @@ class Heat(object):
             if int(status.item()) != 0:
                 # the reference's C++ Expression throws (stabilization.py:132-140)
                 raise RuntimeError('SUPG stabilization: tau > 1e3')
-            self.M = ops.Matrix(lay, 0, lumped.vals + msupg)
+            ops.axpby(1.0, lumped.vals, 1.0, msupg)      # M_lumped + M_supg
+            self.M = ops.Matrix(lay, 0, msupg)
         else:
             self.M = lumped
 
@@ -131,8 +132,9 @@ class Heat(object):
         lib = _hip.lib()
         lay = self.V.layout
         st = _hip.stream()
-        A = ops.Matrix(lay, 0, float(alpha) * self.M.vals
-                       + float(beta) * self.A.vals)
+        A = ops.Matrix(lay, 0)
+        ops.axpby(float(alpha), self.M.vals, 0.0, A.vals)
+        ops.axpby(float(beta), self.A.vals, 1.0, A.vals)
         # The reference computes right_hand_side = -beta*self.b + b but then
         # solves with the raw `b` (reference :109-121); identical when
         # self.b = 0.  Kept.

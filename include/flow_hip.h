@@ -112,6 +112,7 @@ typedef struct {
   int n, nnz, ncolors;
   int nnz_l, nnz_u;
   int off_l, off_u, off_d, lu_size;
+  int max_row;               /* longest row of the pattern */
   const int* color_ptr_host; /* ncolors+1 (host): row range of every colour */
   const int* l_rbptr_host;   /* ncolors+1 (host): first L row block per colour */
   const int* u_rbptr_host;   /* ncolors+1 (host): first U row block per colour */
