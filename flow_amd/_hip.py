@@ -45,6 +45,7 @@ class CoarseS(ctypes.Structure):
         ('agg_ptr', ctypes.c_void_p),
         ('agg_dofs', ctypes.c_void_p),
         ('agg_of', ctypes.c_void_p),
+        ('lda', ctypes.c_int),
         ('Ainv', ctypes.c_void_p),
         ]
 
@@ -234,6 +235,10 @@ def _ptr(t, dtype, numel=None, name='operand'):
 
 def f64(t, numel=None, name='fp64 operand'):
     return _ptr(t, torch.float64, numel, name)
+
+
+def f32(t, numel=None, name='fp32 operand'):
+    return _ptr(t, torch.float32, numel, name)
 
 
 def i32(t, numel=None, name='int32 operand'):

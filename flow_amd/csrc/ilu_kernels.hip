@@ -206,10 +206,20 @@ __global__ __launch_bounds__(kBlock) void ilu_sweep_kernel(
   const int k1 = rowptr[r1];
   const int ka = k0 & ~1;
   const int row = r0 + threadIdx.x;
-  int a = 0, b = 0;
+  int a = 0, b = 0, o = 0;
+  // everything the row's final update needs is requested up front, so that
+  // these (dependent) loads are in flight while the triangle streams in
+  double rhs = 0.0, di = 0.0;
   if (row < r1) {
     a = rowptr[row] - ka;
     b = rowptr[row + 1] - ka;
+    o = old_of_new[row];
+    if (!BWD) {
+      rhs = r[blk * n + o];
+    } else {
+      rhs = y[row];
+      di = dinv[row];
+    }
   }
   const double2* __restrict__ v2p = reinterpret_cast<const double2*>(vals + ka);
   const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
@@ -230,11 +240,10 @@ __global__ __launch_bounds__(kBlock) void ilu_sweep_kernel(
   if (row < r1) {
     double s = 0.0;
     for (int k = a; k < b; ++k) s += prod[k];
-    const int o = old_of_new[row];
     if (!BWD) {
-      y[row] = r[blk * n + o] - s;
+      y[row] = rhs - s;
     } else {
-      const double yi = (y[row] - s) * dinv[row];
+      const double yi = (rhs - s) * di;
       y[row] = yi;
       z[blk * n + o] = yi;
     }

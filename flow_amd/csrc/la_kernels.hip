@@ -37,12 +37,15 @@ constexpr int kTile = 2 * kBlock * kPairs;      // LDS products per workgroup
 static_assert(FLOW_SPMV_ROWS_PER_BLOCK == kBlock, "one lane per row");
 static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTile - 2, "tile minus alignment slack");
 
-// scalar plane(s): blockIdx.y selects the component of a block-diagonal operator
+// scalar plane(s): blockIdx.y selects the component of a block-diagonal operator.
+// DOT: the workgroup also leaves its share of x.y (= x.Ax) in
+// dpart[blockIdx.y * gridDim.x + blockIdx.x] (CG's z.w without another pass).
+template <bool DOT>
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
     int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals0, const double* __restrict__ vals1,
     const int* __restrict__ rowblocks, const double* __restrict__ x,
-    double* __restrict__ y) {
+    double* __restrict__ y, double* __restrict__ dpart) {
   __shared__ double prod[kTile];
   const double* __restrict__ vals = blockIdx.y == 0 ? vals0 : vals1;
   x += static_cast<size_t>(blockIdx.y) * n;
@@ -89,20 +92,27 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
     }
   }
   __syncthreads();
+  double t = 0.0;
   if (r < r1) {
     double s = 0.0;
     for (int k = a; k < b; ++k) s += prod[k];
     y[r] = s;
+    if (DOT) t = s * x[r];
+  }
+  if (DOT) {
+    t = block_sum(t);
+    if (threadIdx.x == 0) dpart[blockIdx.y * gridDim.x + blockIdx.x] = t;
   }
 }
 
 // full 2x2 blocks over one scalar pattern (Newton Jacobian)
+template <bool DOT>
 __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
     int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vxx, const double* __restrict__ vxy,
     const double* __restrict__ vyx, const double* __restrict__ vyy,
     const int* __restrict__ rowblocks, const double* __restrict__ x,
-    double* __restrict__ y) {
+    double* __restrict__ y, double* __restrict__ dpart) {
   __shared__ double prod0[kTile];
   __shared__ double prod1[kTile];
   const int r0 = rowblocks[blockIdx.x];
@@ -137,6 +147,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
     }
   }
   __syncthreads();
+  double t = 0.0;
   if (r < r1) {
     double s0 = 0.0, s1 = 0.0;
     for (int k = a; k < b; ++k) {
@@ -145,6 +156,11 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
     }
     y[r] = s0;
     y[n + r] = s1;
+    if (DOT) t = s0 * x[r] + s1 * x[n + r];
+  }
+  if (DOT) {
+    t = block_sum(t);
+    if (threadIdx.x == 0) dpart[blockIdx.x] = t;
   }
 }
 
@@ -168,18 +184,33 @@ static inline int op_size(const flow_operator* A) {
   return A->kind == 0 ? A->n : 2 * A->n;
 }
 
+// number of x.Ax partials apply() leaves in dpart
+static inline int dot_parts(const flow_operator* A) {
+  return A->kind == 1 ? 2 * A->nblocks : A->nblocks;
+}
+
+// y = A x; with dpart != nullptr also the dot_parts(A) workgroup shares of x.y
 static int apply(const flow_operator* A, const double* x, double* y,
-                 hipStream_t st) {
+                 hipStream_t st, double* dpart = nullptr) {
+  const dim3 grid(A->nblocks, A->kind == 1 ? 2 : 1);
+  const double* v1 = A->kind == 1 ? A->vals[1] : A->vals[0];
   if (A->kind == 2) {
-    hipLaunchKernelGGL(spmv_stream_block2_kernel, dim3(A->nblocks), dim3(kBlock),
-                       0, st, A->n, A->rowptr, A->cols, A->vals[0], A->vals[1],
-                       A->vals[2], A->vals[3], A->rowblocks, x, y);
+    if (dpart)
+      hipLaunchKernelGGL(spmv_stream_block2_kernel<true>, grid, dim3(kBlock), 0,
+                         st, A->n, A->rowptr, A->cols, A->vals[0], A->vals[1],
+                         A->vals[2], A->vals[3], A->rowblocks, x, y, dpart);
+    else
+      hipLaunchKernelGGL(spmv_stream_block2_kernel<false>, grid, dim3(kBlock), 0,
+                         st, A->n, A->rowptr, A->cols, A->vals[0], A->vals[1],
+                         A->vals[2], A->vals[3], A->rowblocks, x, y, dpart);
+  } else if (dpart) {
+    hipLaunchKernelGGL(spmv_stream_kernel<true>, grid, dim3(kBlock), 0, st, A->n,
+                       A->rowptr, A->cols, A->vals[0], v1, A->rowblocks, x, y,
+                       dpart);
   } else {
-    hipLaunchKernelGGL(spmv_stream_kernel,
-                       dim3(A->nblocks, A->kind == 1 ? 2 : 1), dim3(kBlock), 0,
-                       st, A->n, A->rowptr, A->cols, A->vals[0],
-                       A->kind == 1 ? A->vals[1] : A->vals[0], A->rowblocks, x,
-                       y);
+    hipLaunchKernelGGL(spmv_stream_kernel<false>, grid, dim3(kBlock), 0, st,
+                       A->n, A->rowptr, A->cols, A->vals[0], v1, A->rowblocks, x,
+                       y, dpart);
   }
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
@@ -288,15 +319,17 @@ __global__ void residual_kernel(int n, const double* __restrict__ b,
 }
 
 // Chronopoulos-Gear CG scalars from (gamma_new, delta, r.r) partials
+// gamma = r.z and r.r: nparts partials each in partial[0..) / [2*kRedBlocks..);
+// delta = z.w: ndelta partials in dpart (left there by the SpMV itself)
 __global__ __launch_bounds__(kBlock) void cg_scalar_kernel(
-    int nparts, int first, const double* __restrict__ partial,
-    double* __restrict__ S) {
+    int nparts, int ndelta, int first, const double* __restrict__ partial,
+    const double* __restrict__ dpart, double* __restrict__ S) {
   double g = 0.0, d = 0.0, rr = 0.0;
   for (int i = threadIdx.x; i < nparts; i += kBlock) {
     g += partial[i];
-    d += partial[kRedBlocks + i];
     rr += partial[2 * kRedBlocks + i];
   }
+  for (int i = threadIdx.x; i < ndelta; i += kBlock) d += dpart[i];
   g = block_sum(g);
   d = block_sum(d);
   rr = block_sum(rr);
@@ -321,14 +354,17 @@ __global__ __launch_bounds__(kBlock) void cg_scalar_kernel(
 
 // p = z + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; z = dinv r
 // (want_z = 0: z is produced afterwards by the two-level preconditioner)
-__global__ void cg_update_kernel(int n, const double* __restrict__ S,
-                                 const double* __restrict__ dinv,
-                                 const double* __restrict__ w,
-                                 double* __restrict__ z, double* __restrict__ p,
-                                 double* __restrict__ s, double* __restrict__ x,
-                                 double* __restrict__ r, int want_z) {
+// DOTS (needs want_z, gridDim.x <= kRedBlocks): the block's shares of r.z and
+// r.r go to partial[blockIdx.x] / partial[2*kRedBlocks + blockIdx.x].
+template <bool DOTS>
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(
+    int n, const double* __restrict__ S, const double* __restrict__ dinv,
+    const double* __restrict__ w, double* __restrict__ z, double* __restrict__ p,
+    double* __restrict__ s, double* __restrict__ x, double* __restrict__ r,
+    int want_z, double* __restrict__ partial) {
   const double alpha = S[kAlpha];
   const double beta = S[kBeta];
+  double g = 0.0, rr = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
     const double pi = z[i] + beta * p[i];
@@ -338,7 +374,22 @@ __global__ void cg_update_kernel(int n, const double* __restrict__ S,
     x[i] += alpha * pi;
     const double ri = r[i] - alpha * si;
     r[i] = ri;
-    if (want_z) z[i] = dinv ? dinv[i] * ri : ri;
+    if (want_z) {
+      const double zi = dinv ? dinv[i] * ri : ri;
+      z[i] = zi;
+      if (DOTS) {
+        g += ri * zi;
+        rr += ri * ri;
+      }
+    }
+  }
+  if (DOTS) {
+    g = block_sum(g);
+    rr = block_sum(rr);
+    if (threadIdx.x == 0) {
+      partial[blockIdx.x] = g;
+      partial[2 * kRedBlocks + blockIdx.x] = rr;
+    }
   }
 }
 
@@ -364,21 +415,35 @@ __global__ __launch_bounds__(kBlock) void coarse_restrict_kernel(
   }
 }
 
-// zc = Ainv rc (dense, row-major, symmetric): one wavefront per row
+// zc = Ainv rc (dense fp32 rows of lda floats, fp64 accumulation): one
+// wavefront per row, float4 loads; rc 16-byte aligned, nc entries.
 __global__ __launch_bounds__(kBlock) void coarse_gemv_kernel(
-    int nc, const double* __restrict__ Ainv, const double* __restrict__ rc,
-    double* __restrict__ zc) {
+    int nc, int lda, const float* __restrict__ Ainv,
+    const double* __restrict__ rc, double* __restrict__ zc) {
   const int lane = threadIdx.x & 63;
+  const int nq = lda >> 2;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nc;
        row += gridDim.x * 4) {
-    const double* __restrict__ a = Ainv + static_cast<size_t>(row) * nc;
+    const float4* __restrict__ a =
+        reinterpret_cast<const float4*>(Ainv + static_cast<size_t>(row) * lda);
+    const double2* __restrict__ x = reinterpret_cast<const double2*>(rc);
     double s0 = 0.0, s1 = 0.0;
-    int j = lane;
-    for (; j + 64 < nc; j += 128) {
-      s0 += a[j] * rc[j];
-      s1 += a[j + 64] * rc[j + 64];
+    for (int q = lane; q < nq; q += 64) {
+      const float4 v = a[q];
+      double2 x0, x1;
+      if (4 * q + 3 < nc) {
+        x0 = x[2 * q];
+        x1 = x[2 * q + 1];
+      } else {   // last quad of a row whose length is not a multiple of 4
+        const int j = 4 * q;
+        x0.x = rc[j];
+        x0.y = (j + 1 < nc) ? rc[j + 1] : 0.0;
+        x1.x = (j + 2 < nc) ? rc[j + 2] : 0.0;
+        x1.y = 0.0;
+      }
+      s0 += static_cast<double>(v.x) * x0.x + static_cast<double>(v.z) * x1.x;
+      s1 += static_cast<double>(v.y) * x0.y + static_cast<double>(v.w) * x1.y;
     }
-    if (j < nc) s0 += a[j] * rc[j];
     double sum = s0 + s1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
@@ -387,15 +452,32 @@ __global__ __launch_bounds__(kBlock) void coarse_gemv_kernel(
 }
 
 // z = dinv r + zc[agg_of]  on dofs [0, n) of pre-offset arrays
-__global__ void coarse_prolong_kernel(int n, const int* __restrict__ agg_of,
-                                      const double* __restrict__ dinv,
-                                      const double* __restrict__ r,
-                                      const double* __restrict__ zc,
-                                      double* __restrict__ z) {
+// DOTS (gridDim.x <= kRedBlocks): also the block's shares of r.z and r.r, as
+// in cg_update_kernel
+template <bool DOTS>
+__global__ __launch_bounds__(kBlock) void coarse_prolong_kernel(
+    int n, const int* __restrict__ agg_of, const double* __restrict__ dinv,
+    const double* __restrict__ r, const double* __restrict__ zc,
+    double* __restrict__ z, double* __restrict__ partial) {
+  double g = 0.0, rr = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
     const int a = agg_of[i];
-    z[i] = dinv[i] * r[i] + (a >= 0 ? zc[a] : 0.0);
+    const double ri = r[i];
+    const double zi = dinv[i] * ri + (a >= 0 ? zc[a] : 0.0);
+    z[i] = zi;
+    if (DOTS) {
+      g += ri * zi;
+      rr += ri * ri;
+    }
+  }
+  if (DOTS) {
+    g = block_sum(g);
+    rr = block_sum(rr);
+    if (threadIdx.x == 0) {
+      partial[blockIdx.x] = g;
+      partial[2 * kRedBlocks + blockIdx.x] = rr;
+    }
   }
 }
 
@@ -403,19 +485,34 @@ static int check_coarse(const flow_coarse* C, int n) {
   FLOW_REQUIRE(C->nc > 0 && C->n == n, "coarse space size");
   FLOW_REQUIRE(C->agg_ptr && C->agg_dofs && C->agg_of && C->Ainv,
                "coarse space pointers");
+  FLOW_REQUIRE(C->lda >= C->nc && C->lda % 4 == 0 &&
+                   reinterpret_cast<uintptr_t>(C->Ainv) % 16 == 0,
+               "coarse inverse: row stride must be a multiple of 4 floats, "
+               "base 16-byte aligned");
   return FLOW_OK;
 }
 
-// z = M^-1 r with the two-level preconditioner; rc, zc: nc doubles each
+// z = M^-1 r with the two-level preconditioner; rc, zc: lda doubles each.
+// partial != nullptr: the prolongation also leaves the shares of r.z and r.r
+// of its *nparts workgroups there.
 static int two_level(const flow_coarse* C, const double* dinv, const double* r,
-                     double* z, double* rc, double* zc, hipStream_t st) {
+                     double* z, double* rc, double* zc, hipStream_t st,
+                     double* partial = nullptr, int* nparts = nullptr) {
   const int g = grid_for(C->nc, 4, kMaxGrid);
   hipLaunchKernelGGL(coarse_restrict_kernel, dim3(g), dim3(kBlock), 0, st, C->nc,
                      C->agg_ptr, C->agg_dofs, r, 0, C->n, rc);
   hipLaunchKernelGGL(coarse_gemv_kernel, dim3(g), dim3(kBlock), 0, st, C->nc,
-                     C->Ainv, rc, zc);
-  hipLaunchKernelGGL(coarse_prolong_kernel, dim3(grid_for(C->n)), dim3(kBlock),
-                     0, st, C->n, C->agg_of, dinv, r, zc, z);
+                     C->lda, C->Ainv, rc, zc);
+  if (partial) {
+    const int gp = grid_for(C->n, kBlock, kRedBlocks);
+    hipLaunchKernelGGL(coarse_prolong_kernel<true>, dim3(gp), dim3(kBlock), 0,
+                       st, C->n, C->agg_of, dinv, r, zc, z, partial);
+    *nparts = gp;
+  } else {
+    hipLaunchKernelGGL(coarse_prolong_kernel<false>, dim3(grid_for(C->n)),
+                       dim3(kBlock), 0, st, C->n, C->agg_of, dinv, r, zc, z,
+                       partial);
+  }
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -439,12 +536,24 @@ static int read_slot(const double* S, int slot, double* host, hipStream_t st) {
   return FLOW_OK;
 }
 
+// Work of cg(): [reductions | r z w p s | z.w partials of the SpMV | rc zc]
+static inline size_t cg_work_len(const flow_operator* A, const flow_coarse* C) {
+  const size_t N = op_size(A);
+  return FLOW_REDUCE_WORK + 5 * N + dot_parts(A) + 2 +
+         (C ? 2 * static_cast<size_t>(C->lda) : 0);
+}
+
+// Chronopoulos-Gear CG.  Per iteration: update (x, r, p, s) -> preconditioner
+// -> SpMV -> scalars; the three dot products ride in those kernels (r.z and r.r
+// in whichever kernel produces z, z.w in the SpMV), so no vector is re-read for
+// a reduction.
 static int cg(const flow_operator* A, const double* dinv,
               const flow_coarse* C, const double* b,
               double* x, double rtol, double atol, int maxit, int check_every,
               double* work, int* iters_host, double* resid_host,
               hipStream_t st) {
   const int N = op_size(A);
+  const int nd = dot_parts(A);
   double* partial = work;
   double* S = work + 3 * kRedBlocks;
   double* r = work + FLOW_REDUCE_WORK;
@@ -452,9 +561,12 @@ static int cg(const flow_operator* A, const double* dinv,
   double* w = z + N;
   double* p = w + N;
   double* s = p + N;
-  double* crc = s + N;                    // coarse vectors (two-level only)
-  double* czc = crc + (C ? C->nc : 0);
+  double* dpart = s + N;
+  // coarse vectors (two-level only), 16-byte aligned
+  double* crc = dpart + nd + ((N + nd) & 1);
+  double* czc = crc + (C ? C->lda : 0);
   const int gv = grid_for(N);
+  const int gu = grid_for(N, kBlock, kRedBlocks);   // update with fused dots
   int np = 0, rc;
 
   FLOW_CHECK_HIP(hipMemsetAsync(S, 0, kNumSlots * sizeof(double), st));
@@ -468,10 +580,10 @@ static int cg(const flow_operator* A, const double* dinv,
   hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(kBlock), 0, st, N, b, w,
                      dinv, r, z);
   if (C && (rc = two_level(C, dinv, r, z, crc, czc, st))) return rc;
-  if ((rc = apply(A, z, w, st))) return rc;
+  if ((rc = apply(A, z, w, st, dpart))) return rc;
   if ((rc = dots(N, 3, r, z, z, w, r, r, partial, &np, st))) return rc;
-  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, 1,
-                     partial, S);
+  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, nd, 1,
+                     partial, dpart, S);
   FLOW_CHECK_LAUNCH();
 
   double b2 = 0.0, res2 = 0.0;
@@ -496,13 +608,19 @@ static int cg(const flow_operator* A, const double* dinv,
     }
     const int todo = (maxit - it < check_every) ? maxit - it : check_every;
     for (int k = 0; k < todo; ++k) {
-      hipLaunchKernelGGL(cg_update_kernel, dim3(gv), dim3(kBlock), 0, st, N, S,
-                         dinv, w, z, p, s, x, r, C ? 0 : 1);
-      if (C && (rc = two_level(C, dinv, r, z, crc, czc, st))) return rc;
-      if ((rc = apply(A, z, w, st))) return rc;
-      if ((rc = dots(N, 3, r, z, z, w, r, r, partial, &np, st))) return rc;
-      hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, 0,
-                         partial, S);
+      if (C) {
+        hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
+                           st, N, S, dinv, w, z, p, s, x, r, 0, partial);
+        if ((rc = two_level(C, dinv, r, z, crc, czc, st, partial, &np)))
+          return rc;
+      } else {
+        hipLaunchKernelGGL(cg_update_kernel<true>, dim3(gu), dim3(kBlock), 0, st,
+                           N, S, dinv, w, z, p, s, x, r, 1, partial);
+        np = gu;
+      }
+      if ((rc = apply(A, z, w, st, dpart))) return rc;
+      hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, nd,
+                         0, partial, dpart, S);
     }
     FLOW_CHECK_LAUNCH();
     it += todo;
@@ -690,7 +808,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 4; }
+extern "C" int flow_abi_version(void) { return 5; }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {
@@ -795,10 +913,12 @@ extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
     FLOW_REQUIRE(dinv != nullptr, "two-level preconditioner needs dinv");
     FLOW_REQUIRE(A->kind == 0, "two-level preconditioner: scalar operators");
     if ((rc = check_coarse(coarse, A->n))) return rc;
-    FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK + 5 * (size_t)A->n +
-                                 2 * (size_t)coarse->nc,
-                 "solver workspace too small for the coarse vectors");
   }
+  FLOW_REQUIRE(work_len >= cg_work_len(A, coarse),
+               "solver workspace too small (FLOW_REDUCE_WORK + 5 N + SpMV "
+               "workgroups + 2 [+ 2 lda])");
+  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(work) % 16 == 0,
+               "solver workspace must be 16-byte aligned");
   return cg(A, dinv, coarse, b, x, rtol, atol, maxit, check_every, work,
             iters_host, resid_host, as_stream(stream));
 }
@@ -818,9 +938,13 @@ extern "C" int flow_coarse_restrict_dev(const flow_coarse* C, const double* r,
 extern "C" int flow_coarse_solve_dev(const flow_coarse* C, const double* rc_in,
                                      double* zc, void* stream) {
   FLOW_REQUIRE(C && rc_in && zc && rc_in != zc, "coarse solve");
+  int rc = check_coarse(C, C->n);
+  if (rc) return rc;
+  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(rc_in) % 16 == 0,
+               "coarse residual must be 16-byte aligned");
   hipLaunchKernelGGL(coarse_gemv_kernel, dim3(grid_for(C->nc, 4, kMaxGrid)),
-                     dim3(kBlock), 0, as_stream(stream), C->nc, C->Ainv, rc_in,
-                     zc);
+                     dim3(kBlock), 0, as_stream(stream), C->nc, C->lda, C->Ainv,
+                     rc_in, zc);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -857,9 +981,10 @@ extern "C" int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
                                        void* stream) {
   FLOW_REQUIRE(C && dinv && r && zc && z && r0 >= 0 && r1 <= C->n && r0 < r1,
                "prolong");
-  hipLaunchKernelGGL(coarse_prolong_kernel, dim3(grid_for(r1 - r0)), dim3(kBlock),
-                     0, as_stream(stream), r1 - r0, C->agg_of + r0, dinv + r0,
-                     r + r0, zc, z + r0);
+  hipLaunchKernelGGL(coarse_prolong_kernel<false>, dim3(grid_for(r1 - r0)),
+                     dim3(kBlock), 0, as_stream(stream), r1 - r0, C->agg_of + r0,
+                     dinv + r0, r + r0, zc, z + r0,
+                     static_cast<double*>(nullptr));
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -942,8 +1067,9 @@ extern "C" int flow_cg_update_dev(int n, const double* S, const double* dinv,
                                   double* s, double* x, double* r, int want_z,
                                   void* stream) {
   FLOW_REQUIRE(n > 0 && S && w && z && p && s && x && r, "cg update");
-  hipLaunchKernelGGL(cg_update_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
-                     as_stream(stream), n, S, dinv, w, z, p, s, x, r, want_z);
+  hipLaunchKernelGGL(cg_update_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0,
+                     as_stream(stream), n, S, dinv, w, z, p, s, x, r, want_z,
+                     static_cast<double*>(nullptr));
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }

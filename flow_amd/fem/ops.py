@@ -290,16 +290,20 @@ class CoarseSpace(object):
         agg_ptr = numpy.zeros(nc + 1, dtype=numpy.int64)
         numpy.cumsum(numpy.bincount(agg[free], minlength=nc), out=agg_ptr[1:])
         self.agg_of_host = agg.astype(numpy.int32)
+        # fp32 storage, rows padded to a multiple of 4 floats (float4 loads)
+        lda = (nc + 3) // 4 * 4
+        A32 = numpy.zeros((nc, lda), dtype=numpy.float32)
+        A32[:, :nc] = Ainv
         self._keep = (
             device.to_device(agg_ptr.astype(numpy.int32)),
             device.to_device(agg_dofs),
             device.to_device(self.agg_of_host),
-            device.to_device(numpy.ascontiguousarray(Ainv)),
+            device.to_device(A32),
             )
         k = self._keep
         self.struct = _hip.CoarseS(
             n, nc, _hip.i32(k[0], nc + 1), _hip.i32(k[1], len(agg_dofs)),
-            _hip.i32(k[2], n), _hip.f64(k[3], nc * nc)
+            _hip.i32(k[2], n), lda, _hip.f32(k[3], nc * lda)
             )
 
 
@@ -373,7 +377,10 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
         assert dinv == 'jacobi'
         dinv = A.diag_inv() if ilu is None else None
     nvec = 5 if method == 'cg' else 7
-    wk = work(_hip.REDUCE_WORK + nvec * n + (2 * coarse.nc if coarse else 0)
+    nparts = A.operator().nblocks * (2 if A.kind == 1 else 1) + 2
+    wk = work(_hip.REDUCE_WORK + nvec * n
+              + (nparts if method == 'cg' else 0)
+              + (2 * coarse.struct.lda if coarse else 0)
               + (n if ilu is not None else 0))
     if check_every is None:
         check_every = 10 if method == 'bicgstab' else 50

@@ -95,7 +95,11 @@ typedef struct {
   const int* agg_ptr;      /* nc+1 */
   const int* agg_dofs;     /* fine dofs sorted by aggregate */
   const int* agg_of;       /* n */
-  const double* Ainv;      /* nc*nc, row-major */
+  int lda;                 /* row stride of Ainv in floats, multiple of 4, >= nc */
+  const float* Ainv;       /* nc rows of lda floats (pad = 0), 16-B aligned: the
+                              coarse inverse is only a preconditioner, so it is
+                              kept in fp32 (half the HBM bytes of the per-
+                              iteration dense product); sums run in fp64 */
 } flow_coarse;
 
 /* ---- K11: multicolour ILU(0) ----------------------------------------------
@@ -152,8 +156,9 @@ int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
  * dinv may be NULL (no preconditioner).  x holds the initial guess.
  * coarse may be NULL (Jacobi only); ilu may be NULL (Jacobi), else it replaces
  * dinv as the (right) preconditioner of BiCGStab.
- * work: FLOW_REDUCE_WORK + 5*N [+ 2*nc] doubles (cg), FLOW_REDUCE_WORK + 7*N
- * [+ n] (bicgstab), N = operator size. */
+ * work (16-byte aligned): FLOW_REDUCE_WORK + 5*N + B + 2 [+ 2*coarse->lda]
+ * doubles (cg; B = nblocks, twice that for kind 1: the SpMV leaves its z.Az
+ * partials there), FLOW_REDUCE_WORK + 7*N [+ n] (bicgstab); N = operator size. */
 int flow_cg_solve(const flow_operator* A, const double* dinv,
                   const flow_coarse* coarse, const double* b, double* x,
                   double rtol, double atol, int maxit, int check_every,
