@@ -56,16 +56,17 @@ class IluPlanS(ctypes.Structure):
         ('nnz_l', ctypes.c_int), ('nnz_u', ctypes.c_int),
         ('off_l', ctypes.c_int), ('off_u', ctypes.c_int),
         ('off_d', ctypes.c_int), ('lu_size', ctypes.c_int),
-        ('max_row', ctypes.c_int),
+        ('max_row', ctypes.c_int), ('nslices', ctypes.c_int),
         ('color_ptr_host', ctypes.c_void_p),
-        ('l_rbptr_host', ctypes.c_void_p), ('u_rbptr_host', ctypes.c_void_p),
+        ('slice_ptr_host', ctypes.c_void_p),
         ('rowptr', ctypes.c_void_p), ('cols', ctypes.c_void_p),
         ('diag', ctypes.c_void_p), ('src_pos', ctypes.c_void_p),
-        ('old_of_new', ctypes.c_void_p),
-        ('l_rowptr', ctypes.c_void_p), ('l_cols', ctypes.c_void_p),
-        ('l_pos', ctypes.c_void_p), ('l_rowblocks', ctypes.c_void_p),
-        ('u_rowptr', ctypes.c_void_p), ('u_cols', ctypes.c_void_p),
-        ('u_pos', ctypes.c_void_p), ('u_rowblocks', ctypes.c_void_p),
+        ('old_of_new', ctypes.c_void_p), ('new_of_old', ctypes.c_void_p),
+        ('slice_row', ctypes.c_void_p),
+        ('l_slice_off', ctypes.c_void_p), ('l_cols', ctypes.c_void_p),
+        ('l_pos', ctypes.c_void_p),
+        ('u_slice_off', ctypes.c_void_p), ('u_cols', ctypes.c_void_p),
+        ('u_pos', ctypes.c_void_p),
         ]
 
 
@@ -128,6 +129,7 @@ SYMBOLS = {
                       _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
                             _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],
     'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],
     'flow_ilu0_solve': [_P(IluS), _VP, _VP, _VP, _VP],
     'flow_dot3_dev': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],

@@ -1,7 +1,7 @@
 // K11: multicolour ILU(0) on gfx950.  The plan (colouring, colour-major permuted
-// CSR, strictly-lower / strictly-upper streams with CSR-stream row blocks per
-// colour, map back to the operator's value plane) is built once per pattern on
-// the host: flow_amd/fem/ilu.py.
+// CSR, strictly-lower / strictly-upper sweep streams in sliced-ELL form, map
+// back to the operator's value plane) is built once per pattern on the host:
+// flow_amd/fem/ilu.py.
 //
 // Stands in for the sparse LU behind the reference's Newton and heat solves
 // (flow/navier_stokes/pressure_correction.py:224-254, flow/heat.py:117-121) as
@@ -9,20 +9,22 @@
 //
 //  * factorisation: one launch per colour, a lane per row (IKJ with a sorted
 //    merge); runs once per (re)factorisation;
-//  * sweeps: one launch per colour and sweep; rows of a colour are contiguous in
-//    the permuted numbering, so each launch streams its slice of the L (or U)
-//    triangle exactly once with the SpMV's LDS-tiled structure (16-B value
-//    loads, products parked in LDS, one lane per row for the segmented sum) and
-//    applies the sweep update in the epilogue.  Both diagonal blocks of a
-//    two-field operator go through the same launch (blockIdx.y).
+//  * sweeps: one launch per colour and sweep.  A wavefront owns a slice of 64
+//    rows stored column-major (sliced ELL, rows sorted by length inside the
+//    colour so the padding stays small): lane i reads entry k of its own row at
+//    off + 64 k + i -- every load coalesced -- and keeps the row sum in
+//    registers.  No LDS, no barrier, four entries per lane in flight: the
+//    launches are short (a tenth of the triangle each), so what counts is the
+//    length of the dependent-load chain of a wavefront, not only the bytes.
+//    Both diagonal blocks of a two-field operator go through the same launch
+//    (blockIdx.y).
 // HBM-bound: 12 B per factor entry and application.
 #include "common.h"
 
 namespace flow {
 
-constexpr int kPairsI = 4;
-constexpr int kTileI = 2 * kBlock * kPairsI;
-static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTileI - 2, "ILU sweeps reuse the SpMV tiling");
+constexpr int kSlice = FLOW_ILU_SLICE;
+static_assert(kSlice == 64, "one wavefront per slice");
 
 __global__ void ilu_copy_kernel(int nnz, const int* __restrict__ src_pos,
                                 const double* __restrict__ avals,
@@ -177,89 +179,122 @@ __global__ void ilu_split_kernel(int n, int nnz_l, int nnz_u,
   const int total = nnz_l + nnz_u + n;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < total;
        k += gridDim.x * blockDim.x) {
-    if (k < nnz_l) lvals[k] = lu[l_pos[k]];
-    else if (k < nnz_l + nnz_u) uvals[k - nnz_l] = lu[u_pos[k - nnz_l]];
-    else dinv[k - nnz_l - nnz_u] = 1.0 / lu[diag[k - nnz_l - nnz_u]];
+    if (k < nnz_l) {
+      const int p = l_pos[k];
+      lvals[k] = p >= 0 ? lu[p] : 0.0;
+    } else if (k < nnz_l + nnz_u) {
+      const int p = u_pos[k - nnz_l];
+      uvals[k - nnz_l] = p >= 0 ? lu[p] : 0.0;
+    } else {
+      dinv[k - nnz_l - nnz_u] = 1.0 / lu[diag[k - nnz_l - nnz_u]];
+    }
   }
 }
 
-// One colour of one sweep, CSR-stream style.
-//   FWD:  y_i = r[old(i)] - sum_k L_ik y_k
-//   BWD:  y_i = (y_i - sum_j U_ij y_j) / U_ii ;  z[old(i)] = y_i
-// blockIdx.y selects the diagonal block: values at vals + blk*lu_size, vectors
-// at + blk*n.
+// The sweeps run in the permuted (colour-major) numbering on ONE buffer y:
+//   ilu_permute_kernel   y[new(o)] = r[o]     (both loops run over the ORIGINAL
+//   ilu_unpermute_kernel z[o] = y[new(o)]      index o: the vector in original
+// numbering is touched coalesced, the scattered side lands in lines that the
+// neighbouring lanes complete within the same few wavefronts.)  Gathering
+// r[old(i)] inside the sweeps instead would drag the whole of r through every
+// one of the ~10 colour launches: a colour owns 1 in 10 entries of each line.
+__global__ void ilu_permute_kernel(int n, int nblocks,
+                                   const int* __restrict__ new_of_old,
+                                   const double* __restrict__ r,
+                                   double* __restrict__ y) {
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n;
+       o += gridDim.x * blockDim.x) {
+    const int i = new_of_old[o];
+    y[i] = r[o];
+    if (nblocks > 1) y[n + i] = r[n + o];
+  }
+}
+
+__global__ void ilu_unpermute_kernel(int n, int nblocks,
+                                     const int* __restrict__ new_of_old,
+                                     const double* __restrict__ y,
+                                     double* __restrict__ z) {
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n;
+       o += gridDim.x * blockDim.x) {
+    const int i = new_of_old[o];
+    z[o] = y[i];
+    if (nblocks > 1) z[n + o] = y[n + i];
+  }
+}
+
+// One colour of one sweep; a wavefront per slice (slice_off / slice_row are
+// pre-offset to the colour's first slice), rows of the colour end at row_end.
+//   FWD:  y_i = y_i - sum_k L_ik y_k
+//   BWD:  y_i = (y_i - sum_j U_ij y_j) / U_ii
+// blockIdx.y selects the diagonal block: values at vals + blk*lu_size, y at
+// + blk*n.
 template <bool BWD>
 __global__ __launch_bounds__(kBlock) void ilu_sweep_kernel(
-    int n, size_t lu_size, const int* __restrict__ rowptr,
+    int n, size_t lu_size, int nslices, int row_end,
+    const int* __restrict__ slice_off, const int* __restrict__ slice_row,
     const int* __restrict__ cols, const double* __restrict__ vals,
-    const double* __restrict__ dinv, const int* __restrict__ rowblocks,
-    const int* __restrict__ old_of_new, const double* __restrict__ r,
-    double* __restrict__ y, double* __restrict__ z) {
-  __shared__ double prod[kTileI];
+    const double* __restrict__ dinv, double* __restrict__ y) {
+  const int sl = blockIdx.x * (kBlock / kSlice) + (threadIdx.x >> 6);
+  if (sl >= nslices) return;
+  const int lane = threadIdx.x & 63;
   const size_t blk = blockIdx.y;
   vals += blk * lu_size;
   if (BWD) dinv += blk * lu_size;
   y += blk * n;
-  const int r0 = rowblocks[blockIdx.x];
-  const int r1 = rowblocks[blockIdx.x + 1];
-  const int k0 = rowptr[r0];
-  const int k1 = rowptr[r1];
-  const int ka = k0 & ~1;
-  const int row = r0 + threadIdx.x;
-  int a = 0, b = 0, o = 0;
-  // everything the row's final update needs is requested up front, so that
-  // these (dependent) loads are in flight while the triangle streams in
-  double rhs = 0.0, di = 0.0;
-  if (row < r1) {
-    a = rowptr[row] - ka;
-    b = rowptr[row + 1] - ka;
-    o = old_of_new[row];
-    if (!BWD) {
-      rhs = r[blk * n + o];
-    } else {
-      rhs = y[row];
-      di = dinv[row];
-    }
+  const int off = slice_off[sl];
+  const int width = (slice_off[sl + 1] - off) >> 6;
+  const int row = slice_row[sl] + lane;
+  const bool live = row < row_end;
+  // what the row's final update needs is requested up front
+  double rhs = 0.0, di = 1.0;
+  if (live) {
+    rhs = y[row];
+    if (BWD) di = dinv[row];
   }
-  const double2* __restrict__ v2p = reinterpret_cast<const double2*>(vals + ka);
-  const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
-  const int npair = (k1 - ka + 1) >> 1;
+  const double* __restrict__ v = vals + off + lane;
+  const int* __restrict__ c = cols + off + lane;
+  // batches of kBatch entries per lane: all index/value loads of a batch are
+  // issued before the first gather, all gathers before the first use (width is
+  // wavefront-uniform, so the guards are scalar branches)
+  constexpr int kBatch = 12;
+  double s = 0.0;
+  for (int k0 = 0; k0 < width; k0 += kBatch) {
+    int cc[kBatch];
+    double vv[kBatch], yy[kBatch];
 #pragma unroll
-  for (int j = 0; j < kPairsI; ++j) {
-    const int p = threadIdx.x + j * kBlock;
-    if (p < npair) {
-      const double2 v = v2p[p];
-      const int2 c = c2p[p];
-      // the possible extra element past k1 belongs to a later row / the pad
-      // (column 0): its product is never summed
-      prod[2 * p] = v.x * y[c.x];
-      prod[2 * p + 1] = v.y * y[c.y];
+    for (int j = 0; j < kBatch; ++j) {
+      const bool ok = k0 + j < width;
+      cc[j] = ok ? c[(k0 + j) * kSlice] : 0;
+      vv[j] = ok ? v[(k0 + j) * kSlice] : 0.0;
     }
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) yy[j] = (k0 + j < width) ? y[cc[j]] : 0.0;
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) s += vv[j] * yy[j];
   }
-  __syncthreads();
-  if (row < r1) {
-    double s = 0.0;
-    for (int k = a; k < b; ++k) s += prod[k];
-    if (!BWD) {
-      y[row] = rhs - s;
-    } else {
-      const double yi = (rhs - s) * di;
-      y[row] = yi;
-      z[blk * n + o] = yi;
-    }
-  }
+  if (live) y[row] = (rhs - s) * di;
 }
 
 static int check_plan(const flow_ilu_plan* P) {
   FLOW_REQUIRE(P && P->n > 0 && P->nnz > 0 && P->ncolors > 0, "ilu plan sizes");
-  FLOW_REQUIRE(P->color_ptr_host && P->l_rbptr_host && P->u_rbptr_host,
-               "ilu plan host arrays");
+  FLOW_REQUIRE(P->color_ptr_host && P->slice_ptr_host, "ilu plan host arrays");
   FLOW_REQUIRE(P->rowptr && P->cols && P->diag && P->src_pos && P->old_of_new &&
-                   P->l_rowptr && P->l_cols && P->l_pos && P->l_rowblocks &&
-                   P->u_rowptr && P->u_cols && P->u_pos && P->u_rowblocks,
+                   P->new_of_old && P->slice_row && P->l_slice_off && P->l_cols && P->l_pos &&
+                   P->u_slice_off && P->u_cols && P->u_pos,
                "ilu plan pointers");
   FLOW_REQUIRE(P->color_ptr_host[0] == 0 && P->color_ptr_host[P->ncolors] == P->n,
                "ilu colour ranges");
+  FLOW_REQUIRE(P->slice_ptr_host[0] == 0 &&
+                   P->slice_ptr_host[P->ncolors] == P->nslices,
+               "ilu slice ranges");
+  for (int c = 0; c < P->ncolors; ++c) {
+    const int rows = P->color_ptr_host[c + 1] - P->color_ptr_host[c];
+    const int sl = P->slice_ptr_host[c + 1] - P->slice_ptr_host[c];
+    FLOW_REQUIRE(rows >= 0 && sl == (rows + kSlice - 1) / kSlice,
+                 "ilu slices per colour");
+  }
+  FLOW_REQUIRE(P->nnz_l % kSlice == 0 && P->nnz_u % kSlice == 0,
+               "ilu stream padding");
   FLOW_REQUIRE((P->off_l & 1) == 0 && (P->off_u & 1) == 0 && (P->off_d & 1) == 0 &&
                    (P->lu_size & 1) == 0 && P->off_l >= P->nnz &&
                    P->off_u >= P->off_l + P->nnz_l && P->off_d >= P->off_u + P->nnz_u &&
@@ -315,24 +350,33 @@ int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
               hipStream_t st) {
   const flow_ilu_plan* P = ilu->plan;
   const size_t lus = static_cast<size_t>(P->lu_size);
-  for (int c = 0; c < P->ncolors; ++c) {
-    const int nb = P->l_rbptr_host[c + 1] - P->l_rbptr_host[c];
-    if (nb <= 0) continue;
-    hipLaunchKernelGGL((ilu_sweep_kernel<false>), dim3(nb, ilu->nblocks),
-                       dim3(kBlock), 0, st, P->n, lus, P->l_rowptr, P->l_cols,
-                       ilu->lu + P->off_l, static_cast<const double*>(nullptr),
-                       P->l_rowblocks + P->l_rbptr_host[c], P->old_of_new, in, work,
-                       static_cast<double*>(nullptr));
+  constexpr int per_block = kBlock / kSlice;
+  hipLaunchKernelGGL(ilu_permute_kernel, dim3(grid_for(P->n)), dim3(kBlock), 0,
+                     st, P->n, ilu->nblocks, P->new_of_old, in, work);
+  for (int c = 1; c < P->ncolors; ++c) {   // colour 0: y = r already
+    const int s0 = P->slice_ptr_host[c];
+    const int ns = P->slice_ptr_host[c + 1] - s0;
+    if (ns <= 0) continue;
+    hipLaunchKernelGGL((ilu_sweep_kernel<false>),
+                       dim3((ns + per_block - 1) / per_block, ilu->nblocks),
+                       dim3(kBlock), 0, st, P->n, lus, ns,
+                       P->color_ptr_host[c + 1], P->l_slice_off + s0,
+                       P->slice_row + s0, P->l_cols, ilu->lu + P->off_l,
+                       static_cast<const double*>(nullptr), work);
   }
   for (int c = P->ncolors - 1; c >= 0; --c) {
-    const int nb = P->u_rbptr_host[c + 1] - P->u_rbptr_host[c];
-    if (nb <= 0) continue;
-    hipLaunchKernelGGL((ilu_sweep_kernel<true>), dim3(nb, ilu->nblocks),
-                       dim3(kBlock), 0, st, P->n, lus, P->u_rowptr, P->u_cols,
-                       ilu->lu + P->off_u, ilu->lu + P->off_d,
-                       P->u_rowblocks + P->u_rbptr_host[c], P->old_of_new, in, work,
-                       out);
+    const int s0 = P->slice_ptr_host[c];
+    const int ns = P->slice_ptr_host[c + 1] - s0;
+    if (ns <= 0) continue;
+    hipLaunchKernelGGL((ilu_sweep_kernel<true>),
+                       dim3((ns + per_block - 1) / per_block, ilu->nblocks),
+                       dim3(kBlock), 0, st, P->n, lus, ns,
+                       P->color_ptr_host[c + 1], P->u_slice_off + s0,
+                       P->slice_row + s0, P->u_cols, ilu->lu + P->off_u,
+                       ilu->lu + P->off_d, work);
   }
+  hipLaunchKernelGGL(ilu_unpermute_kernel, dim3(grid_for(P->n)), dim3(kBlock), 0,
+                     st, P->n, ilu->nblocks, P->new_of_old, work, out);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -350,6 +394,35 @@ int ilu_check(const flow_ilu* ilu, int op_size) {
 }  // namespace flow
 
 using namespace flow;
+
+// First-fit greedy colouring in the given (mesh) order -- HOST routine, setup
+// only.  On a mesh numbered along its structure this yields a locally periodic
+// colour pattern: consecutive rows of one colour have their k-th neighbours in
+// the same colour at consecutive positions, so the gathers of a sweep
+// wavefront fall into a handful of cache lines (a randomised colouring
+// scatters them over ~64).
+extern "C" int flow_color_greedy_host(int n, const int* rowptr, const int* cols,
+                                      int* colour, int* ncolors) {
+  FLOW_REQUIRE(n > 0 && rowptr && cols && colour && ncolors, "colouring");
+  int nc = 0;
+  for (int v = 0; v < n; ++v) colour[v] = -1;
+  for (int v = 0; v < n; ++v) {
+    unsigned long long used = 0ull;
+    for (int k = rowptr[v]; k < rowptr[v + 1]; ++k) {
+      const int u = cols[k];
+      FLOW_REQUIRE(u >= 0 && u < n, "colouring: column out of range");
+      if (u != v && colour[u] >= 0) used |= 1ull << colour[u];
+    }
+    const unsigned long long freebits = ~used;
+    FLOW_REQUIRE((freebits & ((1ull << 63) - 1)) != 0ull,
+                 "colouring: more than 63 colours");
+    const int c = __builtin_ctzll(freebits);
+    colour[v] = c;
+    if (c + 1 > nc) nc = c + 1;
+  }
+  *ncolors = nc;
+  return FLOW_OK;
+}
 
 extern "C" int flow_ilu0_factor(const flow_ilu_plan* plan, int nblocks,
                                 const double* avals0, const double* avals1,

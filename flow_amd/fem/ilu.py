@@ -2,16 +2,16 @@
 '''
 Host-side plan of the multicolour ILU(0) preconditioner (K11): graph colouring
 of a scalar CSR pattern, the permuted (colour-major) CSR the factor lives in,
-its split into strictly-lower / strictly-upper streams with CSR-stream row
-blocks per colour, and the map from factor entries back to the operator's value
-plane.
+its split into strictly-lower / strictly-upper sweep streams (sliced ELL, one
+wavefront per slice of 64 rows), and the map from factor entries back to the
+operator's value plane.
 
 Why multicolour: a triangular solve on a 2-D mesh matrix in natural ordering has
 only O(sqrt(N)) rows per dependency level (hard part 3).
 Ordering the rows by colour (independent sets) makes every colour one fully
 parallel launch: L holds the couplings to lower colours, U those to higher
-colours, and each sweep streams its triangle exactly once (12 B per entry) with
-the same LDS-tiled kernel structure as the SpMV.  The price is a somewhat weaker
+colours, and each sweep streams its triangle exactly once (12 B per entry, fully
+coalesced, no LDS and no barrier in the kernel).  The price is a somewhat weaker
 factorisation than natural-order ILU(0).  Replaces the role of the sparse LU in
 the reference's Newton and heat solves (pressure_correction.py:224-254,
 heat.py:117-121) as the north star prescribes (BiCGStab + ILU(0)).
@@ -23,56 +23,43 @@ import ctypes
 
 import numpy
 
-from .space import csr_stream_rowblocks
 from .. import _hip
 from .. import device
 
 
-def colour_graph(rowptr, cols, seed=0):
-    '''Parallel greedy colouring: Jones-Plassmann rounds (vertices whose random
-    priority beats all uncoloured neighbours form an independent set) where
-    every selected vertex takes the SMALLEST colour its coloured neighbours do
-    not use.  Returns (colour per vertex, number of colours <= 63).'''
-    rowptr = numpy.asarray(rowptr, dtype=numpy.int64)
-    cols = numpy.asarray(cols, dtype=numpy.int64)
+def colour_graph(rowptr, cols):
+    '''First-fit greedy colouring in mesh order (flow_color_greedy_host, a host
+    routine of the library -- no GPU needed).  On a mesh numbered along its
+    structure the colours come out locally periodic, which is what keeps the
+    gathers of the sweeps inside a few cache lines per wavefront.  Returns
+    (colour per vertex, number of colours <= 63).'''
+    rowptr = numpy.ascontiguousarray(rowptr, dtype=numpy.int32)
+    cols = numpy.ascontiguousarray(cols, dtype=numpy.int32)
     n = len(rowptr) - 1
-    rows = numpy.repeat(numpy.arange(n, dtype=numpy.int64), numpy.diff(rowptr))
-    offdiag = cols != rows
-    prio = numpy.random.RandomState(seed).permutation(n).astype(numpy.int64)
-    colour = numpy.full(n, -1, dtype=numpy.int64)
-    starts = rowptr[:-1]
-    one = numpy.uint64(1)
-    while True:
-        active = colour < 0
-        if not active.any():
-            break
-        pr = numpy.where(active, prio, -1)
-        nb = numpy.where(offdiag, pr[cols], -1)
-        mx = numpy.maximum.reduceat(nb, starts)
-        sel = active & (prio > mx)
-        assert sel.any()
-        # colours used by the neighbours, as a bit mask per vertex
-        cn = colour[cols]
-        bits = numpy.where(
-            (cn >= 0) & offdiag,
-            numpy.left_shift(one, numpy.maximum(cn, 0).astype(numpy.uint64)),
-            numpy.uint64(0)
-            )
-        used = numpy.bitwise_or.reduceat(bits, starts)[sel]
-        # lowest zero bit of `used`
-        low = (~used) & (used + one)
-        c = numpy.round(numpy.log2(low.astype(numpy.float64))).astype(numpy.int64)
-        assert (c < 63).all(), 'more than 63 colours'
-        colour[sel] = c
-    return colour.astype(numpy.int32), int(colour.max()) + 1
+    colour = numpy.empty(n, dtype=numpy.int32)
+    nc = ctypes.c_int(0)
+    as_p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _hip.check(_hip.load_library().flow_color_greedy_host(
+        n, as_p(rowptr), as_p(cols), as_p(colour), ctypes.byref(nc)
+        ))
+    return colour, nc.value
 
 
 def _pad(a, n=2):
     return numpy.concatenate([a, numpy.zeros(n, dtype=a.dtype)])
 
 
+SLICE = 64     # rows per slice of the sliced-ELL sweep streams = one wavefront
+
+
 class IluPlan(object):
-    '''Colour-major permuted pattern of a scalar layout and its L / U streams.'''
+    '''Colour-major permuted pattern of a scalar layout and its L / U sweep
+    streams in sliced-ELL form: within a colour the rows are ordered by their
+    number of lower / higher coloured neighbours, cut into slices of 64 rows
+    (one wavefront), and every slice is stored column-major and padded to its
+    longest row -- lane i of the wavefront reads entry k of ITS row at
+    slice_offset + 64 k + i, fully coalesced, and sums its row in registers.
+    Pad entries carry value 0 and column 0 (a finished row of colour 0).'''
 
     def __init__(self, layout):
         rowptr = layout.pattern('rowptr').astype(numpy.int64)
@@ -80,13 +67,19 @@ class IluPlan(object):
         n = layout.N
         nnz = layout.nnz
         colour, nc = colour_graph(rowptr, cols)
-        old_of_new = numpy.argsort(colour, kind='stable')
+        rows = numpy.repeat(numpy.arange(n, dtype=numpy.int64),
+                            numpy.diff(rowptr))
+        lower = (colour[cols] < colour[rows]).astype(numpy.int64)
+        upper = (colour[cols] > colour[rows]).astype(numpy.int64)
+        starts = rowptr[:-1]
+        l_len = numpy.add.reduceat(lower, starts)
+        u_len = numpy.add.reduceat(upper, starts)
+        # colour-major; inside a colour by (|L row|, |U row|), ties in mesh order
+        old_of_new = numpy.lexsort((numpy.arange(n), u_len, l_len, colour))
         new_of_old = numpy.empty(n, dtype=numpy.int64)
         new_of_old[old_of_new] = numpy.arange(n)
         colour_ptr = numpy.zeros(nc + 1, dtype=numpy.int64)
         numpy.cumsum(numpy.bincount(colour, minlength=nc), out=colour_ptr[1:])
-        rows = numpy.repeat(numpy.arange(n, dtype=numpy.int64),
-                            numpy.diff(rowptr))
         key = new_of_old[rows] * n + new_of_old[cols]
         order = numpy.argsort(key, kind='stable')
         skey = key[order]
@@ -99,44 +92,61 @@ class IluPlan(object):
         diag = numpy.nonzero(p_cols == p_rows)[0]
         assert len(diag) == n
 
+        # slices: every colour starts a new slice
+        p_colour = colour[old_of_new].astype(numpy.int64)
+        nsl_c = (numpy.diff(colour_ptr) + SLICE - 1) // SLICE
+        slptr = numpy.zeros(nc + 1, dtype=numpy.int64)
+        numpy.cumsum(nsl_c, out=slptr[1:])
+        nsl = int(slptr[-1])
+        in_colour = numpy.arange(n) - colour_ptr[p_colour]
+        slice_of_row = slptr[p_colour] + in_colour // SLICE
+        lane_of_row = in_colour % SLICE
+        sl_row = numpy.zeros(nsl, dtype=numpy.int64)
+        sl_row[slice_of_row[lane_of_row == 0]] = \
+            numpy.nonzero(lane_of_row == 0)[0]
+
         def stream(mask):
             pos = numpy.nonzero(mask)[0]
+            r_of = p_rows[pos]
+            length = numpy.bincount(r_of, minlength=n)
             rp = numpy.zeros(n + 1, dtype=numpy.int64)
-            numpy.cumsum(numpy.bincount(p_rows[pos], minlength=n), out=rp[1:])
-            blocks = [numpy.zeros(1, dtype=numpy.int64)]
-            bptr = [0]
-            for c in range(nc):
-                a, b = int(colour_ptr[c]), int(colour_ptr[c + 1])
-                rb = csr_stream_rowblocks(rp[a:b + 1] - rp[a]) + a
-                # consecutive colours share the boundary row
-                blocks.append(rb[1:])
-                bptr.append(bptr[-1] + len(rb) - 1)
-            return (rp.astype(numpy.int32), p_cols[pos].astype(numpy.int32),
-                    pos.astype(numpy.int32),
-                    numpy.concatenate(blocks).astype(numpy.int32),
-                    numpy.ascontiguousarray(bptr, dtype=numpy.int32))
+            numpy.cumsum(length, out=rp[1:])
+            width = numpy.zeros(nsl, dtype=numpy.int64)
+            numpy.maximum.at(width, slice_of_row, length)
+            sl_off = numpy.zeros(nsl + 1, dtype=numpy.int64)
+            numpy.cumsum(width * SLICE, out=sl_off[1:])
+            total = int(sl_off[-1])
+            assert total < 2**31
+            k = numpy.arange(len(pos)) - rp[r_of]
+            dest = sl_off[slice_of_row[r_of]] + k * SLICE + lane_of_row[r_of]
+            s_cols = numpy.zeros(total, dtype=numpy.int32)
+            s_pos = numpy.full(total, -1, dtype=numpy.int32)
+            s_cols[dest] = p_cols[pos]
+            s_pos[dest] = pos
+            return sl_off.astype(numpy.int32), s_cols, s_pos, total
 
-        l_rp, l_cols, l_pos, l_rb, l_rbptr = stream(is_l)
-        u_rp, u_cols, u_pos, u_rb, u_rbptr = stream(is_u)
+        l_off, l_cols, l_pos, total_l = stream(is_l)
+        u_off, u_cols, u_pos, total_u = stream(is_u)
         self.n = n
         self.nnz = nnz
-        self.nnz_l = len(l_cols)
-        self.nnz_u = len(u_cols)
+        self.nnz_l = total_l
+        self.nnz_u = total_u
+        self.fill_l = float(is_l.sum()) / max(total_l, 1)
+        self.fill_u = float(is_u.sum()) / max(total_u, 1)
         self.ncolours = nc
         self.colour = colour
         self.colour_ptr = numpy.ascontiguousarray(colour_ptr, dtype=numpy.int32)
-        self.l_rbptr = l_rbptr
-        self.u_rbptr = u_rbptr
+        self.slptr = numpy.ascontiguousarray(slptr, dtype=numpy.int32)
         self.host = {
             'rowptr': p_rowptr.astype(numpy.int32),
             'cols': p_cols.astype(numpy.int32),
             'diag': diag.astype(numpy.int32),
             'src_pos': order.astype(numpy.int32),
             'old_of_new': old_of_new.astype(numpy.int32),
-            'l_rowptr': l_rp, 'l_cols': _pad(l_cols), 'l_pos': l_pos,
-            'l_rowblocks': l_rb,
-            'u_rowptr': u_rp, 'u_cols': _pad(u_cols), 'u_pos': u_pos,
-            'u_rowblocks': u_rb,
+            'new_of_old': new_of_old.astype(numpy.int32),
+            'sl_row': sl_row.astype(numpy.int32),
+            'l_sl_off': l_off, 'l_cols': _pad(l_cols), 'l_pos': _pad(l_pos),
+            'u_sl_off': u_off, 'u_cols': _pad(u_cols), 'u_pos': _pad(u_pos),
             }
         self._dev = {k: device.to_device(v) for k, v in self.host.items()}
         d = self._dev
@@ -144,23 +154,23 @@ class IluPlan(object):
         # every segment starting 16-byte aligned
         ev = lambda m: m + (m & 1)
         self.off_l = ev(nnz)
-        self.off_u = self.off_l + ev(self.nnz_l + 2)
-        self.off_d = self.off_u + ev(self.nnz_u + 2)
+        self.off_u = self.off_l + ev(total_l + 2)
+        self.off_d = self.off_u + ev(total_u + 2)
         self.lu_size = self.off_d + ev(n)
         self.struct = _hip.IluPlanS(
-            n, nnz, nc, self.nnz_l, self.nnz_u,
+            n, nnz, nc, total_l, total_u,
             self.off_l, self.off_u, self.off_d, self.lu_size,
-            int(numpy.diff(rowptr).max()),
+            int(numpy.diff(rowptr).max()), nsl,
             self.colour_ptr.ctypes.data_as(ctypes.c_void_p),
-            self.l_rbptr.ctypes.data_as(ctypes.c_void_p),
-            self.u_rbptr.ctypes.data_as(ctypes.c_void_p),
+            self.slptr.ctypes.data_as(ctypes.c_void_p),
             _hip.i32(d['rowptr'], n + 1), _hip.i32(d['cols'], nnz),
             _hip.i32(d['diag'], n), _hip.i32(d['src_pos'], nnz),
-            _hip.i32(d['old_of_new'], n),
-            _hip.i32(d['l_rowptr'], n + 1), _hip.i32(d['l_cols'], self.nnz_l),
-            _hip.i32(d['l_pos'], self.nnz_l), _hip.i32(d['l_rowblocks']),
-            _hip.i32(d['u_rowptr'], n + 1), _hip.i32(d['u_cols'], self.nnz_u),
-            _hip.i32(d['u_pos'], self.nnz_u), _hip.i32(d['u_rowblocks']),
+            _hip.i32(d['old_of_new'], n), _hip.i32(d['new_of_old'], n),
+            _hip.i32(d['sl_row'], nsl),
+            _hip.i32(d['l_sl_off'], nsl + 1), _hip.i32(d['l_cols'], total_l),
+            _hip.i32(d['l_pos'], total_l),
+            _hip.i32(d['u_sl_off'], nsl + 1), _hip.i32(d['u_cols'], total_u),
+            _hip.i32(d['u_pos'], total_u),
             )
 
 

@@ -107,38 +107,47 @@ typedef struct {
  * and `LUSolver`, heat.py:117-121, as a BiCGStab preconditioner).  The plan is
  * built once per pattern on the host (flow_amd/fem/ilu.py): rows are ordered by
  * colour (independent sets), so factorisation and both triangular sweeps are
- * one launch per colour; each sweep streams its triangle once with the SpMV's
- * LDS-tiled structure.  The *_host members are HOST arrays; everything else is
- * device memory.  Factor buffer of one block (lu_size doubles, 16-B aligned):
+ * one launch per colour.  The sweep streams are sliced ELL: inside a colour the
+ * rows are sorted by their L / U row lengths and cut into slices of 64 rows (one
+ * wavefront); a slice is stored column-major, padded to its longest row (pad:
+ * value 0, column 0), so lane i reads entry k of its row at off + 64 k + i --
+ * every load coalesced, the row sum stays in registers, no LDS, no barrier.
+ * The *_host members are HOST arrays; everything else is device memory.
+ * Factor buffer of one block (lu_size doubles, 16-B aligned):
  *   [0, nnz) combined L\U in the permuted CSR | [off_l, +nnz_l) L stream |
  *   [off_u, +nnz_u) U stream | [off_d, +n) inverse pivots. */
+#define FLOW_ILU_SLICE 64
 typedef struct {
   int n, nnz, ncolors;
-  int nnz_l, nnz_u;
+  int nnz_l, nnz_u;          /* entries of the sliced streams INCLUDING padding */
   int off_l, off_u, off_d, lu_size;
   int max_row;               /* longest row of the pattern */
+  int nslices;               /* slices over all colours (L and U share them) */
   const int* color_ptr_host; /* ncolors+1 (host): row range of every colour */
-  const int* l_rbptr_host;   /* ncolors+1 (host): first L row block per colour */
-  const int* u_rbptr_host;   /* ncolors+1 (host): first U row block per colour */
+  const int* slice_ptr_host; /* ncolors+1 (host): slice range of every colour */
   const int* rowptr;         /* n+1, permuted (colour-major) numbering */
   const int* cols;           /* nnz, ascending per row, permuted numbering */
   const int* diag;           /* n: position of the diagonal entry */
   const int* src_pos;        /* nnz: entry -> position in the operator plane */
   const int* old_of_new;     /* n: permuted row -> original dof */
-  const int* l_rowptr;       /* n+1: strictly lower stream */
-  const int* l_cols;         /* nnz_l (+2 readable) */
-  const int* l_pos;          /* nnz_l: position in the combined factor */
-  const int* l_rowblocks;    /* CSR-stream row blocks, colour by colour */
-  const int* u_rowptr;       /* n+1: strictly upper stream */
-  const int* u_cols;         /* nnz_u (+2 readable) */
+  const int* new_of_old;     /* n: original dof -> permuted row */
+  const int* slice_row;      /* nslices: first row of the slice */
+  const int* l_slice_off;    /* nslices+1: entry offsets (multiples of 64) */
+  const int* l_cols;         /* nnz_l */
+  const int* l_pos;          /* nnz_l: position in the combined factor, -1 = pad */
+  const int* u_slice_off;
+  const int* u_cols;         /* nnz_u */
   const int* u_pos;
-  const int* u_rowblocks;
 } flow_ilu_plan;
 typedef struct {
   const flow_ilu_plan* plan;
   int nblocks;               /* 1 (scalar) or 2 (diagonal blocks of a 2-field op) */
   const double* lu;          /* nblocks * lu_size */
 } flow_ilu;
+/* HOST routine (setup, no GPU needed): first-fit greedy colouring of the graph
+ * of a CSR pattern in row order; colour: n ints out, *ncolors <= 63 */
+int flow_color_greedy_host(int n, const int* rowptr, const int* cols,
+                           int* colour, int* ncolors);
 /* factor nblocks (1|2) value planes over the plan's pattern into lu
  * (nblocks * lu_size); the blocks share one pass over the index structure */
 int flow_ilu0_factor(const flow_ilu_plan* plan, int nblocks,
