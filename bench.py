@@ -133,6 +133,14 @@ def main():
                     help="torch.distributed backend for N > 1: 'nccl' (= RCCL, "
                          "one GPU per rank); 'gloo' only to rehearse several "
                          "ranks on one GPU")
+    ap.add_argument('--shard', default='auto', choices=['auto', 'always'],
+                    help="N > 1: 'auto' row-shards the pressure solve only "
+                         "from flow_amd.parallel.min_rows() rows on (below "
+                         "that a single GPU is faster and the ranks solve it "
+                         "redundantly); 'always' forces the sharded loop")
+    ap.add_argument('--shard-single', action='store_true',
+                    help='development: run the sharded pressure loop on a '
+                         '1-rank process group (measures its host overhead)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--spmv-reps', type=int, default=100)
     args = ap.parse_args()
@@ -158,7 +166,14 @@ def main():
             dist.init_process_group('nccl', device_id=device.get())
         else:
             dist.init_process_group('gloo')
-        parallel.enable(dist.group.WORLD)
+        parallel.enable(dist.group.WORLD, force=args.shard == 'always')
+    elif args.shard_single:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group(args.backend, rank=0, world_size=1,
+                                **({'device_id': device.get()}
+                                   if args.backend == 'nccl' else {}))
+        parallel.enable(dist.group.WORLD, force=True)
 
     def barrier():
         if world > 1:
@@ -245,7 +260,13 @@ def main():
             'cells': prob.mesh.num_cells(),
             'pressure_rows': n,
             'pressure_nnz': nnz,
-            'parallelism': 'pressure-poisson row-block x%d' % world,
+            'parallelism': (
+                'pressure-poisson row-block x%d' % world
+                if parallel.active(n) else
+                'single GPU' if world == 1 else
+                'replicated x%d (pressure system of %d rows is below the '
+                'sharding threshold of %d rows: latency-bound, see DESIGN.md)'
+                % (world, n, parallel.min_rows())),
             'setup_s': setup_s,
             'dt': [i['dt'] for i in infos],
             'pressure_cg_iterations': p_its,

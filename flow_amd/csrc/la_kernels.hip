@@ -321,18 +321,47 @@ __global__ void residual_kernel(int n, const double* __restrict__ b,
 // Chronopoulos-Gear CG scalars from (gamma_new, delta, r.r) partials
 // gamma = r.z and r.r: nparts partials each in partial[0..) / [2*kRedBlocks..);
 // delta = z.w: ndelta partials in dpart (left there by the SpMV itself)
-__global__ __launch_bounds__(kBlock) void cg_scalar_kernel(
+constexpr int kScalarBlock = 1024;   // 16 wavefronts: many partials, one block
+__global__ __launch_bounds__(kScalarBlock) void cg_scalar_kernel(
     int nparts, int ndelta, int first, const double* __restrict__ partial,
     const double* __restrict__ dpart, double* __restrict__ S) {
-  double g = 0.0, d = 0.0, rr = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += kBlock) {
+  __shared__ double wsum[3][kScalarBlock / 64];
+  double g = 0.0, rr = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kScalarBlock) {
     g += partial[i];
     rr += partial[2 * kRedBlocks + i];
   }
-  for (int i = threadIdx.x; i < ndelta; i += kBlock) d += dpart[i];
-  g = block_sum(g);
-  d = block_sum(d);
-  rr = block_sum(rr);
+  // four independent chains keep the loads of the long list in flight
+  double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * kScalarBlock < ndelta; i += 4 * kScalarBlock) {
+    d0 += dpart[i];
+    d1 += dpart[i + kScalarBlock];
+    d2 += dpart[i + 2 * kScalarBlock];
+    d3 += dpart[i + 3 * kScalarBlock];
+  }
+  for (; i < ndelta; i += kScalarBlock) d0 += dpart[i];
+  double d = (d0 + d1) + (d2 + d3);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    g += __shfl_down(g, off, 64);
+    d += __shfl_down(d, off, 64);
+    rr += __shfl_down(rr, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    wsum[0][threadIdx.x >> 6] = g;
+    wsum[1][threadIdx.x >> 6] = d;
+    wsum[2][threadIdx.x >> 6] = rr;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    g = d = rr = 0.0;
+    for (int w = 0; w < kScalarBlock / 64; ++w) {
+      g += wsum[0][w];
+      d += wsum[1][w];
+      rr += wsum[2][w];
+    }
+  }
   if (threadIdx.x == 0) {
     double alpha, beta;
     if (first) {
@@ -582,8 +611,8 @@ static int cg(const flow_operator* A, const double* dinv,
   if (C && (rc = two_level(C, dinv, r, z, crc, czc, st))) return rc;
   if ((rc = apply(A, z, w, st, dpart))) return rc;
   if ((rc = dots(N, 3, r, z, z, w, r, r, partial, &np, st))) return rc;
-  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, nd, 1,
-                     partial, dpart, S);
+  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kScalarBlock), 0, st, np,
+                     nd, 1, partial, dpart, S);
   FLOW_CHECK_LAUNCH();
 
   double b2 = 0.0, res2 = 0.0;
@@ -619,8 +648,8 @@ static int cg(const flow_operator* A, const double* dinv,
         np = gu;
       }
       if ((rc = apply(A, z, w, st, dpart))) return rc;
-      hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, nd,
-                         0, partial, dpart, S);
+      hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kScalarBlock), 0, st,
+                         np, nd, 0, partial, dpart, S);
     }
     FLOW_CHECK_LAUNCH();
     it += todo;

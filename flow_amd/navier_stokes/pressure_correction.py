@@ -235,8 +235,9 @@ def _compute_tentative_velocity(
 def _pressure_cg(A, dinv, coarse, b, x, tol, par):
     '''CG for the pressure system: rtol = tol, atol = 0 (reference :332-335,
     :420-422), preconditioned with Jacobi [+ the aggregate coarse space];
-    row-sharded over the GPUs of the node when flow_amd.parallel is enabled.'''
-    if parallel.active():
+    row-sharded over the GPUs of the node when flow_amd.parallel is enabled and
+    the system is large enough for that to pay (parallel.min_rows()).'''
+    if parallel.active(A.size):
         return parallel.pressure_cg(
             A, dinv, coarse, b, x, tol, 0.0, par['maxit'], par['check_every']
             )

@@ -24,6 +24,7 @@ iteration, and the solution is all-gathered at the end because the other
 sub-steps are replicated.
 '''
 import ctypes
+import os
 
 import numpy
 import torch
@@ -36,11 +37,14 @@ from .fem.space import csr_stream_rowblocks
 _STATE = {'group': None}
 
 
-def enable(group):
+def enable(group, force=False):
     '''Shard subsequent pressure solves over `group`.  Collective: every rank
     of the group must call it (the first NCCL operation on a group has to
-    involve all of its ranks before point-to-point traffic may start).'''
+    involve all of its ranks before point-to-point traffic may start).
+    force: take the sharded loop even on a 1-rank group (development: measures
+    the loop's host overhead).'''
     _STATE['group'] = group
+    _STATE['force'] = bool(force)
     if dist.get_world_size(group) > 1:
         t = torch.zeros(1, dtype=torch.float64, device=device.get()
                         if dist.get_backend(group) != 'gloo' else 'cpu')
@@ -51,9 +55,29 @@ def disable():
     _STATE['group'] = None
 
 
-def active():
-    return _STATE['group'] is not None and \
-        dist.get_world_size(_STATE['group']) > 1
+# Rows of the pressure system from which sharding pays.  A sharded CG iteration
+# costs two collectives plus ~10 stream-ordered launches whose cost does not
+# shrink with the local row count (measured on MI355X: >= 110 us even on a
+# 1-rank group, against 65-75 us for a complete single-GPU iteration on 1.1 M
+# rows, i.e. ~65 us per million rows), so below a few million rows one GPU is
+# faster than eight and the ranks solve the pressure system redundantly.
+DEFAULT_MIN_ROWS = 4000000
+
+
+def min_rows():
+    return int(os.environ.get('FLOW_AMD_SHARD_MIN_ROWS', DEFAULT_MIN_ROWS))
+
+
+def active(nrows=None):
+    '''Is the pressure solve sharded?  nrows: size of the system about to be
+    solved -- the `auto` policy shards only from min_rows() on.'''
+    if _STATE['group'] is None:
+        return False
+    if _STATE.get('force', False):
+        return True
+    if dist.get_world_size(_STATE['group']) <= 1:
+        return False
+    return nrows is None or nrows >= min_rows()
 
 
 # -- partition (pure host logic, CPU-testable) --------------------------------

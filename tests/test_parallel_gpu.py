@@ -42,7 +42,8 @@ def _worker(rank, world, port, two_level, out):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from flow_amd import parallel
-        parallel.enable(dist.group.WORLD)
+        # force: the auto policy would not shard a system this small
+        parallel.enable(dist.group.WORLD, force=True)
         u, p, infos = _karman_step(two_level)
         out[rank] = (u, p, [i['pressure'].iterations for i in infos],
                      infos[-1]['pressure'].method)
