@@ -62,12 +62,12 @@ def _counter(directory, counter, kernel):
         with open(path) as fh:
             for r in csv.DictReader(fh):
                 if r['Counter_Name'] == counter and \
-                        r['Kernel_Name'].startswith(kernel):
+                        kernel in r['Kernel_Name']:
                     vals.append(float(r['Counter_Value']))
     return vals
 
 
-def pmc(fetch_dir, write_dir, out, kernel='flow::spmv_stream_kernel'):
+def pmc(fetch_dir, write_dir, out, kernel='flow::spmv_stream_kernel<false>'):
     # group by dispatch size: keep the dispatches of the pressure matrix
     # (the most frequent value set is the CG loop + the timed roofline launches)
     f = _counter(fetch_dir, 'FETCH_SIZE', kernel)
