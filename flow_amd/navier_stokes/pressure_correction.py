@@ -63,7 +63,7 @@ solver_parameters = {
     # reference's hypre_amg, :331, :414); False = plain Jacobi
     'pressure': {'maxit': 200000, 'check_every': 10, 'two_level': True,
                  'coarse_size': 4096},
-    'correction': {'maxit': 10000, 'check_every': 10},
+    'correction': {'maxit': 10000, 'check_every': 2},
     }
 
 # iteration counts / residuals of the most recent step()
@@ -393,6 +393,9 @@ def _compute_velocity_correction(
             nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(b), st
             ))
     u1 = Function(W)
+    # the tentative velocity is the natural initial guess: u1 - ui = O(dt), and
+    # ui already carries the boundary values
+    u1.data.copy_(ui.data)
     par = solver_parameters['correction']
     sol = ops.krylov_solve(
         'cg', Mbc, b, u1.data, rtol=tol, atol=0.0, maxit=par['maxit'],
