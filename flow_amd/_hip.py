@@ -35,6 +35,7 @@ class Operator(ctypes.Structure):
         ('cols', ctypes.c_void_p),
         ('rowblocks', ctypes.c_void_p),
         ('vals', ctypes.c_void_p * 4),
+        ('matfree', ctypes.c_void_p),
         ]
 
 
@@ -112,6 +113,19 @@ class NsParams(ctypes.Structure):
         ]
 
 
+class MomentumJvp(ctypes.Structure):
+    _fields_ = [
+        ('mesh', ctypes.POINTER(MeshS)),
+        ('W', ctypes.POINTER(SpaceS)),
+        ('bfmask', ctypes.c_void_p),
+        ('ui', ctypes.c_void_p),
+        ('prm', NsParams),
+        ('scratch', ctypes.c_void_p),
+        ('nbc', ctypes.c_int),
+        ('bc_dofs', ctypes.c_void_p),
+        ]
+
+
 # every symbol include/flow_hip.h declares: (name, argtypes)
 _VP = ctypes.c_void_p
 _I = ctypes.c_int
@@ -148,6 +162,7 @@ SYMBOLS = {
     'flow_assemble_momentum': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _VP, _VP,
                                _VP, _P(CoefS), _P(CoefS), _P(NsParams), _VP,
                                _VP, _VP, ctypes.c_size_t, _VP],
+    'flow_momentum_jvp_apply': [_P(MomentumJvp), _VP, _VP, _VP],
     'flow_assemble_source': [_P(MeshS), _P(SpaceS), _I, _P(CoefS), _VP, _VP,
                              _VP],
     'flow_assemble_magnitude': [_P(MeshS), _P(SpaceS), _I, _VP, _VP, _VP, _VP],

@@ -378,6 +378,95 @@ __global__ __launch_bounds__(kBlock) void momentum_residual_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Matrix-free Jacobian action  J(ui) v = dF/dui [v]: the directional derivative
+// of momentum_residual_kernel's integrand, one thread per cell.
+//   d/dU [ -rho/2 ((u.grad)u . phi - (u.grad phi) . u) ] [v]
+//     = -rho/2 ( ((v.grad)u + (u.grad)v) . phi - (v.grad phi) u - (u.grad phi) v )
+// The viscous and facet terms are linear in u (add_rhs_weak_facets with p = 0).
+// ---------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void momentum_jvp_kernel(
+    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    const int* __restrict__ bfmask, const double* __restrict__ ui,
+    const double* __restrict__ v, flow_ns_params prm,
+    double* __restrict__ scratch) {
+  constexpr int NL = Elem<DEG>::NL;
+  constexpr int NQ = Elem<DEG>::NQ;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const Geom g = load_geom(xy, nc, c);
+  double U[2][NL], V[2][NL];
+  load_local<NL>(ui, nu, cdu, nc, c, 2, U);
+  load_local<NL>(v, nu, cdu, nc, c, 2, V);
+  const int mask = bfmask[c];
+  const double ci = -prm.dt / prm.rho * prm.theta_i;
+  const double hr = 0.5 * prm.rho;
+  const double mu = prm.mu;
+  double acc[2][NL];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc[a][i] = 0.0;
+
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double L[3] = {qpoint<DEG>(q, 0), qpoint<DEG>(q, 1), qpoint<DEG>(q, 2)};
+    const double w = 0.5 * qweight<DEG>(q) * g.adet;
+    double phi[NL], dphi[NL][3], gphi[NL][2];
+    basis<DEG>(L, phi, dphi);
+    phys_grad<NL>(g, dphi, gphi);
+    double uq[2] = {0.0, 0.0}, vq[2] = {0.0, 0.0};
+    double gu[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, gv[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        uq[a] += U[a][j] * phi[j];
+        vq[a] += V[a][j] * phi[j];
+        gu[a][0] += U[a][j] * gphi[j][0];
+        gu[a][1] += U[a][j] * gphi[j][1];
+        gv[a][0] += V[a][j] * gphi[j][0];
+        gv[a][1] += V[a][j] * gphi[j][1];
+      }
+    }
+    double dconv[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+      dconv[a] = gv[a][0] * uq[0] + gv[a][1] * uq[1] + gu[a][0] * vq[0] +
+                 gu[a][1] * vq[1];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const double ugp = uq[0] * gphi[i][0] + uq[1] * gphi[i][1];
+      const double vgp = vq[0] * gphi[i][0] + vq[1] * gphi[i][1];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        double r = -hr * (dconv[a] * phi[i] - vgp * uq[a] - ugp * vq[a]);
+        r -= mu * ((gv[a][0] + gv[0][a]) * gphi[i][0] +
+                   (gv[a][1] + gv[1][a]) * gphi[i][1]);
+        acc[a][i] += w * (vq[a] * phi[i] + ci * r);
+      }
+    }
+  }
+  if (mask && ci != 0.0) {
+    const double P0[3] = {0.0, 0.0, 0.0};
+    add_rhs_weak_facets<DEG>(mask, ci, mu, g, V, P0, acc);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      scratch[static_cast<size_t>(a * NL + i) * nc + c] = acc[a][i];
+}
+
+// out[d] = v[d] on the Dirichlet dofs (identity rows)
+__global__ void bc_copy_kernel(int nbc, const int* __restrict__ dofs,
+                               const double* __restrict__ v,
+                               double* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nbc) out[dofs[k]] = v[dofs[k]];
+}
+
+// ---------------------------------------------------------------------------
 // K5 + K6: Jacobian  J = dF/dui
 // ---------------------------------------------------------------------------
 // basis tables at the quadrature points (wave-uniform index -> scalar loads)
@@ -958,6 +1047,47 @@ extern "C" int flow_assemble_momentum(
     FLOW_CHECK_LAUNCH();
   }
   return FLOW_OK;
+}
+
+int flow::momentum_jvp_check(const flow_momentum_jvp* J) {
+  FLOW_REQUIRE(J != nullptr, "matrix-free Jacobian is NULL");
+  int rc = check_mesh_space(J->mesh, J->W);
+  if (rc) return rc;
+  FLOW_REQUIRE(J->W->vptr && J->W->vsrc, "vector map");
+  FLOW_REQUIRE(J->bfmask && J->ui && J->scratch, "matrix-free Jacobian pointers");
+  FLOW_REQUIRE(J->prm.dt > 0.0 && J->prm.rho > 0.0 && J->prm.mu > 0.0,
+               "parameters");
+  FLOW_REQUIRE(J->nbc >= 0 && (J->nbc == 0 || J->bc_dofs), "Dirichlet dofs");
+  return FLOW_OK;
+}
+
+int flow::momentum_jvp_apply(const flow_momentum_jvp* J, const double* v,
+                             double* out, hipStream_t st) {
+  const flow_mesh* mesh = J->mesh;
+  const flow_space* W = J->W;
+  const int nl = W->deg == 1 ? 3 : 6;
+  int rc;
+  FLOW_DISPATCH_DEG(W->deg, momentum_jvp_kernel, cell_grid(mesh->nc), st,
+                    mesh->nc, mesh->xy, W->cell_dofs, W->n, J->bfmask, J->ui, v,
+                    J->prm, J->scratch);
+  if ((rc = gather(W->n, 2, W->vptr, W->vsrc, J->scratch,
+                   static_cast<size_t>(nl) * mesh->nc, out, st)))
+    return rc;
+  if (J->nbc > 0) {
+    hipLaunchKernelGGL(bc_copy_kernel, dim3(grid_for(J->nbc)), dim3(kBlock), 0,
+                       st, J->nbc, J->bc_dofs, v, out);
+    FLOW_CHECK_LAUNCH();
+  }
+  return FLOW_OK;
+}
+
+extern "C" int flow_momentum_jvp_apply(const flow_momentum_jvp* J,
+                                       const double* v, double* out,
+                                       void* stream) {
+  int rc = momentum_jvp_check(J);
+  if (rc) return rc;
+  FLOW_REQUIRE(v && out && v != out, "jvp vectors");
+  return momentum_jvp_apply(J, v, out, as_stream(stream));
 }
 
 extern "C" int flow_assemble_magnitude(const flow_mesh* mesh, const flow_space* W,

@@ -18,6 +18,11 @@ int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
               hipStream_t st);
 int ilu_check(const flow_ilu* ilu, int op_size);
 
+// assembly_kernels.hip: the matrix-free operator (flow_operator kind 3)
+int momentum_jvp_check(const flow_momentum_jvp* J);
+int momentum_jvp_apply(const flow_momentum_jvp* J, const double* v, double* out,
+                       hipStream_t st);
+
 #define FLOW_CHECK_HIP(expr)                                                 \
   do {                                                                       \
     hipError_t err_ = (expr);                                                \

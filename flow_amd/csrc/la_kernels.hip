@@ -166,7 +166,15 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
 
 static int check_operator(const flow_operator* A) {
   FLOW_REQUIRE(A != nullptr, "operator is NULL");
-  FLOW_REQUIRE(A->kind >= 0 && A->kind <= 2, "operator kind");
+  FLOW_REQUIRE(A->kind >= 0 && A->kind <= 3, "operator kind");
+  if (A->kind == 3) {   // matrix-free: no pattern, no value planes
+    const flow_momentum_jvp* J =
+        static_cast<const flow_momentum_jvp*>(A->matfree);
+    int rc = momentum_jvp_check(J);
+    if (rc) return rc;
+    FLOW_REQUIRE(A->n == J->W->n, "matrix-free operator size");
+    return FLOW_OK;
+  }
   FLOW_REQUIRE(A->n > 0 && A->nnz > 0 && A->nblocks > 0, "operator sizes");
   FLOW_REQUIRE(A->rowptr && A->cols && A->rowblocks, "operator pattern");
   const int planes = A->kind == 0 ? 1 : (A->kind == 1 ? 2 : 4);
@@ -192,6 +200,11 @@ static inline int dot_parts(const flow_operator* A) {
 // y = A x; with dpart != nullptr also the dot_parts(A) workgroup shares of x.y
 static int apply(const flow_operator* A, const double* x, double* y,
                  hipStream_t st, double* dpart = nullptr) {
+  if (A->kind == 3) {
+    FLOW_REQUIRE(dpart == nullptr, "matrix-free operators carry no fused dot");
+    return momentum_jvp_apply(static_cast<const flow_momentum_jvp*>(A->matfree),
+                              x, y, st);
+  }
   const dim3 grid(A->nblocks, A->kind == 1 ? 2 : 1);
   const double* v1 = A->kind == 1 ? A->vals[1] : A->vals[0];
   if (A->kind == 2) {
@@ -837,7 +850,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 6; }
+extern "C" int flow_abi_version(void) { return 7; }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {
@@ -853,6 +866,7 @@ extern "C" int flow_operator_diag_inv(const flow_operator* A,
   int rc = check_operator(A);
   if (rc) return rc;
   FLOW_REQUIRE(diag_idx && dinv, "diag_idx, dinv");
+  FLOW_REQUIRE(A->kind != 3, "a matrix-free operator has no stored diagonal");
   const double* v1 = A->kind == 0 ? A->vals[0]
                                   : (A->kind == 1 ? A->vals[1] : A->vals[3]);
   hipLaunchKernelGGL(diag_inv_kernel, dim3(grid_for(A->n)), dim3(kBlock), 0,
@@ -938,6 +952,7 @@ extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
   int rc = check_solver_args(A, b, x, rtol, atol, maxit, check_every, work,
                              work_len, 5, iters_host, resid_host);
   if (rc) return rc;
+  FLOW_REQUIRE(A->kind != 3, "CG: assembled (symmetric) operators only");
   if (coarse) {
     FLOW_REQUIRE(dinv != nullptr, "two-level preconditioner needs dinv");
     FLOW_REQUIRE(A->kind == 0, "two-level preconditioner: scalar operators");

@@ -192,6 +192,47 @@ class Matrix(object):
         return sp.bmat([[P[0], P[1]], [P[2], P[3]]], format='csr')
 
 
+class MomentumJacobian(object):
+    '''Matrix-free Jacobian of the momentum residual at `ui` (flow_operator
+    kind 3, include/flow_hip.h `flow_momentum_jvp`): `derivative(F1, ui)` of the
+    reference (pressure_correction.py:202) applied cell by cell instead of
+    assembled.  Quacks like a Matrix for krylov_solve ('bicgstab').'''
+    kind = 3
+
+    def __init__(self, W, bfmask, ui, prm, bc_dofs):
+        mesh = W.mesh()
+        self.layout = W.layout
+        self.size = W.size()
+        n2 = self.size
+        nc = mesh.num_cells()
+        self._keep = (bfmask, ui, bc_dofs,
+                      device.empty(2 * W.layout.nloc * nc))
+        self.struct = _hip.MomentumJvp(
+            ctypes.pointer(mesh_struct(mesh)),
+            ctypes.pointer(space_struct(W.layout)),
+            _hip.i32(bfmask, nc, 'bfmask'), _hip.f64(ui, n2, 'ui'), prm,
+            _hip.f64(self._keep[3]), int(bc_dofs.numel()),
+            _hip.i32(bc_dofs) if bc_dofs.numel() else None,
+            )
+        op = _hip.Operator()
+        op.kind = 3
+        op.n = W.layout.N
+        op.matfree = ctypes.cast(ctypes.pointer(self.struct), ctypes.c_void_p)
+        self._op = op
+
+    def operator(self):
+        return self._op
+
+    def apply(self, x, y):
+        lib = _hip.lib()
+        assert x.data_ptr() != y.data_ptr()
+        _hip.check(lib.flow_momentum_jvp_apply(
+            ctypes.byref(self.struct), _hip.f64(x, self.size, 'x'),
+            _hip.f64(y, self.size, 'y'), _hip.stream()
+            ))
+        return y
+
+
 STIFFNESS, MASS, LUMPED_MASS = 0, 1, 2
 
 

@@ -58,7 +58,8 @@ solver_parameters = {
     'newton': {'maximum_iterations': 10, 'linear_maxit': 5000,
                'linear_rtol': 1.0e-13, 'linear_atol_factor': 0.05,
                'forcing': 1.0e-4, 'check_every': 2, 'restart': 400,
-               'preconditioner': 'ilu0', 'ilu_lag': 3.0},
+               'preconditioner': 'ilu0', 'ilu_lag': 3.0,
+               'adaptive_forcing': True, 'matrix_free': True},
     # 'two_level': Jacobi + aggregate coarse space (stands in for the
     # reference's hypre_amg, :331, :414); False = plain Jacobi
     'pressure': {'maxit': 200000, 'check_every': 10, 'two_level': True,
@@ -158,6 +159,7 @@ def _compute_tentative_velocity(
     history = []
     linear_its = []
     it = 0
+    Jop = None
     while True:
         assemble(True, False)
         _hip.check(lib.flow_bc_residual(
@@ -165,6 +167,10 @@ def _compute_tentative_velocity(
             _hip.f64(F), st
             ))
         nrm = ops.vector_norm(F)
+        if history and history[-1] > 0.0:
+            # quadratic-model constant  ||F_{k+1}|| ~ C ||F_k||^2  of this flow
+            # regime (kept across time steps)
+            lay._dev['newton_quad_C'] = nrm / history[-1]**2
         history.append(nrm)
         info('Newton iteration %d: r (abs) = %.3e (tol = %.3e)' % (it, nrm, tol))
         if nrm < tol:
@@ -174,37 +180,57 @@ def _compute_tentative_velocity(
                 'Newton solver did not converge after %d iterations '
                 '(residual history %r)' % (it, history)
                 )
-        assemble(False, True)
-        _hip.check(lib.flow_bc_identity_rows(
-            ctypes.byref(J.operator()), _hip.f64(J.vals),
-            _hip.i32(lay.dev('diag_idx')), nbc, _hip.i32(bc_dofs), st
-            ))
+        def assemble_jacobian():
+            assemble(False, True)
+            _hip.check(lib.flow_bc_identity_rows(
+                ctypes.byref(J.operator()), _hip.f64(J.vals),
+                _hip.i32(lay.dev('diag_idx')), nbc, _hip.i32(bc_dofs), st
+                ))
+
         dx.zero_()
         pre = None
-        if npar.get('preconditioner', 'jacobi') == 'ilu0':
-            # factor once per step (first Newton iteration); later iterations
-            # of the step reuse it as a lagged preconditioner
+        with_ilu = npar.get('preconditioner', 'jacobi') == 'ilu0'
+        # matrix-free Newton-Krylov: J(ui) is applied cell by cell (as cheap
+        # as the assembled 2x2-block SpMV) and only assembled when the lagged
+        # ILU(0) has to be refactored
+        matfree = with_ilu and npar.get('matrix_free', True)
+        if not matfree:
+            assemble_jacobian()
+        if with_ilu:
             from ..fem import ilu
             pre = lay._dev.get('jacobian_ilu')
             key = (rho, mu, theta_i, nbc, hash(bc_dofs_host.tobytes()))
-            if pre is None:
-                pre = ilu.Ilu0(J)
-                pre.dt, pre.key = dt, key
-                lay._dev['jacobian_ilu'] = pre
-            elif pre.key != key or (
+            # lagged preconditioner: J = M + dt (...) changes slowly from
+            # step to step; refactor at the first Newton iteration of a step
+            # when dt has moved by more than `ilu_lag` since the last
+            # factorisation (or the problem itself changed)
+            if pre is None or pre.key != key or (
                     it == 0 and not (1.0 / npar['ilu_lag'] <= dt / pre.dt
                                      <= npar['ilu_lag'])):
-                # lagged preconditioner: J = M + dt (...) changes slowly from
-                # step to step; refactor when dt has moved by more than
-                # `ilu_lag` since the last factorisation (or the problem
-                # itself changed)
-                pre.refactor(J)
+                if matfree:
+                    assemble_jacobian()
+                if pre is None:
+                    pre = ilu.Ilu0(J)
+                    lay._dev['jacobian_ilu'] = pre
+                else:
+                    pre.refactor(J)
                 pre.dt, pre.key = dt, key
+        if matfree and Jop is None:
+            Jop = ops.MomentumJacobian(W, bfmask, ui.data, prm, bc_dofs)
         # Inexact Newton: the linear residual only has to get below what the
         # quadratic term leaves anyway (forcing term 1e-4 ||F||), and below a
         # fraction of the Newton tolerance so that one more step is never
         # needed because of the linear solve.
         lin_atol = max(npar['linear_atol_factor'] * tol, npar['forcing'] * nrm)
+        # Eisenstat-Walker style: when the quadratic model (constant observed
+        # on the previous Newton steps) predicts that this step cannot reach
+        # the tolerance anyway, the linear residual only has to stay below a
+        # tenth of the predicted remainder.
+        quad_c = lay._dev.get('newton_quad_C')
+        if quad_c is not None and npar.get('adaptive_forcing', True):
+            predicted = quad_c * nrm * nrm
+            if predicted > tol:
+                lin_atol = max(lin_atol, min(0.1 * predicted, 1.0e-2 * nrm))
         lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
         # BiCGStab can stagnate when its bi-orthogonality degrades: restart
         # from the current iterate every `restart` iterations (x is updated in
@@ -214,7 +240,8 @@ def _compute_tentative_velocity(
             chunk = min(npar['restart'], npar['linear_maxit'] - its)
             try:
                 sol = ops.krylov_solve(
-                    'bicgstab', J, F, dx, rtol=lin_rtol, atol=0.0,
+                    'bicgstab', Jop if matfree else J, F, dx, rtol=lin_rtol,
+                    atol=0.0,
                     maxit=chunk, check_every=npar['check_every'], ilu=pre
                     )
                 its += sol.iterations

@@ -48,6 +48,8 @@ int flow_abi_version(void);
  *   kind 0: scalar              y = A0 x                      (size n)
  *   kind 1: block diagonal      y_a = A_a x_a, a = 0,1        (size 2n)
  *   kind 2: full 2x2 blocks     y_a = sum_c A_{2a+c} x_c      (size 2n)
+ *   kind 3: matrix-free         y = J(ui) x, `matfree` points to a
+ *           flow_momentum_jvp (below); no pattern, no value planes (size 2n)
  * Replaces the PETSc AIJ matrices behind `solve`/`assemble`
  * (pressure_correction.py:224-254, 326-339, 419-432, 451-464; heat.py:88,106). */
 typedef struct {
@@ -61,6 +63,7 @@ typedef struct {
   const double* vals[4];   /* value planes, nnz each; every plane 16-B aligned
                               and readable up to index nnz (the SpMV loads
                               value PAIRS); cols likewise readable at nnz */
+  const void* matfree;     /* kind 3 only: const flow_momentum_jvp* */
 } flow_operator;
 
 /* ---- K8: SpMV (PETSc MatMult inside every Krylov solve; heat.py:101) ---- */
@@ -285,6 +288,28 @@ int flow_assemble_momentum(const flow_mesh* mesh, const flow_space* W,
                            const flow_coef* f1, const flow_ns_params* prm,
                            double* scratch, double* F, double* Jvals,
                            size_t j_plane_stride, void* stream);
+
+/* Matrix-free action of that Jacobian, out = J(ui) v = dF1/dui [v] (the
+ * directional derivative of the form, evaluated cell by cell like the residual;
+ * `derivative(F1, ui)` applied instead of assembled, pressure_correction.py:202):
+ * costs what the assembled 2x2-block SpMV costs and makes the per-Newton-step
+ * Jacobian assembly unnecessary -- the assembled diagonal blocks are then only
+ * needed when the (lagged) ILU(0) is refactored.  Rows of the nbc Dirichlet
+ * dofs are identity rows (out[d] = v[d]), as flow_bc_identity_rows makes them.
+ * scratch: 2*nloc*nc doubles, private to this operator while a solve runs.
+ * A flow_operator of kind 3 carries a pointer to this struct in `matfree`. */
+typedef struct {
+  const flow_mesh* mesh;
+  const flow_space* W;       /* velocity space, needs vptr/vsrc */
+  const int* bfmask;         /* nc: exterior-facet bits (as flow_assemble_momentum) */
+  const double* ui;          /* 2*W->n: linearisation point */
+  flow_ns_params prm;
+  double* scratch;
+  int nbc;
+  const int* bc_dofs;        /* nbc Dirichlet dofs (component-blocked numbering) */
+} flow_momentum_jvp;
+int flow_momentum_jvp_apply(const flow_momentum_jvp* J, const double* v,
+                            double* out, void* stream);
 
 /* (f, v) for a `dim`-component coefficient: the load vector behind
  * dolfin.project (tests/test_navier_stokes.py:296-308).  scratch: dim*nloc*nc. */

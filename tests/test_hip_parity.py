@@ -220,6 +220,17 @@ def test_momentum_residual_and_jacobian(hip, vdeg, method):
         Jh = J.to_scipy()
         errJ = abs(Jh - J_ref).max() / abs(J_ref).max()
         assert errJ < 1e-11, (name, vdeg, method, 'J', errJ)
+        # the matrix-free action of the same Jacobian (flow_momentum_jvp_apply),
+        # with identity rows on a set of "Dirichlet" dofs
+        v = rng.standard_normal(2 * lay.N)
+        bc = numpy.unique(rng.randint(0, 2 * lay.N, size=7)).astype(numpy.int32)
+        Jop = ops.MomentumJacobian(case.W, bfm, uid, prm, _dev(bc))
+        out = device.empty(2 * lay.N)
+        Jop.apply(_dev(v), out)
+        ref = J_ref.dot(v)
+        ref[bc] = v[bc]
+        errV = abs(out.cpu().numpy() - ref).max() / abs(ref).max()
+        assert errV < 1e-12, (name, vdeg, method, 'J v', errV)
 
 
 @pytest.mark.parametrize('vdeg', [1, 2])
