@@ -21,30 +21,54 @@ namespace flow {
 // ---------------------------------------------------------------------------
 // phase 2
 // ---------------------------------------------------------------------------
-__global__ void gather_kernel(int nout, int nplanes, const int* __restrict__ ptr,
-                              const int* __restrict__ src,
-                              const double* __restrict__ scratch,
-                              size_t plane_stride, size_t out_stride,
-                              double* __restrict__ out) {
+// out[p][k] = sum of scratch[p][src[t]], t in [ptr[k], ptr[k+1]), in that order.
+// The contribution lists are short (<= ~8 cells around a dof), so the cost is
+// the chain ptr -> src -> scratch of dependent loads: four list entries are in
+// flight per step, and all planes share one read of the indices.
+template <int NP>
+__global__ __launch_bounds__(kBlock) void gather_kernel(
+    int nout, const int* __restrict__ ptr, const int* __restrict__ src,
+    const double* __restrict__ scratch, size_t plane_stride, size_t out_stride,
+    double* __restrict__ out) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nout;
        k += gridDim.x * blockDim.x) {
     const int a = ptr[k];
     const int b = ptr[k + 1];
-    for (int p = 0; p < nplanes; ++p) {
-      const double* __restrict__ sp = scratch + p * plane_stride;
-      double s = 0.0;
-      for (int t = a; t < b; ++t) s += sp[src[t]];
-      out[static_cast<size_t>(p) * out_stride + k] = s;
+    double s[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = 0.0;
+    for (int t = a; t < b; t += 4) {
+      int idx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) idx[j] = t + j < b ? src[t + j] : -1;
+      double v[NP][4];
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v[p][j] = idx[j] >= 0 ? scratch[p * plane_stride + idx[j]] : 0.0;
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[p] += v[p][j];
     }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) out[static_cast<size_t>(p) * out_stride + k] = s[p];
   }
 }
 
 static int gather(int nout, int nplanes, const int* ptr, const int* src,
                   const double* scratch, size_t plane_stride, double* out,
                   hipStream_t st, size_t out_stride = 0) {
-  hipLaunchKernelGGL(gather_kernel, dim3(grid_for(nout, kBlock, 1 << 20)),
-                     dim3(kBlock), 0, st, nout, nplanes, ptr, src, scratch,
-                     plane_stride, out_stride ? out_stride : (size_t)nout, out);
+  const dim3 grid(grid_for(nout, kBlock, 1 << 20));
+  const size_t os = out_stride ? out_stride : static_cast<size_t>(nout);
+  FLOW_REQUIRE(nplanes == 1 || nplanes == 2, "gather: 1 or 2 planes");
+  if (nplanes == 1)
+    hipLaunchKernelGGL(gather_kernel<1>, grid, dim3(kBlock), 0, st, nout, ptr,
+                       src, scratch, plane_stride, os, out);
+  else
+    hipLaunchKernelGGL(gather_kernel<2>, grid, dim3(kBlock), 0, st, nout, ptr,
+                       src, scratch, plane_stride, os, out);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
