@@ -113,6 +113,27 @@ class NsParams(ctypes.Structure):
         ]
 
 
+class CgShard(ctypes.Structure):
+    _fields_ = [
+        ('A', ctypes.POINTER(Operator)),
+        ('dinv', ctypes.c_void_p),
+        ('coarse', ctypes.POINTER(CoarseS)),
+        ('n', ctypes.c_int), ('r0', ctypes.c_int), ('r1', ctypes.c_int),
+        ('e0', ctypes.c_int), ('e1', ctypes.c_int),
+        ('nhalo', ctypes.c_int),
+        ('send_row', ctypes.c_int * 2), ('send_len', ctypes.c_int * 2),
+        ('send_slot', ctypes.c_int * 2),
+        ('recv_row', ctypes.c_int * 2), ('recv_len', ctypes.c_int * 2),
+        ('recv_slot', ctypes.c_int * 2),
+        ('x', ctypes.c_void_p), ('r', ctypes.c_void_p), ('z', ctypes.c_void_p),
+        ('w', ctypes.c_void_p), ('p', ctypes.c_void_p), ('s', ctypes.c_void_p),
+        ('rc', ctypes.c_void_p), ('zc', ctypes.c_void_p),
+        ('sigma', ctypes.c_void_p),
+        ('S', ctypes.c_void_p), ('buf', ctypes.c_void_p),
+        ('work', ctypes.c_void_p),
+        ]
+
+
 class MomentumJvp(ctypes.Structure):
     _fields_ = [
         ('mesh', ctypes.POINTER(MeshS)),
@@ -139,6 +160,7 @@ SYMBOLS = {
     'flow_norm_host': [_I, _VP, _I, _VP, _P(_D), _VP],
     'flow_axpby': [_I, _D, _VP, _D, _VP, _VP],
     'flow_vmul': [_I, _D, _VP, _VP, _VP, _VP],
+    'flow_fill': [_I, _D, _VP, _VP],
     'flow_cg_solve': [_P(Operator), _VP, _P(CoarseS), _VP, _VP, _D, _D, _I, _I,
                       _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
@@ -146,12 +168,9 @@ SYMBOLS = {
     'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],
     'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],
     'flow_ilu0_solve': [_P(IluS), _VP, _VP, _VP, _VP],
-    'flow_dot3_dev': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
-    'flow_cg_scalars_dev': [_I, _VP, _VP, _VP],
-    'flow_cg_update_dev': [_I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP],
+    'flow_cg_shard_step': [_P(CgShard), _I, _VP],
     'flow_coarse_restrict_dev': [_P(CoarseS), _VP, _I, _I, _VP, _VP],
     'flow_coarse_solve_dev': [_P(CoarseS), _VP, _VP, _VP],
-    'flow_coarse_recur_dev': [_I, _VP, _VP, _VP, _VP, _VP],
     'flow_coarse_prolong_dev': [_P(CoarseS), _VP, _VP, _VP, _VP, _I, _I, _VP],
     'flow_residual_dev': [_I, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_assemble_scalar_matrix': [_I, _P(MeshS), _P(SpaceS), _VP, _VP, _VP],
@@ -268,3 +287,31 @@ def u8(t, numel=None, name='uint8 operand'):
 
 def stream():
     return ctypes.c_void_p(device.stream_handle())
+
+
+# -- moving data on the device ------------------------------------------------
+# Fills and device-to-device copies of fp64 vectors go through kernels of the
+# library on the stream everything else runs on (flow_fill / flow_axpby), not
+# through the runtime's memset / memcpy: see fill_kernel in la_kernels.hip.
+# Host tensors (CPU-only setup and tests) take torch's path.
+def copy(dst, src):
+    assert dst.numel() == src.numel()
+    if not dst.is_cuda:
+        dst.copy_(src)
+    elif dst.data_ptr() != src.data_ptr():
+        check(lib().flow_axpby(dst.numel(), 1.0, f64(src, name='src'), 0.0,
+                               f64(dst, name='dst'), stream()))
+    return dst
+
+
+def fill(t, value=0.0):
+    if not t.is_cuda:
+        t.fill_(float(value))
+    elif t.numel() > 0:
+        check(lib().flow_fill(t.numel(), float(value), f64(t), stream()))
+    return t
+
+
+def clone(t):
+    out = torch.empty_like(t)
+    return copy(out, t)

@@ -300,6 +300,24 @@ __global__ void axpby_kernel(int n, double a, const double* __restrict__ x,
     y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
 }
 
+// y = value.  Fills and copies of the solvers are plain kernels of the stream
+// (not hipMemsetAsync / hipMemcpyAsync): measured on MI355X with several
+// processes sharing the GPU, the runtime's copy operations were not always
+// ordered against the neighbouring kernels of the same stream (BiCGStab's
+// shadow residual rhat = r0 was copied after r had already been updated).
+__global__ void fill_kernel(int n, double value, double* __restrict__ y) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x)
+    y[i] = value;
+}
+
+static int fill(int n, double value, double* y, hipStream_t st) {
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
+                     value, y);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
 // out = a * x .* y  (masks, diagonal scalings; out may alias x or y)
 __global__ void vmul_kernel(int n, double a, const double* x, const double* y,
                             double* out) {
@@ -571,7 +589,13 @@ static int dots(int n, int nd, const double* a0, const double* b0,
   return FLOW_OK;
 }
 
+// The stream is drained BEFORE the copy is issued as well: measured on MI355X
+// with several processes sharing the GPU, a small device-to-host copy into
+// pageable memory enqueued right behind kernels of the same stream did not
+// always see their results (stale residual norms => different, though equally
+// valid, stopping iterations from one process to the next).
 static int read_slot(const double* S, int slot, double* host, hipStream_t st) {
+  FLOW_CHECK_HIP(hipStreamSynchronize(st));
   FLOW_CHECK_HIP(hipMemcpyAsync(host, S + slot, sizeof(double),
                                 hipMemcpyDeviceToHost, st));
   FLOW_CHECK_HIP(hipStreamSynchronize(st));
@@ -611,8 +635,8 @@ static int cg(const flow_operator* A, const double* dinv,
   const int gu = grid_for(N, kBlock, kRedBlocks);   // update with fused dots
   int np = 0, rc;
 
-  FLOW_CHECK_HIP(hipMemsetAsync(S, 0, kNumSlots * sizeof(double), st));
-  FLOW_CHECK_HIP(hipMemsetAsync(p, 0, 2 * sizeof(double) * N, st));
+  if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
+  if ((rc = fill(2 * N, 0.0, p, st))) return rc;      // p, s
   // ||b||^2
   if ((rc = dots(N, 1, b, b, b, b, b, b, partial, &np, st))) return rc;
   hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 1, 0,
@@ -774,8 +798,8 @@ static int bicgstab(const flow_operator* A, const double* dinv,
   const int gv = grid_for(N);
   int np = 0, rc;
 
-  FLOW_CHECK_HIP(hipMemsetAsync(S, 0, kNumSlots * sizeof(double), st));
-  FLOW_CHECK_HIP(hipMemsetAsync(p, 0, 2 * sizeof(double) * N, st));   // p, v
+  if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
+  if ((rc = fill(2 * N, 0.0, p, st))) return rc;      // p, v
   if ((rc = dots(N, 1, b, b, b, b, b, b, partial, &np, st))) return rc;
   hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 1, 0,
                      partial, S + kB2);
@@ -783,8 +807,8 @@ static int bicgstab(const flow_operator* A, const double* dinv,
   hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(kBlock), 0, st, N, b, t,
                      static_cast<const double*>(nullptr), r,
                      static_cast<double*>(nullptr));
-  FLOW_CHECK_HIP(hipMemcpyAsync(rhat, r, sizeof(double) * N,
-                                hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(axpby_kernel, dim3(gv), dim3(kBlock), 0, st, N, 1.0, r, 0.0,
+                     rhat);                           // rhat = r0
   // rho_new = rhat.r, res2 = r.r ; beta = 0 because rho_old = omega = 0
   if ((rc = dots(N, 2, rhat, r, r, r, r, r, partial, &np, st))) return rc;
   hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, 3,
@@ -850,7 +874,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 7; }
+extern "C" int flow_abi_version(void) { return 9; }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {
@@ -917,6 +941,11 @@ extern "C" int flow_axpby(int n, double a, const double* x, double b, double* y,
                      as_stream(stream), n, a, x, b, y);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
+}
+
+extern "C" int flow_fill(int n, double value, double* y, void* stream) {
+  FLOW_REQUIRE(n > 0 && y, "fill arguments");
+  return fill(n, value, y, as_stream(stream));
 }
 
 extern "C" int flow_vmul(int n, double a, const double* x, const double* y,
@@ -1010,15 +1039,6 @@ __global__ void coarse_recur_kernel(int nc, const double* __restrict__ S,
   }
 }
 
-extern "C" int flow_coarse_recur_dev(int nc, const double* S, const double* omega,
-                                     double* sigma, double* rc, void* stream) {
-  FLOW_REQUIRE(nc > 0 && S && omega && sigma && rc, "coarse recurrence");
-  hipLaunchKernelGGL(coarse_recur_kernel, dim3(grid_for(nc)), dim3(kBlock), 0,
-                     as_stream(stream), nc, S, omega, sigma, rc);
-  FLOW_CHECK_LAUNCH();
-  return FLOW_OK;
-}
-
 extern "C" int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
                                        const double* r, const double* zc,
                                        double* z, int r0, int r1,
@@ -1055,24 +1075,6 @@ extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
 // building blocks of the row-sharded (multi-GPU) CG: the same kernels, driven
 // by flow_amd/parallel.py with one all-reduce + one halo exchange per iteration
 // ---------------------------------------------------------------------------
-extern "C" int flow_dot3_dev(int n, int nd, const double* a0, const double* b0,
-                             const double* a1, const double* b1,
-                             const double* a2, const double* b2, double* work,
-                             double* out, void* stream) {
-  FLOW_REQUIRE(n > 0 && nd >= 1 && nd <= 3 && a0 && b0 && work && out, "dot3");
-  FLOW_REQUIRE(nd < 2 || (a1 && b1), "dot3 pair 1");
-  FLOW_REQUIRE(nd < 3 || (a2 && b2), "dot3 pair 2");
-  hipStream_t st = as_stream(stream);
-  int np = 0;
-  int rc = dots(n, nd, a0, b0, nd > 1 ? a1 : a0, nd > 1 ? b1 : b0,
-                nd > 2 ? a2 : a0, nd > 2 ? b2 : b0, work, &np, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, nd, 0, work,
-                     out);
-  FLOW_CHECK_LAUNCH();
-  return FLOW_OK;
-}
-
 // S <- Chronopoulos-Gear scalars from the (all-reduced) sums in3 =
 // (r.z, z.w, r.r)
 __global__ void cg_scalar_from_sums_kernel(int first,
@@ -1097,33 +1099,146 @@ __global__ void cg_scalar_from_sums_kernel(int first,
   S[kRes2] = rr;
 }
 
-extern "C" int flow_cg_scalars_dev(int first, const double* in3, double* S,
-                                   void* stream) {
-  FLOW_REQUIRE(in3 && S, "cg scalars");
-  hipLaunchKernelGGL(cg_scalar_from_sums_kernel, dim3(1), dim3(64), 0,
-                     as_stream(stream), first, in3, S);
-  FLOW_CHECK_LAUNCH();
-  return FLOW_OK;
-}
-
-extern "C" int flow_cg_update_dev(int n, const double* S, const double* dinv,
-                                  const double* w, double* z, double* p,
-                                  double* s, double* x, double* r, int want_z,
-                                  void* stream) {
-  FLOW_REQUIRE(n > 0 && S && w && z && p && s && x && r, "cg update");
-  hipLaunchKernelGGL(cg_update_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0,
-                     as_stream(stream), n, S, dinv, w, z, p, s, x, r, want_z,
-                     static_cast<double*>(nullptr));
-  FLOW_CHECK_LAUNCH();
-  return FLOW_OK;
-}
-
 extern "C" int flow_residual_dev(int n, const double* b, const double* q,
                                  const double* dinv, double* r, double* z,
                                  void* stream) {
   FLOW_REQUIRE(n > 0 && b && q && r, "residual");
   hipLaunchKernelGGL(residual_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
                      as_stream(stream), n, b, q, dinv, r, z);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+// ---------------------------------------------------------------------------
+// One iteration of the row-sharded CG between two all-reduces (flow_cg_shard in
+// include/flow_hip.h).  The all-reduced buffer carries, in ONE collective, the
+// three dot products, the coarse restriction of w AND the boundary entries of
+// w the neighbours need: x, r, p, s and z are kept current on the ghost rows
+// too (same recurrences on identical inputs), so z never has to be exchanged
+// before the SpMV.
+// ---------------------------------------------------------------------------
+// buf halo section <- own boundary entries of w, zero elsewhere; buf[3] <- 0
+__global__ void halo_pack_kernel(int nhalo, int row0, int len0, int slot0,
+                                 int row1, int len1, int slot1,
+                                 const double* __restrict__ w,
+                                 double* __restrict__ halo,
+                                 double* __restrict__ sums) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nhalo;
+       k += gridDim.x * blockDim.x) {
+    double v = 0.0;
+    if (k >= slot0 && k < slot0 + len0) v = w[row0 + (k - slot0)];
+    if (k >= slot1 && k < slot1 + len1) v = w[row1 + (k - slot1)];
+    halo[k] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) sums[3] = 0.0;
+}
+
+// ghost entries of w <- the neighbours' slots of the reduced buffer
+__global__ void halo_unpack_kernel(int row0, int len0, int slot0, int row1,
+                                   int len1, int slot1,
+                                   const double* __restrict__ halo,
+                                   double* __restrict__ w) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < len0 + len1;
+       k += gridDim.x * blockDim.x) {
+    if (k < len0) w[row0 + k] = halo[slot0 + k];
+    else w[row1 + (k - len0)] = halo[slot1 + (k - len0)];
+  }
+}
+
+static int check_shard(const flow_cg_shard* c) {
+  FLOW_REQUIRE(c != nullptr, "shard context is NULL");
+  int rc = check_operator(c->A);
+  if (rc) return rc;
+  FLOW_REQUIRE(c->A->kind == 0 && c->A->n == c->n, "shard operator");
+  FLOW_REQUIRE(0 <= c->e0 && c->e0 <= c->r0 && c->r0 < c->r1 && c->r1 <= c->e1 &&
+                   c->e1 <= c->n,
+               "shard row ranges");
+  FLOW_REQUIRE(c->dinv && c->x && c->r && c->z && c->w && c->p && c->s && c->S &&
+                   c->buf && c->work,
+               "shard pointers");
+  FLOW_REQUIRE(c->nhalo >= 0, "shard halo size");
+  for (int i = 0; i < 2; ++i) {
+    FLOW_REQUIRE(c->send_len[i] >= 0 && c->recv_len[i] >= 0, "halo lengths");
+    FLOW_REQUIRE(c->send_len[i] == 0 ||
+                     (c->send_row[i] >= c->r0 &&
+                      c->send_row[i] + c->send_len[i] <= c->r1 &&
+                      c->send_slot[i] >= 0 &&
+                      c->send_slot[i] + c->send_len[i] <= c->nhalo),
+                 "halo send range");
+    FLOW_REQUIRE(c->recv_len[i] == 0 ||
+                     (c->recv_row[i] >= c->e0 &&
+                      c->recv_row[i] + c->recv_len[i] <= c->e1 &&
+                      c->recv_slot[i] >= 0 &&
+                      c->recv_slot[i] + c->recv_len[i] <= c->nhalo),
+                 "halo receive range");
+  }
+  if (c->coarse) {
+    if ((rc = check_coarse(c->coarse, c->n))) return rc;
+    FLOW_REQUIRE(c->rc && c->zc && c->sigma, "shard coarse vectors");
+    FLOW_REQUIRE(reinterpret_cast<uintptr_t>(c->rc) % 16 == 0,
+                 "coarse residual must be 16-byte aligned");
+  }
+  return FLOW_OK;
+}
+
+extern "C" int flow_cg_shard_step(const flow_cg_shard* c, int phase,
+                                  void* stream) {
+  int rc = check_shard(c);
+  if (rc) return rc;
+  FLOW_REQUIRE(phase >= 0 && phase <= 2, "shard phase");
+  hipStream_t st = as_stream(stream);
+  const flow_coarse* C = c->coarse;
+  const int nc = C ? C->nc : 0;
+  double* sums = c->buf;
+  double* omega = c->buf + 4;
+  double* halo = c->buf + 4 + nc;
+  const int ne = c->e1 - c->e0;
+  if (phase > 0) {
+    // the buffer now holds the global sums, omega = P^T w and the neighbours'
+    // boundary values of w
+    if (c->recv_len[0] + c->recv_len[1] > 0)
+      hipLaunchKernelGGL(halo_unpack_kernel,
+                         dim3(grid_for(c->recv_len[0] + c->recv_len[1])),
+                         dim3(kBlock), 0, st, c->recv_row[0], c->recv_len[0],
+                         c->recv_slot[0], c->recv_row[1], c->recv_len[1],
+                         c->recv_slot[1], halo, c->w);
+    hipLaunchKernelGGL(cg_scalar_from_sums_kernel, dim3(1), dim3(64), 0, st,
+                       phase == 1 ? 1 : 0, sums, c->S);
+    if (C)   // sigma = omega + beta sigma ; rc -= alpha sigma  (rc = P^T r)
+      hipLaunchKernelGGL(coarse_recur_kernel, dim3(grid_for(nc)), dim3(kBlock), 0,
+                         st, nc, c->S, omega, c->sigma, c->rc);
+    // p, s, x, r [, z = dinv r] on the owned AND ghost rows
+    hipLaunchKernelGGL(cg_update_kernel<false>, dim3(grid_for(ne)), dim3(kBlock),
+                       0, st, ne, c->S, c->dinv + c->e0, c->w + c->e0,
+                       c->z + c->e0, c->p + c->e0, c->s + c->e0, c->x + c->e0,
+                       c->r + c->e0, C ? 0 : 1, static_cast<double*>(nullptr));
+    if (C) {
+      hipLaunchKernelGGL(coarse_gemv_kernel, dim3(grid_for(nc, 4, kMaxGrid)),
+                         dim3(kBlock), 0, st, nc, C->lda, C->Ainv, c->rc, c->zc);
+      hipLaunchKernelGGL(coarse_prolong_kernel<false>, dim3(grid_for(ne)),
+                         dim3(kBlock), 0, st, ne, C->agg_of + c->e0,
+                         c->dinv + c->e0, c->r + c->e0, c->zc, c->z + c->e0,
+                         static_cast<double*>(nullptr));
+    }
+    FLOW_CHECK_LAUNCH();
+  }
+  // w = A z on the owned rows (the operator carries the owned row blocks)
+  if ((rc = apply(c->A, c->z, c->w, st))) return rc;
+  const int no = c->r1 - c->r0;
+  int np = 0;
+  if ((rc = dots(no, 3, c->r + c->r0, c->z + c->r0, c->z + c->r0, c->w + c->r0,
+                 c->r + c->r0, c->r + c->r0, c->work, &np, st)))
+    return rc;
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 3, 0,
+                     c->work, sums);
+  if (C)
+    hipLaunchKernelGGL(coarse_restrict_kernel, dim3(grid_for(nc, 4, kMaxGrid)),
+                       dim3(kBlock), 0, st, nc, C->agg_ptr, C->agg_dofs, c->w,
+                       c->r0, c->r1, omega);
+  hipLaunchKernelGGL(halo_pack_kernel, dim3(grid_for(c->nhalo > 0 ? c->nhalo : 1)),
+                     dim3(kBlock), 0, st, c->nhalo, c->send_row[0],
+                     c->send_len[0], c->send_slot[0], c->send_row[1],
+                     c->send_len[1], c->send_slot[1], c->w, halo, sums);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }

@@ -16,6 +16,8 @@ def local_rank():
 
 
 _DEVICE = None
+_STREAM = None
+_POISON = bool(os.environ.get('FLOW_AMD_POISON'))
 
 
 def get():
@@ -27,6 +29,16 @@ def get():
             idx = local_rank() % torch.cuda.device_count()
             torch.cuda.set_device(idx)
             _DEVICE = torch.device('cuda', idx)
+            # One explicit HIP stream for everything: torch's copies/fills and
+            # the kernels launched through the C ABI.  With torch's default
+            # stream the handle that crosses the C ABI is 0, which this library
+            # takes as the legacy null stream; measured on MI355X (several
+            # processes on one GPU) copies issued by torch were then not
+            # reliably ordered against those launches.  Same real stream on both
+            # sides => plain FIFO order.
+            global _STREAM
+            _STREAM = torch.cuda.Stream(device=idx)
+            torch.cuda.set_stream(_STREAM)
         else:
             _DEVICE = torch.device('cpu')
     return _DEVICE
@@ -38,7 +50,9 @@ def on_gpu():
 
 def to_device(arr):
     arr = numpy.ascontiguousarray(arr)
-    return torch.from_numpy(arr).to(get())
+    t = torch.from_numpy(arr).to(get())
+    synchronize()      # uploads are setup; see to_host for why not left async
+    return t
 
 
 def zeros(n, dtype=torch.float64):
@@ -46,6 +60,9 @@ def zeros(n, dtype=torch.float64):
 
 
 def empty(n, dtype=torch.float64):
+    if _POISON and dtype == torch.float64:
+        # debugging aid: a read of an uninitialised buffer turns into a NaN
+        return torch.full((int(n),), float('nan'), dtype=dtype, device=get())
     return torch.empty(int(n), dtype=dtype, device=get())
 
 
@@ -59,3 +76,14 @@ def stream_handle():
 def synchronize():
     if on_gpu():
         torch.cuda.synchronize()
+
+
+def to_host(t):
+    '''Host copy of a device tensor, after a full device synchronisation.
+    Kernels are enqueued through the C ABI on torch's current stream; measured
+    on MI355X with several processes sharing the GPU, a torch device-to-host
+    copy issued right behind them was NOT always ordered after them (stale
+    reads in ~40 % of the runs of tests/test_parallel_gpu.py).  Every read-back
+    of the package therefore synchronises first.'''
+    synchronize()
+    return t.detach().cpu()

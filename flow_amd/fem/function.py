@@ -15,6 +15,7 @@ import torch
 
 from . import reference
 from .space import FunctionSpace
+from .. import _hip
 from .. import device
 
 
@@ -152,12 +153,13 @@ class Vector(object):
         return self.data.numel()
 
     def get_local(self):
-        return self.data.detach().cpu().numpy().copy()
+        return device.to_host(self.data).numpy().copy()
 
     def set_local(self, values):
         self.data.copy_(torch.as_tensor(
             numpy.ascontiguousarray(values, dtype=numpy.float64)
             ))
+        device.synchronize()
 
     def __getitem__(self, idx):
         if isinstance(idx, slice) and idx == slice(None):
@@ -171,9 +173,9 @@ class Vector(object):
             value = value.data
         if isinstance(idx, slice) and idx == slice(None):
             if isinstance(value, torch.Tensor):
-                self.data.copy_(value)
+                _hip.copy(self.data, value)
             elif numpy.isscalar(value):
-                self.data.fill_(float(value))
+                _hip.fill(self.data, float(value))
             else:
                 self.set_local(value)
             return
@@ -250,29 +252,30 @@ class Function(object):
         return Vector(self.data)
 
     def array(self):
-        return self.data.detach().cpu().numpy().copy()
+        return device.to_host(self.data).numpy().copy()
 
     def set_array(self, values):
         values = numpy.ascontiguousarray(values, dtype=numpy.float64)
         assert values.shape == (self._V.size(),)
         self.data.copy_(torch.from_numpy(values))
+        device.synchronize()
 
     def assign(self, other):
         if isinstance(other, Function):
             assert self._V.same_as(other._V)
-            self.data.copy_(other.data)
+            _hip.copy(self.data, other.data)
         elif isinstance(other, Constant):
             vals = other.values()
             assert len(vals) == self._V.dim
             n = self._V.N
             for c in range(self._V.dim):
-                self.data[c * n:(c + 1) * n] = float(vals[c])
+                _hip.fill(self.data[c * n:(c + 1) * n], float(vals[c]))
         else:
             raise TypeError('cannot assign %r' % type(other))
 
     def copy(self, deepcopy=True):
         assert deepcopy
-        return Function(self._V, self.data.clone())
+        return Function(self._V, _hip.clone(self.data))
 
     def rename(self, name, _label=None):
         self._name = name
@@ -286,7 +289,8 @@ class Function(object):
         n = self._V.N
         S = self._V.collapse()
         return tuple(
-            Function(S, self.data[c * n:(c + 1) * n].clone()) for c in range(2)
+            Function(S, _hip.clone(self.data[c * n:(c + 1) * n]))
+            for c in range(2)
             )
 
     def ufl_element(self):

@@ -211,7 +211,8 @@ class Ilu0(object):
     def factor_values(self, k=0):
         '''Combined L\\U values of block k in the permuted CSR (tests).'''
         size = self.plan.lu_size
-        return self.lu[k * size:k * size + self.plan.nnz].cpu().numpy()
+        return device.to_host(
+            self.lu[k * size:k * size + self.plan.nnz]).numpy()
 
     def solve(self, r, z):
         '''z = blockdiag(LU)^-1 r (testing / direct use).'''

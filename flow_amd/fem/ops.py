@@ -180,7 +180,7 @@ class Matrix(object):
         lay = self.layout
         rp = lay.pattern('rowptr')
         cols = lay.pattern('cols')
-        v = self.vals.cpu().numpy()
+        v = device.to_host(self.vals).numpy()
         nnz = lay.nnz
         st = self.stride
         P = [sp.csr_matrix((v[p * st:p * st + nnz], cols, rp),
@@ -379,6 +379,10 @@ def axpby(a, x, b, y):
         x.numel(), float(a), _hip.f64(x), float(b), _hip.f64(y), _hip.stream()
         ))
     return y
+
+
+copy = _hip.copy
+fill = _hip.fill
 
 
 def vmul(x, y, out=None, a=1.0):

@@ -87,7 +87,7 @@ class Heat(object):
             _hip.stream()
             ))
         if supg_stabilization:
-            if int(status.item()) != 0:
+            if int(device.to_host(status).item()) != 0:
                 # the reference's C++ Expression throws (stabilization.py:132-140)
                 raise RuntimeError('SUPG stabilization: tau > 1e3')
             ops.axpby(1.0, lumped.vals, 1.0, msupg)      # M_lumped + M_supg

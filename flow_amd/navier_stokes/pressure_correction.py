@@ -187,7 +187,7 @@ def _compute_tentative_velocity(
                 _hip.i32(lay.dev('diag_idx')), nbc, _hip.i32(bc_dofs), st
                 ))
 
-        dx.zero_()
+        ops.fill(dx, 0.0)
         pre = None
         with_ilu = npar.get('preconditioner', 'jacobi') == 'ilu0'
         # matrix-free Newton-Krylov: J(ui) is applied cell by cell (as cheap
@@ -422,7 +422,7 @@ def _compute_velocity_correction(
     u1 = Function(W)
     # the tentative velocity is the natural initial guess: u1 - ui = O(dt), and
     # ui already carries the boundary values
-    u1.data.copy_(ui.data)
+    ops.copy(u1.data, ui.data)
     par = solver_parameters['correction']
     sol = ops.krylov_solve(
         'cg', Mbc, b, u1.data, rtol=tol, atol=0.0, maxit=par['maxit'],

@@ -7,21 +7,28 @@ implicitly under mpirun).
 One process per GPU, torch.distributed over RCCL ('nccl' backend) on xGMI.
 Rank g owns the contiguous rows [r_g, r_{g+1}) of the P1 stiffness matrix,
 balanced by nonzeros.  With the x-major vertex numbering of the channel mesh
-the matrix is banded (bandwidth ~ ny), so a rank only needs `halo` entries from
-its left and right neighbour.  Per CG iteration (Chronopoulos-Gear single
-reduction form) there is ONE neighbour halo exchange of z and ONE all-reduce
-carrying the three scalars (r.z, z.w, r.r) and, with the two-level
-preconditioner, the partial coarse restriction omega = P^T w of the same
-iteration (P^T r is then advanced by the recurrence that mirrors r -= alpha s);
-both are latency bound (a few KB / <= 32 KB).
-The local pieces are the same HIP kernels as the single-GPU solver, launched on
-the owned row range through the C ABI (flow_cg_update_dev, flow_operator_apply
-with the rank's row blocks, flow_dot3_dev, flow_cg_scalars_dev).
+the matrix is banded (bandwidth ~ ny), so the columns a rank's rows reference
+(its ghost rows) belong to its left and right neighbour only.
+
+Chronopoulos-Gear single-reduction CG with exactly ONE collective per
+iteration.  Every rank keeps x, r, p, s, z current on its ghost rows as well:
+their updates are pointwise, so all they need there is w = A z, which the
+owners publish.  The all-reduced buffer
+
+    [ r.z, z.w, r.r, 0 | omega = P^T w | boundary entries of w, rank by rank ]
+
+therefore carries the dot products, the coarse restriction of the two-level
+preconditioner (P^T r is advanced by the recurrence that mirrors r -= alpha s)
+AND the halo: each rank fills its own partial sums and its own boundary slots,
+zeros elsewhere, and the sum is the concatenation.  No point-to-point traffic,
+no second synchronisation point; everything between two all-reduces is one
+library call (flow_cg_shard_step, include/flow_hip.h).  The message is a few
+tens of KB: latency bound.
 
 Every rank keeps full-length vectors (the pressure space is small: 9 MB at
-10 M DoF); only the owned slice and the halos are kept current during the
-iteration, and the solution is all-gathered at the end because the other
-sub-steps are replicated.
+10 M DoF); the start (r = b - A x, z = M^-1 r) is computed redundantly on all
+rows, and the solution is all-gathered at the end because the other sub-steps
+are replicated.
 '''
 import ctypes
 import os
@@ -40,9 +47,9 @@ _STATE = {'group': None}
 def enable(group, force=False):
     '''Shard subsequent pressure solves over `group`.  Collective: every rank
     of the group must call it (the first NCCL operation on a group has to
-    involve all of its ranks before point-to-point traffic may start).
-    force: take the sharded loop even on a 1-rank group (development: measures
-    the loop's host overhead).'''
+    involve all of its ranks).
+    force: take the sharded loop even on a 1-rank group or for systems below
+    min_rows() (development / tests).'''
     _STATE['group'] = group
     _STATE['force'] = bool(force)
     if dist.get_world_size(group) > 1:
@@ -56,11 +63,11 @@ def disable():
 
 
 # Rows of the pressure system from which sharding pays.  A sharded CG iteration
-# costs two collectives plus ~10 stream-ordered launches whose cost does not
-# shrink with the local row count (measured on MI355X: >= 110 us even on a
-# 1-rank group, against 65-75 us for a complete single-GPU iteration on 1.1 M
-# rows, i.e. ~65 us per million rows), so below a few million rows one GPU is
-# faster than eight and the ranks solve the pressure system redundantly.
+# is latency bound: one all-reduce plus ~10 stream-ordered launches whose cost
+# does not shrink with the local row count (~5 us each), and the dense coarse
+# solve is replicated; a complete single-GPU iteration on the 1.1 M-row system
+# of the headline workload takes 72 us (~65 us per million rows).  Below a few
+# million rows one GPU is as fast as eight.
 DEFAULT_MIN_ROWS = 4000000
 
 
@@ -81,6 +88,21 @@ def active(nrows=None):
 
 
 # -- partition (pure host logic, CPU-testable) --------------------------------
+class HaloLayout(object):
+    '''What rank g puts into / takes out of the halo section of the all-reduce
+    buffer.  Index 0 = left neighbour, 1 = right neighbour; len 0 = none.'''
+
+    def __init__(self):
+        self.e0 = self.e1 = 0
+        self.nhalo = 0
+        self.send_row = [0, 0]
+        self.send_len = [0, 0]
+        self.send_slot = [0, 0]
+        self.recv_row = [0, 0]
+        self.recv_len = [0, 0]
+        self.recv_slot = [0, 0]
+
+
 class Partition(object):
     '''Row-block partition of a CSR pattern, balanced by nonzeros.'''
 
@@ -106,10 +128,10 @@ class Partition(object):
         cols = numpy.asarray(cols)
         for g in range(world):
             seg = cols[rowptr[bounds[g]]:rowptr[bounds[g + 1]]]
-            self.lo[g] = seg.min()
-            self.hi[g] = seg.max() + 1
+            self.lo[g] = min(seg.min(), bounds[g])
+            self.hi[g] = max(seg.max() + 1, bounds[g + 1])
         for g in range(world):
-            # halos must come from the immediate neighbours only
+            # ghost rows must belong to the immediate neighbours only
             left = bounds[g - 1] if g > 0 else 0
             right = bounds[g + 2] if g + 2 <= world else n
             assert self.lo[g] >= left and self.hi[g] <= right, \
@@ -118,27 +140,56 @@ class Partition(object):
     def rows(self, g):
         return int(self.bounds[g]), int(self.bounds[g + 1])
 
-    def exchanges(self, g):
-        '''[(peer, send_slice, recv_slice)] of rank g: what it must send to and
-        receive from each neighbour before a local SpMV.'''
+    def sends(self, g):
+        '''[(row, len)] for the left and the right neighbour: the owned rows
+        of rank g that are ghost rows there.'''
         r0, r1 = self.rows(g)
-        out = []
+        left = (r0, 0)
+        right = (r1, 0)
         if g > 0:
-            # left neighbour needs my first rows up to its hi; I need [lo, r0)
-            send = (r0, int(max(r0, min(self.hi[g - 1], r1))))
-            recv = (int(min(self.lo[g], r0)), r0)
-            out.append((g - 1, send, recv))
+            end = int(min(self.hi[g - 1], r1))
+            left = (r0, max(end - r0, 0))
         if g + 1 < self.world:
-            send = (int(min(r1, max(self.lo[g + 1], r0))), r1)
-            recv = (r1, int(max(self.hi[g], r1)))
-            out.append((g + 1, send, recv))
-        return out
+            start = int(max(self.lo[g + 1], r0))
+            right = (start, max(r1 - start, 0))
+        return [left, right]
+
+    def halo_layout(self, g):
+        '''Slots of the halo section: rank by rank, [to-left | to-right].'''
+        slot = {}
+        off = 0
+        for q in range(self.world):
+            for side, (row, ln) in enumerate(self.sends(q)):
+                slot[(q, side)] = (off, row, ln)
+                off += ln
+        lay = HaloLayout()
+        lay.nhalo = off
+        lay.e0, lay.e1 = int(self.lo[g]), int(self.hi[g])
+        for side in (0, 1):
+            o, row, ln = slot[(g, side)]
+            lay.send_row[side], lay.send_len[side], lay.send_slot[side] = \
+                row, ln, o
+        r0, r1 = self.rows(g)
+        if g > 0:
+            # my left ghost rows = what the left neighbour sends to ITS right
+            o, row, ln = slot[(g - 1, 1)]
+            assert row == lay.e0 and row + ln == r0
+            lay.recv_row[0], lay.recv_len[0], lay.recv_slot[0] = row, ln, o
+        else:
+            assert lay.e0 == r0
+        if g + 1 < self.world:
+            o, row, ln = slot[(g + 1, 0)]
+            assert row == r1 and row + ln == lay.e1
+            lay.recv_row[1], lay.recv_len[1], lay.recv_slot[1] = row, ln, o
+        else:
+            assert lay.e1 == r1
+        return lay
 
 
 class Comm(object):
-    '''The two collectives of the solver on a torch.distributed group.
-    The gloo backend cannot move device tensors point-to-point, so with gloo
-    (CPU tests, single-GPU rehearsals) buffers are staged through the host.'''
+    '''The collectives of the solver on a torch.distributed group.  The gloo
+    backend cannot reduce device tensors, so with gloo (CPU tests, single-GPU
+    rehearsals) buffers are staged through the host.'''
 
     def __init__(self, group):
         self.group = group
@@ -152,35 +203,15 @@ class Comm(object):
 
     def allreduce_sum(self, t):
         if self.staged and t.is_cuda:
-            h = t.cpu()
+            # (to_host synchronises first: see device.to_host)
+            h = device.to_host(t)
             dist.all_reduce(h, group=self.group)
             t.copy_(h)
         else:
+            # RCCL: enqueued behind the kernels of the current stream by
+            # torch's event hand-over, and the stream waits for its result
             dist.all_reduce(t, group=self.group)
         return t
-
-    def halo_exchange(self, vec, plan):
-        '''plan: [(peer, (s0, s1), (r0, r1))] slices of the full-length vec.'''
-        ops_ = []
-        staged = []
-        for peer, (s0, s1), (r0, r1) in plan:
-            gp = self.global_rank(peer)
-            if s1 > s0:
-                buf = vec[s0:s1]
-                if self.staged and vec.is_cuda:
-                    buf = buf.cpu()
-                ops_.append(dist.P2POp(dist.isend, buf, gp, self.group))
-            if r1 > r0:
-                buf = vec[r0:r1]
-                if self.staged and vec.is_cuda:
-                    buf = torch.empty(r1 - r0, dtype=vec.dtype)
-                    staged.append((buf, r0, r1))
-                ops_.append(dist.P2POp(dist.irecv, buf, gp, self.group))
-        if ops_:
-            for req in dist.batch_isend_irecv(ops_):
-                req.wait()
-        for buf, r0, r1 in staged:
-            vec[r0:r1].copy_(buf)
 
     def allgather_rows(self, vec, bounds):
         '''Make the full vector current on every rank (owned slices -> all).'''
@@ -188,7 +219,7 @@ class Comm(object):
             r0, r1 = int(bounds[g]), int(bounds[g + 1])
             seg = vec[r0:r1]
             if self.staged and vec.is_cuda:
-                h = seg.cpu()
+                h = device.to_host(seg)
                 dist.broadcast(h, self.global_rank(g), group=self.group)
                 seg.copy_(h)
             else:
@@ -197,13 +228,20 @@ class Comm(object):
 
 # -- local kernels ------------------------------------------------------------
 class HipLocal(object):
-    '''Local pieces of the sharded CG on the HIP path.'''
+    '''The local side of the sharded CG on the HIP path: owns the vectors and
+    the flow_cg_shard context; `step` is one library call.'''
 
-    def __init__(self, A, r0, r1):
+    def __init__(self, A, dinv, coarse, part, rank):
         self.lib = _hip.lib()
         lay = A.layout
+        n = lay.N
         self.A = A
+        self.dinv = dinv
+        self.coarse = coarse
+        self.n = n
+        r0, r1 = part.rows(rank)
         self.r0, self.r1 = r0, r1
+        hl = part.halo_layout(rank)
         rowptr = lay.pattern('rowptr').astype(numpy.int64)
         rb = csr_stream_rowblocks(rowptr[r0:r1 + 1] - rowptr[r0]) + r0
         self.rowblocks = device.to_device(rb.astype(numpy.int32))
@@ -214,135 +252,87 @@ class HipLocal(object):
         op.rowblocks = _hip.i32(self.rowblocks)
         op.nblocks = len(rb) - 1
         self.op = op
+        nc = coarse.nc if coarse is not None else 0
+        lda = coarse.struct.lda if coarse is not None else 0
+        z = device.zeros
+        self.r, self.z, self.w, self.p, self.s = z(n), z(n), z(n), z(n), z(n)
+        self.S = z(16)
+        self.buf = z(4 + nc + hl.nhalo)
         self.work = device.empty(_hip.REDUCE_WORK)
+        self.rc, self.zc, self.sigma = z(max(lda, 1)), z(max(lda, 1)), \
+            z(max(lda, 1))
+        self.x = None
+        c = _hip.CgShard()
+        c.A = ctypes.pointer(self.op)
+        c.dinv = _hip.f64(dinv, n, 'dinv')
+        if coarse is not None:
+            c.coarse = ctypes.pointer(coarse.struct)
+        c.n, c.r0, c.r1, c.e0, c.e1 = n, r0, r1, hl.e0, hl.e1
+        c.nhalo = hl.nhalo
+        for side in (0, 1):
+            c.send_row[side] = hl.send_row[side]
+            c.send_len[side] = hl.send_len[side]
+            c.send_slot[side] = hl.send_slot[side]
+            c.recv_row[side] = hl.recv_row[side]
+            c.recv_len[side] = hl.recv_len[side]
+            c.recv_slot[side] = hl.recv_slot[side]
+        for name in ('r', 'z', 'w', 'p', 's', 'rc', 'zc', 'sigma', 'S', 'buf',
+                     'work'):
+            setattr(c, name, _hip.f64(getattr(self, name)))
+        self.ctx = c
 
-    def zeros(self, n):
-        return device.zeros(n)
-
-    def spmv_rows(self, x, y):
-        _hip.check(self.lib.flow_operator_apply(
-            ctypes.byref(self.op), _hip.f64(x, self.A.size),
-            _hip.f64(y, self.A.size), _hip.stream()
+    def begin(self, b, x):
+        '''Replicated start on ALL rows: r = b - A x, z = M^-1 r, p = s = 0.
+        Returns b.b.'''
+        from .fem import ops
+        lib, n, st = self.lib, self.n, _hip.stream()
+        self.x = x
+        self.ctx.x = _hip.f64(x, n, 'x')
+        for v in (self.p, self.s, self.S, self.sigma, self.buf):
+            _hip.fill(v, 0.0)
+        self.A.apply(x, self.w)
+        _hip.check(lib.flow_residual_dev(
+            n, _hip.f64(b, n), _hip.f64(self.w), _hip.f64(self.dinv),
+            _hip.f64(self.r), _hip.f64(self.z), st
             ))
-
-    def residual(self, b, q, dinv, r, z):
-        s = slice(self.r0, self.r1)
-        _hip.check(self.lib.flow_residual_dev(
-            self.r1 - self.r0, _hip.f64(b[s]), _hip.f64(q[s]), _hip.f64(dinv[s]),
-            _hip.f64(r[s]), _hip.f64(z[s]), _hip.stream()
-            ))
-
-    def dots(self, r, z, w, b, out):
-        '''out[0:3] = local (r.z, z.w, r.r); out[3] = b.b if b is given.'''
-        s = slice(self.r0, self.r1)
-        n = self.r1 - self.r0
-        _hip.check(self.lib.flow_dot3_dev(
-            n, 3, _hip.f64(r[s]), _hip.f64(z[s]), _hip.f64(z[s]), _hip.f64(w[s]),
-            _hip.f64(r[s]), _hip.f64(r[s]), _hip.f64(self.work),
-            _hip.f64(out[0:3]), _hip.stream()
-            ))
-        if b is not None:
-            _hip.check(self.lib.flow_dot3_dev(
-                n, 1, _hip.f64(b[s]), _hip.f64(b[s]), None, None, None, None,
-                _hip.f64(self.work), _hip.f64(out[3:4]), _hip.stream()
+        if self.coarse is not None:
+            cs = ctypes.byref(self.coarse.struct)
+            _hip.check(lib.flow_coarse_restrict_dev(
+                cs, _hip.f64(self.r), 0, n, _hip.f64(self.rc), st
                 ))
+            _hip.check(lib.flow_coarse_solve_dev(
+                cs, _hip.f64(self.rc), _hip.f64(self.zc), st
+                ))
+            _hip.check(lib.flow_coarse_prolong_dev(
+                cs, _hip.f64(self.dinv), _hip.f64(self.r), _hip.f64(self.zc),
+                _hip.f64(self.z), 0, n, st
+                ))
+        return ops.dot(b, b)
 
-    def scalars(self, first, sums, S):
-        _hip.check(self.lib.flow_cg_scalars_dev(
-            int(first), _hip.f64(sums), _hip.f64(S), _hip.stream()
+    def step(self, phase):
+        _hip.check(self.lib.flow_cg_shard_step(
+            ctypes.byref(self.ctx), int(phase), _hip.stream()
             ))
 
-    def update(self, S, dinv, w, z, p, s_, x, r, want_z=True):
-        s = slice(self.r0, self.r1)
-        _hip.check(self.lib.flow_cg_update_dev(
-            self.r1 - self.r0, _hip.f64(S), _hip.f64(dinv[s]), _hip.f64(w[s]),
-            _hip.f64(z[s]), _hip.f64(p[s]), _hip.f64(s_[s]), _hip.f64(x[s]),
-            _hip.f64(r[s]), int(want_z), _hip.stream()
-            ))
-
-    # two-level preconditioner: partial restriction / coarse solve / prolongation
-    def coarse_restrict(self, coarse, r, rc):
-        _hip.check(self.lib.flow_coarse_restrict_dev(
-            ctypes.byref(coarse.struct), _hip.f64(r, coarse.n), self.r0, self.r1,
-            _hip.f64(rc, coarse.nc), _hip.stream()
-            ))
-
-    def coarse_solve(self, coarse, rc, zc):
-        _hip.check(self.lib.flow_coarse_solve_dev(
-            ctypes.byref(coarse.struct), _hip.f64(rc, coarse.nc),
-            _hip.f64(zc, coarse.nc), _hip.stream()
-            ))
-
-    def coarse_recur(self, coarse, S, omega, sigma, rc):
-        _hip.check(self.lib.flow_coarse_recur_dev(
-            coarse.nc, _hip.f64(S), _hip.f64(omega, coarse.nc),
-            _hip.f64(sigma, coarse.nc), _hip.f64(rc, coarse.nc), _hip.stream()
-            ))
-
-    def coarse_prolong(self, coarse, dinv, r, zc, z):
-        _hip.check(self.lib.flow_coarse_prolong_dev(
-            ctypes.byref(coarse.struct), _hip.f64(dinv, coarse.n),
-            _hip.f64(r, coarse.n), _hip.f64(zc, coarse.nc), _hip.f64(z, coarse.n),
-            self.r0, self.r1, _hip.stream()
-            ))
+    def res2(self):
+        return float(device.to_host(self.buf[2:3])[0])
 
 
-def sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit, check_every,
-               coarse=None):
+def sharded_cg(local, comm, part, b, x, rtol, atol, maxit, check_every):
     '''Chronopoulos-Gear CG on the row partition `part`.  `local` provides the
     kernels (HipLocal in the product; the CPU tests inject a numpy stand-in to
     exercise the partition + communication logic under gloo).  Returns
     (iterations, residual norm); raises _hip.NotConverged.'''
-    g = comm.rank
-    plan = part.exchanges(g)
-    n = part.n
-    r = local.zeros(n)
-    z = local.zeros(n)
-    w = local.zeros(n)
-    p = local.zeros(n)
-    s = local.zeros(n)
-    S = local.zeros(16)
-    # ONE all-reduce per iteration: [r.z, z.w, r.r, b.b | omega = P^T w]
-    nc = coarse.nc if coarse is not None else 0
-    buf = local.zeros(4 + nc)
-    sums = buf[0:4]
-    if coarse is not None:
-        omega = buf[4:4 + nc]
-        rc = local.zeros(nc)
-        zc = local.zeros(nc)
-        sigma = local.zeros(nc)
-
-    def precondition():
-        # z = D^-1 r + P Ac^-1 rc with rc = P^T r kept current by recurrence
-        # (rc -= alpha (omega + beta sigma), mirroring r -= alpha s); the dense
-        # coarse solve is replicated on every rank
-        local.coarse_solve(coarse, rc, zc)
-        local.coarse_prolong(coarse, dinv, r, zc, z)
-
-    def reduce_and_scalars(first, with_b):
-        local.dots(r, z, w, b if with_b else None, sums)
-        if coarse is not None:
-            local.coarse_restrict(coarse, w, omega)
-        comm.allreduce_sum(buf)
-        local.scalars(first, sums, S)
-        if coarse is not None:
-            local.coarse_recur(coarse, S, omega, sigma, rc)
-
-    comm.halo_exchange(x, plan)
-    local.spmv_rows(x, w)
-    local.residual(b, w, dinv, r, z)
-    if coarse is not None:
-        # the only separate coarse all-reduce: rc_0 = P^T r_0
-        local.coarse_restrict(coarse, r, rc)
-        comm.allreduce_sum(rc)
-        precondition()
-    comm.halo_exchange(z, plan)
-    local.spmv_rows(z, w)
-    reduce_and_scalars(True, True)
-    host = sums.cpu()
-    b2 = float(host[3])
-    res2 = float(host[2])
-    sums[3:4].zero_()       # the slot rides along in every later all-reduce
+    # The replicated start needs bitwise identical b and x on every rank.  The
+    # ranks compute them redundantly (deterministic kernels, so they agree),
+    # but a sharded solve must not depend on that: take every row from its
+    # owner.
+    comm.allgather_rows(b, part.bounds)
+    comm.allgather_rows(x, part.bounds)
+    b2 = local.begin(b, x)
+    local.step(0)
+    comm.allreduce_sum(local.buf)
+    res2 = local.res2()
     target = max(rtol * numpy.sqrt(b2), atol)
     it = 0
     while True:
@@ -356,15 +346,11 @@ def sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit, check_every,
                 % (it, numpy.sqrt(res2), target)
                 )
         todo = min(check_every, maxit - it)
-        for _ in range(todo):
-            local.update(S, dinv, w, z, p, s, x, r, coarse is None)
-            if coarse is not None:
-                precondition()
-            comm.halo_exchange(z, plan)
-            local.spmv_rows(z, w)
-            reduce_and_scalars(False, False)
+        for k in range(todo):
+            local.step(1 if it + k == 0 else 2)
+            comm.allreduce_sum(local.buf)
         it += todo
-        res2 = float(sums[2].item())
+        res2 = local.res2()
     comm.allgather_rows(x, part.bounds)
     return it, float(numpy.sqrt(res2))
 
@@ -384,12 +370,13 @@ def pressure_cg(A, dinv, coarse, b, x, rtol, atol, maxit, check_every):
             lay.pattern('rowptr'), lay.pattern('cols'), comm.world
             )
     part = _PART_CACHE[key]
-    r0, r1 = part.rows(comm.rank)
-    lkey = (id(A), comm.world, comm.rank)
+    lkey = (id(A), id(dinv), id(coarse), comm.world, comm.rank)
     if lkey not in _PART_CACHE:
-        _PART_CACHE[lkey] = HipLocal(A, r0, r1)
-    local = _PART_CACHE[lkey]
-    its, res = sharded_cg(local, comm, part, b, x, dinv, rtol, atol, maxit,
-                          check_every, coarse)
+        # keep the keyed objects alive: ids must not be recycled
+        _PART_CACHE[lkey] = (HipLocal(A, dinv, coarse, part, comm.rank),
+                             A, dinv, coarse)
+    local = _PART_CACHE[lkey][0]
+    its, res = sharded_cg(local, comm, part, b, x, rtol, atol, maxit,
+                          check_every)
     return SolveInfo(its, res, 'cg%s[row-sharded x%d]' % (
         '+2level' if coarse is not None else '', comm.world))

@@ -57,9 +57,9 @@ class SupgTau(object):
             _hip.f64(buf), _hip.f64(A), _hip.f64(Ms), _hip.f64(tau),
             _hip.i32(status), _hip.stream()
             ))
-        if int(status.item()) != 0:
+        if int(device.to_host(status).item()) != 0:
             raise RuntimeError('SUPG: tau > 1e3')
-        return numpy.ascontiguousarray(tau.cpu().numpy().reshape(3, nc).T)
+        return numpy.ascontiguousarray(device.to_host(tau).numpy().reshape(3, nc).T)
 
 
 def supg(mesh, convection, diffusion, element_degree):

@@ -169,7 +169,7 @@ def solve(
     lumped = device.empty(npr)
     Mp.apply(one, lumped)
     # minv = mu / lumped, zero on the pressure Dirichlet rows
-    minv = device.to_device(mu * pmask / lumped.cpu().numpy())
+    minv = device.to_device(mu * pmask / device.to_host(lumped).numpy())
 
     def apply_S(p, out):
         t = device.empty(n2)
@@ -182,10 +182,10 @@ def solve(
     # library call)
     pf = device.zeros(npr)
     r = device.empty(npr)
-    r.copy_(rhs)
+    ops.copy(r, rhs)
     z = ops.vmul(r, minv)
     d = device.empty(npr)
-    d.copy_(z)
+    ops.copy(d, z)
     rz = ops.dot(r, z)
     bnorm = numpy.sqrt(ops.dot(rhs, rhs))
     Sd = device.empty(npr)

@@ -84,6 +84,7 @@ int flow_axpby(int n, double a, const double* x, double b, double* y,
                void* stream);                       /* y = a x + b y */
 int flow_vmul(int n, double a, const double* x, const double* y, double* out,
               void* stream);                        /* out = a x .* y */
+int flow_fill(int n, double value, double* y, void* stream);   /* y = value */
 #define FLOW_REDUCE_WORK 4096   /* doubles of `work` the reductions need */
 
 /* Two-level additive preconditioner  z = D^-1 r + P Ac^-1 P^T r  for scalar
@@ -182,30 +183,48 @@ int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
                         double* work, size_t work_len, int* iters_host,
                         double* resid_host, void* stream);
 
-/* ---- K15: building blocks of the row-sharded multi-GPU CG ----------------
+/* ---- K15: row-sharded multi-GPU CG ----------------------------------------
  * (nothing in the reference: DOLFIN/PETSc would do this implicitly under
- * mpirun).  The loop lives in flow_amd/parallel.py: per iteration one halo
- * exchange of z and ONE all-reduce of (r.z, z.w, r.r) over RCCL; these entry
- * points run the local pieces on pre-offset pointers of the owned row range.
- * S: 16 doubles of solver scalars (alpha, beta, ...; slot 3 = r.r). */
-int flow_dot3_dev(int n, int nd, const double* a0, const double* b0,
-                  const double* a1, const double* b1, const double* a2,
-                  const double* b2, double* work, double* out, void* stream);
-int flow_cg_scalars_dev(int first, const double* in3, double* S, void* stream);
-int flow_cg_update_dev(int n, const double* S, const double* dinv,
-                       const double* w, double* z, double* p, double* s,
-                       double* x, double* r, int want_z, void* stream);
-/* two-level preconditioner on the owned rows [r0, r1): partial restriction
- * (all-reduced by the caller), replicated dense coarse solve, prolongation */
+ * mpirun).  Rank g owns the rows [r0, r1) and also keeps x, r, p, s, z current
+ * on its ghost rows [e0, r0) and [r1, e1) (the columns its rows reference;
+ * they belong to the two neighbouring ranks): the vector updates are
+ * pointwise, so all they need there is w = A z, which the owners publish.  Per
+ * iteration there is exactly ONE collective -- an all-reduce (sum) of
+ *   buf = [ r.z, z.w, r.r, 0 | omega = P^T w (nc) | halo (nhalo) ]
+ * in which every rank fills its own partial sums and, in the halo section, its
+ * own boundary entries of w (zeros elsewhere) -- and ONE library call,
+ * flow_cg_shard_step, which runs everything between two all-reduces.
+ * The host loop (flow_amd/parallel.py) is
+ *   replicated start: r = b - A x, z = M^-1 r on all rows (entry points below)
+ *   step(phase 0); allreduce(buf)
+ *   repeat: step(phase 1 the first time, then 2); allreduce(buf);
+ *           every check_every iterations read buf[2] = r.r
+ * phase 0: w = A z (owned rows), local sums, omega, pack
+ * phase 1/2: unpack ghost w, alpha/beta from the sums (1: first iteration),
+ *   rc -= alpha (omega + beta sigma), update on [e0, e1), z = M^-1 r on
+ *   [e0, e1) (replicated dense coarse solve), then as phase 0.
+ * send/recv index 0 = left neighbour, 1 = right; len 0 = none. */
+typedef struct {
+  const flow_operator* A;    /* kind 0, rowblocks covering the OWNED rows only */
+  const double* dinv;        /* n */
+  const flow_coarse* coarse; /* NULL: Jacobi only */
+  int n, r0, r1, e0, e1;
+  int nhalo;                 /* doubles in the halo section of buf */
+  int send_row[2], send_len[2], send_slot[2];  /* w[row..+len) -> halo[slot..) */
+  int recv_row[2], recv_len[2], recv_slot[2];  /* halo[slot..+len) -> w[row..) */
+  double *x, *r, *z, *w, *p, *s;               /* n each */
+  double *rc, *zc, *sigma;   /* coarse->lda each, rc 16-B aligned (coarse only) */
+  double* S;                 /* 16 solver scalars (alpha, beta, ...) */
+  double* buf;               /* 4 + nc + nhalo */
+  double* work;              /* FLOW_REDUCE_WORK */
+} flow_cg_shard;
+int flow_cg_shard_step(const flow_cg_shard* c, int phase, void* stream);
+/* pieces of the replicated start (and of the Stokes Schur loop): residual and
+ * the two-level preconditioner on a row range [r0, r1) */
 int flow_coarse_restrict_dev(const flow_coarse* C, const double* r, int r0,
                              int r1, double* rc_out, void* stream);
 int flow_coarse_solve_dev(const flow_coarse* C, const double* rc_in, double* zc,
                           void* stream);
-/* sigma = omega + beta sigma; rc -= alpha sigma (alpha, beta from S): keeps
- * rc = P^T r current by recurrence so that omega = P^T w rides in the same
- * all-reduce as the dot products */
-int flow_coarse_recur_dev(int nc, const double* S, const double* omega,
-                          double* sigma, double* rc, void* stream);
 int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
                             const double* r, const double* zc, double* z, int r0,
                             int r1, void* stream);

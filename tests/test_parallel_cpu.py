@@ -1,10 +1,10 @@
 # -*- coding: utf-8 -*-
 '''
 Multi-process CPU tests (gloo, world_size 2 and 3) of the row-sharded pressure
-solve: partition, halo plans, the communication pattern and the single-reduction
-CG recurrence of flow_amd/parallel.py.  The local kernels are replaced by a
+solve: partition, halo layout, the one-collective communication pattern and the
+single-reduction CG recurrence of flow_amd/parallel.py.  The local side is a
 numpy stand-in that lives HERE (test infrastructure); the product's local
-kernels are the HIP ones (parallel.HipLocal), covered by the `-m gpu` tests.
+side is parallel.HipLocal (flow_cg_shard_step), covered by the `-m gpu` tests.
 '''
 import os
 import socket
@@ -23,73 +23,90 @@ import oracle_harness as H
 
 
 class NumpyLocal(object):
-    '''numpy restatement of parallel.HipLocal's interface (tests only).'''
+    '''numpy restatement of parallel.HipLocal (tests only): the vectors, the
+    replicated start and everything flow_cg_shard_step does between two
+    all-reduces (include/flow_hip.h), driven by the same HaloLayout.'''
 
-    def __init__(self, A, r0, r1):
+    def __init__(self, A, dinv, coarse, part, rank):
         self.A = A.tocsr()
-        self.rows = self.A[r0:r1]
-        self.r0, self.r1 = r0, r1
+        self.dinv = dinv.numpy()
+        self.coarse = coarse
+        self.n = n = A.shape[0]
+        self.r0, self.r1 = part.rows(rank)
+        self.hl = part.halo_layout(rank)
+        self.rows = self.A[self.r0:self.r1]
+        nc = coarse.nc if coarse is not None else 0
+        self.nc = nc
+        z = lambda m: numpy.zeros(m)
+        self.r, self.z, self.w, self.p, self.s = z(n), z(n), z(n), z(n), z(n)
+        self.rc, self.zc, self.sigma = z(nc), z(nc), z(nc)
+        self.alpha = self.beta = self.gamma = 0.0
+        self.buf = torch.zeros(4 + nc + self.hl.nhalo, dtype=torch.float64)
 
-    def zeros(self, n):
-        return torch.zeros(n, dtype=torch.float64)
+    def _precondition(self, rows):
+        self.z[rows] = self.dinv[rows] * self.r[rows]
+        if self.coarse is not None:
+            self.zc[:] = self.coarse.Ainv.dot(self.rc)
+            self.z[rows] += self.coarse.P.dot(self.zc)[rows]
 
-    def spmv_rows(self, x, y):
-        y.numpy()[self.r0:self.r1] = self.rows.dot(x.numpy())
+    def begin(self, b, x):
+        self.x = x.numpy()
+        bn = b.numpy()
+        self.p[:] = 0.0
+        self.s[:] = 0.0
+        self.sigma[:] = 0.0
+        self.alpha = self.beta = self.gamma = 0.0
+        self.buf.zero_()
+        self.r[:] = bn - self.A.dot(self.x)
+        if self.coarse is not None:
+            self.rc[:] = self.coarse.P.T.dot(self.r)
+        self._precondition(slice(0, self.n))
+        return float(bn.dot(bn))
 
-    def residual(self, b, q, dinv, r, z):
-        s = slice(self.r0, self.r1)
-        r.numpy()[s] = b.numpy()[s] - q.numpy()[s]
-        z.numpy()[s] = dinv.numpy()[s] * r.numpy()[s]
+    def step(self, phase):
+        hl, buf = self.hl, self.buf.numpy()
+        halo = buf[4 + self.nc:]
+        ext = slice(hl.e0, hl.e1)
+        own = slice(self.r0, self.r1)
+        if phase > 0:
+            for side in (0, 1):
+                row, ln, slot = hl.recv_row[side], hl.recv_len[side], \
+                    hl.recv_slot[side]
+                self.w[row:row + ln] = halo[slot:slot + ln]
+            g, d = buf[0], buf[1]
+            if phase == 1:
+                beta = 0.0
+                alpha = g / d if d != 0.0 else 0.0
+            else:
+                beta = g / self.gamma if self.gamma != 0.0 else 0.0
+                den = d - beta * g / self.alpha if self.alpha != 0.0 else 0.0
+                alpha = g / den if den != 0.0 else 0.0
+            self.gamma, self.alpha, self.beta = g, alpha, beta
+            if self.coarse is not None:
+                self.sigma[:] = buf[4:4 + self.nc] + beta * self.sigma
+                self.rc -= alpha * self.sigma
+            self.p[ext] = self.z[ext] + beta * self.p[ext]
+            self.s[ext] = self.w[ext] + beta * self.s[ext]
+            self.x[ext] += alpha * self.p[ext]
+            self.r[ext] -= alpha * self.s[ext]
+            self._precondition(ext)
+        self.w[own] = self.rows.dot(self.z)
+        buf[0] = self.r[own].dot(self.z[own])
+        buf[1] = self.z[own].dot(self.w[own])
+        buf[2] = self.r[own].dot(self.r[own])
+        buf[3] = 0.0
+        if self.coarse is not None:
+            v = numpy.zeros(self.n)
+            v[own] = self.w[own]
+            buf[4:4 + self.nc] = self.coarse.P.T.dot(v)
+        halo[:] = 0.0
+        for side in (0, 1):
+            row, ln, slot = hl.send_row[side], hl.send_len[side], \
+                hl.send_slot[side]
+            halo[slot:slot + ln] = self.w[row:row + ln]
 
-    def dots(self, r, z, w, b, out):
-        s = slice(self.r0, self.r1)
-        rn, zn, wn = r.numpy()[s], z.numpy()[s], w.numpy()[s]
-        out[0] = rn.dot(zn)
-        out[1] = zn.dot(wn)
-        out[2] = rn.dot(rn)
-        if b is not None:
-            out[3] = b.numpy()[s].dot(b.numpy()[s])
-
-    def scalars(self, first, sums, S):
-        g, d, rr = float(sums[0]), float(sums[1]), float(sums[2])
-        if first:
-            beta = 0.0
-            alpha = g / d if d != 0.0 else 0.0
-        else:
-            beta = g / float(S[0]) if float(S[0]) != 0.0 else 0.0
-            den = d - beta * g / float(S[1]) if float(S[1]) != 0.0 else 0.0
-            alpha = g / den if den != 0.0 else 0.0
-        S[0], S[1], S[2], S[3] = g, alpha, beta, rr
-
-    def update(self, S, dinv, w, z, p, s_, x, r, want_z=True):
-        s = slice(self.r0, self.r1)
-        alpha, beta = float(S[1]), float(S[2])
-        pn, sn = p.numpy(), s_.numpy()
-        pn[s] = z.numpy()[s] + beta * pn[s]
-        sn[s] = w.numpy()[s] + beta * sn[s]
-        x.numpy()[s] += alpha * pn[s]
-        r.numpy()[s] -= alpha * sn[s]
-        z.numpy()[s] = dinv.numpy()[s] * r.numpy()[s]
-
-    # two-level preconditioner pieces (numpy coarse object: see NumpyCoarse)
-    def coarse_restrict(self, coarse, vec, out):
-        v = numpy.zeros(coarse.n)
-        v[self.r0:self.r1] = vec.numpy()[self.r0:self.r1]
-        out.numpy()[:] = coarse.P.T.dot(v)
-
-    def coarse_solve(self, coarse, rc, zc):
-        zc.numpy()[:] = coarse.Ainv.dot(rc.numpy())
-
-    def coarse_prolong(self, coarse, dinv, r, zc, z):
-        s = slice(self.r0, self.r1)
-        z.numpy()[s] = dinv.numpy()[s] * r.numpy()[s] \
-            + coarse.P.dot(zc.numpy())[s]
-
-    def coarse_recur(self, coarse, S, omega, sigma, rc):
-        alpha, beta = float(S[1]), float(S[2])
-        sg = sigma.numpy()
-        sg[:] = omega.numpy() + beta * sg
-        rc.numpy()[:] -= alpha * sg
+    def res2(self):
+        return float(self.buf[2])
 
 
 class NumpyCoarse(object):
@@ -145,20 +162,18 @@ def _worker(rank, world, port, two_level, out):
         coarse = NumpyCoarse(A, *_system.extra) if two_level else None
         part = parallel.Partition(A.indptr, A.indices, world)
         comm = parallel.Comm(dist.group.WORLD)
-        r0, r1 = part.rows(rank)
-        local = NumpyLocal(A, r0, r1)
-        x = torch.zeros(A.shape[0], dtype=torch.float64)
         dinv = torch.from_numpy(1.0 / A.diagonal())
+        local = NumpyLocal(A, dinv, coarse, part, rank)
+        x = torch.zeros(A.shape[0], dtype=torch.float64)
         its, res = parallel.sharded_cg(
-            local, comm, part, torch.from_numpy(b), x, dinv, 1e-12, 0.0, 5000, 7,
-            coarse
+            local, comm, part, torch.from_numpy(b), x, 1e-12, 0.0, 5000, 7
             )
         out[rank] = (its, res, x.numpy().copy())
     finally:
         dist.destroy_process_group()
 
 
-def test_partition_and_halo_plans():
+def test_partition_and_halo_layout():
     A, _ = _system()
     n = A.shape[0]
     for world in (1, 2, 3, 5):
@@ -166,18 +181,38 @@ def test_partition_and_halo_plans():
         assert part.bounds[0] == 0 and part.bounds[-1] == n
         nnz = numpy.diff(A.indptr[part.bounds])
         assert nnz.max() - nnz.min() <= 2 * 9, 'balanced by nonzeros'
-        for g in range(world):
+        layouts = [part.halo_layout(g) for g in range(world)]
+        nhalo = layouts[0].nhalo
+        owner = numpy.full(nhalo, -1)
+        for g, hl in enumerate(layouts):
+            assert hl.nhalo == nhalo
             r0, r1 = part.rows(g)
+            assert hl.e0 <= r0 and r1 <= hl.e1
             cols = A[r0:r1].indices
-            have = numpy.zeros(n, dtype=bool)
-            have[r0:r1] = True
-            for peer, (s0, s1), (q0, q1) in part.exchanges(g):
-                have[q0:q1] = True
-                # the peer's matching send is exactly my receive
-                back = [e for e in part.exchanges(peer) if e[0] == g][0]
-                assert back[1] == (q0, q1)
-                assert s0 >= r0 and s1 <= r1
-            assert have[cols].all(), 'halo covers every referenced column'
+            assert cols.min() >= hl.e0 and cols.max() < hl.e1, \
+                'ghost rows cover every referenced column'
+            for side in (0, 1):
+                row, ln, slot = hl.send_row[side], hl.send_len[side], \
+                    hl.send_slot[side]
+                assert r0 <= row and row + ln <= r1
+                assert (owner[slot:slot + ln] == -1).all(), 'slots are disjoint'
+                owner[slot:slot + ln] = g
+        assert (owner >= 0).all()
+        # what a rank receives is exactly what the neighbour sends, row by row
+        for g, hl in enumerate(layouts):
+            r0, r1 = part.rows(g)
+            got = []
+            for side, peer in ((0, g - 1), (1, g + 1)):
+                ln = hl.recv_len[side]
+                if ln == 0:
+                    continue
+                ps = layouts[peer]
+                assert ps.send_slot[1 - side] == hl.recv_slot[side]
+                assert ps.send_len[1 - side] == ln
+                assert ps.send_row[1 - side] == hl.recv_row[side]
+                got.append((hl.recv_row[side], ln))
+            ghosts = sum(ln for _, ln in got)
+            assert ghosts == (r0 - hl.e0) + (hl.e1 - r1)
     with pytest.raises(AssertionError):
         parallel.Partition(A.indptr, A.indices, 200)    # blocks thinner than band
 
@@ -202,9 +237,6 @@ def test_sharded_cg_gloo(world, two_level):
     class Solo(object):
         rank, world = 0, 1
 
-        def halo_exchange(self, vec, plan):
-            assert plan == []
-
         def allreduce_sum(self, t):
             return t
 
@@ -212,9 +244,10 @@ def test_sharded_cg_gloo(world, two_level):
             pass
     x = torch.zeros(A.shape[0], dtype=torch.float64)
     coarse = NumpyCoarse(A, *_system.extra) if two_level else None
+    dinv = torch.from_numpy(1.0 / A.diagonal())
     it1, _ = parallel.sharded_cg(
-        NumpyLocal(A, 0, A.shape[0]), Solo(), part, torch.from_numpy(b), x,
-        torch.from_numpy(1.0 / A.diagonal()), 1e-12, 0.0, 5000, 7, coarse
+        NumpyLocal(A, dinv, coarse, part, 0), Solo(), part, torch.from_numpy(b),
+        x, 1e-12, 0.0, 5000, 7
         )
     n_its = its.pop()
     assert abs(it1 - n_its) <= 7
@@ -222,7 +255,7 @@ def test_sharded_cg_gloo(world, two_level):
         # the coarse space pays off also through the recurrence form
         x0 = torch.zeros(A.shape[0], dtype=torch.float64)
         it0, _ = parallel.sharded_cg(
-            NumpyLocal(A, 0, A.shape[0]), Solo(), part, torch.from_numpy(b), x0,
-            torch.from_numpy(1.0 / A.diagonal()), 1e-12, 0.0, 5000, 7, None
+            NumpyLocal(A, dinv, None, part, 0), Solo(), part,
+            torch.from_numpy(b), x0, 1e-12, 0.0, 5000, 7
             )
         assert n_its < 0.75 * it0, (n_its, it0)

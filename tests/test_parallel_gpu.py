@@ -2,9 +2,21 @@
 '''
 The row-sharded pressure solve on the HIP path, rehearsed with several ranks on
 ONE GPU (gloo backend, buffers staged through the host; RCCL needs one GPU per
-rank and is only exercised by the driver's multi-GPU bench).  Compares a whole
-Karman step with the pressure solve sharded over 2 and 3 ranks against the
-single-process step.  GPU only; at most 3 processes touch the card.
+rank and is only exercised by the driver's multi-GPU bench).  GPU only; at most
+4 processes touch the card.
+
+1. The sharded CG itself (flow_cg_shard_step + the one-collective loop) on a
+   fixed linear system built identically on every rank: strict comparison with
+   the single-GPU solver and bitwise agreement between the ranks.
+2. A whole Karman step with the pressure solve sharded, against the
+   single-process step.  Here the tolerance on the pressure is looser, and the
+   reason is worth knowing: the ranks compute the tentative velocity
+   redundantly, and with several processes time-slicing ONE GPU the BiCGStab
+   runs of different processes were measured NOT to be bitwise identical (they
+   are when a process has the GPU to itself: tools/debug_determinism.py,
+   tools/debug_contention.py).  Two valid Newton solves that differ by the
+   Newton tolerance (1e-10 absolute in u) give pressure right-hand sides that
+   differ by rho/dt times that, i.e. ~3e-5 relative at dt = 1e-5.
 '''
 import os
 import socket
@@ -24,6 +36,85 @@ def _free_port():
     return port
 
 
+def _init(rank, world, port):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LOCAL_RANK'] = '0'          # every rank shares cuda:0
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    return dist
+
+
+# -- 1. the solver on a fixed system -------------------------------------------
+def _poisson_system(two_level):
+    '''P1 stiffness matrix of a channel mesh with a Dirichlet outlet, Jacobi
+    diagonal, optional coarse space, right-hand side; all from fixed seeds.'''
+    from flow_amd import fem, device
+    from flow_amd.fem import ops
+    mesh = fem.karman_channel(120, 30)
+    P = fem.FunctionSpace(mesh, 'CG', 1)
+    isbc = mesh.points[:, 0] > mesh.points[:, 0].max() - 1e-12
+    K = ops.assemble_stiffness(P)
+    Kbc = ops.symmetric_bc_matrix(K, device.to_device(isbc.astype(numpy.uint8)))
+    dinv = Kbc.diag_inv()
+    coarse = ops.CoarseSpace(Kbc, isbc, target_nc=64) if two_level else None
+    b = 1.0e3 * numpy.random.RandomState(3).standard_normal(P.layout.N)
+    b[isbc] = 0.0
+    return Kbc, dinv, coarse, device.to_device(b)
+
+
+def _solver_worker(rank, world, port, two_level, out):
+    dist = _init(rank, world, port)
+    try:
+        from flow_amd import parallel, device
+        parallel.enable(dist.group.WORLD, force=True)
+        Kbc, dinv, coarse, b = _poisson_system(two_level)
+        x = device.zeros(b.numel())
+        sol = parallel.pressure_cg(Kbc, dinv, coarse, b, x, 1e-11, 0.0, 20000, 10)
+        # second solve on the same context, warm-started: no stale state
+        x2 = device.zeros(b.numel())
+        x2[:] = 0.5 * x
+        sol2 = parallel.pressure_cg(Kbc, dinv, coarse, b, x2, 1e-11, 0.0, 20000,
+                                    10)
+        out[rank] = (device.to_host(x).numpy(), sol.iterations, sol.method,
+                     device.to_host(x2).numpy(), sol2.iterations)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,two_level', [(2, True), (3, False), (3, True)])
+def test_sharded_cg_matches_single_gpu_solver(hip, world, two_level):
+    from flow_amd import device
+    from flow_amd.fem import ops
+    Kbc, dinv, coarse, b = _poisson_system(two_level)
+    x_ref = device.zeros(b.numel())
+    ref = ops.krylov_solve('cg', Kbc, b, x_ref, rtol=1e-11, maxit=20000,
+                           dinv=dinv, check_every=10, coarse=coarse)
+    x_ref = device.to_host(x_ref).numpy()
+    manager = mp.get_context('spawn').Manager()
+    out = manager.dict()
+    mp.spawn(_solver_worker, args=(world, _free_port(), two_level, out),
+             nprocs=world, join=True)
+    for r in range(world):
+        x, its, method, x2, its2 = out[r]
+        assert 'row-sharded x%d' % world in method
+        assert ('2level' in method) == two_level
+        # different summation order of the dot products: agreement to solver
+        # accuracy (rtol 1e-11 on a kappa ~ 1e4..1e5 system)
+        e = numpy.linalg.norm(x - x_ref) / numpy.linalg.norm(x_ref)
+        assert e <= 1e-7, e
+        e2 = numpy.linalg.norm(x2 - x_ref) / numpy.linalg.norm(x_ref)
+        assert e2 <= 1e-7, e2
+        # the stopping test is evaluated every check_every iterations
+        assert abs(its - ref.iterations) <= 30, (its, ref.iterations)
+        assert its2 <= its
+        # every rank holds the same solution, bit for bit
+        assert numpy.array_equal(x, out[0][0])
+        assert numpy.array_equal(x2, out[0][3])
+        assert its == out[0][1]
+
+
+# -- 2. inside a time step -----------------------------------------------------
 def _karman_step(two_level):
     from flow_amd import karman
     import flow_amd.navier_stokes as navsto
@@ -34,12 +125,8 @@ def _karman_step(two_level):
     return prob.u0.array(), prob.p0.array(), infos
 
 
-def _worker(rank, world, port, two_level, out):
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    os.environ['LOCAL_RANK'] = '0'          # every rank shares cuda:0
-    import torch.distributed as dist
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _step_worker(rank, world, port, two_level, out):
+    dist = _init(rank, world, port)
     try:
         from flow_amd import parallel
         # force: the auto policy would not shard a system this small
@@ -52,23 +139,24 @@ def _worker(rank, world, port, two_level, out):
 
 
 @pytest.mark.parametrize('world,two_level', [(2, True), (3, False)])
-def test_sharded_pressure_solve_matches_single_gpu(hip, world, two_level):
+def test_sharded_pressure_solve_inside_a_step(hip, world, two_level):
     u_ref, p_ref, infos = _karman_step(two_level)
     its_ref = [i['pressure'].iterations for i in infos]
     manager = mp.get_context('spawn').Manager()
     out = manager.dict()
-    mp.spawn(_worker, args=(world, _free_port(), two_level, out), nprocs=world,
-             join=True)
+    mp.spawn(_step_worker, args=(world, _free_port(), two_level, out),
+             nprocs=world, join=True)
     for r in range(world):
         u, p, its, method = out[r]
         assert 'row-sharded x%d' % world in method
         assert ('2level' in method) == two_level
-        # different summation order across ranks: agreement to solver accuracy
-        # (tol 1e-12 on a kappa ~ 1e5 system; bar: 1e-6)
         ep = numpy.linalg.norm(p - p_ref) / numpy.linalg.norm(p_ref)
         eu = numpy.linalg.norm(u - u_ref) / numpy.linalg.norm(u_ref)
-        assert ep <= 5e-7, ep
+        # see the module docstring for the pressure tolerance
+        assert ep <= 2e-4, ep
         assert eu <= 5e-7, eu
+        # the pressure is the solution of ONE global system on every rank
+        assert numpy.array_equal(p, out[0][1])
         for a, b in zip(its, its_ref):
             # the stopping test is evaluated every check_every iterations
             assert abs(a - b) <= 60, (its, its_ref)
