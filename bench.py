@@ -133,11 +133,13 @@ def main():
                     help="torch.distributed backend for N > 1: 'nccl' (= RCCL, "
                          "one GPU per rank); 'gloo' only to rehearse several "
                          "ranks on one GPU")
-    ap.add_argument('--shard', default='auto', choices=['auto', 'always'],
-                    help="N > 1: 'auto' row-shards the pressure solve only "
-                         "from flow_amd.parallel.min_rows() rows on (below "
-                         "that a single GPU is faster and the ranks solve it "
-                         "redundantly); 'always' forces the sharded loop")
+    ap.add_argument('--shard', default='always', choices=['auto', 'always'],
+                    help="N > 1: 'always' (default: the configuration "
+                         "BASELINE.json names) row-shards the pressure-Poisson "
+                         "solve over the ranks; 'auto' is the library's own "
+                         "policy, which shards only from "
+                         "flow_amd.parallel.min_rows() rows on (below that the "
+                         "solve is latency-bound and a single GPU is as fast)")
     ap.add_argument('--shard-single', action='store_true',
                     help='development: run the sharded pressure loop on a '
                          '1-rank process group (measures its host overhead)')
