@@ -54,6 +54,27 @@ inline int grid_for(long long n, int per_block = kBlock, int cap = kMaxGrid) {
   return static_cast<int>(g);
 }
 
+// Scalars that one kernel writes and the next one reads, on the same addresses
+// iteration after iteration -- the solver scalars (alpha, beta, omega, ...),
+// the sums a one-block finisher reads, the head of the all-reduce buffer of the
+// sharded CG -- are read with SYSTEM-scope loads, which go past the scalar
+// cache, the L1s and the per-XCD L2s.  Measured on MI355X (ROCm 7.2): with
+// plain loads of `S[kAlpha]` (wave-uniform, so the compiler uses the scalar
+// cache) some workgroups of a kernel launched right behind the one-thread
+// kernel that updates alpha / beta / omega still saw the PREVIOUS iteration's
+// values.  BiCGStab converged all the same -- on twice the iterations, and
+// along a path that depended on where the allocator had put the buffers
+// (tools/debug_placement.py).  Agent scope was enough in the experiment; system
+// scope costs the same here.  Per-lane (vector) loads of the bigger vectors
+// were never seen stale.
+__device__ __forceinline__ double load_scalar(const double* p) {
+  return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void store_scalar(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // block-wide sum, result valid in thread 0 (blockDim.x == 256)
 __device__ inline double block_sum(double v) {
   __shared__ double wave_part[4];

@@ -285,11 +285,11 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(
   for (int j = 0; j < nd; ++j) {
     double v = 0.0;
     for (int i = threadIdx.x; i < nparts; i += kBlock) {
-      const double p = partial[j * kRedBlocks + i];
+      const double p = load_scalar(partial + j * kRedBlocks + i);
       v = is_max ? fmax(v, p) : v + p;
     }
     v = is_max ? block_max(v) : block_sum(v);
-    if (threadIdx.x == 0) out[j] = v;
+    if (threadIdx.x == 0) store_scalar(out + j, v);
   }
 }
 
@@ -333,6 +333,7 @@ enum Slot {
   kGamma = 0, kAlpha, kBeta, kRes2, kB2, kRho, kOmega, kRhoNew, kTmp,
   kBreak, kNumSlots = 16
 };
+// (the scalars move with load_scalar / store_scalar: common.h)
 // work layout: [0, 3*kRedBlocks) partials, [3*kRedBlocks, +kNumSlots) scalars
 static_assert(3 * kRedBlocks + kNumSlots <= FLOW_REDUCE_WORK, "work size");
 
@@ -359,19 +360,19 @@ __global__ __launch_bounds__(kScalarBlock) void cg_scalar_kernel(
   __shared__ double wsum[3][kScalarBlock / 64];
   double g = 0.0, rr = 0.0;
   for (int i = threadIdx.x; i < nparts; i += kScalarBlock) {
-    g += partial[i];
-    rr += partial[2 * kRedBlocks + i];
+    g += load_scalar(partial + i);
+    rr += load_scalar(partial + 2 * kRedBlocks + i);
   }
   // four independent chains keep the loads of the long list in flight
   double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
   int i = threadIdx.x;
   for (; i + 3 * kScalarBlock < ndelta; i += 4 * kScalarBlock) {
-    d0 += dpart[i];
-    d1 += dpart[i + kScalarBlock];
-    d2 += dpart[i + 2 * kScalarBlock];
-    d3 += dpart[i + 3 * kScalarBlock];
+    d0 += load_scalar(dpart + i);
+    d1 += load_scalar(dpart + i + kScalarBlock);
+    d2 += load_scalar(dpart + i + 2 * kScalarBlock);
+    d3 += load_scalar(dpart + i + 3 * kScalarBlock);
   }
-  for (; i < ndelta; i += kScalarBlock) d0 += dpart[i];
+  for (; i < ndelta; i += kScalarBlock) d0 += load_scalar(dpart + i);
   double d = (d0 + d1) + (d2 + d3);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -399,16 +400,16 @@ __global__ __launch_bounds__(kScalarBlock) void cg_scalar_kernel(
       beta = 0.0;
       alpha = (d != 0.0) ? g / d : 0.0;
     } else {
-      const double g_old = S[kGamma];
-      const double a_old = S[kAlpha];
+      const double g_old = load_scalar(S + kGamma);
+      const double a_old = load_scalar(S + kAlpha);
       beta = (g_old != 0.0) ? g / g_old : 0.0;
       const double den = (a_old != 0.0) ? d - beta * g / a_old : 0.0;
       alpha = (den != 0.0) ? g / den : 0.0;
     }
-    S[kGamma] = g;
-    S[kAlpha] = alpha;
-    S[kBeta] = beta;
-    S[kRes2] = rr;
+    store_scalar(S + kGamma, g);
+    store_scalar(S + kAlpha, alpha);
+    store_scalar(S + kBeta, beta);
+    store_scalar(S + kRes2, rr);
   }
 }
 
@@ -422,8 +423,8 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(
     const double* __restrict__ w, double* __restrict__ z, double* __restrict__ p,
     double* __restrict__ s, double* __restrict__ x, double* __restrict__ r,
     int want_z, double* __restrict__ partial) {
-  const double alpha = S[kAlpha];
-  const double beta = S[kBeta];
+  const double alpha = load_scalar(S + kAlpha);
+  const double beta = load_scalar(S + kBeta);
   double g = 0.0, rr = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
@@ -476,7 +477,9 @@ __global__ __launch_bounds__(kBlock) void coarse_restrict_kernel(
 }
 
 // zc = Ainv rc (dense fp32 rows of lda floats, fp64 accumulation): one
-// wavefront per row, float4 loads; rc 16-byte aligned, nc entries.
+// wavefront per row, float4 loads; rc 16-byte aligned, nc entries.  (rc and zc
+// are per-lane -- vector -- loads: the stale reads common.h describes were
+// only ever observed on wave-uniform loads, which go through the scalar cache.)
 __global__ __launch_bounds__(kBlock) void coarse_gemv_kernel(
     int nc, int lda, const float* __restrict__ Ainv,
     const double* __restrict__ rc, double* __restrict__ zc) {
@@ -594,11 +597,31 @@ static int dots(int n, int nd, const double* a0, const double* b0,
 // pageable memory enqueued right behind kernels of the same stream did not
 // always see their results (stale residual norms => different, though equally
 // valid, stopping iterations from one process to the next).
+//
+// Read-backs therefore do not use the runtime's copy at all: a one-thread
+// kernel of the same stream stores the scalar into host-coherent (pinned,
+// mapped) memory with a system-scope fence, the host waits for the stream and
+// reads it.  The mailbox (a few doubles per host thread) is the only memory
+// the library ever allocates.
+__global__ void mailbox_kernel(const double* __restrict__ src,
+                               volatile double* __restrict__ mailbox) {
+  mailbox[0] = load_scalar(src);
+  __threadfence_system();
+}
+
 static int read_slot(const double* S, int slot, double* host, hipStream_t st) {
+  static thread_local double* mailbox = nullptr;
+  if (!mailbox)
+    FLOW_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&mailbox),
+                                 8 * sizeof(double), hipHostMallocMapped));
+  double* dev_view = nullptr;
+  FLOW_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_view),
+                                         mailbox, 0));
+  hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1), 0, st, S + slot,
+                     dev_view);
+  FLOW_CHECK_LAUNCH();
   FLOW_CHECK_HIP(hipStreamSynchronize(st));
-  FLOW_CHECK_HIP(hipMemcpyAsync(host, S + slot, sizeof(double),
-                                hipMemcpyDeviceToHost, st));
-  FLOW_CHECK_HIP(hipStreamSynchronize(st));
+  *host = *static_cast<volatile double*>(mailbox);
   return FLOW_OK;
 }
 
@@ -710,26 +733,27 @@ __global__ __launch_bounds__(kBlock) void bicg_scalar_kernel(
     double* __restrict__ S) {
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < nparts; i += kBlock) {
-    a += partial[i];
-    b += partial[kRedBlocks + i];
+    a += load_scalar(partial + i);
+    b += load_scalar(partial + kRedBlocks + i);
   }
   a = block_sum(a);
   b = block_sum(b);
   if (threadIdx.x != 0) return;
   if (mode == 1) {
-    S[kAlpha] = (a != 0.0) ? S[kRhoNew] / a : 0.0;
-    if (a == 0.0) S[kBreak] = 1.0;
+    store_scalar(S + kAlpha, (a != 0.0) ? load_scalar(S + kRhoNew) / a : 0.0);
+    if (a == 0.0) store_scalar(S + kBreak, 1.0);
   } else if (mode == 2) {
-    S[kOmega] = (b != 0.0) ? a / b : 0.0;
+    store_scalar(S + kOmega, (b != 0.0) ? a / b : 0.0);
   } else {   // mode 3 (also used for initialisation)
-    const double rho_old = S[kRhoNew];
-    const double omega = S[kOmega];
-    const double alpha = S[kAlpha];
-    S[kRho] = rho_old;
-    S[kRhoNew] = a;
-    S[kRes2] = b;
-    S[kBeta] = (rho_old != 0.0 && omega != 0.0) ? (a / rho_old) * (alpha / omega)
-                                                : 0.0;
+    const double rho_old = load_scalar(S + kRhoNew);
+    const double omega = load_scalar(S + kOmega);
+    const double alpha = load_scalar(S + kAlpha);
+    store_scalar(S + kRho, rho_old);
+    store_scalar(S + kRhoNew, a);
+    store_scalar(S + kRes2, b);
+    store_scalar(S + kBeta, (rho_old != 0.0 && omega != 0.0)
+                                ? (a / rho_old) * (alpha / omega)
+                                : 0.0);
   }
 }
 
@@ -739,8 +763,8 @@ __global__ void bicg_p_kernel(int n, const double* __restrict__ S,
                               const double* __restrict__ r,
                               const double* __restrict__ v,
                               double* __restrict__ p, double* __restrict__ y) {
-  const double beta = S[kBeta];
-  const double omega = S[kOmega];
+  const double beta = load_scalar(S + kBeta);
+  const double omega = load_scalar(S + kOmega);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
     const double pi = r[i] + beta * (p[i] - omega * v[i]);
@@ -754,7 +778,7 @@ __global__ void bicg_s_kernel(int n, const double* __restrict__ S,
                               const double* __restrict__ dinv,
                               const double* __restrict__ v,
                               double* __restrict__ r, double* __restrict__ z) {
-  const double alpha = S[kAlpha];
+  const double alpha = load_scalar(S + kAlpha);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
     const double si = r[i] - alpha * v[i];
@@ -769,8 +793,8 @@ __global__ void bicg_x_kernel(int n, const double* __restrict__ S,
                               const double* __restrict__ z,
                               const double* __restrict__ t,
                               double* __restrict__ x, double* __restrict__ r) {
-  const double alpha = S[kAlpha];
-  const double omega = S[kOmega];
+  const double alpha = load_scalar(S + kAlpha);
+  const double omega = load_scalar(S + kOmega);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
     x[i] += alpha * y[i] + omega * z[i];
@@ -1029,11 +1053,11 @@ __global__ void coarse_recur_kernel(int nc, const double* __restrict__ S,
                                     const double* __restrict__ omega,
                                     double* __restrict__ sigma,
                                     double* __restrict__ rc) {
-  const double alpha = S[kAlpha];
-  const double beta = S[kBeta];
+  const double alpha = load_scalar(S + kAlpha);
+  const double beta = load_scalar(S + kBeta);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc;
        i += gridDim.x * blockDim.x) {
-    const double s = omega[i] + beta * sigma[i];
+    const double s = load_scalar(omega + i) + beta * sigma[i];
     sigma[i] = s;
     rc[i] -= alpha * s;
   }
@@ -1081,7 +1105,8 @@ __global__ void cg_scalar_from_sums_kernel(int first,
                                            const double* __restrict__ in3,
                                            double* __restrict__ S) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double g = in3[0], d = in3[1], rr = in3[2];
+  const double g = load_scalar(in3), d = load_scalar(in3 + 1),
+               rr = load_scalar(in3 + 2);
   double alpha, beta;
   if (first) {
     beta = 0.0;
@@ -1093,10 +1118,10 @@ __global__ void cg_scalar_from_sums_kernel(int first,
     const double den = (a_old != 0.0) ? d - beta * g / a_old : 0.0;
     alpha = (den != 0.0) ? g / den : 0.0;
   }
-  S[kGamma] = g;
-  S[kAlpha] = alpha;
-  S[kBeta] = beta;
-  S[kRes2] = rr;
+  store_scalar(S + kGamma, g);
+  store_scalar(S + kAlpha, alpha);
+  store_scalar(S + kBeta, beta);
+  store_scalar(S + kRes2, rr);
 }
 
 extern "C" int flow_residual_dev(int n, const double* b, const double* q,
@@ -1140,8 +1165,8 @@ __global__ void halo_unpack_kernel(int row0, int len0, int slot0, int row1,
                                    double* __restrict__ w) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < len0 + len1;
        k += gridDim.x * blockDim.x) {
-    if (k < len0) w[row0 + k] = halo[slot0 + k];
-    else w[row1 + (k - len0)] = halo[slot1 + (k - len0)];
+    if (k < len0) w[row0 + k] = load_scalar(halo + slot0 + k);
+    else w[row1 + (k - len0)] = load_scalar(halo + slot1 + (k - len0));
   }
 }
 

@@ -50,16 +50,38 @@ def on_gpu():
 
 def to_device(arr):
     arr = numpy.ascontiguousarray(arr)
-    t = torch.from_numpy(arr).to(get())
+    if _GUARD and arr.dtype == numpy.float64 and on_gpu():
+        t = _guarded(arr.size, None)
+        t.copy_(torch.from_numpy(arr.reshape(-1)))
+    else:
+        t = torch.from_numpy(arr).to(get())
     synchronize()      # uploads are setup; see to_host for why not left async
     return t
 
 
+_GUARD = 64 if os.environ.get('FLOW_AMD_GUARD') else 0
+
+
+def _guarded(n, fill):
+    '''Debugging aid (FLOW_AMD_GUARD=1): fp64 buffers sit between two 512-byte
+    NaN fences, so an out-of-bounds READ that reaches a result shows up.'''
+    buf = torch.full((int(n) + 2 * _GUARD,), float('nan'), dtype=torch.float64,
+                     device=get())
+    view = buf[_GUARD:_GUARD + int(n)]
+    if fill is not None:
+        view.fill_(fill)
+    return view
+
+
 def zeros(n, dtype=torch.float64):
+    if _GUARD and dtype == torch.float64:
+        return _guarded(n, 0.0)
     return torch.zeros(int(n), dtype=dtype, device=get())
 
 
 def empty(n, dtype=torch.float64):
+    if _GUARD and dtype == torch.float64:
+        return _guarded(n, float('nan') if _POISON else 0.0)
     if _POISON and dtype == torch.float64:
         # debugging aid: a read of an uninitialised buffer turns into a NaN
         return torch.full((int(n),), float('nan'), dtype=dtype, device=get())

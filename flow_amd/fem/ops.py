@@ -75,6 +75,8 @@ def scratch(mesh, ndoubles):
         mesh._cache['scratch'] = None
         buf = device.empty(ndoubles)
         mesh._cache['scratch'] = buf
+    if device._POISON:      # debugging aid: stale scratch reads become NaNs
+        _hip.fill(buf, float('nan'))
     return buf
 
 
@@ -427,6 +429,8 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
               + (nparts if method == 'cg' else 0)
               + (2 * coarse.struct.lda if coarse else 0)
               + (n if ilu is not None else 0))
+    if device._POISON:      # debugging aid: stale workspace reads become NaNs
+        _hip.fill(wk, float('nan'))
     if check_every is None:
         check_every = 10 if method == 'bicgstab' else 50
     its = ctypes.c_int(0)

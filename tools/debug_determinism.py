@@ -7,18 +7,26 @@ import numpy, torch
 from flow_amd import karman
 import flow_amd.navier_stokes as navsto
 
-for key, val in [a.split('=') for a in sys.argv[1:]]:
+SIZE = (96, 24, 2)
+args = []
+for a in sys.argv[1:]:
+    if a.startswith('size='):
+        SIZE = tuple(int(v) for v in a[5:].split(','))
+    else:
+        args.append(a)
+for key, val in [a.split('=') for a in args]:
     sec, name = key.split('.')
     navsto.solver_parameters[sec][name] = eval(val)
 print(navsto.solver_parameters['newton'])
 res = []
 for trial in range(4):
-    prob = karman.KarmanProblem(96, 24, velocity_degree=2)
+    prob = karman.KarmanProblem(SIZE[0], SIZE[1], velocity_degree=SIZE[2])
     prob.set_initial_profile()
-    infos = [prob.step(tol=1e-12) for _ in range(2)]
+    prob.dt = 1e-5
+    infos = [prob.step(tol=1e-10) for _ in range(3)]
     ui = navsto.last_step_info.get('tentative_velocity')
     res.append((prob.u0.array().copy(), prob.p0.array().copy(),
-                [i['newton_linear_iterations'] for i in infos]))
+                [(i['newton_linear_iterations'], i['pressure'].iterations, i['correction'].iterations) for i in infos]))
 for k in range(1, len(res)):
     du = abs(res[k][0] - res[0][0]).max()
     dp = abs(res[k][1] - res[0][1]).max()
