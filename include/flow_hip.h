@@ -12,7 +12,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
- *     the library never allocates or frees memory and keeps no state;
+ *     the library never allocates or frees device memory and keeps no state
+ *     (one exception: a 64-byte host-coherent mailbox per host thread, through
+ *     which a kernel of the stream hands scalar results to the host);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
  *     work is enqueued on it; only the *_solve entry points and the *_host
  *     readbacks synchronise it;

@@ -9,14 +9,12 @@ rank and is only exercised by the driver's multi-GPU bench).  GPU only; at most
    fixed linear system built identically on every rank: strict comparison with
    the single-GPU solver and bitwise agreement between the ranks.
 2. A whole Karman step with the pressure solve sharded, against the
-   single-process step.  Here the tolerance on the pressure is looser, and the
-   reason is worth knowing: the ranks compute the tentative velocity
-   redundantly, and with several processes time-slicing ONE GPU the BiCGStab
-   runs of different processes were measured NOT to be bitwise identical (they
-   are when a process has the GPU to itself: tools/debug_determinism.py,
-   tools/debug_contention.py).  Two valid Newton solves that differ by the
-   Newton tolerance (1e-10 absolute in u) give pressure right-hand sides that
-   differ by rho/dt times that, i.e. ~3e-5 relative at dt = 1e-5.
+   single-process step.  The ranks compute the tentative velocity redundantly;
+   this test is what exposed the stale solver scalars described in
+   flow_amd/csrc/common.h (load_scalar): replicas that ran BiCGStab along
+   different paths produced pressure right-hand sides that differed by rho/dt
+   times the Newton tolerance (~3e-5 relative at dt = 1e-5).  With the fix the
+   replicas are bitwise identical again (tools/debug_contention.py).
 '''
 import os
 import socket
@@ -152,8 +150,9 @@ def test_sharded_pressure_solve_inside_a_step(hip, world, two_level):
         assert ('2level' in method) == two_level
         ep = numpy.linalg.norm(p - p_ref) / numpy.linalg.norm(p_ref)
         eu = numpy.linalg.norm(u - u_ref) / numpy.linalg.norm(u_ref)
-        # see the module docstring for the pressure tolerance
-        assert ep <= 2e-4, ep
+        # different summation order across ranks: agreement to solver accuracy
+        # (tol 1e-12 on a kappa ~ 1e5 system; bar: 1e-6)
+        assert ep <= 5e-7, ep
         assert eu <= 5e-7, eu
         # the pressure is the solution of ONE global system on every rank
         assert numpy.array_equal(p, out[0][1])
