@@ -51,6 +51,25 @@ class CoarseS(ctypes.Structure):
         ]
 
 
+MG_MAX_LEVELS = 8
+
+
+class MgS(ctypes.Structure):
+    _fields_ = [
+        ('nlevels', ctypes.c_int),
+        ('A', Operator * MG_MAX_LEVELS),
+        ('dinv', ctypes.c_void_p * MG_MAX_LEVELS),
+        ('P', Operator * MG_MAX_LEVELS),
+        ('R', Operator * MG_MAX_LEVELS),
+        ('r', ctypes.c_void_p * MG_MAX_LEVELS),
+        ('x', ctypes.c_void_p * MG_MAX_LEVELS),
+        ('t', ctypes.c_void_p * MG_MAX_LEVELS),
+        ('nc', ctypes.c_int), ('lda', ctypes.c_int),
+        ('Ainv', ctypes.c_void_p),
+        ('omega', ctypes.c_double),
+        ]
+
+
 class IluPlanS(ctypes.Structure):
     _fields_ = [
         ('n', ctypes.c_int), ('nnz', ctypes.c_int), ('ncolors', ctypes.c_int),
@@ -161,8 +180,8 @@ SYMBOLS = {
     'flow_axpby': [_I, _D, _VP, _D, _VP, _VP],
     'flow_vmul': [_I, _D, _VP, _VP, _VP, _VP],
     'flow_fill': [_I, _D, _VP, _VP],
-    'flow_cg_solve': [_P(Operator), _VP, _P(CoarseS), _VP, _VP, _D, _D, _I, _I,
-                      _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_cg_solve': [_P(Operator), _VP, _P(CoarseS), _P(MgS), _VP, _VP, _D, _D,
+                      _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
                             _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],

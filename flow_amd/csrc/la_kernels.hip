@@ -580,6 +580,112 @@ static int two_level(const flow_coarse* C, const double* dinv, const double* r,
   return FLOW_OK;
 }
 
+// ---------------------------------------------------------------------------
+// smoothed-aggregation multigrid V(1,1) cycle (flow_mg, include/flow_hip.h)
+// ---------------------------------------------------------------------------
+// post-smoothing  x += w D^-1 (r - t), t = A x ; DOTS: the shares of r.x, r.r
+template <bool DOTS>
+__global__ __launch_bounds__(kBlock) void mg_correct_kernel(
+    int n, double omega, const double* __restrict__ dinv,
+    const double* __restrict__ r, const double* __restrict__ t,
+    double* __restrict__ x, double* __restrict__ partial) {
+  double g = 0.0, rr = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    const double ri = r[i];
+    const double xi = x[i] + omega * dinv[i] * (ri - t[i]);
+    x[i] = xi;
+    if (DOTS) {
+      g += ri * xi;
+      rr += ri * ri;
+    }
+  }
+  if (DOTS) {
+    g = block_sum(g);
+    rr = block_sum(rr);
+    if (threadIdx.x == 0) {
+      partial[blockIdx.x] = g;
+      partial[2 * kRedBlocks + blockIdx.x] = rr;
+    }
+  }
+}
+
+static int check_mg(const flow_mg* M, int n) {
+  FLOW_REQUIRE(M->nlevels >= 1 && M->nlevels <= FLOW_MG_MAX_LEVELS, "mg levels");
+  FLOW_REQUIRE(M->omega > 0.0 && M->omega < 2.0, "mg damping");
+  int rows = n;
+  for (int l = 0; l + 1 < M->nlevels; ++l) {
+    int rc = check_operator(&M->A[l]);
+    if (rc) return rc;
+    if ((rc = check_operator(&M->P[l]))) return rc;
+    if ((rc = check_operator(&M->R[l]))) return rc;
+    FLOW_REQUIRE(M->A[l].kind == 0 && M->P[l].kind == 0 && M->R[l].kind == 0,
+                 "mg operators are scalar");
+    FLOW_REQUIRE(M->A[l].n == rows && M->P[l].n == rows, "mg level sizes");
+    FLOW_REQUIRE(M->dinv[l] && M->t[l], "mg level vectors");
+    FLOW_REQUIRE(l == 0 || (M->r[l] && M->x[l]), "mg level vectors");
+    rows = M->R[l].n;
+  }
+  const int last = M->nlevels - 1;
+  FLOW_REQUIRE(M->nc == rows && M->Ainv && M->lda >= M->nc && M->lda % 4 == 0 &&
+                   reinterpret_cast<uintptr_t>(M->Ainv) % 16 == 0,
+               "mg coarsest level");
+  FLOW_REQUIRE(last == 0 || (M->r[last] && M->x[last] &&
+                             reinterpret_cast<uintptr_t>(M->r[last]) % 16 == 0),
+               "mg coarsest vectors");
+  return FLOW_OK;
+}
+
+// z = V-cycle(r) on level 0; partial != nullptr: the last kernel also leaves
+// the *nparts workgroup shares of r.z and r.r
+static int vcycle(const flow_mg* M, const double* r0, double* z0, hipStream_t st,
+                  double* partial = nullptr, int* nparts = nullptr) {
+  const int L = M->nlevels;
+  int rc;
+  for (int l = 0; l + 1 < L; ++l) {
+    const double* r = l == 0 ? r0 : M->r[l];
+    double* x = l == 0 ? z0 : M->x[l];
+    double* t = M->t[l];
+    const int n = M->A[l].n;
+    // x = w D^-1 r ; t = r - A x ; r_{l+1} = R t
+    hipLaunchKernelGGL(vmul_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
+                       M->omega, M->dinv[l], r, x);
+    if ((rc = apply(&M->A[l], x, t, st))) return rc;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
+                       1.0, r, -1.0, t);
+    if ((rc = apply(&M->R[l], t, M->r[l + 1], st))) return rc;
+  }
+  {
+    const double* r = L == 1 ? r0 : M->r[L - 1];
+    double* x = L == 1 ? z0 : M->x[L - 1];
+    hipLaunchKernelGGL(coarse_gemv_kernel, dim3(grid_for(M->nc, 4, kMaxGrid)),
+                       dim3(kBlock), 0, st, M->nc, M->lda, M->Ainv, r, x);
+  }
+  for (int l = L - 2; l >= 0; --l) {
+    const double* r = l == 0 ? r0 : M->r[l];
+    double* x = l == 0 ? z0 : M->x[l];
+    double* t = M->t[l];
+    const int n = M->A[l].n;
+    // x += P x_{l+1} ; x += w D^-1 (r - A x)
+    if ((rc = apply(&M->P[l], M->x[l + 1], t, st))) return rc;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
+                       1.0, t, 1.0, x);
+    if ((rc = apply(&M->A[l], x, t, st))) return rc;
+    if (l == 0 && partial) {
+      const int g = grid_for(n, kBlock, kRedBlocks);
+      hipLaunchKernelGGL(mg_correct_kernel<true>, dim3(g), dim3(kBlock), 0, st, n,
+                         M->omega, M->dinv[l], r, t, x, partial);
+      *nparts = g;
+    } else {
+      hipLaunchKernelGGL(mg_correct_kernel<false>, dim3(grid_for(n)),
+                         dim3(kBlock), 0, st, n, M->omega, M->dinv[l], r, t, x,
+                         static_cast<double*>(nullptr));
+    }
+  }
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
 static int dots(int n, int nd, const double* a0, const double* b0,
                 const double* a1, const double* b1, const double* a2,
                 const double* b2, double* partial, int* nparts,
@@ -637,7 +743,7 @@ static inline size_t cg_work_len(const flow_operator* A, const flow_coarse* C) {
 // in whichever kernel produces z, z.w in the SpMV), so no vector is re-read for
 // a reduction.
 static int cg(const flow_operator* A, const double* dinv,
-              const flow_coarse* C, const double* b,
+              const flow_coarse* C, const flow_mg* M, const double* b,
               double* x, double rtol, double atol, int maxit, int check_every,
               double* work, int* iters_host, double* resid_host,
               hipStream_t st) {
@@ -669,6 +775,7 @@ static int cg(const flow_operator* A, const double* dinv,
   hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(kBlock), 0, st, N, b, w,
                      dinv, r, z);
   if (C && (rc = two_level(C, dinv, r, z, crc, czc, st))) return rc;
+  if (M && (rc = vcycle(M, r, z, st))) return rc;
   if ((rc = apply(A, z, w, st, dpart))) return rc;
   if ((rc = dots(N, 3, r, z, z, w, r, r, partial, &np, st))) return rc;
   hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kScalarBlock), 0, st, np,
@@ -702,6 +809,10 @@ static int cg(const flow_operator* A, const double* dinv,
                            st, N, S, dinv, w, z, p, s, x, r, 0, partial);
         if ((rc = two_level(C, dinv, r, z, crc, czc, st, partial, &np)))
           return rc;
+      } else if (M) {
+        hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
+                           st, N, S, dinv, w, z, p, s, x, r, 0, partial);
+        if ((rc = vcycle(M, r, z, st, partial, &np))) return rc;
       } else {
         hipLaunchKernelGGL(cg_update_kernel<true>, dim3(gu), dim3(kBlock), 0, st,
                            N, S, dinv, w, z, p, s, x, r, 1, partial);
@@ -898,7 +1009,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 9; }
+extern "C" int flow_abi_version(void) { return 10; }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {
@@ -997,7 +1108,8 @@ static int check_solver_args(const flow_operator* A, const double* b,
 }
 
 extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
-                             const flow_coarse* coarse, const double* b,
+                             const flow_coarse* coarse, const flow_mg* mg,
+                             const double* b,
                              double* x, double rtol, double atol, int maxit,
                              int check_every, double* work, size_t work_len,
                              int* iters_host, double* resid_host,
@@ -1016,7 +1128,14 @@ extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
                "workgroups + 2 [+ 2 lda])");
   FLOW_REQUIRE(reinterpret_cast<uintptr_t>(work) % 16 == 0,
                "solver workspace must be 16-byte aligned");
-  return cg(A, dinv, coarse, b, x, rtol, atol, maxit, check_every, work,
+  if (mg) {
+    FLOW_REQUIRE(coarse == nullptr, "multigrid and two-level are exclusive");
+    FLOW_REQUIRE(dinv != nullptr && A->kind == 0,
+                 "multigrid preconditioner: scalar operators with dinv");
+    if ((rc = check_mg(mg, A->n))) return rc;
+    FLOW_REQUIRE(mg->nlevels >= 2, "multigrid: at least two levels");
+  }
+  return cg(A, dinv, coarse, mg, b, x, rtol, atol, maxit, check_every, work,
             iters_host, resid_host, as_stream(stream));
 }
 

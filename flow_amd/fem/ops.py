@@ -414,7 +414,7 @@ class SolveInfo(object):
 
 
 def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
-                 check_every=None, coarse=None, ilu=None):
+                 check_every=None, coarse=None, ilu=None, mg=None):
     '''Solve A x = b on the device; x holds the initial guess.  Raises
     _hip.NotConverged (a RuntimeError) like dolfin's
     'error_on_nonconvergence'.'''
@@ -439,12 +439,13 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
         rc = lib.flow_cg_solve(
             ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
             ctypes.byref(coarse.struct) if coarse is not None else None,
+            ctypes.byref(mg.struct) if mg is not None else None,
             _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
             int(maxit), int(check_every), _hip.f64(wk), wk.numel(),
             ctypes.byref(its), ctypes.byref(res), _hip.stream()
             )
     else:
-        assert coarse is None
+        assert coarse is None and mg is None
         rc = lib.flow_bicgstab_solve(
             ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
             ctypes.byref(ilu.struct) if ilu is not None else None,
@@ -455,6 +456,7 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     _hip.check(rc)
     return SolveInfo(its.value, res.value,
                      method + ('+2level' if coarse is not None else '')
+                     + ('+mg%d' % mg.nlevels if mg is not None else '')
                      + ('+ilu0' if ilu is not None else ''))
 
 

@@ -62,8 +62,10 @@ solver_parameters = {
                'adaptive_forcing': True, 'matrix_free': True},
     # 'two_level': Jacobi + aggregate coarse space (stands in for the
     # reference's hypre_amg, :331, :414); False = plain Jacobi
+    # 'multigrid': smoothed-aggregation V-cycle (single GPU); else / sharded:
+    # the two-level scheme below
     'pressure': {'maxit': 200000, 'check_every': 10, 'two_level': True,
-                 'coarse_size': 4096},
+                 'multigrid': True, 'coarse_size': 4096},
     'correction': {'maxit': 10000, 'check_every': 2},
     }
 
@@ -259,30 +261,45 @@ def _compute_tentative_velocity(
     return ui, alpha
 
 
-def _pressure_cg(A, dinv, coarse, b, x, tol, par):
+def _pressure_cg(A, dinv, prec, b, x, tol, par):
     '''CG for the pressure system: rtol = tol, atol = 0 (reference :332-335,
-    :420-422), preconditioned with Jacobi [+ the aggregate coarse space];
-    row-sharded over the GPUs of the node when flow_amd.parallel is enabled and
-    the system is large enough for that to pay (parallel.min_rows()).'''
+    :420-422), preconditioned with the multigrid V-cycle, with Jacobi + the
+    aggregate coarse space, or with Jacobi alone (`prec` from
+    _preconditioner); row-sharded over the GPUs of the node when
+    flow_amd.parallel is enabled and the system is large enough for that to pay
+    (parallel.min_rows()).'''
+    coarse, mg = prec
     if parallel.active(A.size):
         return parallel.pressure_cg(
             A, dinv, coarse, b, x, tol, 0.0, par['maxit'], par['check_every']
             )
     return ops.krylov_solve(
         'cg', A, b, x, rtol=tol, atol=0.0, maxit=par['maxit'], dinv=dinv,
-        check_every=par['check_every'], coarse=coarse
+        check_every=2 if mg is not None else par['check_every'],
+        coarse=coarse, mg=mg
         )
 
 
-def _coarse_space(lay, key, A, isbc, singular, par):
+def _preconditioner(lay, key, A, isbc, singular, par):
+    '''(coarse, mg): the smoothed-aggregation multigrid hierarchy (default), or
+    the two-level aggregate coarse space -- which is what the row-sharded loop
+    uses, and the fallback for systems too small to coarsen -- or (None, None)
+    for plain Jacobi ('two_level': False).  Built once per (operator, BC set).'''
     if not par.get('two_level', False):
-        return None
+        return None, None
+    if par.get('multigrid', True) and not parallel.active(A.size):
+        mkey = ('mg', key)
+        if mkey not in lay._dev:
+            from ..fem.multigrid import Multigrid
+            lay._dev[mkey] = Multigrid(A, isbc, singular=singular)
+        if lay._dev[mkey].nlevels >= 2:
+            return None, lay._dev[mkey]
     ckey = ('coarse', key, par['coarse_size'])
     if ckey not in lay._dev:
         lay._dev[ckey] = ops.CoarseSpace(
             A, isbc, singular=singular, target_nc=par['coarse_size']
             )
-    return lay._dev[ckey]
+    return lay._dev[ckey], None
 
 
 def _compute_pressure(
@@ -347,7 +364,7 @@ def _compute_pressure(
         _hip.check(lib.flow_bc_set_values(
             nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(b), st
             ))
-        coarse = _coarse_space(lay, key, Kbc, _bc_mask(dofs, P.N) != 0, False,
+        coarse = _preconditioner(lay, key, Kbc, _bc_mask(dofs, P.N) != 0, False,
                                par)
         # the initial guess satisfies the Dirichlet data
         _hip.check(lib.flow_bc_set_values(
@@ -360,7 +377,7 @@ def _compute_pressure(
         key = ('K_dinv',)
         if key not in lay._dev:
             lay._dev[key] = K.diag_inv()
-        coarse = _coarse_space(lay, key, K, None, True, par)
+        coarse = _preconditioner(lay, key, K, None, True, par)
         sol = _pressure_cg(K, lay._dev[key], coarse, b, p1.data, tol, par)
     if verbose:
         info('pressure: %r' % sol)

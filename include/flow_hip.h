@@ -108,6 +108,31 @@ typedef struct {
                               iteration dense product); sums run in fp64 */
 } flow_coarse;
 
+/* Smoothed-aggregation multigrid V(1,1)-cycle as a CG preconditioner for scalar
+ * SPD systems (the AMG-class stand-in for 'hypre_amg', pressure_correction.py
+ * :331,414-418).  The hierarchy is built once per (operator, BC
+ * set) on the host (flow_amd/fem/multigrid.py): aggregates of ~3x3 vertices,
+ * prolongation P = (I - 4/(3 rho) D^-1 A) P0, Galerkin operators R A P with
+ * R = P^T, until the coarsest level is small enough for a dense (pseudo-)
+ * inverse.  Per application, level by level:
+ *   x = w D^-1 r ; r' = R (r - A x) ; [coarse] ; x += P x' ; x += w D^-1 (r - A x)
+ * All operators are kind-0 flow_operators (P and R rectangular: `n` = rows).
+ * Levels 0 .. nlevels-1; the last one is solved with the dense inverse. */
+#define FLOW_MG_MAX_LEVELS 8
+typedef struct {
+  int nlevels;
+  flow_operator A[FLOW_MG_MAX_LEVELS];    /* A[l], l < nlevels-1 (level 0 = the system) */
+  const double* dinv[FLOW_MG_MAX_LEVELS]; /* 1 / diag A[l] */
+  flow_operator P[FLOW_MG_MAX_LEVELS];    /* n_l x n_{l+1} */
+  flow_operator R[FLOW_MG_MAX_LEVELS];    /* n_{l+1} x n_l */
+  double* r[FLOW_MG_MAX_LEVELS];          /* work vectors of level l >= 1 (n_l) */
+  double* x[FLOW_MG_MAX_LEVELS];
+  double* t[FLOW_MG_MAX_LEVELS];          /* all levels l < nlevels-1 (n_l) */
+  int nc, lda;                            /* coarsest level: size, row stride */
+  const float* Ainv;                      /* nc rows of lda floats, as flow_coarse */
+  double omega;                           /* Jacobi damping (0.8) */
+} flow_mg;
+
 /* ---- K11: multicolour ILU(0) ----------------------------------------------
  * (replaces the sparse LU of the Newton solve, pressure_correction.py:224-254,
  * and `LUSolver`, heat.py:117-121, as a BiCGStab preconditioner).  The plan is
@@ -169,13 +194,15 @@ int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
  * FLOW_NOT_CONVERGED after maxit iterations (dolfin raises RuntimeError:
  * 'error_on_nonconvergence', pressure_correction.py:337,424,462).
  * dinv may be NULL (no preconditioner).  x holds the initial guess.
- * coarse may be NULL (Jacobi only); ilu may be NULL (Jacobi), else it replaces
+ * coarse may be NULL (Jacobi only); mg != NULL selects the multigrid V-cycle
+ * instead (coarse must then be NULL); ilu may be NULL (Jacobi), else it replaces
  * dinv as the (right) preconditioner of BiCGStab.
  * work (16-byte aligned): FLOW_REDUCE_WORK + 5*N + B + 2 [+ 2*coarse->lda]
  * doubles (cg; B = nblocks, twice that for kind 1: the SpMV leaves its z.Az
  * partials there), FLOW_REDUCE_WORK + 7*N [+ n] (bicgstab); N = operator size. */
 int flow_cg_solve(const flow_operator* A, const double* dinv,
-                  const flow_coarse* coarse, const double* b, double* x,
+                  const flow_coarse* coarse, const flow_mg* mg,
+                  const double* b, double* x,
                   double rtol, double atol, int maxit, int check_every,
                   double* work, size_t work_len, int* iters_host,
                   double* resid_host, void* stream);
