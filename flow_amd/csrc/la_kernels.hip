@@ -1140,6 +1140,16 @@ extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
 }
 
 // pieces of the two-level preconditioner for the row-sharded loop
+// z = V-cycle(r): one application of the multigrid preconditioner (tests, and
+// callers that drive their own Krylov loop)
+extern "C" int flow_mg_apply(const flow_mg* mg, int n, const double* r,
+                             double* z, void* stream) {
+  FLOW_REQUIRE(mg && r && z && r != z && n > 0, "mg apply");
+  int rc = check_mg(mg, n);
+  if (rc) return rc;
+  return vcycle(mg, r, z, as_stream(stream));
+}
+
 extern "C" int flow_coarse_restrict_dev(const flow_coarse* C, const double* r,
                                         int r0, int r1, double* rc_out,
                                         void* stream) {

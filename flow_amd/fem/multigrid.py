@@ -158,3 +158,12 @@ class Multigrid(object):
         M.Ainv = _hip.f32(self._Ainv, nc * lda).value
         M.omega = float(omega)
         self.struct = M
+
+    def apply(self, r, z):
+        '''z = V-cycle(r): one application of the preconditioner.'''
+        n = self.sizes[0]
+        _hip.check(_hip.lib().flow_mg_apply(
+            ctypes.byref(self.struct), n, _hip.f64(r, n, 'r'),
+            _hip.f64(z, n, 'z'), _hip.stream()
+            ))
+        return z

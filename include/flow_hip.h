@@ -132,6 +132,9 @@ typedef struct {
   const float* Ainv;                      /* nc rows of lda floats, as flow_coarse */
   double omega;                           /* Jacobi damping (0.8) */
 } flow_mg;
+/* z = V-cycle(r) on level 0 (n = its size): one preconditioner application */
+int flow_mg_apply(const flow_mg* mg, int n, const double* r, double* z,
+                  void* stream);
 
 /* ---- K11: multicolour ILU(0) ----------------------------------------------
  * (replaces the sparse LU of the Newton solve, pressure_correction.py:224-254,
