@@ -121,10 +121,10 @@ class KarmanProblem(object):
         info['t'] = self.t
         if adapt:
             # CFL-like step-size control on ||project(|u|)||_inf (:262-286)
-            # (mass solve to 1e-9, started from the previous step's projection:
-            # the value only steers dt)
+            # (mass solve to 1e-7, started from the previous step's projection:
+            # the value only steers dt, which inherits that relative accuracy)
             self._umag = fem.project_magnitude(
-                self.u0, tol=1.0e-9, initial_guess=getattr(self, '_umag', None)
+                self.u0, tol=1.0e-7, initial_guess=getattr(self, '_umag', None)
                 )
             unorm = self._umag.vector().norm('linf')
             target_dt = 1.0 * self.hmax / unorm

@@ -58,7 +58,7 @@ solver_parameters = {
     'newton': {'maximum_iterations': 10, 'linear_maxit': 5000,
                'linear_rtol': 1.0e-13, 'linear_atol_factor': 0.05,
                'forcing': 1.0e-4, 'check_every': 2, 'restart': 400,
-               'preconditioner': 'ilu0', 'ilu_lag': 3.0,
+               'preconditioner': 'ilu0', 'ilu_lag': 8.0,
                'adaptive_forcing': True, 'matrix_free': True},
     # 'two_level': Jacobi + aggregate coarse space (stands in for the
     # reference's hypre_amg, :331, :414); False = plain Jacobi
@@ -203,10 +203,15 @@ def _compute_tentative_velocity(
             pre = lay._dev.get('jacobian_ilu')
             key = (rho, mu, theta_i, nbc, hash(bc_dofs_host.tobytes()))
             # lagged preconditioner: J = M + dt (...) changes slowly from
-            # step to step; refactor at the first Newton iteration of a step
-            # when dt has moved by more than `ilu_lag` since the last
-            # factorisation (or the problem itself changed)
-            if pre is None or pre.key != key or (
+            # step to step.  Refactor when the problem itself changed, when dt
+            # has moved by more than `ilu_lag` since the last factorisation
+            # (checked at the first Newton iteration of a step), or when the
+            # factors have gone stale: a solve needed more than twice the
+            # iterations the fresh factors needed (while the flow spins up at
+            # tiny dt the matrix is mass-dominated and old factors stay good;
+            # at CFL-sized steps they do not).
+            refactored = False
+            if pre is None or pre.key != key or pre.stale or (
                     it == 0 and not (1.0 / npar['ilu_lag'] <= dt / pre.dt
                                      <= npar['ilu_lag'])):
                 if matfree:
@@ -216,7 +221,8 @@ def _compute_tentative_velocity(
                     lay._dev['jacobian_ilu'] = pre
                 else:
                     pre.refactor(J)
-                pre.dt, pre.key = dt, key
+                pre.dt, pre.key, pre.stale = dt, key, False
+                refactored = True
         if matfree and Jop is None:
             Jop = ops.MomentumJacobian(W, bfmask, ui.data, prm, bc_dofs)
         # Inexact Newton: the linear residual only has to get below what the
@@ -253,6 +259,11 @@ def _compute_tentative_velocity(
                 if its >= npar['linear_maxit']:
                     raise
         linear_its.append(its)
+        if pre is not None:
+            if refactored:
+                pre.base_its = max(its, npar['check_every'])
+            elif its > 2 * pre.base_its:
+                pre.stale = True
         ops.axpby(-1.0, dx, 1.0, ui.data)
         it += 1
     del keep0, keep1
