@@ -57,14 +57,22 @@ def stats(directory, out):
 
 
 def _counter(directory, counter, kernel):
-    vals = []
+    '''Counter values of the dispatches of `kernel` on the pressure matrix: the
+    same kernel also serves the (smaller) multigrid levels and, a few times,
+    the (larger) velocity operators -- keep the largest grid that was
+    dispatched at least 20 times (the timed roofline launches alone are 50).'''
+    by_grid = {}
     for path in _find(directory, 'counter_collection.csv'):
         with open(path) as fh:
             for r in csv.DictReader(fh):
                 if r['Counter_Name'] == counter and \
                         kernel in r['Kernel_Name']:
-                    vals.append(float(r['Counter_Value']))
-    return vals
+                    grid = int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0)
+                    by_grid.setdefault(grid, []).append(float(r['Counter_Value']))
+    grids = [g for g, v in by_grid.items() if len(v) >= 20]
+    if not grids:
+        return []
+    return by_grid[max(grids)]
 
 
 def pmc(fetch_dir, write_dir, out, kernel='flow::spmv_stream_kernel<false>'):
