@@ -57,7 +57,7 @@ solver_parameters = {
     # than Jacobi at CFL-sized steps) or 'jacobi'
     'newton': {'maximum_iterations': 10, 'linear_maxit': 5000,
                'linear_rtol': 1.0e-13, 'linear_atol_factor': 0.05,
-               'forcing': 1.0e-4, 'check_every': 2, 'restart': 400,
+               'forcing': 1.0e-4, 'check_every': 1, 'restart': 400,
                'preconditioner': 'ilu0', 'ilu_lag': 8.0,
                'adaptive_forcing': True, 'matrix_free': True},
     # 'two_level': Jacobi + aggregate coarse space (stands in for the
