@@ -133,13 +133,15 @@ def main():
                     help="torch.distributed backend for N > 1: 'nccl' (= RCCL, "
                          "one GPU per rank); 'gloo' only to rehearse several "
                          "ranks on one GPU")
-    ap.add_argument('--shard', default='always', choices=['auto', 'always'],
-                    help="N > 1: 'always' (default: the configuration "
-                         "BASELINE.json names) row-shards the pressure-Poisson "
-                         "solve over the ranks; 'auto' is the library's own "
-                         "policy, which shards only from "
-                         "flow_amd.parallel.min_rows() rows on (below that the "
-                         "solve is latency-bound and a single GPU is as fast)")
+    ap.add_argument('--shard', default='auto', choices=['auto', 'always'],
+                    help="N > 1: 'auto' (default) is the library's policy: the "
+                         "pressure-Poisson solve is row-sharded over the ranks "
+                         "only from flow_amd.parallel.min_rows() rows on; below "
+                         "that one GPU solves it faster (multigrid CG, 5 ms on "
+                         "the headline workload) than the latency-bound sharded "
+                         "two-level loop (19 ms on a 1-rank RCCL group) and the "
+                         "ranks run redundantly.  'always' forces the sharded "
+                         "loop (the configuration BASELINE.json names)")
     ap.add_argument('--shard-single', action='store_true',
                     help='development: run the sharded pressure loop on a '
                          '1-rank process group (measures its host overhead)')
@@ -267,7 +269,9 @@ def main():
                 if parallel.active(n) else
                 'single GPU' if world == 1 else
                 'replicated x%d (pressure system of %d rows is below the '
-                'sharding threshold of %d rows: latency-bound, see DESIGN.md)'
+                'sharding threshold of %d rows, where the single-GPU multigrid '
+                'solve beats the latency-bound sharded loop: DESIGN.md section '
+                '6; --shard always forces it)'
                 % (world, n, parallel.min_rows())),
             'setup_s': setup_s,
             'dt': [i['dt'] for i in infos],
