@@ -59,7 +59,9 @@ solver_parameters = {
                'linear_rtol': 1.0e-13, 'linear_atol_factor': 0.05,
                'forcing': 1.0e-4, 'check_every': 1, 'restart': 400,
                'preconditioner': 'ilu0', 'ilu_lag': 8.0,
-               'adaptive_forcing': True, 'matrix_free': True},
+               'adaptive_forcing': True, 'matrix_free': True,
+               # 'previous' = always u0, the reference's choice (:204-220)
+               'initial_guess': 'best', 'guess_retry': 4},
     # 'two_level': Jacobi + aggregate coarse space (stands in for the
     # reference's hypre_amg, :331, :414); False = plain Jacobi
     # 'multigrid': smoothed-aggregation V-cycle (single GPU); else / sharded:
@@ -120,8 +122,29 @@ def _compute_tentative_velocity(
     n2 = W.size()
 
     ui = Function(W)
-    # initial guess: previous velocity (reference :204-220)
+    # initial guess: previous velocity (reference :204-220) ...
     ui.assign(u[0])
+    # ... or ('initial_guess': 'best'), when this call continues the trajectory
+    # of the previous one (u[0] IS the velocity the last step returned), the
+    # previous step's TENTATIVE velocity if its residual is smaller (choice (2)
+    # of the reference's comment, :204-220: worse than u0 in a transient, but
+    # as the flow settles it is almost the solution -- 1-2 Newton iterations
+    # instead of 4 on the developed Karman flow).  The guess only changes the
+    # Newton path, not what it converges to.  Which of the two won is
+    # remembered; the loser is re-tried every few steps.
+    hist = lay._dev.get('step_history')
+    candidates = ['u0']
+    if hist is not None and 'ui' in hist and \
+            solver_parameters['newton'].get('initial_guess') == 'best':
+        tmp = _hip.clone(u[0].data)
+        ops.axpby(-1.0, hist['u_out'], 1.0, tmp)
+        if ops.vector_norm(tmp, 'linf') == 0.0:
+            if hist.get('countdown', 0) > 0:
+                hist['countdown'] -= 1
+                candidates = [hist['winner']]
+            else:
+                candidates = ['u0', 'ui']
+        del tmp
 
     f0 = as_cell_coefficient(f[0], mesh, 2)
     f1 = as_cell_coefficient(f[1], mesh, 2)
@@ -158,17 +181,42 @@ def _compute_tentative_velocity(
             _hip.f64(J.vals, 4 * J.stride) if want_j else None, J.stride, st
             ))
 
-    history = []
-    linear_its = []
-    it = 0
-    Jop = None
-    while True:
+    def residual():
         assemble(True, False)
         _hip.check(lib.flow_bc_residual(
             nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(ui.data),
             _hip.f64(F), st
             ))
-        nrm = ops.vector_norm(F)
+        return ops.vector_norm(F)
+
+    # pick the start among the candidates by the residual it leaves
+    first_nrm = None
+    if candidates != ['u0']:
+        best = None
+        for name in candidates:
+            ops.copy(ui.data, u[0].data if name == 'u0' else hist['ui'])
+            nrm_c = residual()
+            if best is None or nrm_c < best[1]:
+                best = (name, nrm_c, _hip.clone(F) if len(candidates) > 1
+                        else None)
+        if len(candidates) > 1:
+            hist['winner'] = best[0]
+            hist['countdown'] = npar['guess_retry']
+            if best[0] != candidates[-1]:        # not the one F belongs to
+                ops.copy(ui.data, u[0].data if best[0] == 'u0' else hist['ui'])
+                ops.copy(F, best[2])
+        first_nrm = best[1]
+        last_step_info['initial_guess'] = best[0]
+
+    history = []
+    linear_its = []
+    it = 0
+    Jop = None
+    while True:
+        if first_nrm is not None:
+            nrm, first_nrm = first_nrm, None
+        else:
+            nrm = residual()
         if history and history[-1] > 0.0:
             # quadratic-model constant  ||F_{k+1}|| ~ C ||F_k||^2  of this flow
             # regime (kept across time steps)
@@ -515,6 +563,15 @@ def _step(
         'correction_s': t_3 - t_2,
         }
     last_step_info['tentative_velocity'] = ui
+    if solver_parameters['newton'].get('initial_guess') == 'best':
+        lay = u[0].function_space().layout
+        hist = lay._dev.setdefault('step_history', {})
+        if 'ui' not in hist:
+            hist['ui'] = _hip.clone(ui.data)
+            hist['u_out'] = _hip.clone(u1.data)
+        else:
+            ops.copy(hist['ui'], ui.data)
+            ops.copy(hist['u_out'], u1.data)
     return u1, p1
 
 
