@@ -57,9 +57,9 @@ MG_MAX_LEVELS = 8
 class MgS(ctypes.Structure):
     _fields_ = [
         ('nlevels', ctypes.c_int),
-        ('A', Operator * MG_MAX_LEVELS),
+        ('Ah', Operator * MG_MAX_LEVELS),
         ('dinv', ctypes.c_void_p * MG_MAX_LEVELS),
-        ('P', Operator * MG_MAX_LEVELS),
+        ('Ps', Operator * MG_MAX_LEVELS),
         ('R', Operator * MG_MAX_LEVELS),
         ('r', ctypes.c_void_p * MG_MAX_LEVELS),
         ('x', ctypes.c_void_p * MG_MAX_LEVELS),

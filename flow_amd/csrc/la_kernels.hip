@@ -40,25 +40,22 @@ static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTile - 2, "tile minus alignment slack"
 // scalar plane(s): blockIdx.y selects the component of a block-diagonal operator.
 // DOT: the workgroup also leaves its share of x.y (= x.Ax) in
 // dpart[blockIdx.y * gridDim.x + blockIdx.x] (CG's z.w without another pass).
-template <bool DOT>
-__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
-    int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
-    const double* __restrict__ vals0, const double* __restrict__ vals1,
-    const int* __restrict__ rowblocks, const double* __restrict__ x,
-    double* __restrict__ y, double* __restrict__ dpart) {
-  __shared__ double prod[kTile];
-  const double* __restrict__ vals = blockIdx.y == 0 ? vals0 : vals1;
-  x += static_cast<size_t>(blockIdx.y) * n;
-  y += static_cast<size_t>(blockIdx.y) * n;
+// One tile of the CSR stream -- the rows [r0, r1) of workgroup blockIdx.x: the
+// products go through LDS (prod, kTile doubles), then lane i sums row r0 + i.
+// Returns that row's sum; r / r1 tell the caller whether the lane has a row.
+__device__ __forceinline__ double stream_tile_row_sum(
+    const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vals, const int* __restrict__ rowblocks,
+    const double* __restrict__ x, double* __restrict__ prod, int& r, int& r1) {
   const int r0 = rowblocks[blockIdx.x];
-  const int r1 = rowblocks[blockIdx.x + 1];
+  r1 = rowblocks[blockIdx.x + 1];
   const int k0 = rowptr[r0];
   const int k1 = rowptr[r1];
   // 16-byte value loads / 8-byte index loads: every lane owns PAIRS pairs of
   // consecutive nonzeros; the tile base is aligned down to an even index (value
   // planes start 16-B aligned and the host caps a block at kTile-2 nonzeros).
   const int ka = k0 & ~1;
-  const int r = r0 + threadIdx.x;
+  r = r0 + threadIdx.x;
   int a = 0, b = 0;
   if (r < r1) {
     a = rowptr[r] - ka;
@@ -92,16 +89,72 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
     }
   }
   __syncthreads();
+  double s = 0.0;
+  for (int k = a; k < b; ++k) s += prod[k];
+  return s;
+}
+
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
+    int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vals0, const double* __restrict__ vals1,
+    const int* __restrict__ rowblocks, const double* __restrict__ x,
+    double* __restrict__ y, double* __restrict__ dpart) {
+  __shared__ double prod[kTile];
+  const double* __restrict__ vals = blockIdx.y == 0 ? vals0 : vals1;
+  x += static_cast<size_t>(blockIdx.y) * n;
+  y += static_cast<size_t>(blockIdx.y) * n;
+  int r, r1;
+  const double s =
+      stream_tile_row_sum(rowptr, cols, vals, rowblocks, x, prod, r, r1);
   double t = 0.0;
   if (r < r1) {
-    double s = 0.0;
-    for (int k = a; k < b; ++k) s += prod[k];
     y[r] = s;
     if (DOT) t = s * x[r];
   }
   if (DOT) {
     t = block_sum(t);
     if (threadIdx.x == 0) dpart[blockIdx.y * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+// The two kernels of a multigrid level (flow_mg) on the same tiles:
+//   UP = 0:  y = c - A x                     (A = Ah, x = c = r:  t = r - Ah r)
+//   UP = 1:  y = A x + w dinv (c + t)        (A = Ps, x = x_{l+1}, c = r)
+//            DOTS: the workgroup's shares of c.y and c.c -> gpart / rpart
+template <int UP, bool DOTS>
+__global__ __launch_bounds__(kBlock) void mg_level_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vals, const int* __restrict__ rowblocks,
+    const double* __restrict__ x, const double* __restrict__ c,
+    const double* __restrict__ t, const double* __restrict__ dinv, double omega,
+    double* __restrict__ y, double* __restrict__ gpart,
+    double* __restrict__ rpart) {
+  __shared__ double prod[kTile];
+  int r, r1;
+  const double s =
+      stream_tile_row_sum(rowptr, cols, vals, rowblocks, x, prod, r, r1);
+  double g = 0.0, rr = 0.0;
+  if (r < r1) {
+    const double ci = c[r];
+    if (UP) {
+      const double yi = s + omega * dinv[r] * (ci + t[r]);
+      y[r] = yi;
+      if (DOTS) {
+        g = ci * yi;
+        rr = ci * ci;
+      }
+    } else {
+      y[r] = ci - s;
+    }
+  }
+  if (DOTS) {
+    g = block_sum(g);
+    rr = block_sum(rr);
+    if (threadIdx.x == 0) {
+      gpart[blockIdx.x] = g;
+      rpart[blockIdx.x] = rr;
+    }
   }
 }
 
@@ -351,17 +404,18 @@ __global__ void residual_kernel(int n, const double* __restrict__ b,
 }
 
 // Chronopoulos-Gear CG scalars from (gamma_new, delta, r.r) partials
-// gamma = r.z and r.r: nparts partials each in partial[0..) / [2*kRedBlocks..);
+// gamma = r.z and r.r: nparts partials each in gpart / rpart;
 // delta = z.w: ndelta partials in dpart (left there by the SpMV itself)
 constexpr int kScalarBlock = 1024;   // 16 wavefronts: many partials, one block
 __global__ __launch_bounds__(kScalarBlock) void cg_scalar_kernel(
-    int nparts, int ndelta, int first, const double* __restrict__ partial,
-    const double* __restrict__ dpart, double* __restrict__ S) {
+    int nparts, int ndelta, int first, const double* __restrict__ gpart,
+    const double* __restrict__ rpart, const double* __restrict__ dpart,
+    double* __restrict__ S) {
   __shared__ double wsum[3][kScalarBlock / 64];
   double g = 0.0, rr = 0.0;
   for (int i = threadIdx.x; i < nparts; i += kScalarBlock) {
-    g += load_scalar(partial + i);
-    rr += load_scalar(partial + 2 * kRedBlocks + i);
+    g += load_scalar(gpart + i);
+    rr += load_scalar(rpart + i);
   }
   // four independent chains keep the loads of the long list in flight
   double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
@@ -583,45 +637,19 @@ static int two_level(const flow_coarse* C, const double* dinv, const double* r,
 // ---------------------------------------------------------------------------
 // smoothed-aggregation multigrid V(1,1) cycle (flow_mg, include/flow_hip.h)
 // ---------------------------------------------------------------------------
-// post-smoothing  x += w D^-1 (r - t), t = A x ; DOTS: the shares of r.x, r.r
-template <bool DOTS>
-__global__ __launch_bounds__(kBlock) void mg_correct_kernel(
-    int n, double omega, const double* __restrict__ dinv,
-    const double* __restrict__ r, const double* __restrict__ t,
-    double* __restrict__ x, double* __restrict__ partial) {
-  double g = 0.0, rr = 0.0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += gridDim.x * blockDim.x) {
-    const double ri = r[i];
-    const double xi = x[i] + omega * dinv[i] * (ri - t[i]);
-    x[i] = xi;
-    if (DOTS) {
-      g += ri * xi;
-      rr += ri * ri;
-    }
-  }
-  if (DOTS) {
-    g = block_sum(g);
-    rr = block_sum(rr);
-    if (threadIdx.x == 0) {
-      partial[blockIdx.x] = g;
-      partial[2 * kRedBlocks + blockIdx.x] = rr;
-    }
-  }
-}
-
+// multigrid V-cycle (flow_mg)
 static int check_mg(const flow_mg* M, int n) {
   FLOW_REQUIRE(M->nlevels >= 1 && M->nlevels <= FLOW_MG_MAX_LEVELS, "mg levels");
   FLOW_REQUIRE(M->omega > 0.0 && M->omega < 2.0, "mg damping");
   int rows = n;
   for (int l = 0; l + 1 < M->nlevels; ++l) {
-    int rc = check_operator(&M->A[l]);
+    int rc = check_operator(&M->Ah[l]);
     if (rc) return rc;
-    if ((rc = check_operator(&M->P[l]))) return rc;
+    if ((rc = check_operator(&M->Ps[l]))) return rc;
     if ((rc = check_operator(&M->R[l]))) return rc;
-    FLOW_REQUIRE(M->A[l].kind == 0 && M->P[l].kind == 0 && M->R[l].kind == 0,
+    FLOW_REQUIRE(M->Ah[l].kind == 0 && M->Ps[l].kind == 0 && M->R[l].kind == 0,
                  "mg operators are scalar");
-    FLOW_REQUIRE(M->A[l].n == rows && M->P[l].n == rows, "mg level sizes");
+    FLOW_REQUIRE(M->Ah[l].n == rows && M->Ps[l].n == rows, "mg level sizes");
     FLOW_REQUIRE(M->dinv[l] && M->t[l], "mg level vectors");
     FLOW_REQUIRE(l == 0 || (M->r[l] && M->x[l]), "mg level vectors");
     rows = M->R[l].n;
@@ -636,24 +664,22 @@ static int check_mg(const flow_mg* M, int n) {
   return FLOW_OK;
 }
 
-// z = V-cycle(r) on level 0; partial != nullptr: the last kernel also leaves
-// the *nparts workgroup shares of r.z and r.r
+// z = V-cycle(r) on level 0; gpart != nullptr: the last kernel also leaves the
+// *nparts (= Ps[0].nblocks) workgroup shares of r.z in gpart and r.r in rpart
 static int vcycle(const flow_mg* M, const double* r0, double* z0, hipStream_t st,
-                  double* partial = nullptr, int* nparts = nullptr) {
+                  double* gpart = nullptr, double* rpart = nullptr,
+                  int* nparts = nullptr) {
   const int L = M->nlevels;
   int rc;
+  double* const none = nullptr;
   for (int l = 0; l + 1 < L; ++l) {
     const double* r = l == 0 ? r0 : M->r[l];
-    double* x = l == 0 ? z0 : M->x[l];
-    double* t = M->t[l];
-    const int n = M->A[l].n;
-    // x = w D^-1 r ; t = r - A x ; r_{l+1} = R t
-    hipLaunchKernelGGL(vmul_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
-                       M->omega, M->dinv[l], r, x);
-    if ((rc = apply(&M->A[l], x, t, st))) return rc;
-    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
-                       1.0, r, -1.0, t);
-    if ((rc = apply(&M->R[l], t, M->r[l + 1], st))) return rc;
+    const flow_operator* A = &M->Ah[l];
+    // t = r - Ah r ; r_{l+1} = R t
+    hipLaunchKernelGGL((mg_level_kernel<0, false>), dim3(A->nblocks), dim3(kBlock),
+                       0, st, A->rowptr, A->cols, A->vals[0], A->rowblocks, r, r,
+                       none, none, M->omega, M->t[l], none, none);
+    if ((rc = apply(&M->R[l], M->t[l], M->r[l + 1], st))) return rc;
   }
   {
     const double* r = L == 1 ? r0 : M->r[L - 1];
@@ -664,22 +690,19 @@ static int vcycle(const flow_mg* M, const double* r0, double* z0, hipStream_t st
   for (int l = L - 2; l >= 0; --l) {
     const double* r = l == 0 ? r0 : M->r[l];
     double* x = l == 0 ? z0 : M->x[l];
-    double* t = M->t[l];
-    const int n = M->A[l].n;
-    // x += P x_{l+1} ; x += w D^-1 (r - A x)
-    if ((rc = apply(&M->P[l], M->x[l + 1], t, st))) return rc;
-    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
-                       1.0, t, 1.0, x);
-    if ((rc = apply(&M->A[l], x, t, st))) return rc;
-    if (l == 0 && partial) {
-      const int g = grid_for(n, kBlock, kRedBlocks);
-      hipLaunchKernelGGL(mg_correct_kernel<true>, dim3(g), dim3(kBlock), 0, st, n,
-                         M->omega, M->dinv[l], r, t, x, partial);
-      *nparts = g;
+    const flow_operator* P = &M->Ps[l];
+    // x = Ps x_{l+1} + w D^-1 (r + t)
+    if (l == 0 && gpart) {
+      hipLaunchKernelGGL((mg_level_kernel<1, true>), dim3(P->nblocks),
+                         dim3(kBlock), 0, st, P->rowptr, P->cols, P->vals[0],
+                         P->rowblocks, M->x[l + 1], r, M->t[l], M->dinv[l],
+                         M->omega, x, gpart, rpart);
+      *nparts = P->nblocks;
     } else {
-      hipLaunchKernelGGL(mg_correct_kernel<false>, dim3(grid_for(n)),
-                         dim3(kBlock), 0, st, n, M->omega, M->dinv[l], r, t, x,
-                         static_cast<double*>(nullptr));
+      hipLaunchKernelGGL((mg_level_kernel<1, false>), dim3(P->nblocks),
+                         dim3(kBlock), 0, st, P->rowptr, P->cols, P->vals[0],
+                         P->rowblocks, M->x[l + 1], r, M->t[l], M->dinv[l],
+                         M->omega, x, none, none);
     }
   }
   FLOW_CHECK_LAUNCH();
@@ -731,11 +754,14 @@ static int read_slot(const double* S, int slot, double* host, hipStream_t st) {
   return FLOW_OK;
 }
 
-// Work of cg(): [reductions | r z w p s | z.w partials of the SpMV | rc zc]
-static inline size_t cg_work_len(const flow_operator* A, const flow_coarse* C) {
+// Work of cg(): [reductions | r z w p s | z.w partials of the SpMV | rc zc |
+// r.z, r.r partials of the V-cycle's last kernel]
+static inline size_t cg_work_len(const flow_operator* A, const flow_coarse* C,
+                                 const flow_mg* M) {
   const size_t N = op_size(A);
   return FLOW_REDUCE_WORK + 5 * N + dot_parts(A) + 2 +
-         (C ? 2 * static_cast<size_t>(C->lda) : 0);
+         (C ? 2 * static_cast<size_t>(C->lda) : 0) +
+         (M && M->nlevels > 1 ? 2 * static_cast<size_t>(M->Ps[0].nblocks) : 0);
 }
 
 // Chronopoulos-Gear CG.  Per iteration: update (x, r, p, s) -> preconditioner
@@ -760,6 +786,10 @@ static int cg(const flow_operator* A, const double* dinv,
   // coarse vectors (two-level only), 16-byte aligned
   double* crc = dpart + nd + ((N + nd) & 1);
   double* czc = crc + (C ? C->lda : 0);
+  double* mpart = czc + (C ? C->lda : 0);     // V-cycle partials (multigrid only)
+  const int nm = (M && M->nlevels > 1) ? M->Ps[0].nblocks : 0;
+  const double* gpart = M ? mpart : partial;
+  const double* rpart = M ? mpart + nm : partial + 2 * kRedBlocks;
   const int gv = grid_for(N);
   const int gu = grid_for(N, kBlock, kRedBlocks);   // update with fused dots
   int np = 0, rc;
@@ -779,7 +809,7 @@ static int cg(const flow_operator* A, const double* dinv,
   if ((rc = apply(A, z, w, st, dpart))) return rc;
   if ((rc = dots(N, 3, r, z, z, w, r, r, partial, &np, st))) return rc;
   hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kScalarBlock), 0, st, np,
-                     nd, 1, partial, dpart, S);
+                     nd, 1, partial, partial + 2 * kRedBlocks, dpart, S);
   FLOW_CHECK_LAUNCH();
 
   double b2 = 0.0, res2 = 0.0;
@@ -812,7 +842,7 @@ static int cg(const flow_operator* A, const double* dinv,
       } else if (M) {
         hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
                            st, N, S, dinv, w, z, p, s, x, r, 0, partial);
-        if ((rc = vcycle(M, r, z, st, partial, &np))) return rc;
+        if ((rc = vcycle(M, r, z, st, mpart, mpart + nm, &np))) return rc;
       } else {
         hipLaunchKernelGGL(cg_update_kernel<true>, dim3(gu), dim3(kBlock), 0, st,
                            N, S, dinv, w, z, p, s, x, r, 1, partial);
@@ -820,7 +850,7 @@ static int cg(const flow_operator* A, const double* dinv,
       }
       if ((rc = apply(A, z, w, st, dpart))) return rc;
       hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kScalarBlock), 0, st,
-                         np, nd, 0, partial, dpart, S);
+                         np, nd, 0, gpart, rpart, dpart, S);
     }
     FLOW_CHECK_LAUNCH();
     it += todo;
@@ -1009,7 +1039,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 10; }
+extern "C" int flow_abi_version(void) { return 11; }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {
@@ -1123,11 +1153,6 @@ extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
     FLOW_REQUIRE(A->kind == 0, "two-level preconditioner: scalar operators");
     if ((rc = check_coarse(coarse, A->n))) return rc;
   }
-  FLOW_REQUIRE(work_len >= cg_work_len(A, coarse),
-               "solver workspace too small (FLOW_REDUCE_WORK + 5 N + SpMV "
-               "workgroups + 2 [+ 2 lda])");
-  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(work) % 16 == 0,
-               "solver workspace must be 16-byte aligned");
   if (mg) {
     FLOW_REQUIRE(coarse == nullptr, "multigrid and two-level are exclusive");
     FLOW_REQUIRE(dinv != nullptr && A->kind == 0,
@@ -1135,6 +1160,11 @@ extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
     if ((rc = check_mg(mg, A->n))) return rc;
     FLOW_REQUIRE(mg->nlevels >= 2, "multigrid: at least two levels");
   }
+  FLOW_REQUIRE(work_len >= cg_work_len(A, coarse, mg),
+               "solver workspace too small (FLOW_REDUCE_WORK + 5 N + SpMV "
+               "workgroups + 2 [+ 2 lda] [+ 2 mg->Ps[0].nblocks])");
+  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(work) % 16 == 0,
+               "solver workspace must be 16-byte aligned");
   return cg(A, dinv, coarse, mg, b, x, rtol, atol, maxit, check_every, work,
             iters_host, resid_host, as_stream(stream));
 }

@@ -15,6 +15,12 @@ application of the V-cycle runs in the HIP kernels behind flow_cg_solve.
                (power iteration), P0 the piecewise-constant prolongation
   A_{l+1}      P^T A_l P
   coarsest     dense (pseudo-)inverse in fp32, as CoarseSpace
+  per level    the device cycle works with Ah = A w D^-1 (column-scaled) and
+               Ps = (I - w D^-1 A) P: with them the textbook V(1,1) cycle from
+               a zero start, x = w D^-1 r; r' = P^T (r - A x); ...;
+               x += P x'; x += w D^-1 (r - A x), becomes t = r - Ah r;
+               r' = P^T t; ...; x = Ps x' + w D^-1 (r + t) -- one product with
+               A and three launches per level (include/flow_hip.h, flow_mg)
 Measured on the 1.1 M-row pressure system of the headline workload: 21 CG
 iterations instead of 180-210 with the two-level preconditioner.
 '''
@@ -75,7 +81,7 @@ class Multigrid(object):
     the coarsest level.'''
 
     def __init__(self, A, isbc=None, singular=False, s=3.0, coarsest=4200,
-                 omega=0.8):
+                 omega=0.8, keep_host=False):
         import scipy.sparse as sp
         assert A.kind == 0
         lay = A.layout
@@ -86,7 +92,8 @@ class Multigrid(object):
         width = s * numpy.sqrt(2.0 * lay.mesh.cell_areas().mean())
         free = ~isbc
         Ah = A.to_scipy().tocsr()
-        self.levels = []          # (CsrOperator A, dinv, CsrOperator P, R)
+        self.levels = []          # device operators Ah, Ps, R + dinv, t per level
+        self.host_levels = []     # keep_host: scipy (A, D, P) for the tests
         self.sizes = [n]
         rng = numpy.random.RandomState(1)
         self.fine = A
@@ -106,13 +113,17 @@ class Multigrid(object):
                 lam = numpy.linalg.norm(v)
                 v /= lam
             P = (P0 - (4.0 / (3.0 * lam)) * sp.diags(1.0 / D).dot(Ah.dot(P0))).tocsr()
-            Ac = (P.T.dot(Ah).dot(P)).tocsr()
+            AP = Ah.dot(P).tocsr()
+            Ac = (P.T.dot(AP)).tocsr()
+            wD = sp.diags(omega / D)
             self.levels.append(dict(
-                A=A if not self.levels else CsrOperator(Ah),
+                Ah=CsrOperator(Ah.dot(wD)),
                 dinv=device.to_device(1.0 / D),
-                P=CsrOperator(P), R=CsrOperator(P.T.tocsr()),
+                Ps=CsrOperator(P - wD.dot(AP)), R=CsrOperator(P.T.tocsr()),
                 t=device.zeros(m),
                 ))
+            if keep_host:
+                self.host_levels.append((Ah, D, P))
             cnt = numpy.bincount(agg[idx], minlength=nc)
             x = numpy.stack([
                 numpy.bincount(agg[idx], weights=x[idx, d], minlength=nc) / cnt
@@ -142,10 +153,9 @@ class Multigrid(object):
         M = _hip.MgS()
         M.nlevels = self.nlevels
         for l, L in enumerate(self.levels):
-            op = L['A'].operator() if l == 0 else L['A'].op
-            ctypes.memmove(ctypes.byref(M.A[l]), ctypes.byref(op),
+            ctypes.memmove(ctypes.byref(M.Ah[l]), ctypes.byref(L['Ah'].op),
                            ctypes.sizeof(_hip.Operator))
-            ctypes.memmove(ctypes.byref(M.P[l]), ctypes.byref(L['P'].op),
+            ctypes.memmove(ctypes.byref(M.Ps[l]), ctypes.byref(L['Ps'].op),
                            ctypes.sizeof(_hip.Operator))
             ctypes.memmove(ctypes.byref(M.R[l]), ctypes.byref(L['R'].op),
                            ctypes.sizeof(_hip.Operator))
@@ -158,6 +168,8 @@ class Multigrid(object):
         M.Ainv = _hip.f32(self._Ainv, nc * lda).value
         M.omega = float(omega)
         self.struct = M
+        self.omega = float(omega)
+        self.Ainv_host = Ainv if keep_host else None
 
     def apply(self, r, z):
         '''z = V-cycle(r): one application of the preconditioner.'''

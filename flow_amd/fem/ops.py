@@ -428,6 +428,7 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     wk = work(_hip.REDUCE_WORK + nvec * n
               + (nparts if method == 'cg' else 0)
               + (2 * coarse.struct.lda if coarse else 0)
+              + (2 * mg.struct.Ps[0].nblocks if mg is not None else 0)
               + (n if ilu is not None else 0))
     if device._POISON:      # debugging aid: stale workspace reads become NaNs
         _hip.fill(wk, float('nan'))

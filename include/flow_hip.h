@@ -114,23 +114,28 @@ typedef struct {
  * set) on the host (flow_amd/fem/multigrid.py): aggregates of ~3x3 vertices,
  * prolongation P = (I - 4/(3 rho) D^-1 A) P0, Galerkin operators R A P with
  * R = P^T, until the coarsest level is small enough for a dense (pseudo-)
- * inverse.  Per application, level by level:
+ * inverse.  One application is the textbook cycle (zero start, one damped-
+ * Jacobi sweep before and after the coarse correction)
  *   x = w D^-1 r ; r' = R (r - A x) ; [coarse] ; x += P x' ; x += w D^-1 (r - A x)
- * All operators are kind-0 flow_operators (P and R rectangular: `n` = rows).
+ * regrouped so that a level costs three launches and ONE product with A:
+ *   t = r - Ah r ; r' = R t ; [coarse] ; x = Ps x' + w D^-1 (r + t)
+ * with Ah = A w D^-1 (columns scaled; shares A's pattern arrays) and
+ * Ps = (I - w D^-1 A) P, both formed at setup.
+ * All operators are kind-0 flow_operators (Ps and R rectangular: `n` = rows).
  * Levels 0 .. nlevels-1; the last one is solved with the dense inverse. */
 #define FLOW_MG_MAX_LEVELS 8
 typedef struct {
   int nlevels;
-  flow_operator A[FLOW_MG_MAX_LEVELS];    /* A[l], l < nlevels-1 (level 0 = the system) */
+  flow_operator Ah[FLOW_MG_MAX_LEVELS];   /* A[l] w D[l]^-1, l < nlevels-1 (level 0 = the system) */
   const double* dinv[FLOW_MG_MAX_LEVELS]; /* 1 / diag A[l] */
-  flow_operator P[FLOW_MG_MAX_LEVELS];    /* n_l x n_{l+1} */
-  flow_operator R[FLOW_MG_MAX_LEVELS];    /* n_{l+1} x n_l */
+  flow_operator Ps[FLOW_MG_MAX_LEVELS];   /* n_l x n_{l+1} */
+  flow_operator R[FLOW_MG_MAX_LEVELS];    /* n_{l+1} x n_l, R = P^T */
   double* r[FLOW_MG_MAX_LEVELS];          /* work vectors of level l >= 1 (n_l) */
   double* x[FLOW_MG_MAX_LEVELS];
   double* t[FLOW_MG_MAX_LEVELS];          /* all levels l < nlevels-1 (n_l) */
   int nc, lda;                            /* coarsest level: size, row stride */
   const float* Ainv;                      /* nc rows of lda floats, as flow_coarse */
-  double omega;                           /* Jacobi damping (0.8) */
+  double omega;                           /* Jacobi damping w (0.8) */
 } flow_mg;
 /* z = V-cycle(r) on level 0 (n = its size): one preconditioner application */
 int flow_mg_apply(const flow_mg* mg, int n, const double* r, double* z,
@@ -201,8 +206,9 @@ int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
  * instead (coarse must then be NULL); ilu may be NULL (Jacobi), else it replaces
  * dinv as the (right) preconditioner of BiCGStab.
  * work (16-byte aligned): FLOW_REDUCE_WORK + 5*N + B + 2 [+ 2*coarse->lda]
- * doubles (cg; B = nblocks, twice that for kind 1: the SpMV leaves its z.Az
- * partials there), FLOW_REDUCE_WORK + 7*N [+ n] (bicgstab); N = operator size. */
+ * [+ 2*mg->Ps[0].nblocks] doubles (cg; B = nblocks, twice that for kind 1: the
+ * SpMV leaves its z.Az partials there, the V-cycle's last kernel its r.z and
+ * r.r partials), FLOW_REDUCE_WORK + 7*N [+ n] (bicgstab); N = operator size. */
 int flow_cg_solve(const flow_operator* A, const double* dinv,
                   const flow_coarse* coarse, const flow_mg* mg,
                   const double* b, double* x,

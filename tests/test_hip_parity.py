@@ -150,8 +150,22 @@ def test_two_level_cg(hip, neumann):
     # smoothed-aggregation multigrid V-cycle: same solution again, an order of
     # magnitude fewer iterations still, and nearly mesh independent
     from flow_amd.fem.multigrid import Multigrid
-    mg = Multigrid(A, isbc, singular=neumann, coarsest=300)
+    mg = Multigrid(A, isbc, singular=neumann, coarsest=300, keep_host=True)
     assert mg.nlevels >= 3 and mg.sizes[-1] <= 300, mg.sizes
+    # the device cycle (regrouped: one product with A per level) against the
+    # textbook V(1,1) cycle it restates, on the host with the same hierarchy
+    def textbook(l, r):
+        if l == mg.nlevels - 1:
+            return mg.Ainv_host.dot(r)
+        Al, D, P = mg.host_levels[l]
+        x = mg.omega * r / D
+        x = x + P.dot(textbook(l + 1, P.T.dot(r - Al.dot(x))))
+        return x + mg.omega * (r - Al.dot(x)) / D
+    rv = rng.standard_normal(n)
+    zv = _dev(numpy.zeros(n))
+    mg.apply(_dev(rv), zv)
+    # (the coarsest inverse is held in fp32 on the device)
+    assert cases.rel_l2(zv.cpu().numpy(), textbook(0, rv)) < 1e-6
     x3 = _dev(numpy.zeros(n))
     i3 = ops.krylov_solve('cg', A, _dev(b), x3, rtol=1e-12, maxit=500, mg=mg,
                           check_every=1)
