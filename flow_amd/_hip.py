@@ -181,10 +181,10 @@ SYMBOLS = {
     'flow_vmul': [_I, _D, _VP, _VP, _VP, _VP],
     'flow_fill': [_I, _D, _VP, _VP],
     'flow_cg_solve': [_P(Operator), _VP, _P(CoarseS), _P(MgS), _VP, _VP, _D, _D,
-                      _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
+                      _I, _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_mg_apply': [_P(MgS), _I, _VP, _VP, _VP],
     'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
-                            _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
+                            _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],
     'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],
     'flow_ilu0_solve': [_P(IluS), _VP, _VP, _VP, _VP],

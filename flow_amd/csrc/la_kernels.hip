@@ -732,13 +732,17 @@ static int dots(int n, int nd, const double* a0, const double* b0,
 // mapped) memory with a system-scope fence, the host waits for the stream and
 // reads it.  The mailbox (a few doubles per host thread) is the only memory
 // the library ever allocates.
-__global__ void mailbox_kernel(const double* __restrict__ src,
+__global__ void mailbox_kernel(const double* __restrict__ src0,
+                               const double* __restrict__ src1,
                                volatile double* __restrict__ mailbox) {
-  mailbox[0] = load_scalar(src);
+  mailbox[0] = load_scalar(src0);
+  mailbox[1] = load_scalar(src1);
   __threadfence_system();
 }
 
-static int read_slot(const double* S, int slot, double* host, hipStream_t st) {
+// two scalars of the stream's device memory -> host, with ONE synchronisation
+static int read_slots(const double* S, int slot0, int slot1, double* host0,
+                      double* host1, hipStream_t st) {
   static thread_local double* mailbox = nullptr;
   if (!mailbox)
     FLOW_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&mailbox),
@@ -746,12 +750,18 @@ static int read_slot(const double* S, int slot, double* host, hipStream_t st) {
   double* dev_view = nullptr;
   FLOW_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_view),
                                          mailbox, 0));
-  hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1), 0, st, S + slot,
-                     dev_view);
+  hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1), 0, st, S + slot0,
+                     S + slot1, dev_view);
   FLOW_CHECK_LAUNCH();
   FLOW_CHECK_HIP(hipStreamSynchronize(st));
-  *host = *static_cast<volatile double*>(mailbox);
+  *host0 = static_cast<volatile double*>(mailbox)[0];
+  *host1 = static_cast<volatile double*>(mailbox)[1];
   return FLOW_OK;
+}
+
+static int read_slot(const double* S, int slot, double* host, hipStream_t st) {
+  double again;
+  return read_slots(S, slot, slot, host, &again, st);
 }
 
 // Work of cg(): [reductions | r z w p s | z.w partials of the SpMV | rc zc |
@@ -771,8 +781,8 @@ static inline size_t cg_work_len(const flow_operator* A, const flow_coarse* C,
 static int cg(const flow_operator* A, const double* dinv,
               const flow_coarse* C, const flow_mg* M, const double* b,
               double* x, double rtol, double atol, int maxit, int check_every,
-              double* work, int* iters_host, double* resid_host,
-              hipStream_t st) {
+              int first_check, double* work, int* iters_host,
+              double* resid_host, hipStream_t st) {
   const int N = op_size(A);
   const int nd = dot_parts(A);
   double* partial = work;
@@ -813,8 +823,7 @@ static int cg(const flow_operator* A, const double* dinv,
   FLOW_CHECK_LAUNCH();
 
   double b2 = 0.0, res2 = 0.0;
-  if ((rc = read_slot(S, kB2, &b2, st))) return rc;
-  if ((rc = read_slot(S, kRes2, &res2, st))) return rc;
+  if ((rc = read_slots(S, kB2, kRes2, &b2, &res2, st))) return rc;
   const double target = fmax(rtol * sqrt(b2), atol);
   int it = 0;
   while (true) {
@@ -832,7 +841,8 @@ static int cg(const flow_operator* A, const double* dinv,
                 sqrt(res2), target);
       return FLOW_NOT_CONVERGED;
     }
-    const int todo = (maxit - it < check_every) ? maxit - it : check_every;
+    const int batch = (it == 0 && first_check > 0) ? first_check : check_every;
+    const int todo = (maxit - it < batch) ? maxit - it : batch;
     for (int k = 0; k < todo; ++k) {
       if (C) {
         hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
@@ -946,8 +956,8 @@ __global__ void bicg_x_kernel(int n, const double* __restrict__ S,
 static int bicgstab(const flow_operator* A, const double* dinv,
                     const flow_ilu* ilu, const double* b,
                     double* x, double rtol, double atol, int maxit,
-                    int check_every, double* work, int* iters_host,
-                    double* resid_host, hipStream_t st) {
+                    int check_every, int first_check, double* work,
+                    int* iters_host, double* resid_host, hipStream_t st) {
   const int N = op_size(A);
   double* partial = work;
   double* S = work + 3 * kRedBlocks;
@@ -981,8 +991,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
   FLOW_CHECK_LAUNCH();
 
   double b2 = 0.0, res2 = 0.0;
-  if ((rc = read_slot(S, kB2, &b2, st))) return rc;
-  if ((rc = read_slot(S, kRes2, &res2, st))) return rc;
+  if ((rc = read_slots(S, kB2, kRes2, &b2, &res2, st))) return rc;
   const double target = fmax(rtol * sqrt(b2), atol);
   int it = 0;
   while (true) {
@@ -1000,7 +1009,8 @@ static int bicgstab(const flow_operator* A, const double* dinv,
                 it, sqrt(res2), target);
       return FLOW_NOT_CONVERGED;
     }
-    const int todo = (maxit - it < check_every) ? maxit - it : check_every;
+    const int batch = (it == 0 && first_check > 0) ? first_check : check_every;
+    const int todo = (maxit - it < batch) ? maxit - it : batch;
     for (int k = 0; k < todo; ++k) {
       hipLaunchKernelGGL(bicg_p_kernel, dim3(gv), dim3(kBlock), 0, st, N, S,
                          dinv, r, v, p, y);
@@ -1039,7 +1049,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 11; }
+extern "C" int flow_abi_version(void) { return 12; }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {
@@ -1124,13 +1134,14 @@ extern "C" int flow_vmul(int n, double a, const double* x, const double* y,
 
 static int check_solver_args(const flow_operator* A, const double* b,
                              const double* x, double rtol, double atol,
-                             int maxit, int check_every, const double* work,
-                             size_t work_len, size_t nvec, const int* iters_host,
-                             const double* resid_host) {
+                             int maxit, int check_every, int first_check,
+                             const double* work, size_t work_len, size_t nvec,
+                             const int* iters_host, const double* resid_host) {
   int rc = check_operator(A);
   if (rc) return rc;
   FLOW_REQUIRE(b && x && work && iters_host && resid_host, "solver pointers");
-  FLOW_REQUIRE(rtol >= 0.0 && atol >= 0.0 && maxit >= 0 && check_every > 0,
+  FLOW_REQUIRE(rtol >= 0.0 && atol >= 0.0 && maxit >= 0 && check_every > 0 &&
+                   first_check >= 0,
                "solver tolerances");
   FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK + nvec * (size_t)op_size(A),
                "solver workspace too small");
@@ -1141,11 +1152,12 @@ extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
                              const flow_coarse* coarse, const flow_mg* mg,
                              const double* b,
                              double* x, double rtol, double atol, int maxit,
-                             int check_every, double* work, size_t work_len,
-                             int* iters_host, double* resid_host,
-                             void* stream) {
-  int rc = check_solver_args(A, b, x, rtol, atol, maxit, check_every, work,
-                             work_len, 5, iters_host, resid_host);
+                             int check_every, int first_check, double* work,
+                             size_t work_len, int* iters_host,
+                             double* resid_host, void* stream) {
+  int rc = check_solver_args(A, b, x, rtol, atol, maxit, check_every,
+                             first_check, work, work_len, 5, iters_host,
+                             resid_host);
   if (rc) return rc;
   FLOW_REQUIRE(A->kind != 3, "CG: assembled (symmetric) operators only");
   if (coarse) {
@@ -1165,8 +1177,8 @@ extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
                "workgroups + 2 [+ 2 lda] [+ 2 mg->Ps[0].nblocks])");
   FLOW_REQUIRE(reinterpret_cast<uintptr_t>(work) % 16 == 0,
                "solver workspace must be 16-byte aligned");
-  return cg(A, dinv, coarse, mg, b, x, rtol, atol, maxit, check_every, work,
-            iters_host, resid_host, as_stream(stream));
+  return cg(A, dinv, coarse, mg, b, x, rtol, atol, maxit, check_every,
+            first_check, work, iters_host, resid_host, as_stream(stream));
 }
 
 // pieces of the two-level preconditioner for the row-sharded loop
@@ -1239,19 +1251,21 @@ extern "C" int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
 extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
                                    const flow_ilu* ilu, const double* b,
                                    double* x, double rtol, double atol,
-                                   int maxit, int check_every, double* work,
+                                   int maxit, int check_every,
+                                   int first_check, double* work,
                                    size_t work_len, int* iters_host,
                                    double* resid_host, void* stream) {
-  int rc = check_solver_args(A, b, x, rtol, atol, maxit, check_every, work,
-                             work_len, 7, iters_host, resid_host);
+  int rc = check_solver_args(A, b, x, rtol, atol, maxit, check_every,
+                             first_check, work, work_len, 7, iters_host,
+                             resid_host);
   if (rc) return rc;
   if (ilu) {
     if ((rc = ilu_check(ilu, op_size(A)))) return rc;
     FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK + 8 * (size_t)op_size(A),
                  "solver workspace too small for the ILU sweep buffer");
   }
-  return bicgstab(A, dinv, ilu, b, x, rtol, atol, maxit, check_every, work,
-                  iters_host, resid_host, as_stream(stream));
+  return bicgstab(A, dinv, ilu, b, x, rtol, atol, maxit, check_every,
+                  first_check, work, iters_host, resid_host, as_stream(stream));
 }
 
 // ---------------------------------------------------------------------------

@@ -50,10 +50,32 @@ class DirichletBC(object):
             self.space = V
             self.components = list(range(V.dim))
         self._facet_cache = None
+        self._value_cache = (None, None)
         return
 
     def function_space(self):
         return self.V
+
+    def signature(self):
+        '''Hashable description of the boundary data, or None when it cannot
+        be told whether they changed (Functions, Python callables): time
+        loops hand the same conditions to every step, and the merged
+        (dofs, values) arrays are then reused (`collect`).'''
+        value = self.value
+        try:
+            if isinstance(value, (tuple, list, float, int)):
+                return ('c', tuple(numpy.ravel(value).tolist()))
+            if isinstance(value, Constant):
+                return ('c', tuple(value.values().tolist()))
+            if isinstance(value, Expression) and all(
+                    isinstance(c, str) for c in value._codes):
+                sig = ('e', tuple(value._codes),
+                       tuple(sorted(value.user_parameters.items())))
+                hash(sig)
+                return sig
+        except TypeError:
+            pass
+        return None
 
     def _scalar_dofs(self):
         '''Scalar dof ids on the marked boundary facets (sorted, unique).'''
@@ -78,6 +100,14 @@ class DirichletBC(object):
 
     def dofs_and_values(self):
         '''(dofs, values) in the dof numbering of the (parent) space.'''
+        sig = self.signature()
+        if sig is not None and self._value_cache[0] == sig:
+            return self._value_cache[1]
+        out = self._dofs_and_values()
+        self._value_cache = (sig, out)
+        return out
+
+    def _dofs_and_values(self):
         sd = self._scalar_dofs()
         n = self.space.N
         x = self.space.layout.dof_coords[sd]            # (m, 2)
@@ -109,9 +139,17 @@ class DirichletBC(object):
 def collect(bcs, size):
     '''Merge a list of conditions (later ones win) into sorted unique
     (dofs int32, values fp64) arrays.'''
-    table = {}
     if not bcs:
         return (numpy.zeros(0, dtype=numpy.int32), numpy.zeros(0))
+    sigs = tuple(
+        (id(bc), bc.signature() if hasattr(bc, 'signature') else None)
+        for bc in bcs
+        )
+    cacheable = all(s[1] is not None for s in sigs)
+    if cacheable:
+        hit = _COLLECTED.get((sigs, size))
+        if hit is not None:
+            return hit[1]
     dofs_all = []
     vals_all = []
     for bc in bcs:
@@ -120,7 +158,6 @@ def collect(bcs, size):
         vals_all.append(v)
     d = numpy.concatenate(dofs_all)
     v = numpy.concatenate(vals_all)
-    del table
     # keep the LAST occurrence of every dof
     order = numpy.argsort(d, kind='stable')
     d = d[order]
@@ -130,7 +167,17 @@ def collect(bcs, size):
     d = d[last]
     v = v[last]
     assert len(d) == 0 or (d[0] >= 0 and d[-1] < size)
-    return d.astype(numpy.int32), v
+    out = (d.astype(numpy.int32), v)
+    if cacheable:
+        if len(_COLLECTED) >= 16:
+            _COLLECTED.clear()
+        # the conditions are kept alive with the entry: their ids stay unique
+        _COLLECTED[(sigs, size)] = (list(bcs), out)
+    return out
+
+
+# merged arrays of lists of conditions whose data are unchanged (see signature)
+_COLLECTED = {}
 
 
 class FixedDofsBC(object):

@@ -414,10 +414,14 @@ class SolveInfo(object):
 
 
 def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
-                 check_every=None, coarse=None, ilu=None, mg=None):
+                 check_every=None, coarse=None, ilu=None, mg=None,
+                 first_check=0, tag=None):
     '''Solve A x = b on the device; x holds the initial guess.  Raises
     _hip.NotConverged (a RuntimeError) like dolfin's
-    'error_on_nonconvergence'.'''
+    'error_on_nonconvergence'.  first_check > 0: iterations before the first
+    residual read-back (then every check_every).  tag (CG): the solve recurs
+    in a time loop under that name -- the iteration count of the previous
+    call (kept on A) places the first read-back two iterations before it.'''
     lib = _hip.lib()
     n = A.size
     if isinstance(dinv, str):
@@ -436,13 +440,19 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
         check_every = 10 if method == 'bicgstab' else 50
     its = ctypes.c_int(0)
     res = ctypes.c_double(0.0)
+    history = None
+    if tag is not None and method == 'cg':
+        history = A.__dict__.setdefault('_solve_history', {})
+        if first_check == 0 and tag in history:
+            first_check = max(int(check_every), history[tag] - 2)
     if method == 'cg':
         rc = lib.flow_cg_solve(
             ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
             ctypes.byref(coarse.struct) if coarse is not None else None,
             ctypes.byref(mg.struct) if mg is not None else None,
             _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
-            int(maxit), int(check_every), _hip.f64(wk), wk.numel(),
+            int(maxit), int(check_every), int(first_check), _hip.f64(wk),
+            wk.numel(),
             ctypes.byref(its), ctypes.byref(res), _hip.stream()
             )
     else:
@@ -451,10 +461,13 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
             ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
             ctypes.byref(ilu.struct) if ilu is not None else None,
             _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
-            int(maxit), int(check_every), _hip.f64(wk), wk.numel(),
+            int(maxit), int(check_every), int(first_check), _hip.f64(wk),
+            wk.numel(),
             ctypes.byref(its), ctypes.byref(res), _hip.stream()
             )
     _hip.check(rc)
+    if history is not None:
+        history[tag] = its.value
     return SolveInfo(its.value, res.value,
                      method + ('+2level' if coarse is not None else '')
                      + ('+mg%d' % mg.nlevels if mg is not None else '')
@@ -521,7 +534,8 @@ def project_magnitude(u, mode=0, tol=1.0e-12, initial_guess=None):
     if initial_guess is not None:
         out.assign(initial_guess)
     krylov_solve('cg', M, b, out.data, tol, maxit=1000, dinv=lay._dev[key],
-                 check_every=4)
+                 check_every=2,
+                 tag='project_magnitude' if initial_guess is not None else None)
     return out
 
 

@@ -84,10 +84,22 @@ _THETA = {
 def _bc_arrays(bcs, size):
     '''Sorted unique (dofs, values) on the device.'''
     dofs, vals = collect(bcs, size)
-    return (
+    # `collect` returns the same arrays while the conditions are unchanged:
+    # upload once
+    hit = _BC_UPLOADS.get(id(vals))
+    if hit is not None and hit[0] is vals and hit[1] is dofs:
+        return hit[2]
+    out = (
         dofs, device.to_device(dofs.astype(numpy.int32)),
         device.to_device(vals.astype(numpy.float64)),
         )
+    if len(_BC_UPLOADS) >= 16:
+        _BC_UPLOADS.clear()
+    _BC_UPLOADS[id(vals)] = (vals, dofs, out)
+    return out
+
+
+_BC_UPLOADS = {}
 
 
 def _bc_mask(dofs, n, comp=None):
@@ -335,7 +347,7 @@ def _pressure_cg(A, dinv, prec, b, x, tol, par):
     return ops.krylov_solve(
         'cg', A, b, x, rtol=tol, atol=0.0, maxit=par['maxit'], dinv=dinv,
         check_every=2 if mg is not None else par['check_every'],
-        coarse=coarse, mg=mg
+        coarse=coarse, mg=mg, tag='pressure'
         )
 
 
@@ -502,7 +514,7 @@ def _compute_velocity_correction(
     par = solver_parameters['correction']
     sol = ops.krylov_solve(
         'cg', Mbc, b, u1.data, rtol=tol, atol=0.0, maxit=par['maxit'],
-        dinv=dinv, check_every=par['check_every']
+        dinv=dinv, check_every=par['check_every'], tag='correction'
         )
     if verbose:
         info('velocity correction: %r' % sol)

@@ -198,7 +198,9 @@ int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
 
 /* ---- K12: Krylov drivers -------------------------------------------------
  * Device-resident loops; the host reads the residual norm every check_every
- * iterations.  Stop when ||r||_2 <= max(rtol*||b||_2, atol); return
+ * iterations -- the first time after first_check iterations when that is > 0
+ * (a time loop knows how many the previous step needed; every read-back drains
+ * the stream).  Stop when ||r||_2 <= max(rtol*||b||_2, atol); return
  * FLOW_NOT_CONVERGED after maxit iterations (dolfin raises RuntimeError:
  * 'error_on_nonconvergence', pressure_correction.py:337,424,462).
  * dinv may be NULL (no preconditioner).  x holds the initial guess.
@@ -213,13 +215,13 @@ int flow_cg_solve(const flow_operator* A, const double* dinv,
                   const flow_coarse* coarse, const flow_mg* mg,
                   const double* b, double* x,
                   double rtol, double atol, int maxit, int check_every,
-                  double* work, size_t work_len, int* iters_host,
-                  double* resid_host, void* stream);
+                  int first_check, double* work, size_t work_len,
+                  int* iters_host, double* resid_host, void* stream);
 int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
                         const flow_ilu* ilu, const double* b, double* x,
                         double rtol, double atol, int maxit, int check_every,
-                        double* work, size_t work_len, int* iters_host,
-                        double* resid_host, void* stream);
+                        int first_check, double* work, size_t work_len,
+                        int* iters_host, double* resid_host, void* stream);
 
 /* ---- K15: row-sharded multi-GPU CG ----------------------------------------
  * (nothing in the reference: DOLFIN/PETSc would do this implicitly under

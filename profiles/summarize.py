@@ -4,6 +4,7 @@ Summarise rocprofv3 CSV output into the small files committed under profiles/.
 
   python profiles/summarize.py stats  <dir> <out.md>     kernel-trace summary
   python profiles/summarize.py pmc    <fetch_dir> <write_dir> <out.json>
+  python profiles/summarize.py gaps   <dir> <out.md>     idle time between kernels
 
 The PMC summary follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
 FETCH_SIZE and WRITE_SIZE come from separate passes, are in KiB, and on gfx950
@@ -56,6 +57,58 @@ def stats(directory, out):
     print('\n'.join(lines[:14]))
 
 
+def gaps(directory, out, threshold_us=8.0):
+    '''Where the GPU waits for the host: idle intervals between consecutive
+    kernels of the trace, grouped by (kernel before -> kernel after).'''
+    ev = []
+    for path in _find(directory, 'kernel_trace.csv'):
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']),
+                           r['Kernel_Name'].split('(')[0].replace('void ', '')))
+    ev.sort()
+    busy = sum(e - s for s, e, _ in ev) * 1e-3
+    span = (ev[-1][1] - ev[0][0]) * 1e-3
+    sites = defaultdict(lambda: [0, 0.0])
+    small = 0.0
+    end = ev[0][1]
+    prev = ev[0][2]
+    for s, e, name in ev[1:]:
+        gap = (s - end) * 1e-3
+        if gap > threshold_us:
+            key = '%s -> %s' % (prev, name)
+            sites[key][0] += 1
+            sites[key][1] += gap
+        elif gap > 0:
+            small += gap
+        if e > end:
+            end, prev = e, name
+    lines = [
+        'kernels %d, span %.1f ms, busy %.1f ms, gaps <= %.0f us: %.1f ms' % (
+            len(ev), span * 1e-3, busy * 1e-3, threshold_us, small * 1e-3),
+        '', '| before -> after | count | total ms | avg us |', '|---|---|---|---|',
+        ]
+    for key, (cnt, us) in sorted(sites.items(), key=lambda kv: -kv[1][1])[:40]:
+        lines.append('| %s | %d | %.3f | %.1f |' % (key, cnt, us * 1e-3, us / cnt))
+    # context of the last few long gaps: the kernels around them
+    ctx = []
+    end = ev[0][1]
+    for i in range(1, len(ev)):
+        s, e, name = ev[i]
+        if 300.0 < (s - end) * 1e-3 < 5000.0:
+            ctx.append((i, (s - end) * 1e-3))
+        end = max(end, e)
+    lines += ['', 'context of the last long gaps (300 us .. 5 ms):']
+    for i, gap in ctx[-6:]:
+        lines.append('gap %.0f us:' % gap)
+        for j in range(max(0, i - 5), min(len(ev), i + 4)):
+            lines.append('   %s%s  %.1f us' % (
+                '>> ' if j == i else '   ', ev[j][2], (ev[j][1] - ev[j][0]) * 1e-3))
+    with open(out, 'w') as fh:
+        fh.write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[:30]))
+
+
 def _counter(directory, counter, kernel):
     '''Counter values of the dispatches of `kernel` on the pressure matrix: the
     same kernel also serves the (smaller) multigrid levels and, a few times,
@@ -102,7 +155,9 @@ def pmc(fetch_dir, write_dir, out, kernel='flow::spmv_stream_kernel<false>'):
 
 
 if __name__ == '__main__':
-    if sys.argv[1] == 'stats':
+    if sys.argv[1] == 'gaps':
+        gaps(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
