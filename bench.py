@@ -127,6 +127,11 @@ def main():
                     choices=['jacobi', 'ilu0'],
                     help='BiCGStab preconditioner of the tentative-velocity '
                          'Newton systems (default: the library default)')
+    ap.add_argument('--newton', action='append', default=[],
+                    metavar='KEY=VALUE',
+                    help='override an entry of solver_parameters["newton"] '
+                         '(development: e.g. linear_solver=bicgstab, '
+                         'linear_atol_factor=0.05); recorded in config')
     ap.add_argument('--dt0', type=float, default=1.0e-5,
                     help='initial step size (reference driver: 1e-5)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -194,6 +199,11 @@ def main():
     if args.newton_preconditioner:
         navsto.solver_parameters['newton']['preconditioner'] = \
             args.newton_preconditioner
+    for kv in args.newton:
+        key, val = kv.split('=', 1)
+        old = navsto.solver_parameters['newton'][key]
+        navsto.solver_parameters['newton'][key] = \
+            val if isinstance(old, str) else type(old)(float(val))
     setup_s = time.perf_counter() - t_setup
 
     for _ in range(args.warmup):
@@ -233,7 +243,7 @@ def main():
 
     p_its = [i['pressure'].iterations for i in infos]
     c_its = [i['correction'].iterations for i in infos]
-    n_its = [sum(i['newton_linear_iterations']) for i in infos]
+    n_its = [sum(i.get('newton_linear_applications', [])) for i in infos]
     tim = {}
     for key in ('tentative_s', 'pressure_s', 'correction_s'):
         tim[key] = sum(i.get('timings', {}).get(key, 0.0) for i in infos) \
@@ -278,7 +288,10 @@ def main():
             'pressure_cg_iterations': p_its,
             'correction_cg_iterations': c_its,
             'newton_iterations': [len(i['newton_residuals']) - 1 for i in infos],
-            'newton_bicgstab_iterations': n_its,
+            'newton_linear_solver': navsto.solver_parameters['newton'].get(
+                'linear_solver', 'gmres') + '+ilu0',
+            'newton_linear_applications': n_its,
+            'newton_overrides': args.newton,
             'substep_s': tim,
             },
         'roofline': {

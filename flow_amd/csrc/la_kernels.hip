@@ -740,16 +740,25 @@ __global__ void mailbox_kernel(const double* __restrict__ src0,
   __threadfence_system();
 }
 
-// two scalars of the stream's device memory -> host, with ONE synchronisation
-static int read_slots(const double* S, int slot0, int slot1, double* host0,
-                      double* host1, hipStream_t st) {
+// the calling thread's mailbox: kMailbox doubles of pinned, mapped host memory
+constexpr int kMailbox = 64;
+static int mailbox_of_thread(double** host, double** dev) {
   static thread_local double* mailbox = nullptr;
   if (!mailbox)
     FLOW_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&mailbox),
-                                 8 * sizeof(double), hipHostMallocMapped));
-  double* dev_view = nullptr;
-  FLOW_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_view),
-                                         mailbox, 0));
+                                 kMailbox * sizeof(double), hipHostMallocMapped));
+  *host = mailbox;
+  FLOW_CHECK_HIP(
+      hipHostGetDevicePointer(reinterpret_cast<void**>(dev), mailbox, 0));
+  return FLOW_OK;
+}
+
+// two scalars of the stream's device memory -> host, with ONE synchronisation
+static int read_slots(const double* S, int slot0, int slot1, double* host0,
+                      double* host1, hipStream_t st) {
+  double *mailbox = nullptr, *dev_view = nullptr;
+  int rc = mailbox_of_thread(&mailbox, &dev_view);
+  if (rc) return rc;
   hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1), 0, st, S + slot0,
                      S + slot1, dev_view);
   FLOW_CHECK_LAUNCH();
@@ -1049,7 +1058,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 12; }
+extern "C" int flow_abi_version(void) { return 13; }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {
@@ -1129,6 +1138,322 @@ extern "C" int flow_vmul(int n, double a, const double* x, const double* y,
   hipLaunchKernelGGL(vmul_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
                      as_stream(stream), n, a, x, y, out);
   FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+// ---------------------------------------------------------------------------
+// GMRES(m), right-preconditioned (Saad & Schultz 1986), classical Gram-Schmidt
+// with ONE read-back per Arnoldi step:
+//   w = A M^-1 V_j ; the dots w.V_k (k <= j), w.w and |V_j|^2 go to the host in
+//   one mailbox read; h_{j+1,j} follows from Pythagoras, the new basis vector is
+//   formed (and scaled with that estimate) in one fused pass that also leaves
+//   the partial sums of its true norm -- read with the next step's dots and
+//   put into H then.  The small least-squares problem lives on the host.
+// Basis vectors are handled eight at a time (compile-time unrolled).
+// ---------------------------------------------------------------------------
+constexpr int kGmresMax = FLOW_GMRES_MAX_RESTART;
+static_assert((kGmresMax + 2) * kRedBlocks == FLOW_GMRES_PARTIALS, "gmres work");
+static_assert(kGmresMax + 2 <= kMailbox, "mailbox size");
+struct Coef8 {
+  double c[8];
+};
+
+// block partials of w.V_k, k < NV (V_k = V + k stride) [and of w.w]
+template <int NV>
+__global__ __launch_bounds__(kBlock) void gmres_dots_kernel(
+    int n, const double* __restrict__ w, const double* __restrict__ V,
+    size_t stride, int with_ww, double* __restrict__ partial,
+    double* __restrict__ ww_partial) {
+  double acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+  double ww = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    const double wi = w[i];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] += wi * V[k * stride + i];
+    ww += wi * wi;
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const double a = block_sum(acc[k]);
+    if (threadIdx.x == 0) partial[k * kRedBlocks + blockIdx.x] = a;
+  }
+  if (with_ww) {
+    ww = block_sum(ww);
+    if (threadIdx.x == 0) ww_partial[blockIdx.x] = ww;
+  }
+}
+
+// out = (first ? cw w : out) + sum_{k<NV} c_k V_k ; nn_partial != nullptr: the
+// block partials of |out|^2.  out may be w.
+template <int NV>
+__global__ __launch_bounds__(kBlock) void gmres_combine_kernel(
+    int n, Coef8 coef, double cw, int first, const double* w,
+    const double* __restrict__ V, size_t stride, double* out,
+    double* __restrict__ nn_partial) {
+  double nn = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    double acc = first ? (w ? cw * w[i] : 0.0) : out[i];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc += coef.c[k] * V[k * stride + i];
+    out[i] = acc;
+    nn += acc * acc;
+  }
+  if (nn_partial) {
+    nn = block_sum(nn);
+    if (threadIdx.x == 0) nn_partial[blockIdx.x] = nn;
+  }
+}
+
+// block b sums the partials of value b (< nd: w.V_b ; nd: w.w ; nd+1: |V_j|^2)
+// straight into the host-coherent mailbox
+__global__ __launch_bounds__(kBlock) void gmres_finish_kernel(
+    int nparts, int nd, const double* __restrict__ partial,
+    volatile double* __restrict__ mailbox) {
+  const int b = blockIdx.x;
+  const int v = b < nd ? b : kGmresMax + (b - nd);
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock)
+    s += load_scalar(partial + v * kRedBlocks + i);
+  s = block_sum(s);
+  if (threadIdx.x == 0) {
+    mailbox[b] = s;
+    __threadfence_system();
+  }
+}
+
+#define FLOW_NV_SWITCH(nv, CALL) \
+  switch (nv) {                  \
+    case 1: CALL(1); break;      \
+    case 2: CALL(2); break;      \
+    case 3: CALL(3); break;      \
+    case 4: CALL(4); break;      \
+    case 5: CALL(5); break;      \
+    case 6: CALL(6); break;      \
+    case 7: CALL(7); break;      \
+    default: CALL(8); break;     \
+  }
+
+// out = [accumulate ? out : cw w] + sum_{k<nv} c[k] V_k (w == nullptr: no w
+// term); nn_partial as above
+static int gmres_combine(int N, int nv, const double* c, double cw,
+                         const double* w, const double* V, double* out,
+                         double* nn_partial, bool accumulate, hipStream_t st) {
+  const int g = grid_for(N, kBlock, kRedBlocks);
+  if (nv == 0) {   // only the w term (cannot happen in the Arnoldi loop)
+    FLOW_REQUIRE(w != nullptr, "gmres combine");
+    Coef8 none = {};
+    hipLaunchKernelGGL(gmres_combine_kernel<1>, dim3(g), dim3(kBlock), 0, st, N,
+                       none, cw, 1, w, V, static_cast<size_t>(N), out,
+                       nn_partial);
+  }
+  for (int k0 = 0; k0 < nv; k0 += 8) {
+    const int chunk = nv - k0 < 8 ? nv - k0 : 8;
+    Coef8 coef = {};
+    for (int k = 0; k < chunk; ++k) coef.c[k] = c[k0 + k];
+    double* nnp = (k0 + 8 >= nv) ? nn_partial : nullptr;
+#define FLOW_CALL(NV)                                                          \
+  hipLaunchKernelGGL(gmres_combine_kernel<NV>, dim3(g), dim3(kBlock), 0, st, N, \
+                     coef, cw, (k0 == 0 && !accumulate) ? 1 : 0, w,            \
+                     V + static_cast<size_t>(k0) * N, static_cast<size_t>(N),  \
+                     out, nnp)
+    FLOW_NV_SWITCH(chunk, FLOW_CALL)
+#undef FLOW_CALL
+  }
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+// least squares  min | beta e1 - H y |  for the (j+1) x j Hessenberg matrix H
+// (column-major H[col][row]); returns the residual norm
+static double gmres_least_squares(const double (*H)[kGmresMax + 1], int j,
+                                  double beta, double* y) {
+  double R[kGmresMax][kGmresMax + 1];
+  double g[kGmresMax + 1];
+  double cs[kGmresMax], sn[kGmresMax];
+  g[0] = beta;
+  for (int c = 0; c < j; ++c) {
+    for (int r = 0; r <= c + 1; ++r) R[c][r] = H[c][r];
+    for (int i = 0; i < c; ++i) {
+      const double t = cs[i] * R[c][i] + sn[i] * R[c][i + 1];
+      R[c][i + 1] = -sn[i] * R[c][i] + cs[i] * R[c][i + 1];
+      R[c][i] = t;
+    }
+    const double d = hypot(R[c][c], R[c][c + 1]);
+    cs[c] = d > 0.0 ? R[c][c] / d : 1.0;
+    sn[c] = d > 0.0 ? R[c][c + 1] / d : 0.0;
+    R[c][c] = d;
+    g[c + 1] = -sn[c] * g[c];
+    g[c] = cs[c] * g[c];
+  }
+  for (int i = j - 1; i >= 0; --i) {
+    double t = g[i];
+    for (int c = i + 1; c < j; ++c) t -= R[c][i] * y[c];
+    y[i] = R[i][i] != 0.0 ? t / R[i][i] : 0.0;
+  }
+  return fabs(g[j]);
+}
+
+// work: [reductions | V_0 .. V_m | Z_0 .. Z_{m-1} | sweep buffer | partials];
+// Z_j = M^-1 V_j is kept, so that the update x += sum_j y_j Z_j needs no
+// further preconditioner application (memory is not the scarce resource)
+static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu,
+                 const double* b, double* x, double rtol, double atol, int maxit,
+                 int m, int x_is_zero, double* work, int* iters_host,
+                 double* resid_host, hipStream_t st) {
+  const int N = op_size(A);
+  double* partial = work;
+  double* S = work + 3 * kRedBlocks;
+  double* V = work + FLOW_REDUCE_WORK;
+  double* Z = V + static_cast<size_t>(m + 1) * N;
+  double* iwork = Z + static_cast<size_t>(m) * N;
+  double* P = iwork + N;                    // (kGmresMax + 2) x kRedBlocks
+  double* Pww = P + kGmresMax * kRedBlocks;
+  double* Pnn = Pww + kRedBlocks;
+  const int gv = grid_for(N);
+  const int gd = grid_for(N, kBlock, kRedBlocks);
+  double *mailbox = nullptr, *mailbox_dev = nullptr;
+  int np = 0, rc;
+  if ((rc = mailbox_of_thread(&mailbox, &mailbox_dev))) return rc;
+
+  // Z_j = M^-1 V_j (without a preconditioner Z_j is V_j itself)
+  const bool precond = ilu || dinv;
+  const double* Zbase = precond ? Z : V;
+  auto precondition = [&](int j) -> int {
+    const double* in = V + static_cast<size_t>(j) * N;
+    double* out = Z + static_cast<size_t>(j) * N;
+    if (ilu) return ilu_apply(ilu, in, out, iwork, st);
+    if (dinv)
+      hipLaunchKernelGGL(vmul_kernel, dim3(gv), dim3(kBlock), 0, st, N, 1.0, dinv,
+                         in, out);
+    return FLOW_OK;
+  };
+
+  if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
+  if ((rc = dots(N, 1, b, b, b, b, b, b, partial, &np, st))) return rc;
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 1, 0,
+                     partial, S + kB2);
+  double b2 = 0.0, target = 0.0, resid = 0.0;
+  int it = 0;
+  bool have_target = false;
+  while (true) {
+    // r0 = b - A x -> V_0, beta = |r0|
+    if (x_is_zero && it == 0) {
+      hipLaunchKernelGGL(axpby_kernel, dim3(gv), dim3(kBlock), 0, st, N, 1.0, b,
+                         0.0, V);
+    } else {
+      if ((rc = apply(A, x, iwork, st))) return rc;
+      hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(kBlock), 0, st, N, b,
+                         iwork,
+                         static_cast<const double*>(nullptr), V,
+                         static_cast<double*>(nullptr));
+    }
+    if ((rc = dots(N, 1, V, V, V, V, V, V, partial, &np, st))) return rc;
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 1, 0,
+                       partial, S + kRes2);
+    FLOW_CHECK_LAUNCH();
+    double res2 = 0.0;
+    if ((rc = read_slots(S, kB2, kRes2, &b2, &res2, st))) return rc;
+    if (!have_target) {
+      target = fmax(rtol * sqrt(b2), atol);
+      have_target = true;
+    }
+    const double beta = sqrt(res2);
+    resid = beta;
+    if (!(res2 == res2)) {
+      *iters_host = it;
+      *resid_host = res2;
+      set_error("GMRES broke down (NaN residual) at iteration %d", it);
+      return FLOW_NOT_CONVERGED;
+    }
+    if (beta <= target) break;
+    if (it >= maxit) {
+      *iters_host = it;
+      *resid_host = beta;
+      set_error("GMRES did not converge in %d iterations: |r| = %.3e > %.3e", it,
+                beta, target);
+      return FLOW_NOT_CONVERGED;
+    }
+
+    double H[kGmresMax][kGmresMax + 1] = {};   // H[column][row]
+    double nrm[kGmresMax + 1];                 // true norms of the stored V_k
+    double eta[kGmresMax];                     // h_{j+1,j} used to scale V_{j+1}
+    double y[kGmresMax], c[kGmresMax];
+    nrm[0] = beta;
+    int j = 0;
+    bool converged = false;
+    while (j < m && it < maxit) {
+      double* w = V + static_cast<size_t>(j + 1) * N;
+      if ((rc = precondition(j))) return rc;
+      if ((rc = apply(A, Zbase + static_cast<size_t>(j) * N, w, st))) return rc;
+      for (int k0 = 0; k0 <= j; k0 += 8) {
+        const int chunk = j + 1 - k0 < 8 ? j + 1 - k0 : 8;
+#define FLOW_CALL(NV)                                                         \
+  hipLaunchKernelGGL(gmres_dots_kernel<NV>, dim3(gd), dim3(kBlock), 0, st, N,  \
+                     w, V + static_cast<size_t>(k0) * N,                      \
+                     static_cast<size_t>(N), k0 == 0 ? 1 : 0,                 \
+                     P + k0 * kRedBlocks, Pww)
+        FLOW_NV_SWITCH(chunk, FLOW_CALL)
+#undef FLOW_CALL
+      }
+      const int nd = j + 1;
+      hipLaunchKernelGGL(gmres_finish_kernel, dim3(nd + 1 + (j > 0 ? 1 : 0)),
+                         dim3(kBlock), 0, st, gd, nd, P, mailbox_dev);
+      FLOW_CHECK_LAUNCH();
+      FLOW_CHECK_HIP(hipStreamSynchronize(st));
+      const volatile double* mb = mailbox;
+      if (j > 0) {
+        // the true norm of V_j (scaled with the Pythagoras estimate eta)
+        nrm[j] = sqrt(mb[nd + 1]);
+        H[j - 1][j] = eta[j - 1] * nrm[j];
+      }
+      const double ww = mb[nd] / (nrm[j] * nrm[j]);
+      double sum = 0.0;
+      bool bad = !(ww == ww) || !(nrm[j] > 0.0);
+      for (int k = 0; k <= j; ++k) {
+        H[j][k] = mb[k] / (nrm[j] * nrm[k]);
+        sum += H[j][k] * H[j][k];
+      }
+      if (bad) {
+        *iters_host = it;
+        *resid_host = resid;
+        set_error("GMRES broke down (NaN) at iteration %d", it);
+        return FLOW_NOT_CONVERGED;
+      }
+      const double e2 = ww - sum;
+      // (nearly) invariant subspace: the least-squares residual is then zero
+      const bool lucky = !(e2 > 1.0e-28 * ww);
+      eta[j] = lucky ? 0.0 : sqrt(e2);
+      H[j][j + 1] = eta[j];
+      ++it;
+      ++j;
+      resid = gmres_least_squares(H, j, beta, y);
+      if (resid <= target || lucky) {
+        converged = true;
+        break;
+      }
+      if (j < m && it < maxit) {
+        // V_j = (w / nrm_{j-1} - sum_k H[j-1][k] V_k / nrm_k) / eta, in place
+        const double inv = 1.0 / eta[j - 1];
+        for (int k = 0; k < j; ++k) c[k] = -H[j - 1][k] * inv / nrm[k];
+        if ((rc = gmres_combine(N, j, c, inv / nrm[j - 1], w, V, w, Pnn, false,
+                                st)))
+          return rc;
+      }
+    }
+    // x += sum_k y_k Z_k / nrm_k
+    for (int k = 0; k < j; ++k) c[k] = y[k] / nrm[k];
+    if ((rc = gmres_combine(N, j, c, 0.0, nullptr, Zbase, x, nullptr, true, st)))
+      return rc;
+    x_is_zero = 0;
+    if (converged) break;
+    // else: restart from the true residual (or report non-convergence there)
+  }
+  *iters_host = it;
+  *resid_host = resid;
   return FLOW_OK;
 }
 
@@ -1266,6 +1591,28 @@ extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
   }
   return bicgstab(A, dinv, ilu, b, x, rtol, atol, maxit, check_every,
                   first_check, work, iters_host, resid_host, as_stream(stream));
+}
+
+extern "C" int flow_gmres_solve(const flow_operator* A, const double* dinv,
+                                const flow_ilu* ilu, const double* b, double* x,
+                                double rtol, double atol, int maxit, int restart,
+                                int x_is_zero, double* work, size_t work_len,
+                                int* iters_host, double* resid_host,
+                                void* stream) {
+  int rc = check_solver_args(A, b, x, rtol, atol, maxit, 1, 0, work, work_len, 0,
+                             iters_host, resid_host);
+  if (rc) return rc;
+  FLOW_REQUIRE(restart >= 1 && restart <= FLOW_GMRES_MAX_RESTART,
+               "GMRES restart length");
+  FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK +
+                               (2 * static_cast<size_t>(restart) + 2) *
+                                   op_size(A) +
+                               FLOW_GMRES_PARTIALS,
+               "solver workspace too small (FLOW_REDUCE_WORK + (2 restart + 2) N "
+               "+ FLOW_GMRES_PARTIALS)");
+  if (ilu && (rc = ilu_check(ilu, op_size(A)))) return rc;
+  return gmres(A, dinv, ilu, b, x, rtol, atol, maxit, restart, x_is_zero, work,
+               iters_host, resid_host, as_stream(stream));
 }
 
 // ---------------------------------------------------------------------------

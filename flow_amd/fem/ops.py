@@ -415,25 +415,30 @@ class SolveInfo(object):
 
 def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
                  check_every=None, coarse=None, ilu=None, mg=None,
-                 first_check=0, tag=None):
+                 first_check=0, tag=None, restart=20, x_is_zero=False):
     '''Solve A x = b on the device; x holds the initial guess.  Raises
     _hip.NotConverged (a RuntimeError) like dolfin's
     'error_on_nonconvergence'.  first_check > 0: iterations before the first
     residual read-back (then every check_every).  tag (CG): the solve recurs
     in a time loop under that name -- the iteration count of the previous
-    call (kept on A) places the first read-back two iterations before it.'''
+    call (kept on A) places the first read-back two iterations before it.
+    method 'gmres': GMRES(restart); x_is_zero promises x = 0 on entry;
+    `iterations` then counts operator applications (a BiCGStab iteration is
+    two).'''
     lib = _hip.lib()
     n = A.size
     if isinstance(dinv, str):
         assert dinv == 'jacobi'
         dinv = A.diag_inv() if ilu is None else None
-    nvec = 5 if method == 'cg' else 7
+    assert method in ('cg', 'bicgstab', 'gmres'), method
+    nvec = {'cg': 5, 'bicgstab': 7, 'gmres': 2 * restart + 2}[method]
     nparts = A.operator().nblocks * (2 if A.kind == 1 else 1) + 2
     wk = work(_hip.REDUCE_WORK + nvec * n
               + (nparts if method == 'cg' else 0)
               + (2 * coarse.struct.lda if coarse else 0)
               + (2 * mg.struct.Ps[0].nblocks if mg is not None else 0)
-              + (n if ilu is not None else 0))
+              + (n if ilu is not None and method == 'bicgstab' else 0)
+              + (_hip.GMRES_PARTIALS if method == 'gmres' else 0))
     if device._POISON:      # debugging aid: stale workspace reads become NaNs
         _hip.fill(wk, float('nan'))
     if check_every is None:
@@ -454,6 +459,15 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
             int(maxit), int(check_every), int(first_check), _hip.f64(wk),
             wk.numel(),
             ctypes.byref(its), ctypes.byref(res), _hip.stream()
+            )
+    elif method == 'gmres':
+        assert coarse is None and mg is None
+        rc = lib.flow_gmres_solve(
+            ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
+            ctypes.byref(ilu.struct) if ilu is not None else None,
+            _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
+            int(maxit), int(restart), int(bool(x_is_zero)), _hip.f64(wk),
+            wk.numel(), ctypes.byref(its), ctypes.byref(res), _hip.stream()
             )
     else:
         assert coarse is None and mg is None

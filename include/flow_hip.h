@@ -222,6 +222,25 @@ int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
                         double rtol, double atol, int maxit, int check_every,
                         int first_check, double* work, size_t work_len,
                         int* iters_host, double* resid_host, void* stream);
+/* GMRES(restart), right-preconditioned with ILU(0) (ilu != NULL), Jacobi (dinv
+ * != NULL) or nothing: the Newton systems of the tentative velocity
+ * (pressure_correction.py:224-254) -- one operator + preconditioner application
+ * per iteration, ~15 % fewer of them than BiCGStab needs there.  Classical
+ * Gram-Schmidt with one host read-back per iteration (the dot products of the
+ * step); the small least-squares problem is solved on the host.  Stops on the
+ * least-squares residual estimate, `iters_host` = operator applications.
+ * x_is_zero != 0: the caller guarantees x = 0 on entry (Newton increments), the
+ * initial residual is then b without an operator application.
+ * work: FLOW_REDUCE_WORK + (2*restart + 2)*N + FLOW_GMRES_PARTIALS doubles
+ * (the preconditioned basis vectors are kept: no extra preconditioner
+ * application for the solution update). */
+#define FLOW_GMRES_MAX_RESTART 30
+#define FLOW_GMRES_PARTIALS ((FLOW_GMRES_MAX_RESTART + 2) * 1024)
+int flow_gmres_solve(const flow_operator* A, const double* dinv,
+                     const flow_ilu* ilu, const double* b, double* x,
+                     double rtol, double atol, int maxit, int restart,
+                     int x_is_zero, double* work, size_t work_len,
+                     int* iters_host, double* resid_host, void* stream);
 
 /* ---- K15: row-sharded multi-GPU CG ----------------------------------------
  * (nothing in the reference: DOLFIN/PETSc would do this implicitly under

@@ -139,3 +139,30 @@ def test_newton_with_ilu0_preconditioner(hip):
     assert cases.rel_l2(uii, uij) < 1e-7
     assert cases.rel_l2(u1i, u1j) < 1e-7
     assert its_i < its_j, (its_i, its_j)
+
+
+@pytest.mark.gpu
+def test_newton_gmres_and_bicgstab_agree(hip):
+    '''The Newton systems solved with GMRES (default) or BiCGStab, both with
+    the ILU(0) preconditioner: the same converged step, GMRES with no more
+    operator applications.'''
+    import flow_amd.navier_stokes as navsto
+    mesh = fem.karman_channel(30, 10)
+    case = cases.Case(mesh, vdeg=2, dt=0.05, bc_kind='channel', rho=1.5,
+                      mu=0.05, seed=3)
+    npar = navsto.solver_parameters['newton']
+    default = npar['linear_solver']
+    out = {}
+    try:
+        for solver in ('bicgstab', 'gmres'):
+            npar['linear_solver'] = solver
+            u1, p1, ui = case.product_step('rotational')
+            out[solver] = (u1, p1, ui, sum(
+                navsto.last_step_info['newton_linear_applications']))
+    finally:
+        npar['linear_solver'] = default
+    assert default == 'gmres'
+    for k in range(3):
+        assert cases.rel_l2(out['gmres'][k], out['bicgstab'][k]) < 1e-7
+    assert out['gmres'][3] <= out['bicgstab'][3], (out['gmres'][3],
+                                                  out['bicgstab'][3])

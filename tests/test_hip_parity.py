@@ -202,6 +202,23 @@ def test_bicgstab_matches_direct_solve(hip):
     info = ops.krylov_solve('bicgstab', A, _dev(b), x, rtol=1e-13, maxit=2000)
     ref = spla.splu(A.to_scipy().tocsc()).solve(b)
     assert cases.rel_l2(x.cpu().numpy(), ref) < 1e-9, info
+    # GMRES on the same system: one long cycle, short cycles (restarts), a
+    # nonzero start, no preconditioner
+    for kw in (dict(restart=30, x_is_zero=True), dict(restart=4, x_is_zero=True),
+               dict(restart=7), dict(restart=30, dinv=None, x_is_zero=True)):
+        xg = _dev(numpy.zeros(2 * V.N) if kw.get('x_is_zero')
+                  else rng.standard_normal(2 * V.N))
+        ig = ops.krylov_solve('gmres', A, _dev(b), xg, rtol=1e-13, maxit=4000,
+                              **kw)
+        assert cases.rel_l2(xg.cpu().numpy(), ref) < 1e-9, (kw, ig)
+    # fewer operator applications than BiCGStab (two per iteration) needs
+    xg = _dev(numpy.zeros(2 * V.N))
+    ig = ops.krylov_solve('gmres', A, _dev(b), xg, rtol=1e-13, maxit=4000,
+                          restart=30, x_is_zero=True)
+    assert ig.iterations <= 2 * info.iterations, (ig, info)
+    with pytest.raises(RuntimeError):
+        ops.krylov_solve('gmres', A, _dev(b), _dev(numpy.zeros(2 * V.N)),
+                         rtol=1e-13, maxit=3, restart=30, x_is_zero=True)
 
 
 @pytest.mark.parametrize('vdeg', [1, 2])
