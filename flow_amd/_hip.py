@@ -38,6 +38,7 @@ class Operator(ctypes.Structure):
         ('rowblocks', ctypes.c_void_p),
         ('vals', ctypes.c_void_p * 4),
         ('matfree', ctypes.c_void_p),
+        ('rowmask', ctypes.c_void_p),
         ]
 
 

@@ -217,9 +217,82 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
   }
 }
 
+// one value plane applied to both components of a component-blocked vector,
+// identity on the rows with mask 0 (flow_operator kind 4): the matrix is read
+// once for the two products
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
+    int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vals, const int* __restrict__ rowblocks,
+    const unsigned char* __restrict__ mask, const double* __restrict__ x,
+    double* __restrict__ y, double* __restrict__ dpart) {
+  __shared__ double prod0[kTile];
+  __shared__ double prod1[kTile];
+  const int r0 = rowblocks[blockIdx.x];
+  const int r1 = rowblocks[blockIdx.x + 1];
+  const int k0 = rowptr[r0];
+  const int k1 = rowptr[r1];
+  const int ka = k0 & ~1;
+  const int r = r0 + threadIdx.x;
+  int a = 0, b = 0;
+  if (r < r1) {
+    a = rowptr[r] - ka;
+    b = rowptr[r + 1] - ka;
+  }
+  const double2* __restrict__ v2p = reinterpret_cast<const double2*>(vals + ka);
+  const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
+  const int npair = (k1 - ka + 1) >> 1;
+  double2 v[kPairs];
+  int2 c[kPairs];
+#pragma unroll
+  for (int j = 0; j < kPairs; ++j) {
+    const int p = threadIdx.x + j * kBlock;
+    const bool ok = p < npair;
+    v[j] = ok ? v2p[p] : make_double2(0.0, 0.0);
+    c[j] = ok ? c2p[p] : make_int2(0, 0);
+  }
+  double xa[kPairs], xb[kPairs], ua[kPairs], ub[kPairs];
+#pragma unroll
+  for (int j = 0; j < kPairs; ++j) {   // all gathers in flight before any use
+    xa[j] = x[c[j].x];
+    xb[j] = x[c[j].y];
+    ua[j] = x[n + c[j].x];
+    ub[j] = x[n + c[j].y];
+  }
+#pragma unroll
+  for (int j = 0; j < kPairs; ++j) {
+    const int p = threadIdx.x + j * kBlock;
+    if (p < npair) {
+      prod0[2 * p] = v[j].x * xa[j];
+      prod0[2 * p + 1] = v[j].y * xb[j];
+      prod1[2 * p] = v[j].x * ua[j];
+      prod1[2 * p + 1] = v[j].y * ub[j];
+    }
+  }
+  __syncthreads();
+  double t = 0.0;
+  if (r < r1) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = a; k < b; ++k) {
+      s0 += prod0[k];
+      s1 += prod1[k];
+    }
+    const double x0 = x[r], x1 = x[n + r];
+    if (!mask[r]) s0 = x0;
+    if (!mask[n + r]) s1 = x1;
+    y[r] = s0;
+    y[n + r] = s1;
+    if (DOT) t = s0 * x0 + s1 * x1;
+  }
+  if (DOT) {
+    t = block_sum(t);
+    if (threadIdx.x == 0) dpart[blockIdx.x] = t;
+  }
+}
+
 static int check_operator(const flow_operator* A) {
   FLOW_REQUIRE(A != nullptr, "operator is NULL");
-  FLOW_REQUIRE(A->kind >= 0 && A->kind <= 3, "operator kind");
+  FLOW_REQUIRE(A->kind >= 0 && A->kind <= 4, "operator kind");
   if (A->kind == 3) {   // matrix-free: no pattern, no value planes
     const flow_momentum_jvp* J =
         static_cast<const flow_momentum_jvp*>(A->matfree);
@@ -230,7 +303,8 @@ static int check_operator(const flow_operator* A) {
   }
   FLOW_REQUIRE(A->n > 0 && A->nnz > 0 && A->nblocks > 0, "operator sizes");
   FLOW_REQUIRE(A->rowptr && A->cols && A->rowblocks, "operator pattern");
-  const int planes = A->kind == 0 ? 1 : (A->kind == 1 ? 2 : 4);
+  const int planes = (A->kind == 0 || A->kind == 4) ? 1 : (A->kind == 1 ? 2 : 4);
+  FLOW_REQUIRE(A->kind != 4 || A->rowmask != nullptr, "operator row mask");
   for (int p = 0; p < planes; ++p) {
     FLOW_REQUIRE(A->vals[p] != nullptr, "operator value plane");
     FLOW_REQUIRE((reinterpret_cast<size_t>(A->vals[p]) & 15) == 0,
@@ -260,7 +334,16 @@ static int apply(const flow_operator* A, const double* x, double* y,
   }
   const dim3 grid(A->nblocks, A->kind == 1 ? 2 : 1);
   const double* v1 = A->kind == 1 ? A->vals[1] : A->vals[0];
-  if (A->kind == 2) {
+  if (A->kind == 4) {
+    if (dpart)
+      hipLaunchKernelGGL(spmv_stream_pair_kernel<true>, grid, dim3(kBlock), 0, st,
+                         A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
+                         A->rowmask, x, y, dpart);
+    else
+      hipLaunchKernelGGL(spmv_stream_pair_kernel<false>, grid, dim3(kBlock), 0,
+                         st, A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
+                         A->rowmask, x, y, dpart);
+  } else if (A->kind == 2) {
     if (dpart)
       hipLaunchKernelGGL(spmv_stream_block2_kernel<true>, grid, dim3(kBlock), 0,
                          st, A->n, A->rowptr, A->cols, A->vals[0], A->vals[1],
@@ -286,12 +369,14 @@ __global__ void diag_inv_kernel(int n, int planes_kind,
                                 const int* __restrict__ diag_idx,
                                 const double* __restrict__ v0,
                                 const double* __restrict__ v1,
+                                const unsigned char* __restrict__ mask,
                                 double* __restrict__ dinv) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
     const int k = diag_idx[i];
-    dinv[i] = 1.0 / v0[k];
-    if (planes_kind > 0) dinv[n + i] = 1.0 / v1[k];
+    dinv[i] = (mask && !mask[i]) ? 1.0 : 1.0 / v0[k];
+    if (planes_kind > 0)
+      dinv[n + i] = (mask && !mask[n + i]) ? 1.0 : 1.0 / v1[k];
   }
 }
 
@@ -1058,7 +1143,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 13; }
+extern "C" int flow_abi_version(void) { return 14; }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {
@@ -1075,10 +1160,13 @@ extern "C" int flow_operator_diag_inv(const flow_operator* A,
   if (rc) return rc;
   FLOW_REQUIRE(diag_idx && dinv, "diag_idx, dinv");
   FLOW_REQUIRE(A->kind != 3, "a matrix-free operator has no stored diagonal");
-  const double* v1 = A->kind == 0 ? A->vals[0]
-                                  : (A->kind == 1 ? A->vals[1] : A->vals[3]);
+  const double* v1 = (A->kind == 0 || A->kind == 4)
+                         ? A->vals[0]
+                         : (A->kind == 1 ? A->vals[1] : A->vals[3]);
   hipLaunchKernelGGL(diag_inv_kernel, dim3(grid_for(A->n)), dim3(kBlock), 0,
                      as_stream(stream), A->n, A->kind, diag_idx, A->vals[0], v1,
+                     A->kind == 4 ? A->rowmask
+                                  : static_cast<const unsigned char*>(nullptr),
                      dinv);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;

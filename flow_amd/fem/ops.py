@@ -107,13 +107,20 @@ def value_plane(layout):
 
 class Matrix(object):
     '''Value planes over the CSR pattern of a scalar layout.
-    kind 0: scalar (1 plane), 1: block-diagonal (2 planes), 2: 2x2 (4 planes);
+    kind 0: scalar (1 plane), 1: block-diagonal (2 planes), 2: 2x2 (4 planes),
+    4: one plane for both components of a vector field with identity rows
+    where `rowmask` (uint8, 2N) is 0 (include/flow_hip.h, flow_operator);
     `vals` is one tensor of nplanes*stride doubles, stride = plane_stride().'''
-    NPLANES = {0: 1, 1: 2, 2: 4}
+    NPLANES = {0: 1, 1: 2, 2: 4, 4: 1}
 
-    def __init__(self, layout, kind, vals=None):
+    def __init__(self, layout, kind, vals=None, rowmask=None):
         self.layout = layout
         self.kind = kind
+        assert (rowmask is not None) == (kind == 4)
+        if rowmask is not None:
+            assert rowmask.dtype == torch.uint8 and \
+                rowmask.numel() == 2 * layout.N
+        self.rowmask = rowmask
         self.nplanes = self.NPLANES[kind]
         nnz = layout.nnz
         self.stride = plane_stride(layout)
@@ -154,6 +161,8 @@ class Matrix(object):
             base = _hip.f64(self.vals, self.nplanes * self.stride, 'vals').value
             for p in range(self.nplanes):
                 op.vals[p] = base + 8 * p * self.stride
+            if self.rowmask is not None:
+                op.rowmask = _hip.u8(self.rowmask, 2 * lay.N, 'rowmask').value
             self._op = op
         return self._op
 
@@ -189,6 +198,14 @@ class Matrix(object):
                            shape=(lay.N, lay.N)) for p in range(self.nplanes)]
         if self.kind == 0:
             return P[0]
+        if self.kind == 4:
+            m = device.to_host(self.rowmask).numpy().astype(float)
+            blocks = [
+                sp.diags(m[c * lay.N:(c + 1) * lay.N]).dot(P[0])
+                + sp.diags(1.0 - m[c * lay.N:(c + 1) * lay.N])
+                for c in range(2)
+                ]
+            return sp.block_diag(blocks, format='csr')
         if self.kind == 1:
             return sp.block_diag(P, format='csr')
         return sp.bmat([[P[0], P[1]], [P[2], P[3]]], format='csr')

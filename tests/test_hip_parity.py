@@ -94,6 +94,51 @@ def test_blas1(hip):
     assert a == ops.dot(xd, yd)
 
 
+def test_identity_row_operator(hip):
+    '''flow_operator kind 4: one plane for both components, Dirichlet rows by
+    mask.  Product, Jacobi diagonal, and CG from a start vector that carries the
+    boundary values against the symmetrically eliminated system (what
+    `solve(..., 'symmetric': True)` assembles, reference :451-464).'''
+    import torch
+    rng = numpy.random.RandomState(21)
+    mesh = fem.karman_channel(48, 12)
+    V = fem.FunctionSpace(mesh, 'CG', 2)
+    lay = V.layout
+    n = lay.N
+    M = ops.assemble_mass(V)
+    free = (rng.uniform(size=2 * n) > 0.07).astype(numpy.uint8)
+    A = ops.Matrix(lay, 4, M.vals, rowmask=_dev(free))
+    assert A.size == 2 * n
+    x = rng.standard_normal(2 * n)
+    y = _dev(numpy.zeros(2 * n))
+    A.apply(_dev(x), y)
+    Ms = M.to_scipy()
+    ref = numpy.concatenate([Ms.dot(x[:n]), Ms.dot(x[n:])])
+    ref = numpy.where(free != 0, ref, x)
+    assert abs(y.cpu().numpy() - ref).max() <= 1e-13 * abs(ref).max()
+    assert abs(A.to_scipy().dot(x) - ref).max() <= 1e-13 * abs(ref).max()
+    dinv = A.diag_inv().cpu().numpy()
+    dref = numpy.where(free != 0, 1.0 / numpy.tile(Ms.diagonal(), 2), 1.0)
+    assert numpy.allclose(dinv, dref, rtol=1e-14)
+    # the Dirichlet problem: u = g on the masked rows, (M u)_i = b_i elsewhere
+    g = rng.standard_normal(2 * n)
+    b = rng.standard_normal(2 * n)
+    b[free == 0] = g[free == 0]
+    x0 = rng.standard_normal(2 * n)
+    x0[free == 0] = g[free == 0]
+    xd = _dev(x0)
+    info = ops.krylov_solve('cg', A, _dev(b), xd, rtol=1e-13, maxit=2000,
+                            check_every=5)
+    M2 = sp.block_diag([Ms, Ms], format='csr')
+    D = sp.diags((free != 0).astype(float))
+    Asym = D.dot(M2).dot(D) + sp.diags((free == 0).astype(float))
+    bsym = numpy.where(free != 0, b - M2.dot(numpy.where(free == 0, g, 0.0)), g)
+    uref = spla.splu(Asym.tocsc()).solve(bsym)
+    assert cases.rel_l2(xd.cpu().numpy(), uref) < 1e-9, info
+    assert (xd.cpu().numpy()[free == 0] == g[free == 0]).all()
+    assert torch.isfinite(xd).all()
+
+
 def test_cg_matches_direct_solve(hip):
     rng = numpy.random.RandomState(3)
     mesh = fem.karman_channel(48, 12)
