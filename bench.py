@@ -243,6 +243,7 @@ def main():
 
     p_its = [i['pressure'].iterations for i in infos]
     c_its = [i['correction'].iterations for i in infos]
+    m_its = [i.get('projection_iterations', 0) for i in infos]
     n_its = [sum(i.get('newton_linear_applications', [])) for i in infos]
     tim = {}
     for key in ('tentative_s', 'pressure_s', 'correction_s'):
@@ -287,6 +288,7 @@ def main():
             'dt': [i['dt'] for i in infos],
             'pressure_cg_iterations': p_its,
             'correction_cg_iterations': c_its,
+            'cfl_projection_cg_iterations': m_its,
             'newton_iterations': [len(i['newton_residuals']) - 1 for i in infos],
             'newton_linear_solver': navsto.solver_parameters['newton'].get(
                 'linear_solver', 'gmres') + '+ilu0',

@@ -564,9 +564,10 @@ def project_magnitude(u, mode=0, tol=1.0e-12, initial_guess=None):
     out = Function(S)
     if initial_guess is not None:
         out.assign(initial_guess)
-    krylov_solve('cg', M, b, out.data, tol, maxit=1000, dinv=lay._dev[key],
-                 check_every=2,
-                 tag='project_magnitude' if initial_guess is not None else None)
+    out.solve_info = krylov_solve(
+        'cg', M, b, out.data, tol, maxit=1000, dinv=lay._dev[key],
+        check_every=2,
+        tag='project_magnitude' if initial_guess is not None else None)
     return out
 
 

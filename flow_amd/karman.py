@@ -86,6 +86,8 @@ class KarmanProblem(object):
         self.t = 0.0
         self.hmax = self.mesh.hmax()
         self.history = []
+        self._umag_hist = (None, None)
+        self.extrapolate_projection = True
         return
 
     def num_dofs(self):
@@ -123,10 +125,19 @@ class KarmanProblem(object):
             # CFL-like step-size control on ||project(|u|)||_inf (:262-286)
             # (mass solve to 1e-7, started from the previous step's projection:
             # the value only steers dt, which inherits that relative accuracy)
-            self._umag = fem.project_magnitude(
-                self.u0, tol=1.0e-7, initial_guess=getattr(self, '_umag', None)
-                )
-            unorm = self._umag.vector().norm('linf')
+            # ... extrapolated linearly in time through the last two)
+            prev, prev2 = self._umag_hist
+            guess = prev[0] if prev is not None else None
+            if self.extrapolate_projection and prev2 is not None:
+                r = self.dt / prev[1]
+                guess = fem.Function(prev[0].function_space())
+                guess.assign(prev[0])
+                fem.ops.axpby(-r, prev2[0].data, 1.0 + r, guess.data)
+            umag = fem.project_magnitude(self.u0, tol=1.0e-7, initial_guess=guess)
+            # (projection, length of the step that led to it)
+            self._umag_hist = ((umag, self.dt), prev)
+            info['projection_iterations'] = umag.solve_info.iterations
+            unorm = umag.vector().norm('linf')
             target_dt = 1.0 * self.hmax / unorm
             alpha = 0.5
             self.dt = min(
