@@ -226,8 +226,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
     const double* __restrict__ vals, const int* __restrict__ rowblocks,
     const unsigned char* __restrict__ mask, const double* __restrict__ x,
     double* __restrict__ y, double* __restrict__ dpart) {
-  __shared__ double prod0[kTile];
-  __shared__ double prod1[kTile];
+  // ONE product array, used by the two components in turn (two would halve the
+  // occupancy: 32 KB of LDS per workgroup)
+  __shared__ double prod[kTile];
   const int r0 = rowblocks[blockIdx.x];
   const int r1 = rowblocks[blockIdx.x + 1];
   const int k0 = rowptr[r0];
@@ -263,20 +264,26 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
   for (int j = 0; j < kPairs; ++j) {
     const int p = threadIdx.x + j * kBlock;
     if (p < npair) {
-      prod0[2 * p] = v[j].x * xa[j];
-      prod0[2 * p + 1] = v[j].y * xb[j];
-      prod1[2 * p] = v[j].x * ua[j];
-      prod1[2 * p + 1] = v[j].y * ub[j];
+      prod[2 * p] = v[j].x * xa[j];
+      prod[2 * p + 1] = v[j].y * xb[j];
     }
   }
   __syncthreads();
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = a; k < b; ++k) s0 += prod[k];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kPairs; ++j) {
+    const int p = threadIdx.x + j * kBlock;
+    if (p < npair) {
+      prod[2 * p] = v[j].x * ua[j];
+      prod[2 * p + 1] = v[j].y * ub[j];
+    }
+  }
+  __syncthreads();
+  for (int k = a; k < b; ++k) s1 += prod[k];
   double t = 0.0;
   if (r < r1) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = a; k < b; ++k) {
-      s0 += prod0[k];
-      s1 += prod1[k];
-    }
     const double x0 = x[r], x1 = x[n + r];
     if (!mask[r]) s0 = x0;
     if (!mask[n + r]) s1 = x1;
