@@ -64,6 +64,13 @@ class CsrOperator(object):
         self.op = op
 
 
+def _scale_rows(M, d):
+    '''diag(d) M for a CSR matrix M.'''
+    out = M.copy()
+    out.data = out.data * numpy.repeat(d, numpy.diff(out.indptr))
+    return out
+
+
 def _bin_aggregates(x, free, width):
     ix = numpy.floor((x[:, 0] - x[:, 0].min()) / width + 1e-9).astype(numpy.int64)
     iy = numpy.floor((x[:, 1] - x[:, 1].min()) / width + 1e-9).astype(numpy.int64)
@@ -112,14 +119,19 @@ class Multigrid(object):
                 v = Ah.dot(v) / D
                 lam = numpy.linalg.norm(v)
                 v /= lam
-            P = (P0 - (4.0 / (3.0 * lam)) * sp.diags(1.0 / D).dot(Ah.dot(P0))).tocsr()
+            # (diagonal scalings act on the value arrays: a product with a
+            # sparse diagonal matrix costs scipy a full sparse matmat)
+            P = (P0 - _scale_rows(Ah.dot(P0).tocsr(), (4.0 / (3.0 * lam)) / D)
+                 ).tocsr()
             AP = Ah.dot(P).tocsr()
-            Ac = (P.T.dot(AP)).tocsr()
-            wD = sp.diags(omega / D)
+            R = P.T.tocsr()
+            Ac = (R.dot(AP)).tocsr()
+            Ahat = Ah.copy()
+            Ahat.data = Ahat.data * (omega / D)[Ahat.indices]
             self.levels.append(dict(
-                Ah=CsrOperator(Ah.dot(wD)),
+                Ah=CsrOperator(Ahat),
                 dinv=device.to_device(1.0 / D),
-                Ps=CsrOperator(P - wD.dot(AP)), R=CsrOperator(P.T.tocsr()),
+                Ps=CsrOperator(P - _scale_rows(AP, omega / D)), R=CsrOperator(R),
                 t=device.zeros(m),
                 ))
             if keep_host:

@@ -35,6 +35,14 @@ from . import _hip
 from . import device
 
 last_solve_info = {}
+# 'multigrid': smoothed-aggregation V-cycle for the velocity solves inside the
+# Schur complement instead of Jacobi + aggregate coarse space.  Measured on the
+# 2 M-DoF cavity (tools/run_configs.py stokes): 23 instead of 590 CG iterations
+# per velocity solve (1.7 s of solves instead of 4.5 s), but 11 s of host-side
+# hierarchy setup (scipy triple products on the P2 stiffness matrix) against
+# 0.3 s -- a one-shot solve is faster with the two-level scheme (5.5 s vs
+# 14.5 s in total); it pays when the same operator is solved with many times.
+solver_parameters = {'multigrid': False}
 
 
 def solve(
@@ -46,7 +54,9 @@ def solve(
         tol=1.0e-13,
         max_iter=500
         ):
+    from .fem.multigrid import Multigrid
     lib = _hip.lib()
+    multigrid = solver_parameters['multigrid']
     mu = scalar_value(mu)
     assert mu > 0.0
     assert isinstance(WP, MixedFunctionSpace)
@@ -88,6 +98,7 @@ def solve(
     K = ops.assemble_scalar_matrix(lay, ops.STIFFNESS)
     planes = []
     coarse = []
+    hierarchies = {}
     for comp in range(2):
         isbc = (umask[comp * n:(comp + 1) * n] == 0.0)
         Kc = ops.symmetric_bc_matrix(
@@ -97,9 +108,24 @@ def solve(
         ops.axpby(mu, Kc.vals, 0.0, Kc.vals)
         Kc.vals[lay.dev('diag_idx').long()[device.to_device(isbc)]] = 1.0
         planes.append(Kc)
-        coarse.append(ops.CoarseSpace(
-            Kc, isbc, singular=not isbc.any(), target_nc=2048
-            ))
+        # preconditioner of the velocity solves: the smoothed-aggregation
+        # V-cycle (aggregates of ~3x3 dofs: half a mesh width per dof for P2),
+        # the two-level scheme for systems too small to coarsen
+        mg = None
+        if multigrid:
+            # both components usually carry Dirichlet data on the same dofs:
+            # one hierarchy then serves both (same operator)
+            mkey = isbc.tobytes()
+            if mkey not in hierarchies:
+                hierarchies[mkey] = Multigrid(
+                    Kc, isbc, singular=not isbc.any(), s=3.0 / lay.degree)
+            mg = hierarchies[mkey]
+        if mg is not None and mg.nlevels >= 2:
+            coarse.append((None, mg))
+        else:
+            coarse.append((ops.CoarseSpace(
+                Kc, isbc, singular=not isbc.any(), target_nc=2048
+                ), None))
     dinvs = [Kc.diag_inv() for Kc in planes]
     Kfull = ops.Matrix(lay, 1, torch.cat([K.vals, K.vals]))
 
@@ -114,8 +140,10 @@ def solve(
             x = out[sl]
             sol = ops.krylov_solve(
                 'cg', planes[comp], rhs[sl], x, rtol=inner_tol, atol=1.0e-300,
-                maxit=20000, dinv=dinvs[comp], check_every=10,
-                coarse=coarse[comp]
+                maxit=20000, dinv=dinvs[comp],
+                check_every=2 if coarse[comp][1] is not None else 10,
+                coarse=coarse[comp][0], mg=coarse[comp][1],
+                tag='stokes_velocity_%d' % comp
                 )
             inner['its'] += sol.iterations
             inner['solves'] += 1
