@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void pressure_rhs_kernel(
     const double* __restrict__ p0, double alpha_rho_dt, double mu,
     int rotational, double* __restrict__ scratch) {
   constexpr int NL = Elem<DEG>::NL;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const Geom g = load_geom(xy, nc, c);
   double U[2][NL];
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void correction_rhs_kernel(
     double mu, int rotational, double* __restrict__ scratch) {
   constexpr int NL = Elem<DEG>::NL;
   constexpr int NQ = Elem<2>::NQ;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const Geom g = load_geom(xy, nc, c);
   double U[2][NL];
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void momentum_residual_kernel(
     flow_ns_params prm, double* __restrict__ scratch) {
   constexpr int NL = Elem<DEG>::NL;
   constexpr int NQ = Elem<DEG>::NQ;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const Geom g = load_geom(xy, nc, c);
   double Ui[2][NL], U0[2][NL], P[3];
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void momentum_jvp_kernel(
     double* __restrict__ scratch) {
   constexpr int NL = Elem<DEG>::NL;
   constexpr int NQ = Elem<DEG>::NQ;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const Geom g = load_geom(xy, nc, c);
   double U[2][NL], V[2][NL];
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(kBlock) void magnitude_kernel(
     const double* __restrict__ u, int mode, double* __restrict__ scratch) {
   constexpr int NL = Elem<DEG>::NL;
   constexpr int NQ = 7;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   const Geom g = load_geom(xy, nc, c);
   double U[2][NL];

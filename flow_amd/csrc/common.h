@@ -76,6 +76,16 @@ __device__ __forceinline__ void store_scalar(double* p, double v) {
 }
 
 // block-wide sum, result valid in thread 0 (blockDim.x == 256)
+// Workgroups are dealt round-robin to the 8 XCDs (observed on MI355X, not
+// promised by HIP: a speed matter only): the blocks b, b+8, b+16, ... share an
+// XCD and its 4 MB L2.  Give them a contiguous run of tiles, so that the x[col]
+// windows of successive tiles of a banded matrix overlap in THAT L2 instead of
+// being fetched once per XCD.  Bijective for any workgroup count.
+__device__ __forceinline__ int xcd_tile(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
 __device__ inline double block_sum(double v) {
   __shared__ double wave_part[4];
 #pragma unroll

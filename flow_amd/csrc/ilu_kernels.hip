@@ -234,7 +234,9 @@ __global__ __launch_bounds__(kBlock) void ilu_sweep_kernel(
     const int* __restrict__ slice_off, const int* __restrict__ slice_row,
     const int* __restrict__ cols, const double* __restrict__ vals,
     const double* __restrict__ dinv, double* __restrict__ y) {
-  const int sl = blockIdx.x * (kBlock / kSlice) + (threadIdx.x >> 6);
+  // (XCD-aware: neighbouring slices gather from neighbouring windows of y)
+  const int sl = xcd_tile(blockIdx.x, gridDim.x) * (kBlock / kSlice) +
+                 (threadIdx.x >> 6);
   if (sl >= nslices) return;
   const int lane = threadIdx.x & 63;
   const size_t blk = blockIdx.y;

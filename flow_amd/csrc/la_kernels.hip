@@ -47,8 +47,9 @@ __device__ __forceinline__ double stream_tile_row_sum(
     const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals, const int* __restrict__ rowblocks,
     const double* __restrict__ x, double* __restrict__ prod, int& r, int& r1) {
-  const int r0 = rowblocks[blockIdx.x];
-  r1 = rowblocks[blockIdx.x + 1];
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int r0 = rowblocks[tile];
+  r1 = rowblocks[tile + 1];
   const int k0 = rowptr[r0];
   const int k1 = rowptr[r1];
   // 16-byte value loads / 8-byte index loads: every lane owns PAIRS pairs of
@@ -168,8 +169,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
     double* __restrict__ y, double* __restrict__ dpart) {
   __shared__ double prod0[kTile];
   __shared__ double prod1[kTile];
-  const int r0 = rowblocks[blockIdx.x];
-  const int r1 = rowblocks[blockIdx.x + 1];
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int r0 = rowblocks[tile];
+  const int r1 = rowblocks[tile + 1];
   const int k0 = rowptr[r0];
   const int k1 = rowptr[r1];
   const int ka = k0 & ~1;
@@ -229,8 +231,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
   // ONE product array, used by the two components in turn (two would halve the
   // occupancy: 32 KB of LDS per workgroup)
   __shared__ double prod[kTile];
-  const int r0 = rowblocks[blockIdx.x];
-  const int r1 = rowblocks[blockIdx.x + 1];
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int r0 = rowblocks[tile];
+  const int r1 = rowblocks[tile + 1];
   const int k0 = rowptr[r0];
   const int k1 = rowptr[r1];
   const int ka = k0 & ~1;
