@@ -78,12 +78,26 @@ __device__ __forceinline__ void store_scalar(double* p, double v) {
 // block-wide sum, result valid in thread 0 (blockDim.x == 256)
 // Workgroups are dealt round-robin to the 8 XCDs (observed on MI355X, not
 // promised by HIP: a speed matter only): the blocks b, b+8, b+16, ... share an
-// XCD and its 4 MB L2.  Give them a contiguous run of tiles, so that the x[col]
-// windows of successive tiles of a banded matrix overlap in THAT L2 instead of
-// being fetched once per XCD.  Bijective for any workgroup count.
+// XCD and its 4 MB L2.  Give them contiguous runs of kXcdRun tiles, so that the
+// x[col] windows of successive tiles of a banded matrix overlap in THAT L2
+// instead of being fetched once per XCD -- but keep the eight runs next to each
+// other (groups of 8 kXcdRun tiles), so that the chip still streams ONE region
+// of HBM at a time (one run per XCD over the whole matrix costs an
+// HBM-resident 4 GB matrix 12 % of its bandwidth; measured, tools/
+// spmv_stress.py).  Bijective for any workgroup count.
+constexpr int kXcdRun = 32;
 __device__ __forceinline__ int xcd_tile(int b, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  constexpr int kGroup = 8 * kXcdRun;
+  const int full = (nwg / kGroup) * kGroup;
+  if (b < full) {
+    const int g = b / kGroup, i = b - g * kGroup;
+    return g * kGroup + (i & 7) * kXcdRun + (i >> 3);
+  }
+  // the last, partial group: runs of q or q+1 tiles
+  const int nt = nwg - full, i = b - full;
+  const int q = nt >> 3, r = nt & 7, xcd = i & 7;
+  return full + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) +
+         (i >> 3);
 }
 
 __device__ inline double block_sum(double v) {
