@@ -176,6 +176,7 @@ _D = ctypes.c_double
 _P = ctypes.POINTER
 SYMBOLS = {
     'flow_abi_version': [],
+    'flow_xcd_tile_host': [_I, _I],
     'flow_operator_apply': [_P(Operator), _VP, _VP, _VP],
     'flow_operator_diag_inv': [_P(Operator), _VP, _VP, _VP],
     'flow_dot_host': [_I, _VP, _VP, _VP, _P(_D), _VP],

@@ -86,7 +86,7 @@ __device__ __forceinline__ void store_scalar(double* p, double v) {
 // HBM-resident 4 GB matrix 12 % of its bandwidth; measured, tools/
 // spmv_stress.py).  Bijective for any workgroup count.
 constexpr int kXcdRun = 32;
-__device__ __forceinline__ int xcd_tile(int b, int nwg) {
+__host__ __device__ __forceinline__ int xcd_tile(int b, int nwg) {
   constexpr int kGroup = 8 * kXcdRun;
   const int full = (nwg / kGroup) * kGroup;
   if (b < full) {

@@ -1153,7 +1153,12 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 14; }
+extern "C" int flow_abi_version(void) { return 15; }
+
+// the workgroup -> tile mapping of the CSR-stream kernels, for host-side tests
+extern "C" int flow_xcd_tile_host(int block, int nblocks) {
+  return xcd_tile(block, nblocks);
+}
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
                                    double* y, void* stream) {

@@ -45,6 +45,9 @@ extern "C" {
 
 const char* flow_last_error(void);
 int flow_abi_version(void);
+/* Host copy of the workgroup -> tile mapping the CSR-stream kernels use
+ * (XCD-aware, a permutation of [0, nblocks)); for tests. */
+int flow_xcd_tile_host(int block, int nblocks);
 
 /* A linear operator over ONE scalar CSR pattern (n rows, nnz entries).
  *   kind 0: scalar              y = A0 x                      (size n)

@@ -181,13 +181,26 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert declared - {'flow_last_error'} == set(_hip.SYMBOLS), \
         declared ^ set(_hip.SYMBOLS)
-    assert lib.flow_abi_version() == 14
+    assert lib.flow_abi_version() == 15
     assert _hip.SPMV_ROWS_PER_BLOCK == int(
         re.search(r'FLOW_SPMV_ROWS_PER_BLOCK (\d+)', header).group(1))
     assert _hip.SPMV_NNZ_PER_BLOCK == int(
         re.search(r'FLOW_SPMV_NNZ_PER_BLOCK (\d+)', header).group(1))
     assert _hip.REDUCE_WORK == int(
         re.search(r'FLOW_REDUCE_WORK (\d+)', header).group(1))
+
+
+def test_xcd_tile_mapping_is_a_permutation():
+    '''The XCD-aware workgroup -> tile mapping of the CSR-stream kernels (host
+    copy of the device function): every tile exactly once, for any grid size;
+    blocks b, b+8, ... (one XCD) get runs of consecutive tiles.'''
+    lib = _hip.load_library()
+    for n in list(range(1, 530)) + [767, 1024, 4286, 24685]:
+        tiles = [lib.flow_xcd_tile_host(b, n) for b in range(n)]
+        assert sorted(tiles) == list(range(n)), n
+    n = 4286
+    same_xcd = [lib.flow_xcd_tile_host(b, n) for b in range(3, 3 + 8 * 32, 8)]
+    assert same_xcd == list(range(same_xcd[0], same_xcd[0] + 32))
 
 
 def test_no_cpu_fallback():
