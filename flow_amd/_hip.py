@@ -21,7 +21,7 @@ REDUCE_WORK = 4096
 GMRES_MAX_RESTART = 30
 GMRES_PARTIALS = (GMRES_MAX_RESTART + 2) * 1024
 SPMV_ROWS_PER_BLOCK = 256
-SPMV_NNZ_PER_BLOCK = 2046
+SPMV_NNZ_PER_BLOCK = 1022
 
 c_double_p = ctypes.c_void_p
 c_int_p = ctypes.c_void_p

@@ -85,7 +85,7 @@ __device__ __forceinline__ void store_scalar(double* p, double v) {
 // of HBM at a time (one run per XCD over the whole matrix costs an
 // HBM-resident 4 GB matrix 12 % of its bandwidth; measured, tools/
 // spmv_stress.py).  Bijective for any workgroup count.
-constexpr int kXcdRun = 32;
+constexpr int kXcdRun = 64;
 __host__ __device__ __forceinline__ int xcd_tile(int b, int nwg) {
   constexpr int kGroup = 8 * kXcdRun;
   const int full = (nwg / kGroup) * kGroup;

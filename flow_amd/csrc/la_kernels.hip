@@ -32,7 +32,7 @@ void set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 // SpMV
 // ---------------------------------------------------------------------------
-constexpr int kPairs = 4;                       // nonzero pairs per lane
+constexpr int kPairs = 2;                       // nonzero pairs per lane
 constexpr int kTile = 2 * kBlock * kPairs;      // LDS products per workgroup
 static_assert(FLOW_SPMV_ROWS_PER_BLOCK == kBlock, "one lane per row");
 static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTile - 2, "tile minus alignment slack");

@@ -24,7 +24,7 @@ from . import reference
 
 # CSR-stream tiling (must match flow_amd/csrc/la_kernels.hip)
 SPMV_ROWS_PER_BLOCK = 256
-SPMV_NNZ_PER_BLOCK = 2046     # LDS tile (2048) minus the alignment slack
+SPMV_NNZ_PER_BLOCK = 1022     # LDS tile (1024) minus the alignment slack
 
 
 class ScalarLayout(object):

@@ -41,7 +41,7 @@ extern "C" {
 
 /* CSR-stream tiling of flow_spmv (row blocks are built on the host). */
 #define FLOW_SPMV_ROWS_PER_BLOCK 256
-#define FLOW_SPMV_NNZ_PER_BLOCK 2046
+#define FLOW_SPMV_NNZ_PER_BLOCK 1022
 
 const char* flow_last_error(void);
 int flow_abi_version(void);

@@ -199,8 +199,9 @@ def test_xcd_tile_mapping_is_a_permutation():
         tiles = [lib.flow_xcd_tile_host(b, n) for b in range(n)]
         assert sorted(tiles) == list(range(n)), n
     n = 4286
-    same_xcd = [lib.flow_xcd_tile_host(b, n) for b in range(3, 3 + 8 * 32, 8)]
-    assert same_xcd == list(range(same_xcd[0], same_xcd[0] + 32))
+    run = 64            # kXcdRun, flow_amd/csrc/common.h
+    same_xcd = [lib.flow_xcd_tile_host(b, n) for b in range(3, 3 + 8 * run, 8)]
+    assert same_xcd == list(range(same_xcd[0], same_xcd[0] + run))
 
 
 def test_no_cpu_fallback():

@@ -13,7 +13,7 @@ lib.spmv_variant.restype = ctypes.c_int
 lib.spmv_variant.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 7
 
 
-def bench(name, rowptr, cols, vals, variants=(0, 1, 2, 6, 7, 8, 9, 10)):
+def bench(name, rowptr, cols, vals, variants=(11, 15, 18, 19, 20, 21, 22, 23)):
     n = len(rowptr) - 1
     nnz = len(cols)
     dev = device.get()
@@ -33,6 +33,14 @@ def bench(name, rowptr, cols, vals, variants=(0, 1, 2, 6, 7, 8, 9, 10)):
         9: torch.from_numpy(csr_stream_rowblocks(rowptr, 256, 4094)).to(dev),
         10: torch.from_numpy(csr_stream_rowblocks(rowptr, 128, 1022)).to(dev),
         }
+    rbs.update({11: rbs[8], 12: rbs[6], 13: rbs[9], 14: rbs[10], 16: rbs[8],
+                17: rbs[8],
+                15: torch.from_numpy(csr_stream_rowblocks(rowptr, 256, 1022)).to(dev)})
+    rbs.update({18: torch.from_numpy(csr_stream_rowblocks(rowptr, 256, 1534)).to(dev),
+                19: torch.from_numpy(csr_stream_rowblocks(rowptr, 512, 2046)).to(dev),
+                20: rbs[15], 23: rbs[15],
+                21: torch.from_numpy(csr_stream_rowblocks(rowptr, 128, 510)).to(dev),
+                22: torch.from_numpy(csr_stream_rowblocks(rowptr, 256, 510)).to(dev)})
     import scipy.sparse as sp
     ref = sp.csr_matrix((vals, cols, rowptr), shape=(n, n)).dot(x.cpu().numpy())
     B = 12 * nnz + 4 * (n + 1) + 16 * n
@@ -78,10 +86,10 @@ if __name__ == '__main__':
         bench('pressure P1 2182x509', lay.pattern('rowptr'), lay.pattern('cols'),
               rng.standard_normal(lay.nnz))
     if 'mass' in which:
-        mesh = fem.karman_channel(1091, 254)
+        mesh = fem.karman_channel(2182, 509)
         lay = fem.FunctionSpace(mesh, 'CG', 2).layout
         rng = numpy.random.RandomState(0)
-        bench('scalar P2 1091x254', lay.pattern('rowptr'), lay.pattern('cols'),
+        bench('scalar P2 2182x509', lay.pattern('rowptr'), lay.pattern('cols'),
               rng.standard_normal(lay.nnz))
     if 'stress' in which:
         rowptr, cols, vals = banded(10000000, 1540)

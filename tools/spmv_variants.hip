@@ -191,12 +191,27 @@ __global__ __launch_bounds__(KB) void v5(int n, const int* __restrict__ rowptr,
 
 // V6/V7/V8: templated V2 -- 16-B value loads; NT threads, PAIRS pairs per thread
 // (tile = 2*NT*PAIRS nonzeros, host limits blocks to tile-2 nnz)
-template <int NT, int PAIRS, bool PERSIST>
+// XCD-aware tile mapping of the product (flow_amd/csrc/common.h, xcd_tile)
+template <int RUN>
+__device__ __forceinline__ int xcd_map(int b, int nwg) {
+  constexpr int G = 8 * RUN;
+  const int full = (nwg / G) * G;
+  if (b < full) {
+    const int g = b / G, i = b - g * G;
+    return g * G + (i & 7) * RUN + (i >> 3);
+  }
+  const int nt = nwg - full, i = b - full;
+  const int q = nt >> 3, r = nt & 7, xcd = i & 7;
+  return full + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (i >> 3);
+}
+
+template <int NT, int PAIRS, bool PERSIST, int RUN = 0>
 __global__ __launch_bounds__(NT) void v2t(int nblocks, const int* __restrict__ rowptr,
     const int* __restrict__ cols, const double* __restrict__ vals,
     const int* __restrict__ rb, const double* __restrict__ x, double* __restrict__ y) {
   __shared__ double prod[2 * NT * PAIRS];
-  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+  for (int blk0 = blockIdx.x; blk0 < nblocks; blk0 += gridDim.x) {
+    const int blk = RUN > 0 ? xcd_map<(RUN > 0 ? RUN : 1)>(blk0, nblocks) : blk0;
     const int r0 = rb[blk], r1 = rb[blk + 1];
     const int k0 = rowptr[r0], k1 = rowptr[r1];
     const int ka = k0 & ~1;
@@ -252,6 +267,19 @@ extern "C" int spmv_variant(int variant, int n, int nblocks, const int* rowptr,
     case 8: hipLaunchKernelGGL((v2t<256, 4, false>), dim3(nblocks), dim3(256), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
     case 9: hipLaunchKernelGGL((v2t<256, 8, false>), dim3(nblocks), dim3(256), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
     case 10: hipLaunchKernelGGL((v2t<128, 4, false>), dim3(nblocks), dim3(128), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 11: hipLaunchKernelGGL((v2t<256, 4, false, 32>), dim3(nblocks), dim3(256), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 12: hipLaunchKernelGGL((v2t<512, 4, false, 16>), dim3(nblocks), dim3(512), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 13: hipLaunchKernelGGL((v2t<256, 8, false, 16>), dim3(nblocks), dim3(256), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 14: hipLaunchKernelGGL((v2t<128, 4, false, 64>), dim3(nblocks), dim3(128), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 15: hipLaunchKernelGGL((v2t<256, 2, false, 64>), dim3(nblocks), dim3(256), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 16: hipLaunchKernelGGL((v2t<256, 4, false, 64>), dim3(nblocks), dim3(256), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 17: hipLaunchKernelGGL((v2t<256, 4, false, 128>), dim3(nblocks), dim3(256), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 18: hipLaunchKernelGGL((v2t<256, 3, false, 64>), dim3(nblocks), dim3(256), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 19: hipLaunchKernelGGL((v2t<512, 2, false, 32>), dim3(nblocks), dim3(512), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 20: hipLaunchKernelGGL((v2t<256, 2, false, 32>), dim3(nblocks), dim3(256), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 21: hipLaunchKernelGGL((v2t<128, 2, false, 128>), dim3(nblocks), dim3(128), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 22: hipLaunchKernelGGL((v2t<256, 1, false, 128>), dim3(nblocks), dim3(256), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
+    case 23: hipLaunchKernelGGL((v2t<256, 2, false, 128>), dim3(nblocks), dim3(256), 0, st, nblocks, rowptr, cols, vals, rb, x, y); break;
     default: return 2;
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;
