@@ -113,6 +113,21 @@ __device__ inline double block_sum(double v) {
   return v;
 }
 
+// the same for a kernel that reduces exactly once: no barrier to protect the
+// partials of an earlier call (the CSR-stream kernels run one of these per
+// 1022-nonzero tile, where a barrier is a measurable share of the tile's time)
+__device__ inline double block_sum_once(double v) {
+  __shared__ double wave_part_once[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) wave_part_once[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    v = wave_part_once[0] + wave_part_once[1] + wave_part_once[2] +
+        wave_part_once[3];
+  return v;
+}
+
 __device__ inline double block_max(double v) {
   __shared__ double wave_part_m[4];
 #pragma unroll

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
     if (DOT) t = s * x[r];
   }
   if (DOT) {
-    t = block_sum(t);
+    t = block_sum_once(t);
     if (threadIdx.x == 0) dpart[blockIdx.y * gridDim.x + blockIdx.x] = t;
   }
 }
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
     if (DOT) t = s0 * x[r] + s1 * x[n + r];
   }
   if (DOT) {
-    t = block_sum(t);
+    t = block_sum_once(t);
     if (threadIdx.x == 0) dpart[blockIdx.x] = t;
   }
 }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
     if (DOT) t = s0 * x0 + s1 * x1;
   }
   if (DOT) {
-    t = block_sum(t);
+    t = block_sum_once(t);
     if (threadIdx.x == 0) dpart[blockIdx.x] = t;
   }
 }
