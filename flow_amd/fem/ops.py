@@ -17,7 +17,7 @@ from . import reference
 from .function import (
     Function, Expression, Constant, as_cell_coefficient, cell_lattice_points,
     )
-from .space import FunctionSpace, mesh_geometry_dev
+from .space import mesh_geometry_dev
 from .. import _hip
 from .. import device
 

@@ -40,7 +40,6 @@ import ctypes
 import time
 
 import numpy
-import torch
 
 from ..fem import ops
 from ..fem.bcs import collect
@@ -314,15 +313,12 @@ def _compute_tentative_velocity(
             if predicted > tol:
                 lin_atol = max(lin_atol, min(0.1 * predicted, 1.0e-2 * nrm))
         lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
-        # BiCGStab can stagnate when its bi-orthogonality degrades: restart
-        # from the current iterate every `restart` iterations (x is updated in
-        # place also when the solver reports non-convergence).
-        its = 0
-        while npar.get('linear_solver', 'gmres') == 'gmres':
+        operator = Jop if matfree else J
+        if npar.get('linear_solver', 'gmres') == 'gmres':
             # GMRES(restart): one Jacobian action + one preconditioner
             # application per iteration, the least of the Krylov methods here
             sol = ops.krylov_solve(
-                'gmres', Jop if matfree else J, F, dx, rtol=lin_rtol, atol=0.0,
+                'gmres', operator, F, dx, rtol=lin_rtol, atol=0.0,
                 maxit=npar['linear_maxit'], ilu=pre,
                 restart=npar['gmres_restart'], x_is_zero=True,
                 dinv='jacobi' if pre is None else None
@@ -331,24 +327,10 @@ def _compute_tentative_velocity(
             # staleness test of the lagged factors below
             its = (sol.iterations + 1) // 2
             applications.append(sol.iterations)
-            last_linear_residual = sol.residual
-            break
-        while npar.get('linear_solver', 'gmres') != 'gmres':
-            chunk = min(npar['restart'], npar['linear_maxit'] - its)
-            try:
-                sol = ops.krylov_solve(
-                    'bicgstab', Jop if matfree else J, F, dx, rtol=lin_rtol,
-                    atol=0.0,
-                    maxit=chunk, check_every=npar['check_every'], ilu=pre
-                    )
-                its += sol.iterations
-                applications.append(2 * its)
-                last_linear_residual = sol.residual
-                break
-            except _hip.NotConverged:
-                its += chunk
-                if its >= npar['linear_maxit']:
-                    raise
+        else:
+            sol, its = _bicgstab_with_restarts(operator, F, dx, lin_rtol, pre, npar)
+            applications.append(2 * its)
+        last_linear_residual = sol.residual
         linear_its.append(its)
         if pre is not None:
             if refactored:
@@ -363,6 +345,25 @@ def _compute_tentative_velocity(
     # operator + preconditioner applications of the linear solves
     last_step_info['newton_linear_applications'] = applications
     return ui, alpha
+
+
+def _bicgstab_with_restarts(A, b, x, rtol, pre, npar):
+    '''BiCGStab can stagnate when its bi-orthogonality degrades: restart from
+    the current iterate every `restart` iterations (x is updated in place also
+    when the solver reports non-convergence).  Returns (info, iterations).'''
+    its = 0
+    while True:
+        chunk = min(npar['restart'], npar['linear_maxit'] - its)
+        try:
+            sol = ops.krylov_solve(
+                'bicgstab', A, b, x, rtol=rtol, atol=0.0, maxit=chunk,
+                check_every=npar['check_every'], ilu=pre
+                )
+            return sol, its + sol.iterations
+        except _hip.NotConverged:
+            its += chunk
+            if its >= npar['linear_maxit']:
+                raise
 
 
 def _pressure_cg(A, dinv, prec, b, x, tol, par):
