@@ -418,6 +418,34 @@ def vmul(x, y, out=None, a=1.0):
 
 
 # -- Krylov -------------------------------------------------------------------
+class StartChooser(object):
+    '''Which extrapolation order (1 linear, 2 quadratic) gives a recurring
+    solve the better start vector?  Quadratic wins while the fields evolve,
+    linear once they only differ by solver noise (which the quadratic weights
+    amplify more).  Decided by the iteration counts themselves: the mode in
+    use is kept, the other one is tried every `period`-th call.'''
+
+    def __init__(self, period=8):
+        self.period = period
+        self.calls = 0
+        self.mode = 2
+        self.its = {}
+
+    def pick(self):
+        self.calls += 1
+        if self.calls % self.period == 0:
+            return 3 - self.mode          # trial of the other mode
+        return self.mode
+
+    def report(self, mode, iterations):
+        self.its[mode] = iterations
+        other = 3 - self.mode
+        if other in self.its and self.mode in self.its:
+            if self.its[other] < self.its[self.mode] or (
+                    self.its[other] == self.its[self.mode] and other == 1):
+                self.mode = other
+
+
 class SolveInfo(object):
     def __init__(self, iterations, residual, method):
         self.iterations = iterations

@@ -86,7 +86,8 @@ class KarmanProblem(object):
         self.t = 0.0
         self.hmax = self.mesh.hmax()
         self.history = []
-        self._umag_hist = (None, None)
+        self._umag_hist = []
+        self._umag_start = fem.ops.StartChooser()
         self.extrapolate_projection = True
         return
 
@@ -125,18 +126,35 @@ class KarmanProblem(object):
             # CFL-like step-size control on ||project(|u|)||_inf (:262-286)
             # (mass solve to 1e-7, started from the previous step's projection:
             # the value only steers dt, which inherits that relative accuracy)
-            # ... extrapolated linearly in time through the last two)
-            prev, prev2 = self._umag_hist
-            guess = prev[0] if prev is not None else None
-            if self.extrapolate_projection and prev2 is not None:
-                r = self.dt / prev[1]
-                guess = fem.Function(prev[0].function_space())
-                guess.assign(prev[0])
-                fem.ops.axpby(-r, prev2[0].data, 1.0 + r, guess.data)
+            # ... extrapolated in time through the last two or three: linearly,
+            # or quadratically once the step size has settled)
+            hist = self._umag_hist
+            guess = hist[0][0] if hist else None
+            mode = None
+            if self.extrapolate_projection and len(hist) >= 2:
+                c, a = self.dt, hist[0][1]
+                guess = fem.Function(hist[0][0].function_space())
+                guess.assign(hist[0][0])
+                mode = 1
+                if len(hist) >= 3 and 0.7 <= c / a <= 1.5 and \
+                        0.7 <= a / hist[1][1] <= 1.5:
+                    mode = self._umag_start.pick()
+                if mode == 2:
+                    b = hist[1][1]
+                    w0 = (c + a) * (c + a + b) / (a * (a + b))
+                    w1 = -c * (c + a + b) / (a * b)
+                    w2 = c * (c + a) / ((a + b) * b)
+                    fem.ops.axpby(w1, hist[1][0].data, w0, guess.data)
+                    fem.ops.axpby(w2, hist[2][0].data, 1.0, guess.data)
+                else:
+                    r = c / a
+                    fem.ops.axpby(-r, hist[1][0].data, 1.0 + r, guess.data)
             umag = fem.project_magnitude(self.u0, tol=1.0e-7, initial_guess=guess)
-            # (projection, length of the step that led to it)
-            self._umag_hist = ((umag, self.dt), prev)
+            # (projection, length of the step that led to it), newest first
+            self._umag_hist = [(umag, self.dt)] + hist[:2]
             info['projection_iterations'] = umag.solve_info.iterations
+            if mode is not None:
+                self._umag_start.report(mode, umag.solve_info.iterations)
             unorm = umag.vector().norm('linf')
             target_dt = 1.0 * self.hmax / unorm
             alpha = 0.5

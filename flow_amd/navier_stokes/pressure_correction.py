@@ -452,6 +452,7 @@ def _compute_pressure(
 
     par = solver_parameters['pressure']
     p1 = Function(P)
+    start_mode = None
     if par.get('initial_guess', 'previous') == 'previous':
         # The reference starts its Krylov solve from a fresh (zero) Function
         # (:313).  Starting from p0 is the natural choice for an incremental
@@ -464,9 +465,27 @@ def _compute_pressure(
         hist = ui.function_space().layout._dev.get('step_history')
         if par.get('extrapolate', True) and hist and hist.get('continuing') \
                 and 'p_in' in hist and 0.7 <= dt / hist['dt'] <= 1.5:
-            r = dt / hist['dt']
-            ops.axpby(r, p0.data, 1.0, p1.data)
-            ops.axpby(-r, hist['p_in'], 1.0, p1.data)
+            a, c = hist['dt'], dt
+            b = hist.get('dt_prev')
+            start_mode = 1
+            if 'p_in2' in hist and b and 0.7 <= a / b <= 1.5:
+                # (quadratic while the flow evolves, linear once successive
+                # pressures differ by solver noise only: ops.StartChooser)
+                start_mode = hist.setdefault(
+                    'p_start', ops.StartChooser()).pick()
+            if start_mode == 2:
+                # quadratic through the last three pressures (Lagrange
+                # weights for the times -(a+b), -a, 0 evaluated at c)
+                w0 = (c + a) * (c + a + b) / (a * (a + b))
+                w1 = -c * (c + a + b) / (a * b)
+                w2 = c * (c + a) / ((a + b) * b)
+                ops.axpby(w0 - 1.0, p0.data, 1.0, p1.data)
+                ops.axpby(w1, hist['p_in'], 1.0, p1.data)
+                ops.axpby(w2, hist['p_in2'], 1.0, p1.data)
+            else:
+                r = c / a
+                ops.axpby(r, p0.data, 1.0, p1.data)
+                ops.axpby(-r, hist['p_in'], 1.0, p1.data)
     K = ops.assemble_stiffness(P)
     b = device.empty(P.N)
     buf = ops.scratch(mesh, 3 * nc)
@@ -517,6 +536,8 @@ def _compute_pressure(
     if verbose:
         info('pressure: %r' % sol)
     last_step_info['pressure'] = sol
+    if start_mode is not None and 'p_start' in hist:
+        hist['p_start'].report(start_mode, sol.iterations)
     return p1
 
 
@@ -666,8 +687,14 @@ def _step(
             ops.copy(hist['u_out'], u1.data)
         if 'p_in' not in hist or hist['p_in'].numel() != p0.data.numel():
             hist['p_in'] = _hip.clone(p0.data)
+            hist.pop('p_in2', None)
         else:
+            if 'p_in2' not in hist:
+                hist['p_in2'] = _hip.clone(hist['p_in'])
+            else:
+                ops.copy(hist['p_in2'], hist['p_in'])
             ops.copy(hist['p_in'], p0.data)
+        hist['dt_prev'] = hist.get('dt')
         hist['dt'] = dt_
     return u1, p1
 
