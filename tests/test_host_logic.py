@@ -204,6 +204,67 @@ def test_xcd_tile_mapping_is_a_permutation():
     assert same_xcd == list(range(same_xcd[0], same_xcd[0] + run))
 
 
+def test_boundary_data_cache_follows_the_data():
+    '''`collect` reuses the merged (dofs, values) arrays of a list of
+    conditions only while their data are unchanged (time loops pass the same
+    conditions every step): a parameter of an Expression or the value of a
+    Constant changing must show up in the next call.'''
+    from flow_amd.fem.bcs import collect
+    mesh = fem.UnitSquareMesh(4, 4)
+    V = fem.FunctionSpace(mesh, 'CG', 2)
+    ramp = fem.Expression('t * (1.0 + x[0])', degree=1, t=1.0)
+    const = fem.Constant(2.0)
+
+    class Left(fem.SubDomain):
+        def inside(self, x, on_boundary):
+            return on_boundary & (x[0] < 1e-12)
+
+    class Right(fem.SubDomain):
+        def inside(self, x, on_boundary):
+            return on_boundary & (x[0] > 1.0 - 1e-12)
+    bcs = [fem.DirichletBC(V, ramp, Left()), fem.DirichletBC(V, const, Right())]
+    d0, v0 = collect(bcs, V.N)
+    d1, v1 = collect(bcs, V.N)
+    assert d1 is d0 and v1 is v0                      # unchanged: same arrays
+    ramp.t = 3.0
+    d2, v2 = collect(bcs, V.N)
+    assert numpy.array_equal(d2, d0) and not numpy.array_equal(v2, v0)
+    left = V.layout.dof_coords[d2, 0] < 1e-12
+    assert numpy.allclose(v2[left], 3.0) and numpy.allclose(v2[~left], 2.0)
+    const.assign(5.0)
+    d3, v3 = collect(bcs, V.N)
+    assert numpy.allclose(v3[~left], 5.0) and numpy.allclose(v3[left], 3.0)
+    # a Python callable may depend on anything: never cached
+    state = {'a': 1.0}
+    call = fem.Expression(lambda x: state['a'] + 0.0 * x[0], degree=1)
+    bc = [fem.DirichletBC(V, call, Left())]
+    _, w0 = collect(bc, V.N)
+    state['a'] = 4.0
+    _, w1 = collect(bc, V.N)
+    assert numpy.allclose(w0, 1.0) and numpy.allclose(w1, 4.0)
+
+
+def test_start_chooser_switches_on_iteration_counts():
+    '''ops.StartChooser: keeps the extrapolation order that needs fewer
+    iterations, tries the other one every `period`-th call.'''
+    from flow_amd.fem.ops import StartChooser
+    ch = StartChooser(period=4)
+    cost = {1: 10, 2: 6}                 # quadratic is better
+    used = []
+    for _ in range(12):
+        m = ch.pick()
+        used.append(m)
+        ch.report(m, cost[m])
+    assert used.count(2) >= 9 and ch.mode == 2
+    cost = {1: 6, 2: 12}                 # now solver noise: linear is better
+    used = []
+    for _ in range(12):
+        m = ch.pick()
+        used.append(m)
+        ch.report(m, cost[m])
+    assert ch.mode == 1 and used.count(1) >= 7
+
+
 def test_no_cpu_fallback():
     from flow_amd import device
     if device.on_gpu():
