@@ -166,3 +166,44 @@ def test_newton_gmres_and_bicgstab_agree(hip):
         assert cases.rel_l2(out['gmres'][k], out['bicgstab'][k]) < 1e-7
     assert out['gmres'][3] <= out['bicgstab'][3], (out['gmres'][3],
                                                   out['bicgstab'][3])
+
+
+@pytest.mark.gpu
+def test_start_vectors_do_not_change_the_solution(hip):
+    '''The time loop starts its solves from extrapolated fields (Newton start
+    candidates, pressure, velocity correction, CFL projection).  Those are
+    start vectors only: the same run without any of them converges to the
+    same fields, step sizes included.'''
+    import flow_amd.navier_stokes as navsto
+    from flow_amd import karman
+
+    def run(tricks):
+        npar = navsto.solver_parameters
+        saved = (npar['newton']['initial_guess'],
+                 npar['pressure'].get('extrapolate', True),
+                 npar['correction'].get('extrapolate', True))
+        try:
+            npar['newton']['initial_guess'] = 'best' if tricks else 'previous'
+            npar['pressure']['extrapolate'] = tricks
+            npar['correction']['extrapolate'] = tricks
+            prob = karman.KarmanProblem(150, 35)
+            prob.extrapolate_projection = tricks
+            prob.set_initial_profile()
+            starts = set()
+            for _ in range(26):
+                info = prob.step()
+                starts.add(info.get('initial_guess', 'u0'))
+            return (prob.u0.vector().get_local(), prob.p0.vector().get_local(),
+                    prob.t, starts)
+        finally:
+            (npar['newton']['initial_guess'], npar['pressure']['extrapolate'],
+             npar['correction']['extrapolate']) = saved
+    u_a, p_a, t_a, starts = run(True)
+    u_b, p_b, t_b, _ = run(False)
+    assert starts - {'u0'}, starts          # the candidates were exercised
+    # (the step sizes come from a projection solved to 1e-7, so the two runs
+    # drift apart by ~1e-6 in dt per step; the fields are compared at those
+    # slightly different times)
+    diffs = (abs(t_a - t_b) / t_b, cases.rel_l2(u_a, u_b), cases.rel_l2(p_a, p_b))
+    assert diffs[0] < 5e-5 and diffs[1] < 5e-5 and diffs[2] < 3e-4, diffs
+    print('start vectors on/off: dt, u, p differences', diffs)
