@@ -178,12 +178,15 @@ SYMBOLS = {
     'flow_abi_version': [],
     'flow_xcd_tile_host': [_I, _I],
     'flow_operator_apply': [_P(Operator), _VP, _VP, _VP],
+    'flow_profile_spmv_begin': [_I, _I],
+    'flow_profile_spmv_end': [_P(_D), _P(_I)],
     'flow_operator_diag_inv': [_P(Operator), _VP, _VP, _VP],
     'flow_dot_host': [_I, _VP, _VP, _VP, _P(_D), _VP],
     'flow_norm_host': [_I, _VP, _I, _VP, _P(_D), _VP],
     'flow_axpby': [_I, _D, _VP, _D, _VP, _VP],
     'flow_vmul': [_I, _D, _VP, _VP, _VP, _VP],
     'flow_fill': [_I, _D, _VP, _VP],
+    'flow_scale_rows': [_I, _VP, _VP, _VP, _VP],
     'flow_cg_solve': [_P(Operator), _VP, _P(CoarseS), _P(MgS), _VP, _VP, _D, _D,
                       _I, _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_mg_apply': [_P(MgS), _I, _VP, _VP, _VP],

@@ -30,6 +30,31 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------------------
+// Krylov: scalar slots in HBM
+// ---------------------------------------------------------------------------
+enum Slot {
+  kGamma = 0, kAlpha, kBeta, kRes2, kB2, kRho, kOmega, kRhoNew, kTmp,
+  kBreak, kTarget2, kDone, kConvIt, kIter, kNumSlots = 16
+};
+// (the scalars move with load_scalar / store_scalar: common.h)
+// work layout: [0, 3*kRedBlocks) partials, [3*kRedBlocks, +kNumSlots) scalars
+static_assert(3 * kRedBlocks + kNumSlots <= FLOW_REDUCE_WORK, "work size");
+
+// Convergence is decided ON THE DEVICE: the kernel that computes the solver
+// scalars compares the (preconditioned) residual with the target, and from the first iterate that passes
+// the test on sets the sticky flag S[kDone] (1 converged, 2 breakdown); every
+// kernel of the iteration body takes `stop` = S + kDone and returns at once
+// when it is set.  The host can therefore enqueue iterations ahead of its
+// read-backs without the solution moving past the iterate the stopping test
+// accepted (running CG on after its recurrence residual has reached rounding
+// level is not harmless: measured on the P2 mass matrix, 8 iterations past
+// convergence moved the solution by 1.8e-4 relative), and the iteration count
+// it reports is the exact one.
+__device__ __forceinline__ bool stopped(const double* stop) {
+  return stop != nullptr && load_scalar(stop) != 0.0;
+}
+
+// ---------------------------------------------------------------------------
 // SpMV
 // ---------------------------------------------------------------------------
 constexpr int kPairs = 2;                       // nonzero pairs per lane
@@ -100,8 +125,10 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
     int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals0, const double* __restrict__ vals1,
     const int* __restrict__ rowblocks, const double* __restrict__ x,
-    double* __restrict__ y, double* __restrict__ dpart) {
+    double* __restrict__ y, double* __restrict__ dpart,
+    const double* __restrict__ stop) {
   __shared__ double prod[kTile];
+  if (stopped(stop)) return;
   const double* __restrict__ vals = blockIdx.y == 0 ? vals0 : vals1;
   x += static_cast<size_t>(blockIdx.y) * n;
   y += static_cast<size_t>(blockIdx.y) * n;
@@ -122,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
 // The two kernels of a multigrid level (flow_mg) on the same tiles:
 //   UP = 0:  y = c - A x                     (A = Ah, x = c = r:  t = r - Ah r)
 //   UP = 1:  y = A x + w dinv (c + t)        (A = Ps, x = x_{l+1}, c = r)
-//            DOTS: the workgroup's shares of c.y and c.c -> gpart / rpart
+//            DOTS: the workgroup's shares of c.y and y.y -> gpart / rpart
 template <int UP, bool DOTS>
 __global__ __launch_bounds__(kBlock) void mg_level_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ cols,
@@ -130,8 +157,9 @@ __global__ __launch_bounds__(kBlock) void mg_level_kernel(
     const double* __restrict__ x, const double* __restrict__ c,
     const double* __restrict__ t, const double* __restrict__ dinv, double omega,
     double* __restrict__ y, double* __restrict__ gpart,
-    double* __restrict__ rpart) {
+    double* __restrict__ rpart, const double* __restrict__ stop) {
   __shared__ double prod[kTile];
+  if (stopped(stop)) return;
   int r, r1;
   const double s =
       stream_tile_row_sum(rowptr, cols, vals, rowblocks, x, prod, r, r1);
@@ -143,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void mg_level_kernel(
       y[r] = yi;
       if (DOTS) {
         g = ci * yi;
-        rr = ci * ci;
+        rr = yi * yi;
       }
     } else {
       y[r] = ci - s;
@@ -166,9 +194,11 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
     const double* __restrict__ vxx, const double* __restrict__ vxy,
     const double* __restrict__ vyx, const double* __restrict__ vyy,
     const int* __restrict__ rowblocks, const double* __restrict__ x,
-    double* __restrict__ y, double* __restrict__ dpart) {
+    double* __restrict__ y, double* __restrict__ dpart,
+    const double* __restrict__ stop) {
   __shared__ double prod0[kTile];
   __shared__ double prod1[kTile];
+  if (stopped(stop)) return;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int r0 = rowblocks[tile];
   const int r1 = rowblocks[tile + 1];
@@ -227,10 +257,12 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
     int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals, const int* __restrict__ rowblocks,
     const unsigned char* __restrict__ mask, const double* __restrict__ x,
-    double* __restrict__ y, double* __restrict__ dpart) {
+    double* __restrict__ y, double* __restrict__ dpart,
+    const double* __restrict__ stop) {
   // ONE product array, used by the two components in turn (two would halve the
   // occupancy: 32 KB of LDS per workgroup)
   __shared__ double prod[kTile];
+  if (stopped(stop)) return;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int r0 = rowblocks[tile];
   const int r1 = rowblocks[tile + 1];
@@ -334,9 +366,21 @@ static inline int dot_parts(const flow_operator* A) {
   return A->kind == 1 ? 2 * A->nblocks : A->nblocks;
 }
 
+// Per-kernel timing of the in-solver SpMV (flow_profile_spmv_begin / _end in
+// include/flow_hip.h): while it is on, every launch of the fused-dot SpMV of a
+// scalar operator with `rows` rows -- the product with A inside a CG iteration,
+// in the cache state the solver leaves -- is bracketed by a pair of HIP events
+// on the launch stream.
+struct SpmvProfile {
+  int rows = 0, cap = 0, used = 0;
+  hipEvent_t* ev = nullptr;   // 2 * cap events
+};
+static SpmvProfile g_spmv_profile;
+
 // y = A x; with dpart != nullptr also the dot_parts(A) workgroup shares of x.y
 static int apply(const flow_operator* A, const double* x, double* y,
-                 hipStream_t st, double* dpart = nullptr) {
+                 hipStream_t st, double* dpart = nullptr,
+                 const double* stop = nullptr) {
   if (A->kind == 3) {
     FLOW_REQUIRE(dpart == nullptr, "matrix-free operators carry no fused dot");
     return momentum_jvp_apply(static_cast<const flow_momentum_jvp*>(A->matfree),
@@ -348,28 +392,34 @@ static int apply(const flow_operator* A, const double* x, double* y,
     if (dpart)
       hipLaunchKernelGGL(spmv_stream_pair_kernel<true>, grid, dim3(kBlock), 0, st,
                          A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
-                         A->rowmask, x, y, dpart);
+                         A->rowmask, x, y, dpart, stop);
     else
       hipLaunchKernelGGL(spmv_stream_pair_kernel<false>, grid, dim3(kBlock), 0,
                          st, A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
-                         A->rowmask, x, y, dpart);
+                         A->rowmask, x, y, dpart, stop);
   } else if (A->kind == 2) {
     if (dpart)
       hipLaunchKernelGGL(spmv_stream_block2_kernel<true>, grid, dim3(kBlock), 0,
                          st, A->n, A->rowptr, A->cols, A->vals[0], A->vals[1],
-                         A->vals[2], A->vals[3], A->rowblocks, x, y, dpart);
+                         A->vals[2], A->vals[3], A->rowblocks, x, y, dpart,
+                         stop);
     else
       hipLaunchKernelGGL(spmv_stream_block2_kernel<false>, grid, dim3(kBlock), 0,
                          st, A->n, A->rowptr, A->cols, A->vals[0], A->vals[1],
-                         A->vals[2], A->vals[3], A->rowblocks, x, y, dpart);
+                         A->vals[2], A->vals[3], A->rowblocks, x, y, dpart,
+                         stop);
   } else if (dpart) {
+    SpmvProfile& pf = g_spmv_profile;
+    const bool timed = pf.used < pf.cap && A->kind == 0 && A->n == pf.rows;
+    if (timed) FLOW_CHECK_HIP(hipEventRecord(pf.ev[2 * pf.used], st));
     hipLaunchKernelGGL(spmv_stream_kernel<true>, grid, dim3(kBlock), 0, st, A->n,
                        A->rowptr, A->cols, A->vals[0], v1, A->rowblocks, x, y,
-                       dpart);
+                       dpart, stop);
+    if (timed) FLOW_CHECK_HIP(hipEventRecord(pf.ev[2 * pf.used++ + 1], st));
   } else {
     hipLaunchKernelGGL(spmv_stream_kernel<false>, grid, dim3(kBlock), 0, st,
                        A->n, A->rowptr, A->cols, A->vals[0], v1, A->rowblocks, x,
-                       y, dpart);
+                       y, dpart, stop);
   }
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
@@ -474,17 +524,6 @@ __global__ void vmul_kernel(int n, double a, const double* x, const double* y,
     out[i] = a * x[i] * y[i];
 }
 
-// ---------------------------------------------------------------------------
-// Krylov: scalar slots in HBM
-// ---------------------------------------------------------------------------
-enum Slot {
-  kGamma = 0, kAlpha, kBeta, kRes2, kB2, kRho, kOmega, kRhoNew, kTmp,
-  kBreak, kNumSlots = 16
-};
-// (the scalars move with load_scalar / store_scalar: common.h)
-// work layout: [0, 3*kRedBlocks) partials, [3*kRedBlocks, +kNumSlots) scalars
-static_assert(3 * kRedBlocks + kNumSlots <= FLOW_REDUCE_WORK, "work size");
-
 // r = b - q ; z = dinv*r
 __global__ void residual_kernel(int n, const double* __restrict__ b,
                                 const double* __restrict__ q,
@@ -498,15 +537,16 @@ __global__ void residual_kernel(int n, const double* __restrict__ b,
   }
 }
 
-// Chronopoulos-Gear CG scalars from (gamma_new, delta, r.r) partials
-// gamma = r.z and r.r: nparts partials each in gpart / rpart;
+// Chronopoulos-Gear CG scalars from (gamma_new, delta, z.z) partials
+// gamma = r.z and z.z: nparts partials each in gpart / rpart;
 // delta = z.w: ndelta partials in dpart (left there by the SpMV itself)
 constexpr int kScalarBlock = 1024;   // 16 wavefronts: many partials, one block
 __global__ __launch_bounds__(kScalarBlock) void cg_scalar_kernel(
     int nparts, int ndelta, int first, const double* __restrict__ gpart,
     const double* __restrict__ rpart, const double* __restrict__ dpart,
-    double* __restrict__ S) {
+    double rtol2, double atol2, double* __restrict__ S) {
   __shared__ double wsum[3][kScalarBlock / 64];
+  if (stopped(S + kDone)) return;
   double g = 0.0, rr = 0.0;
   for (int i = threadIdx.x; i < nparts; i += kScalarBlock) {
     g += load_scalar(gpart + i);
@@ -548,6 +588,11 @@ __global__ __launch_bounds__(kScalarBlock) void cg_scalar_kernel(
     if (first) {
       beta = 0.0;
       alpha = (d != 0.0) ? g / d : 0.0;
+      // the stopping test of the whole solve, in the PRECONDITIONED norm like
+      // PETSc's KSPCG (its default, which the reference's `solve` runs with):
+      // |B r| <= max(rtol |B b|, atol), z = B r, S[kB2] = |B b|^2
+      store_scalar(S + kTarget2, fmax(rtol2 * load_scalar(S + kB2), atol2));
+      store_scalar(S + kIter, 0.0);
     } else {
       const double g_old = load_scalar(S + kGamma);
       const double a_old = load_scalar(S + kAlpha);
@@ -555,6 +600,17 @@ __global__ __launch_bounds__(kScalarBlock) void cg_scalar_kernel(
       const double den = (a_old != 0.0) ? d - beta * g / a_old : 0.0;
       alpha = (den != 0.0) ? g / den : 0.0;
     }
+    // rr = z.z belongs to the iterate x_k, k = S[kIter] updates behind the
+    // start: the first one that passes the test (or is not a number) stops
+    // the iteration for good
+    const double k = load_scalar(S + kIter);
+    const bool nan = !(rr == rr);
+    if (nan || rr <= load_scalar(S + kTarget2)) {
+      store_scalar(S + kConvIt, k);
+      store_scalar(S + kDone, nan ? 2.0 : 1.0);
+      alpha = beta = 0.0;
+    }
+    store_scalar(S + kIter, k + 1.0);
     store_scalar(S + kGamma, g);
     store_scalar(S + kAlpha, alpha);
     store_scalar(S + kBeta, beta);
@@ -565,13 +621,14 @@ __global__ __launch_bounds__(kScalarBlock) void cg_scalar_kernel(
 // p = z + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; z = dinv r
 // (want_z = 0: z is produced afterwards by the two-level preconditioner)
 // DOTS (needs want_z, gridDim.x <= kRedBlocks): the block's shares of r.z and
-// r.r go to partial[blockIdx.x] / partial[2*kRedBlocks + blockIdx.x].
+// z.z go to partial[blockIdx.x] / partial[2*kRedBlocks + blockIdx.x].
 template <bool DOTS>
 __global__ __launch_bounds__(kBlock) void cg_update_kernel(
     int n, const double* __restrict__ S, const double* __restrict__ dinv,
     const double* __restrict__ w, double* __restrict__ z, double* __restrict__ p,
     double* __restrict__ s, double* __restrict__ x, double* __restrict__ r,
     int want_z, double* __restrict__ partial) {
+  if (stopped(S + kDone)) return;
   const double alpha = load_scalar(S + kAlpha);
   const double beta = load_scalar(S + kBeta);
   double g = 0.0, rr = 0.0;
@@ -589,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(
       z[i] = zi;
       if (DOTS) {
         g += ri * zi;
-        rr += ri * ri;
+        rr += zi * zi;
       }
     }
   }
@@ -611,7 +668,9 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(
 // wavefront per aggregate, fixed order => reproducible
 __global__ __launch_bounds__(kBlock) void coarse_restrict_kernel(
     int nc, const int* __restrict__ agg_ptr, const int* __restrict__ agg_dofs,
-    const double* __restrict__ r, int r0, int r1, double* __restrict__ rc) {
+    const double* __restrict__ r, int r0, int r1, double* __restrict__ rc,
+    const double* __restrict__ stop) {
+  if (stopped(stop)) return;
   const int lane = threadIdx.x & 63;
   for (int a = blockIdx.x * 4 + (threadIdx.x >> 6); a < nc; a += gridDim.x * 4) {
     double sum = 0.0;
@@ -631,7 +690,9 @@ __global__ __launch_bounds__(kBlock) void coarse_restrict_kernel(
 // only ever observed on wave-uniform loads, which go through the scalar cache.)
 __global__ __launch_bounds__(kBlock) void coarse_gemv_kernel(
     int nc, int lda, const float* __restrict__ Ainv,
-    const double* __restrict__ rc, double* __restrict__ zc) {
+    const double* __restrict__ rc, double* __restrict__ zc,
+    const double* __restrict__ stop) {
+  if (stopped(stop)) return;
   const int lane = threadIdx.x & 63;
   const int nq = lda >> 2;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nc;
@@ -664,13 +725,15 @@ __global__ __launch_bounds__(kBlock) void coarse_gemv_kernel(
 }
 
 // z = dinv r + zc[agg_of]  on dofs [0, n) of pre-offset arrays
-// DOTS (gridDim.x <= kRedBlocks): also the block's shares of r.z and r.r, as
+// DOTS (gridDim.x <= kRedBlocks): also the block's shares of r.z and z.z, as
 // in cg_update_kernel
 template <bool DOTS>
 __global__ __launch_bounds__(kBlock) void coarse_prolong_kernel(
     int n, const int* __restrict__ agg_of, const double* __restrict__ dinv,
     const double* __restrict__ r, const double* __restrict__ zc,
-    double* __restrict__ z, double* __restrict__ partial) {
+    double* __restrict__ z, double* __restrict__ partial,
+    const double* __restrict__ stop) {
+  if (stopped(stop)) return;
   double g = 0.0, rr = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
@@ -680,7 +743,7 @@ __global__ __launch_bounds__(kBlock) void coarse_prolong_kernel(
     z[i] = zi;
     if (DOTS) {
       g += ri * zi;
-      rr += ri * ri;
+      rr += zi * zi;
     }
   }
   if (DOTS) {
@@ -705,25 +768,26 @@ static int check_coarse(const flow_coarse* C, int n) {
 }
 
 // z = M^-1 r with the two-level preconditioner; rc, zc: lda doubles each.
-// partial != nullptr: the prolongation also leaves the shares of r.z and r.r
+// partial != nullptr: the prolongation also leaves the shares of r.z and z.z
 // of its *nparts workgroups there.
 static int two_level(const flow_coarse* C, const double* dinv, const double* r,
                      double* z, double* rc, double* zc, hipStream_t st,
-                     double* partial = nullptr, int* nparts = nullptr) {
+                     double* partial = nullptr, int* nparts = nullptr,
+                     const double* stop = nullptr) {
   const int g = grid_for(C->nc, 4, kMaxGrid);
   hipLaunchKernelGGL(coarse_restrict_kernel, dim3(g), dim3(kBlock), 0, st, C->nc,
-                     C->agg_ptr, C->agg_dofs, r, 0, C->n, rc);
+                     C->agg_ptr, C->agg_dofs, r, 0, C->n, rc, stop);
   hipLaunchKernelGGL(coarse_gemv_kernel, dim3(g), dim3(kBlock), 0, st, C->nc,
-                     C->lda, C->Ainv, rc, zc);
+                     C->lda, C->Ainv, rc, zc, stop);
   if (partial) {
     const int gp = grid_for(C->n, kBlock, kRedBlocks);
     hipLaunchKernelGGL(coarse_prolong_kernel<true>, dim3(gp), dim3(kBlock), 0,
-                       st, C->n, C->agg_of, dinv, r, zc, z, partial);
+                       st, C->n, C->agg_of, dinv, r, zc, z, partial, stop);
     *nparts = gp;
   } else {
     hipLaunchKernelGGL(coarse_prolong_kernel<false>, dim3(grid_for(C->n)),
                        dim3(kBlock), 0, st, C->n, C->agg_of, dinv, r, zc, z,
-                       partial);
+                       partial, stop);
   }
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
@@ -760,10 +824,10 @@ static int check_mg(const flow_mg* M, int n) {
 }
 
 // z = V-cycle(r) on level 0; gpart != nullptr: the last kernel also leaves the
-// *nparts (= Ps[0].nblocks) workgroup shares of r.z in gpart and r.r in rpart
+// *nparts (= Ps[0].nblocks) workgroup shares of r.z in gpart and z.z in rpart
 static int vcycle(const flow_mg* M, const double* r0, double* z0, hipStream_t st,
                   double* gpart = nullptr, double* rpart = nullptr,
-                  int* nparts = nullptr) {
+                  int* nparts = nullptr, const double* stop = nullptr) {
   const int L = M->nlevels;
   int rc;
   double* const none = nullptr;
@@ -773,14 +837,15 @@ static int vcycle(const flow_mg* M, const double* r0, double* z0, hipStream_t st
     // t = r - Ah r ; r_{l+1} = R t
     hipLaunchKernelGGL((mg_level_kernel<0, false>), dim3(A->nblocks), dim3(kBlock),
                        0, st, A->rowptr, A->cols, A->vals[0], A->rowblocks, r, r,
-                       none, none, M->omega, M->t[l], none, none);
-    if ((rc = apply(&M->R[l], M->t[l], M->r[l + 1], st))) return rc;
+                       none, none, M->omega, M->t[l], none, none, stop);
+    if ((rc = apply(&M->R[l], M->t[l], M->r[l + 1], st, nullptr, stop)))
+      return rc;
   }
   {
     const double* r = L == 1 ? r0 : M->r[L - 1];
     double* x = L == 1 ? z0 : M->x[L - 1];
     hipLaunchKernelGGL(coarse_gemv_kernel, dim3(grid_for(M->nc, 4, kMaxGrid)),
-                       dim3(kBlock), 0, st, M->nc, M->lda, M->Ainv, r, x);
+                       dim3(kBlock), 0, st, M->nc, M->lda, M->Ainv, r, x, stop);
   }
   for (int l = L - 2; l >= 0; --l) {
     const double* r = l == 0 ? r0 : M->r[l];
@@ -791,13 +856,13 @@ static int vcycle(const flow_mg* M, const double* r0, double* z0, hipStream_t st
       hipLaunchKernelGGL((mg_level_kernel<1, true>), dim3(P->nblocks),
                          dim3(kBlock), 0, st, P->rowptr, P->cols, P->vals[0],
                          P->rowblocks, M->x[l + 1], r, M->t[l], M->dinv[l],
-                         M->omega, x, gpart, rpart);
+                         M->omega, x, gpart, rpart, stop);
       *nparts = P->nblocks;
     } else {
       hipLaunchKernelGGL((mg_level_kernel<1, false>), dim3(P->nblocks),
                          dim3(kBlock), 0, st, P->rowptr, P->cols, P->vals[0],
                          P->rowblocks, M->x[l + 1], r, M->t[l], M->dinv[l],
-                         M->omega, x, none, none);
+                         M->omega, x, none, none, stop);
     }
   }
   FLOW_CHECK_LAUNCH();
@@ -863,13 +928,32 @@ static int read_slots(const double* S, int slot0, int slot1, double* host0,
   return FLOW_OK;
 }
 
+// all the solver scalars S[0, kNumSlots) -> host (one synchronisation)
+__global__ void mailbox_state_kernel(const double* __restrict__ S,
+                                     volatile double* __restrict__ mailbox) {
+  if (threadIdx.x < kNumSlots) mailbox[threadIdx.x] = load_scalar(S + threadIdx.x);
+  __threadfence_system();
+}
+
+static int read_state(const double* S, double* host, hipStream_t st) {
+  double *mailbox = nullptr, *dev_view = nullptr;
+  int rc = mailbox_of_thread(&mailbox, &dev_view);
+  if (rc) return rc;
+  hipLaunchKernelGGL(mailbox_state_kernel, dim3(1), dim3(64), 0, st, S, dev_view);
+  FLOW_CHECK_LAUNCH();
+  FLOW_CHECK_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < kNumSlots; ++i)
+    host[i] = static_cast<volatile double*>(mailbox)[i];
+  return FLOW_OK;
+}
+
 static int read_slot(const double* S, int slot, double* host, hipStream_t st) {
   double again;
   return read_slots(S, slot, slot, host, &again, st);
 }
 
 // Work of cg(): [reductions | r z w p s | z.w partials of the SpMV | rc zc |
-// r.z, r.r partials of the V-cycle's last kernel]
+// r.z, z.z partials of the V-cycle's last kernel]
 static inline size_t cg_work_len(const flow_operator* A, const flow_coarse* C,
                                  const flow_mg* M) {
   const size_t N = op_size(A);
@@ -879,7 +963,7 @@ static inline size_t cg_work_len(const flow_operator* A, const flow_coarse* C,
 }
 
 // Chronopoulos-Gear CG.  Per iteration: update (x, r, p, s) -> preconditioner
-// -> SpMV -> scalars; the three dot products ride in those kernels (r.z and r.r
+// -> SpMV -> scalars; the three dot products ride in those kernels (r.z and z.z
 // in whichever kernel produces z, z.w in the SpMV), so no vector is re-read for
 // a reduction.
 static int cg(const flow_operator* A, const double* dinv,
@@ -908,71 +992,89 @@ static int cg(const flow_operator* A, const double* dinv,
   const int gu = grid_for(N, kBlock, kRedBlocks);   // update with fused dots
   int np = 0, rc;
 
+  const double* stop = S + kDone;
+  const double rtol2 = rtol * rtol, atol2 = atol * atol;
   if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
   if ((rc = fill(2 * N, 0.0, p, st))) return rc;      // p, s
-  // ||b||^2
-  if ((rc = dots(N, 1, b, b, b, b, b, b, partial, &np, st))) return rc;
+  // |B b|^2, B the preconditioner (z is free until the start below)
+  if (C) {
+    if ((rc = two_level(C, dinv, b, z, crc, czc, st))) return rc;
+  } else if (M) {
+    if ((rc = vcycle(M, b, z, st))) return rc;
+  } else if (dinv) {
+    hipLaunchKernelGGL(vmul_kernel, dim3(gv), dim3(kBlock), 0, st, N, 1.0, dinv,
+                       b, z);
+  }
+  const double* Bb = (C || M || dinv) ? z : b;
+  if ((rc = dots(N, 1, Bb, Bb, Bb, Bb, Bb, Bb, partial, &np, st))) return rc;
   hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 1, 0,
                      partial, S + kB2);
-  // r = b - A x ; z = M^-1 r ; w = A z
+  // r = b - A x ; z = B r ; w = A z
   if ((rc = apply(A, x, w, st))) return rc;
   hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(kBlock), 0, st, N, b, w,
                      dinv, r, z);
   if (C && (rc = two_level(C, dinv, r, z, crc, czc, st))) return rc;
   if (M && (rc = vcycle(M, r, z, st))) return rc;
   if ((rc = apply(A, z, w, st, dpart))) return rc;
-  if ((rc = dots(N, 3, r, z, z, w, r, r, partial, &np, st))) return rc;
+  if ((rc = dots(N, 3, r, z, z, w, z, z, partial, &np, st))) return rc;
   hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kScalarBlock), 0, st, np,
-                     nd, 1, partial, partial + 2 * kRedBlocks, dpart, S);
+                     nd, 1, partial, partial + 2 * kRedBlocks, dpart, rtol2,
+                     atol2, S);
   FLOW_CHECK_LAUNCH();
 
-  double b2 = 0.0, res2 = 0.0;
-  if ((rc = read_slots(S, kB2, kRes2, &b2, &res2, st))) return rc;
-  const double target = fmax(rtol * sqrt(b2), atol);
-  int it = 0;
+  // Iterations are enqueued in batches; the device decides which iterate
+  // passes the stopping test (cg_scalar_kernel) and turns everything behind it
+  // into no-ops, so a batch may overshoot: the first one is `first_check`
+  // iterations (the caller's guess of what the solve needs), later ones
+  // `check_every`; the start is only read back with the first batch.
+  double state[kNumSlots];
+  int launched = 0;
   while (true) {
-    if (!(res2 == res2)) {   // NaN
-      *iters_host = it;
-      *resid_host = res2;
-      set_error("CG broke down (NaN residual) at iteration %d", it);
-      return FLOW_NOT_CONVERGED;
-    }
-    if (sqrt(res2) <= target) break;
-    if (it >= maxit) {
-      *iters_host = it;
-      *resid_host = sqrt(res2);
-      set_error("CG did not converge in %d iterations: |r| = %.3e > %.3e", it,
-                sqrt(res2), target);
-      return FLOW_NOT_CONVERGED;
-    }
-    const int batch = (it == 0 && first_check > 0) ? first_check : check_every;
-    const int todo = (maxit - it < batch) ? maxit - it : batch;
+    const int batch = (launched == 0 && first_check > 0) ? first_check
+                                                         : check_every;
+    const int todo = (maxit - launched < batch) ? maxit - launched : batch;
     for (int k = 0; k < todo; ++k) {
       if (C) {
         hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
                            st, N, S, dinv, w, z, p, s, x, r, 0, partial);
-        if ((rc = two_level(C, dinv, r, z, crc, czc, st, partial, &np)))
+        if ((rc = two_level(C, dinv, r, z, crc, czc, st, partial, &np, stop)))
           return rc;
       } else if (M) {
         hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
                            st, N, S, dinv, w, z, p, s, x, r, 0, partial);
-        if ((rc = vcycle(M, r, z, st, mpart, mpart + nm, &np))) return rc;
+        if ((rc = vcycle(M, r, z, st, mpart, mpart + nm, &np, stop))) return rc;
       } else {
         hipLaunchKernelGGL(cg_update_kernel<true>, dim3(gu), dim3(kBlock), 0, st,
                            N, S, dinv, w, z, p, s, x, r, 1, partial);
         np = gu;
       }
-      if ((rc = apply(A, z, w, st, dpart))) return rc;
+      if ((rc = apply(A, z, w, st, dpart, stop))) return rc;
       hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kScalarBlock), 0, st,
-                         np, nd, 0, gpart, rpart, dpart, S);
+                         np, nd, 0, gpart, rpart, dpart, rtol2, atol2, S);
     }
     FLOW_CHECK_LAUNCH();
-    it += todo;
-    if ((rc = read_slot(S, kRes2, &res2, st))) return rc;
+    launched += todo;
+    if ((rc = read_state(S, state, st))) return rc;
+    const double res2 = state[kRes2];
+    if (state[kDone] == 2.0 || !(res2 == res2)) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = res2;
+      set_error("CG broke down (NaN residual) at iteration %d", *iters_host);
+      return FLOW_NOT_CONVERGED;
+    }
+    if (state[kDone] == 1.0) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = sqrt(res2);
+      return FLOW_OK;
+    }
+    if (launched >= maxit) {
+      *iters_host = launched;
+      *resid_host = sqrt(res2);
+      set_error("CG did not converge in %d iterations: |B r| = %.3e > %.3e",
+                launched, sqrt(res2), sqrt(state[kTarget2]));
+      return FLOW_NOT_CONVERGED;
+    }
   }
-  *iters_host = it;
-  *resid_host = sqrt(res2);
-  return FLOW_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -983,9 +1085,12 @@ static int cg(const flow_operator* A, const double* dinv,
 // mode 2: omega = partial0/partial1 (= t.s / t.t); rho = rho_new;
 //         rho_new = partial2 (= rhat.r of the NEW r needs another pass: see 3)
 // mode 3: rho_new = partial0 (rhat.r), res2 = partial1 (r.r)
+// mode 3 also decides convergence on the device (see `stopped`): first != 0
+// sets the target from |b|^2; the first r that passes the test freezes x, r, p.
 __global__ __launch_bounds__(kBlock) void bicg_scalar_kernel(
-    int nparts, int mode, const double* __restrict__ partial,
-    double* __restrict__ S) {
+    int nparts, int mode, int first, double rtol2, double atol2,
+    const double* __restrict__ partial, double* __restrict__ S) {
+  if (stopped(S + kDone)) return;
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < nparts; i += kBlock) {
     a += load_scalar(partial + i);
@@ -1009,6 +1114,17 @@ __global__ __launch_bounds__(kBlock) void bicg_scalar_kernel(
     store_scalar(S + kBeta, (rho_old != 0.0 && omega != 0.0)
                                 ? (a / rho_old) * (alpha / omega)
                                 : 0.0);
+    if (first) {
+      store_scalar(S + kTarget2, fmax(rtol2 * load_scalar(S + kB2), atol2));
+      store_scalar(S + kIter, 0.0);
+    }
+    const double k = load_scalar(S + kIter);
+    const bool nan = !(b == b);
+    if (nan || b <= load_scalar(S + kTarget2)) {
+      store_scalar(S + kConvIt, k);
+      store_scalar(S + kDone, nan ? 2.0 : 1.0);
+    }
+    store_scalar(S + kIter, k + 1.0);
   }
 }
 
@@ -1018,6 +1134,7 @@ __global__ void bicg_p_kernel(int n, const double* __restrict__ S,
                               const double* __restrict__ r,
                               const double* __restrict__ v,
                               double* __restrict__ p, double* __restrict__ y) {
+  if (stopped(S + kDone)) return;
   const double beta = load_scalar(S + kBeta);
   const double omega = load_scalar(S + kOmega);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -1033,6 +1150,7 @@ __global__ void bicg_s_kernel(int n, const double* __restrict__ S,
                               const double* __restrict__ dinv,
                               const double* __restrict__ v,
                               double* __restrict__ r, double* __restrict__ z) {
+  if (stopped(S + kDone)) return;
   const double alpha = load_scalar(S + kAlpha);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
@@ -1048,6 +1166,7 @@ __global__ void bicg_x_kernel(int n, const double* __restrict__ S,
                               const double* __restrict__ z,
                               const double* __restrict__ t,
                               double* __restrict__ x, double* __restrict__ r) {
+  if (stopped(S + kDone)) return;
   const double alpha = load_scalar(S + kAlpha);
   const double omega = load_scalar(S + kOmega);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -1089,32 +1208,20 @@ static int bicgstab(const flow_operator* A, const double* dinv,
   hipLaunchKernelGGL(axpby_kernel, dim3(gv), dim3(kBlock), 0, st, N, 1.0, r, 0.0,
                      rhat);                           // rhat = r0
   // rho_new = rhat.r, res2 = r.r ; beta = 0 because rho_old = omega = 0
+  const double rtol2 = rtol * rtol, atol2 = atol * atol;
   if ((rc = dots(N, 2, rhat, r, r, r, r, r, partial, &np, st))) return rc;
-  hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, 3,
-                     partial, S);
+  hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np, 3, 1,
+                     rtol2, atol2, partial, S);
   FLOW_CHECK_LAUNCH();
 
-  double b2 = 0.0, res2 = 0.0;
-  if ((rc = read_slots(S, kB2, kRes2, &b2, &res2, st))) return rc;
-  const double target = fmax(rtol * sqrt(b2), atol);
-  int it = 0;
+  // batches of iterations; the device freezes x, r, p at the first residual
+  // that passes the stopping test (bicg_scalar_kernel mode 3), see cg()
+  double state[kNumSlots];
+  int launched = 0;
   while (true) {
-    if (!(res2 == res2)) {
-      *iters_host = it;
-      *resid_host = res2;
-      set_error("BiCGStab broke down (NaN residual) at iteration %d", it);
-      return FLOW_NOT_CONVERGED;
-    }
-    if (sqrt(res2) <= target) break;
-    if (it >= maxit) {
-      *iters_host = it;
-      *resid_host = sqrt(res2);
-      set_error("BiCGStab did not converge in %d iterations: |r| = %.3e > %.3e",
-                it, sqrt(res2), target);
-      return FLOW_NOT_CONVERGED;
-    }
-    const int batch = (it == 0 && first_check > 0) ? first_check : check_every;
-    const int todo = (maxit - it < batch) ? maxit - it : batch;
+    const int batch = (launched == 0 && first_check > 0) ? first_check
+                                                         : check_every;
+    const int todo = (maxit - launched < batch) ? maxit - launched : batch;
     for (int k = 0; k < todo; ++k) {
       hipLaunchKernelGGL(bicg_p_kernel, dim3(gv), dim3(kBlock), 0, st, N, S,
                          dinv, r, v, p, y);
@@ -1122,27 +1229,44 @@ static int bicgstab(const flow_operator* A, const double* dinv,
       if ((rc = apply(A, y, v, st))) return rc;
       if ((rc = dots(N, 1, rhat, v, v, v, v, v, partial, &np, st))) return rc;
       hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np,
-                         1, partial, S);
+                         1, 0, rtol2, atol2, partial, S);
       hipLaunchKernelGGL(bicg_s_kernel, dim3(gv), dim3(kBlock), 0, st, N, S,
                          dinv, v, r, z);
       if (ilu && (rc = ilu_apply(ilu, r, z, iwork, st))) return rc;
       if ((rc = apply(A, z, t, st))) return rc;
       if ((rc = dots(N, 2, t, r, t, t, t, t, partial, &np, st))) return rc;
       hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np,
-                         2, partial, S);
+                         2, 0, rtol2, atol2, partial, S);
       hipLaunchKernelGGL(bicg_x_kernel, dim3(gv), dim3(kBlock), 0, st, N, S, y,
                          z, t, x, r);
       if ((rc = dots(N, 2, rhat, r, r, r, r, r, partial, &np, st))) return rc;
       hipLaunchKernelGGL(bicg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, np,
-                         3, partial, S);
+                         3, 0, rtol2, atol2, partial, S);
     }
     FLOW_CHECK_LAUNCH();
-    it += todo;
-    if ((rc = read_slot(S, kRes2, &res2, st))) return rc;
+    launched += todo;
+    if ((rc = read_state(S, state, st))) return rc;
+    const double res2 = state[kRes2];
+    if (state[kDone] == 2.0 || !(res2 == res2)) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = res2;
+      set_error("BiCGStab broke down (NaN residual) at iteration %d",
+                *iters_host);
+      return FLOW_NOT_CONVERGED;
+    }
+    if (state[kDone] == 1.0) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = sqrt(res2);
+      return FLOW_OK;
+    }
+    if (launched >= maxit) {
+      *iters_host = launched;
+      *resid_host = sqrt(res2);
+      set_error("BiCGStab did not converge in %d iterations: |r| = %.3e > %.3e",
+                launched, sqrt(res2), sqrt(state[kTarget2]));
+      return FLOW_NOT_CONVERGED;
+    }
   }
-  *iters_host = it;
-  *resid_host = sqrt(res2);
-  return FLOW_OK;
 }
 
 }  // namespace flow
@@ -1153,11 +1277,48 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 15; }
+extern "C" int flow_abi_version(void) { return 16; }
 
 // the workgroup -> tile mapping of the CSR-stream kernels, for host-side tests
 extern "C" int flow_xcd_tile_host(int block, int nblocks) {
   return xcd_tile(block, nblocks);
+}
+
+extern "C" int flow_profile_spmv_begin(int rows, int max_launches) {
+  SpmvProfile& pf = g_spmv_profile;
+  FLOW_REQUIRE(rows > 0 && max_launches > 0 && max_launches <= 100000,
+               "profile arguments");
+  FLOW_REQUIRE(pf.ev == nullptr, "a profile is already running");
+  pf.ev = new hipEvent_t[2 * static_cast<size_t>(max_launches)];
+  for (int i = 0; i < 2 * max_launches; ++i)
+    FLOW_CHECK_HIP(hipEventCreate(&pf.ev[i]));
+  pf.rows = rows;
+  pf.used = 0;
+  pf.cap = max_launches;
+  return FLOW_OK;
+}
+
+extern "C" int flow_profile_spmv_end(double* total_us, int* launches) {
+  SpmvProfile& pf = g_spmv_profile;
+  FLOW_REQUIRE(total_us && launches, "profile results");
+  FLOW_REQUIRE(pf.ev != nullptr, "no profile is running");
+  double total = 0.0;
+  int rc = FLOW_OK;
+  for (int i = 0; i < pf.used && rc == FLOW_OK; ++i) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(pf.ev[2 * i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&ms, pf.ev[2 * i], pf.ev[2 * i + 1]) != hipSuccess) {
+      set_error("reading the SpMV profile events failed");
+      rc = FLOW_HIP_ERROR;
+    }
+    total += 1.0e3 * ms;
+  }
+  for (int i = 0; i < 2 * pf.cap; ++i) (void)hipEventDestroy(pf.ev[i]);
+  delete[] pf.ev;
+  *total_us = total;
+  *launches = pf.used;
+  pf = SpmvProfile();
+  return rc;
 }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
@@ -1183,6 +1344,27 @@ extern "C" int flow_operator_diag_inv(const flow_operator* A,
                      A->kind == 4 ? A->rowmask
                                   : static_cast<const unsigned char*>(nullptr),
                      dinv);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+// vals[k] *= d[row of k]: row equilibration of a scalar CSR plane (a Krylov
+// residual test needs balanced rows: flow_amd/heat.py)
+__global__ void scale_rows_kernel(int n, const int* __restrict__ rowptr,
+                                  const double* __restrict__ d,
+                                  double* __restrict__ vals) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n;
+       r += gridDim.x * blockDim.x) {
+    const double di = d[r];
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) vals[k] *= di;
+  }
+}
+
+extern "C" int flow_scale_rows(int n, const int* rowptr, const double* d,
+                               double* vals, void* stream) {
+  FLOW_REQUIRE(n > 0 && rowptr && d && vals, "scale rows arguments");
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
+                     as_stream(stream), n, rowptr, d, vals);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -1626,7 +1808,7 @@ extern "C" int flow_coarse_restrict_dev(const flow_coarse* C, const double* r,
   FLOW_REQUIRE(C && r && rc_out && r0 >= 0 && r1 <= C->n && r0 < r1, "restrict");
   hipLaunchKernelGGL(coarse_restrict_kernel, dim3(grid_for(C->nc, 4, kMaxGrid)),
                      dim3(kBlock), 0, as_stream(stream), C->nc, C->agg_ptr,
-                     C->agg_dofs, r, r0, r1, rc_out);
+                     C->agg_dofs, r, r0, r1, rc_out, static_cast<const double*>(nullptr));
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -1640,7 +1822,7 @@ extern "C" int flow_coarse_solve_dev(const flow_coarse* C, const double* rc_in,
                "coarse residual must be 16-byte aligned");
   hipLaunchKernelGGL(coarse_gemv_kernel, dim3(grid_for(C->nc, 4, kMaxGrid)),
                      dim3(kBlock), 0, as_stream(stream), C->nc, C->lda, C->Ainv,
-                     rc_in, zc);
+                     rc_in, zc, static_cast<const double*>(nullptr));
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -1671,7 +1853,7 @@ extern "C" int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
   hipLaunchKernelGGL(coarse_prolong_kernel<false>, dim3(grid_for(r1 - r0)),
                      dim3(kBlock), 0, as_stream(stream), r1 - r0, C->agg_of + r0,
                      dinv + r0, r + r0, zc, z + r0,
-                     static_cast<double*>(nullptr));
+                     static_cast<double*>(nullptr), static_cast<const double*>(nullptr));
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -1723,7 +1905,7 @@ extern "C" int flow_gmres_solve(const flow_operator* A, const double* dinv,
 // by flow_amd/parallel.py with one all-reduce + one halo exchange per iteration
 // ---------------------------------------------------------------------------
 // S <- Chronopoulos-Gear scalars from the (all-reduced) sums in3 =
-// (r.z, z.w, r.r)
+// (r.z, z.w, z.z)
 __global__ void cg_scalar_from_sums_kernel(int first,
                                            const double* __restrict__ in3,
                                            double* __restrict__ S) {
@@ -1735,8 +1917,8 @@ __global__ void cg_scalar_from_sums_kernel(int first,
     beta = 0.0;
     alpha = (d != 0.0) ? g / d : 0.0;
   } else {
-    const double g_old = S[kGamma];
-    const double a_old = S[kAlpha];
+    const double g_old = load_scalar(S + kGamma);
+    const double a_old = load_scalar(S + kAlpha);
     beta = (g_old != 0.0) ? g / g_old : 0.0;
     const double den = (a_old != 0.0) ? d - beta * g / a_old : 0.0;
     alpha = (den != 0.0) ? g / den : 0.0;
@@ -1862,11 +2044,12 @@ extern "C" int flow_cg_shard_step(const flow_cg_shard* c, int phase,
                        c->r + c->e0, C ? 0 : 1, static_cast<double*>(nullptr));
     if (C) {
       hipLaunchKernelGGL(coarse_gemv_kernel, dim3(grid_for(nc, 4, kMaxGrid)),
-                         dim3(kBlock), 0, st, nc, C->lda, C->Ainv, c->rc, c->zc);
+                         dim3(kBlock), 0, st, nc, C->lda, C->Ainv, c->rc, c->zc,
+                         static_cast<const double*>(nullptr));
       hipLaunchKernelGGL(coarse_prolong_kernel<false>, dim3(grid_for(ne)),
                          dim3(kBlock), 0, st, ne, C->agg_of + c->e0,
                          c->dinv + c->e0, c->r + c->e0, c->zc, c->z + c->e0,
-                         static_cast<double*>(nullptr));
+                         static_cast<double*>(nullptr), static_cast<const double*>(nullptr));
     }
     FLOW_CHECK_LAUNCH();
   }
@@ -1875,14 +2058,14 @@ extern "C" int flow_cg_shard_step(const flow_cg_shard* c, int phase,
   const int no = c->r1 - c->r0;
   int np = 0;
   if ((rc = dots(no, 3, c->r + c->r0, c->z + c->r0, c->z + c->r0, c->w + c->r0,
-                 c->r + c->r0, c->r + c->r0, c->work, &np, st)))
+                 c->z + c->r0, c->z + c->r0, c->work, &np, st)))
     return rc;
   hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 3, 0,
                      c->work, sums);
   if (C)
     hipLaunchKernelGGL(coarse_restrict_kernel, dim3(grid_for(nc, 4, kMaxGrid)),
                        dim3(kBlock), 0, st, nc, C->agg_ptr, C->agg_dofs, c->w,
-                       c->r0, c->r1, omega);
+                       c->r0, c->r1, omega, static_cast<const double*>(nullptr));
   hipLaunchKernelGGL(halo_pack_kernel, dim3(grid_for(c->nhalo > 0 ? c->nhalo : 1)),
                      dim3(kBlock), 0, st, c->nhalo, c->send_row[0],
                      c->send_len[0], c->send_slot[0], c->send_row[1],

@@ -464,9 +464,11 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     '''Solve A x = b on the device; x holds the initial guess.  Raises
     _hip.NotConverged (a RuntimeError) like dolfin's
     'error_on_nonconvergence'.  first_check > 0: iterations before the first
-    residual read-back (then every check_every).  tag (CG): the solve recurs
-    in a time loop under that name -- the iteration count of the previous
-    call (kept on A) places the first read-back two iterations before it.
+    residual read-back (then every check_every); the device itself freezes
+    the solution at the first iterate that passes the stopping test, so a
+    late read-back costs idle launches, never accuracy.  tag (CG): the solve
+    recurs in a time loop under that name -- the first read-back comes one
+    iteration after the count the previous call (kept on A) needed.
     method 'gmres': GMRES(restart); x_is_zero promises x = 0 on entry;
     `iterations` then counts operator applications (a BiCGStab iteration is
     two).'''
@@ -494,7 +496,7 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     if tag is not None and method == 'cg':
         history = A.__dict__.setdefault('_solve_history', {})
         if first_check == 0 and tag in history:
-            first_check = max(int(check_every), history[tag] - 2)
+            first_check = history[tag] + 1
     if method == 'cg':
         rc = lib.flow_cg_solve(
             ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),

@@ -152,6 +152,19 @@ class Heat(object):
             _hip.check(lib.flow_bc_set_values(
                 nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(bvec), st
                 ))
+        # Row equilibration: Dirichlet rows carry temperatures (~300) in b, the
+        # lumped mass rows O(h^2) entries, the zero-mass edge rows of P2 only
+        # beta*A (~1e-9): a residual test on the raw rows would not see an
+        # error on the small ones.  The reference's LU is insensitive to that;
+        # the Krylov solve gets diag(A)^-1 A x = diag(A)^-1 b, where a relative
+        # residual is a relative error to within the conditioning of a
+        # diagonally scaled M-matrix-like operator.
+        dinv = A.diag_inv()
+        _hip.check(lib.flow_scale_rows(
+            lay.N, _hip.i32(lay.dev('rowptr')), _hip.f64(dinv, lay.N),
+            _hip.f64(A.vals, lay.nnz), st
+            ))
+        bvec = ops.vmul(dinv, bvec)
         u = Function(self.V)
         # warm start is not used: x0 = 0 like a direct solve has no history
         par = solver_parameters

@@ -5,9 +5,11 @@ bench.py and the tests.  Counterpart of the reference driver
 tests/test_karman_vortex_street.py:56-289 with the same geometry (:18-23,
 :35-38), boundary conditions (:128-145, :190-203), parameters (mu = 0.002 :167,
 dt0 = 1e-5 :210, dt_max = 1 :211, tol = 1e-10 :239) and step-size controller
-(:262-286).  gmsh and the Stokes bootstrap (flow.stokes.solve)
-are not available: the mesh is the structured channel of fem.karman_channel and
-the run starts from the inflow profile.
+(:262-286).  gmsh is not available: the mesh is the structured channel of
+fem.karman_channel (staircase obstacle: cells whose centroid lies in the
+cylinder are removed, so the geometry at the cylinder is first order).  The run
+starts from the Stokes solution like the reference's (`set_initial_stokes`,
+:171-179) or impulsively from the inflow profile (`set_initial_profile`).
 '''
 from __future__ import print_function
 
@@ -91,6 +93,20 @@ class KarmanProblem(object):
         self.extrapolate_projection = True
         return
 
+    def reset(self, dt=1.0e-5):
+        '''Back to the state before the first step (fields, clock, step size,
+        the controller's memory, and what the steps of mode 'fast' remember).'''
+        fem.ops.fill(self.u0.data, 0.0)
+        fem.ops.fill(self.p0.data, 0.0)
+        self.dt = dt
+        self.t = 0.0
+        self.history = []
+        self._umag_hist = []
+        self._umag_start = fem.ops.StartChooser()
+        self.W.layout._dev.pop('step_history', None)
+        self.W.layout._dev.pop('newton_quad_C', None)
+        return
+
     def num_dofs(self):
         return self.W.size() + self.P.size()
 
@@ -100,6 +116,33 @@ class KarmanProblem(object):
             (self.inflow.cppcode, '0.0'), degree=2
             )
         self.u0.assign(fem.interpolate(prof, self.W))
+        return
+
+    def set_initial_stokes(self, tol=1.0e-13, max_iter=10000):
+        '''Start from the Stokes solution, as the reference driver does
+        (tests/test_karman_vortex_street.py:171-179: the velocity conditions
+        only -- its pressure condition list is empty at that point --,
+        mu = 0.002, f = 0, tol = 1e-13).'''
+        from . import stokes
+        mesh = self.mesh
+        WP = fem.FunctionSpace(
+            mesh,
+            fem.VectorElement('Lagrange', mesh.ufl_cell(), self.W.degree)
+            * fem.FiniteElement('Lagrange', mesh.ufl_cell(), 1))
+        W = WP.sub(0)
+        bcs = [
+            fem.DirichletBC(W, (0.0, 0.0), UpperBoundary()),
+            fem.DirichletBC(W, (0.0, 0.0), LowerBoundary()),
+            fem.DirichletBC(W, (0.0, 0.0), ObstacleBoundary()),
+            fem.DirichletBC(W.sub(0), self.inflow, LeftBoundary()),
+            fem.DirichletBC(W.sub(0), self.outflow, RightBoundary()),
+            ]
+        u, p = stokes.solve(WP, bcs, fem.Constant(self.mu),
+                            f=fem.Constant((0.0, 0.0)), verbose=False,
+                            tol=tol, max_iter=max_iter)
+        fem.ops.copy(self.u0.data, u.data)
+        fem.ops.copy(self.p0.data, p.data)
+        self.stokes_info = dict(stokes.last_solve_info)
         return
 
     def reynolds(self):

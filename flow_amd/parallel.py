@@ -87,6 +87,17 @@ def active(nrows=None):
     return nrows is None or nrows >= min_rows()
 
 
+def describe(world, nrows):
+    '''One line for bench.py's `config.parallelism`.'''
+    if active(nrows):
+        return 'pressure-poisson row-block x%d' % world
+    if world == 1:
+        return 'single GPU'
+    return ('replicated x%d (pressure system of %d rows is below the sharding '
+            'threshold of %d rows: DESIGN.md section 6; --shard always forces '
+            'it)' % (world, nrows, min_rows()))
+
+
 # -- partition (pure host logic, CPU-testable) --------------------------------
 class HaloLayout(object):
     '''What rank g puts into / takes out of the halo section of the all-reduce
@@ -281,18 +292,11 @@ class HipLocal(object):
             setattr(c, name, _hip.f64(getattr(self, name)))
         self.ctx = c
 
-    def begin(self, b, x):
-        '''Replicated start on ALL rows: r = b - A x, z = M^-1 r, p = s = 0.
-        Returns b.b.'''
-        from .fem import ops
+    def _start(self, b, q):
+        '''r = b - q, z = B r on ALL rows (replicated).'''
         lib, n, st = self.lib, self.n, _hip.stream()
-        self.x = x
-        self.ctx.x = _hip.f64(x, n, 'x')
-        for v in (self.p, self.s, self.S, self.sigma, self.buf):
-            _hip.fill(v, 0.0)
-        self.A.apply(x, self.w)
         _hip.check(lib.flow_residual_dev(
-            n, _hip.f64(b, n), _hip.f64(self.w), _hip.f64(self.dinv),
+            n, _hip.f64(b, n), _hip.f64(q), _hip.f64(self.dinv),
             _hip.f64(self.r), _hip.f64(self.z), st
             ))
         if self.coarse is not None:
@@ -307,7 +311,22 @@ class HipLocal(object):
                 cs, _hip.f64(self.dinv), _hip.f64(self.r), _hip.f64(self.zc),
                 _hip.f64(self.z), 0, n, st
                 ))
-        return ops.dot(b, b)
+
+    def begin(self, b, x):
+        '''Replicated start on ALL rows: r = b - A x, z = B r, p = s = 0.
+        Returns |B b|^2 (the stopping test is in the preconditioned norm, as
+        in flow_cg_solve).'''
+        from .fem import ops
+        n = self.n
+        self.x = x
+        self.ctx.x = _hip.f64(x, n, 'x')
+        for v in (self.p, self.s, self.S, self.sigma, self.buf, self.w):
+            _hip.fill(v, 0.0)
+        self._start(b, self.w)
+        bb2 = ops.dot(self.z, self.z)
+        self.A.apply(x, self.w)
+        self._start(b, self.w)
+        return bb2
 
     def step(self, phase):
         _hip.check(self.lib.flow_cg_shard_step(

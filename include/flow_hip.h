@@ -90,9 +90,25 @@ int flow_operator_apply(const flow_operator* A, const double* x, double* y,
 int flow_operator_diag_inv(const flow_operator* A, const int* diag_idx,
                            double* dinv, void* stream);
 
+/* Per-kernel timer of the roofline kernel in solver context: from
+ * _begin on, up to max_launches launches of the fused-dot CSR-stream SpMV of a
+ * scalar operator with `rows` rows -- the product with A inside a CG iteration,
+ * with whatever the rest of the iteration left in the caches -- are bracketed by
+ * HIP events on the launch stream; _end waits for them and returns the summed
+ * durations (microseconds) and the number of launches seen.  One profile at a
+ * time, not thread safe: a measuring aid for bench.py. */
+int flow_profile_spmv_begin(int rows, int max_launches);
+int flow_profile_spmv_end(double* total_us, int* launches);
+
 /* ---- K9: BLAS-1 (PETSc VecDot/VecAXPY/VecNorm) -------------------------- */
 int flow_dot_host(int n, const double* x, const double* y, double* work,
                   double* result_host, void* stream);
+/* vals[k] *= d[row(k)] for a scalar CSR plane of n rows: row equilibration
+ * before a Krylov solve that stands in for the reference's sparse LU
+ * (flow/heat.py:117-121) */
+int flow_scale_rows(int n, const int* rowptr, const double* d, double* vals,
+                    void* stream);
+
 /* kind 0: l2, 1: linf (norm(vec,'linf'), tests/test_karman_vortex_street.py:268) */
 int flow_norm_host(int n, const double* x, int kind, double* work,
                    double* result_host, void* stream);
@@ -211,10 +227,22 @@ int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
                     double* work, void* stream);
 
 /* ---- K12: Krylov drivers -------------------------------------------------
- * Device-resident loops; the host reads the residual norm every check_every
- * iterations -- the first time after first_check iterations when that is > 0
- * (a time loop knows how many the previous step needed; every read-back drains
- * the stream).  Stop when ||r||_2 <= max(rtol*||b||_2, atol); return
+ * Device-resident loops.  Convergence is decided ON THE DEVICE: the kernel
+ * that computes the solver scalars compares the residual norm with the target
+ * and freezes the solution at the first iterate that passes (everything
+ * enqueued behind it returns at once), so *iters_host is the exact count and
+ * the solution never moves past the accepted iterate, however late the host
+ * looks: it reads the state every check_every iterations -- the first time
+ * after first_check iterations when that is > 0 (a time loop knows how many the
+ * previous step needed; every read-back drains the stream).
+ * Stopping test: CG tests the PRECONDITIONED residual like PETSc's KSPCG (the
+ * default the reference's `solve` runs with, pressure_correction.py:326-339,
+ * 419-432, 451-464): ||B r||_2 <= max(rtol*||B b||_2, atol), B = the
+ * preconditioner (Jacobi, two-level, V-cycle; identity without one) -- with
+ * Dirichlet rows carrying boundary VALUES in b next to O(h^2) interior
+ * entries, the unpreconditioned norm would let the interior equations off at
+ * rtol*|g|/h^2.  *resid_host is that norm.  BiCGStab and GMRES are right-
+ * preconditioned: ||r||_2 <= max(rtol*||b||_2, atol).  Return
  * FLOW_NOT_CONVERGED after maxit iterations (dolfin raises RuntimeError:
  * 'error_on_nonconvergence', pressure_correction.py:337,424,462).
  * dinv may be NULL (no preconditioner).  x holds the initial guess.
@@ -224,7 +252,7 @@ int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
  * work (16-byte aligned): FLOW_REDUCE_WORK + 5*N + B + 2 [+ 2*coarse->lda]
  * [+ 2*mg->Ps[0].nblocks] doubles (cg; B = nblocks, twice that for kind 1: the
  * SpMV leaves its z.Az partials there, the V-cycle's last kernel its r.z and
- * r.r partials), FLOW_REDUCE_WORK + 7*N [+ n] (bicgstab); N = operator size. */
+ * z.z partials), FLOW_REDUCE_WORK + 7*N [+ n] (bicgstab); N = operator size. */
 int flow_cg_solve(const flow_operator* A, const double* dinv,
                   const flow_coarse* coarse, const flow_mg* mg,
                   const double* b, double* x,

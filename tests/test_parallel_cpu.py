@@ -57,11 +57,17 @@ class NumpyLocal(object):
         self.sigma[:] = 0.0
         self.alpha = self.beta = self.gamma = 0.0
         self.buf.zero_()
+        # |B b|^2: the stopping test is in the preconditioned norm
+        self.r[:] = bn
+        if self.coarse is not None:
+            self.rc[:] = self.coarse.P.T.dot(self.r)
+        self._precondition(slice(0, self.n))
+        bb2 = float(self.z.dot(self.z))
         self.r[:] = bn - self.A.dot(self.x)
         if self.coarse is not None:
             self.rc[:] = self.coarse.P.T.dot(self.r)
         self._precondition(slice(0, self.n))
-        return float(bn.dot(bn))
+        return bb2
 
     def step(self, phase):
         hl, buf = self.hl, self.buf.numpy()
@@ -93,7 +99,7 @@ class NumpyLocal(object):
         self.w[own] = self.rows.dot(self.z)
         buf[0] = self.r[own].dot(self.z[own])
         buf[1] = self.z[own].dot(self.w[own])
-        buf[2] = self.r[own].dot(self.r[own])
+        buf[2] = self.z[own].dot(self.z[own])
         buf[3] = 0.0
         if self.coarse is not None:
             v = numpy.zeros(self.n)
