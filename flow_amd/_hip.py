@@ -102,7 +102,8 @@ class IluS(ctypes.Structure):
 
 
 class MeshS(ctypes.Structure):
-    _fields_ = [('nc', ctypes.c_int), ('xy', ctypes.c_void_p)]
+    _fields_ = [('nc', ctypes.c_int), ('xy', ctypes.c_void_p),
+                ('c0', ctypes.c_int), ('c1', ctypes.c_int)]
 
 
 class SpaceS(ctypes.Structure):
@@ -115,6 +116,8 @@ class SpaceS(ctypes.Structure):
         ('csrc', ctypes.c_void_p),
         ('vptr', ctypes.c_void_p),
         ('vsrc', ctypes.c_void_p),
+        ('r0', ctypes.c_int), ('r1', ctypes.c_int),
+        ('nnz0', ctypes.c_int), ('nnz1', ctypes.c_int),
         ]
 
 
@@ -135,24 +138,32 @@ class NsParams(ctypes.Structure):
         ]
 
 
-class CgShard(ctypes.Structure):
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
+
+
+class CommS(ctypes.Structure):
     _fields_ = [
-        ('A', ctypes.POINTER(Operator)),
-        ('dinv', ctypes.c_void_p),
-        ('coarse', ctypes.POINTER(CoarseS)),
+        ('rank', ctypes.c_int), ('world', ctypes.c_int),
+        ('buf', ctypes.c_void_p), ('capacity', ctypes.c_int),
+        ('allreduce', ALLREDUCE_FN), ('user', ctypes.c_void_p),
+        ]
+
+
+class RowsS(ctypes.Structure):
+    _fields_ = [
         ('n', ctypes.c_int), ('r0', ctypes.c_int), ('r1', ctypes.c_int),
-        ('e0', ctypes.c_int), ('e1', ctypes.c_int),
-        ('nhalo', ctypes.c_int),
+        ('e0', ctypes.c_int), ('e1', ctypes.c_int), ('nhalo', ctypes.c_int),
         ('send_row', ctypes.c_int * 2), ('send_len', ctypes.c_int * 2),
         ('send_slot', ctypes.c_int * 2),
         ('recv_row', ctypes.c_int * 2), ('recv_len', ctypes.c_int * 2),
         ('recv_slot', ctypes.c_int * 2),
-        ('x', ctypes.c_void_p), ('r', ctypes.c_void_p), ('z', ctypes.c_void_p),
-        ('w', ctypes.c_void_p), ('p', ctypes.c_void_p), ('s', ctypes.c_void_p),
-        ('rc', ctypes.c_void_p), ('zc', ctypes.c_void_p),
-        ('sigma', ctypes.c_void_p),
-        ('S', ctypes.c_void_p), ('buf', ctypes.c_void_p),
-        ('work', ctypes.c_void_p),
+        ]
+
+
+class MgShardS(ctypes.Structure):
+    _fields_ = [
+        ('mg', ctypes.POINTER(MgS)),
+        ('Ah0', Operator), ('Ps0', Operator), ('Rg', Operator),
         ]
 
 
@@ -197,11 +208,18 @@ SYMBOLS = {
     'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],
     'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],
     'flow_ilu0_solve': [_P(IluS), _VP, _VP, _VP, _VP],
-    'flow_cg_shard_step': [_P(CgShard), _I, _VP],
-    'flow_coarse_restrict_dev': [_P(CoarseS), _VP, _I, _I, _VP, _VP],
-    'flow_coarse_solve_dev': [_P(CoarseS), _VP, _VP, _VP],
-    'flow_coarse_prolong_dev': [_P(CoarseS), _VP, _VP, _VP, _VP, _I, _I, _VP],
-    'flow_residual_dev': [_I, _VP, _VP, _VP, _VP, _VP, _VP],
+    'flow_shard_halo': [_P(CommS), _P(RowsS), _I, _VP, _I, _VP],
+    'flow_shard_reduce_host': [_P(CommS), _P(RowsS), _I, _VP, _VP, _I, _I, _VP,
+                               _P(_D), _VP],
+    'flow_shard_cg_solve': [_P(CommS), _P(RowsS), _P(Operator), _VP, _VP, _VP,
+                            _D, _D, _I, _I, _I, _VP, ctypes.c_size_t, _P(_I),
+                            _P(_D), _VP],
+    'flow_shard_mgcg_solve': [_P(CommS), _P(RowsS), _P(Operator), _VP,
+                              _P(MgShardS), _VP, _VP, _D, _D, _I, _I, _I, _VP,
+                              ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_shard_gmres_solve': [_P(CommS), _P(RowsS), _P(Operator), _P(IluS),
+                               _VP, _VP, _D, _D, _I, _I, _I, _VP,
+                               ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_assemble_scalar_matrix': [_I, _P(MeshS), _P(SpaceS), _VP, _VP, _VP],
     'flow_assemble_pressure_rhs': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _VP,
                                    _D, _D, _I, _VP, _VP, _VP],

@@ -57,11 +57,17 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(
   }
 }
 
+// rows [r0, r1) of the nout (r1 = 0: all); out_stride = 0: nout
 static int gather(int nout, int nplanes, const int* ptr, const int* src,
                   const double* scratch, size_t plane_stride, double* out,
-                  hipStream_t st, size_t out_stride = 0) {
-  const dim3 grid(grid_for(nout, kBlock, 1 << 20));
+                  hipStream_t st, size_t out_stride = 0, int r0 = 0, int r1 = 0) {
   const size_t os = out_stride ? out_stride : static_cast<size_t>(nout);
+  if (r1 > 0) {
+    ptr += r0;
+    out += r0;
+    nout = r1 - r0;
+  }
+  const dim3 grid(grid_for(nout, kBlock, 1 << 20));
   FLOW_REQUIRE(nplanes == 1 || nplanes == 2, "gather: 1 or 2 planes");
   if (nplanes == 1)
     hipLaunchKernelGGL(gather_kernel<1>, grid, dim3(kBlock), 0, st, nout, ptr,
@@ -140,13 +146,13 @@ __global__ __launch_bounds__(kBlock) void scalar_matrix_kernel(
 // ---------------------------------------------------------------------------
 template <int DEG>
 __global__ __launch_bounds__(kBlock) void pressure_rhs_kernel(
-    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    int nc, int cb, int ce, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
     const int* __restrict__ cdp, const double* __restrict__ u,
     const double* __restrict__ p0, double alpha_rho_dt, double mu,
     int rotational, double* __restrict__ scratch) {
   constexpr int NL = Elem<DEG>::NL;
-  const int c = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (c >= nc) return;
+  const int c = cb + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (c >= ce) return;
   const Geom g = load_geom(xy, nc, c);
   double U[2][NL];
   load_local<NL>(u, nu, cdu, nc, c, 2, U);
@@ -175,14 +181,14 @@ __global__ __launch_bounds__(kBlock) void pressure_rhs_kernel(
 // ---------------------------------------------------------------------------
 template <int DEG>
 __global__ __launch_bounds__(kBlock) void correction_rhs_kernel(
-    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    int nc, int cb, int ce, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
     const int* __restrict__ cdp, const double* __restrict__ u,
     const double* __restrict__ p1, const double* __restrict__ p0, double dt_rho,
     double mu, int rotational, double* __restrict__ scratch) {
   constexpr int NL = Elem<DEG>::NL;
   constexpr int NQ = Elem<2>::NQ;
-  const int c = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (c >= nc) return;
+  const int c = cb + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (c >= ce) return;
   const Geom g = load_geom(xy, nc, c);
   double U[2][NL];
   load_local<NL>(u, nu, cdu, nc, c, 2, U);
@@ -343,15 +349,15 @@ __device__ __forceinline__ void add_rhs_weak_facets(
 
 template <int DEG>
 __global__ __launch_bounds__(kBlock) void momentum_residual_kernel(
-    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    int nc, int cb, int ce, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
     const int* __restrict__ cdp, const int* __restrict__ bfmask,
     const double* __restrict__ ui, const double* __restrict__ u0,
     const double* __restrict__ p0, flow_coef f0, flow_coef f1,
     flow_ns_params prm, double* __restrict__ scratch) {
   constexpr int NL = Elem<DEG>::NL;
   constexpr int NQ = Elem<DEG>::NQ;
-  const int c = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (c >= nc) return;
+  const int c = cb + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (c >= ce) return;
   const Geom g = load_geom(xy, nc, c);
   double Ui[2][NL], U0[2][NL], P[3];
   load_local<NL>(ui, nu, cdu, nc, c, 2, Ui);
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void momentum_residual_kernel(
   for (int k = 0; k < 3; ++k) P[k] = p0[cdp[k * nc + c]];
   const int mask = bfmask[c];
   const double ci = -prm.dt / prm.rho * prm.theta_i;
-  const double ce = -prm.dt / prm.rho * prm.theta_e;
+  const double cexp = -prm.dt / prm.rho * prm.theta_e;
   double acc[2][NL];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -385,15 +391,15 @@ __global__ __launch_bounds__(kBlock) void momentum_residual_kernel(
     }
     if (ci != 0.0)
       add_rhs_weak_point<NL>(w * ci, prm.rho, prm.mu, Ui, P, L, phi, gphi, acc);
-    if (ce != 0.0)
-      add_rhs_weak_point<NL>(w * ce, prm.rho, prm.mu, U0, P, L, phi, gphi, acc);
+    if (cexp != 0.0)
+      add_rhs_weak_point<NL>(w * cexp, prm.rho, prm.mu, U0, P, L, phi, gphi, acc);
   }
   if (mask) {
     if (ci != 0.0) add_rhs_weak_facets<DEG>(mask, ci, prm.mu, g, Ui, P, acc);
-    if (ce != 0.0) add_rhs_weak_facets<DEG>(mask, ce, prm.mu, g, U0, P, acc);
+    if (cexp != 0.0) add_rhs_weak_facets<DEG>(mask, cexp, prm.mu, g, U0, P, acc);
   }
   if (ci != 0.0) add_source<NL>(f1, nc, c, 2, ci * g.adet, acc);
-  if (ce != 0.0) add_source<NL>(f0, nc, c, 2, ce * g.adet, acc);
+  if (cexp != 0.0) add_source<NL>(f0, nc, c, 2, cexp * g.adet, acc);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -410,18 +416,19 @@ __global__ __launch_bounds__(kBlock) void momentum_residual_kernel(
 // ---------------------------------------------------------------------------
 template <int DEG>
 __global__ __launch_bounds__(kBlock) void momentum_jvp_kernel(
-    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    int nc, int cb, int ce, const double* __restrict__ xy,
+    const int* __restrict__ cdu, int nu, int nv,
     const int* __restrict__ bfmask, const double* __restrict__ ui,
     const double* __restrict__ v, flow_ns_params prm,
     double* __restrict__ scratch) {
   constexpr int NL = Elem<DEG>::NL;
   constexpr int NQ = Elem<DEG>::NQ;
-  const int c = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (c >= nc) return;
+  const int c = cb + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (c >= ce) return;
   const Geom g = load_geom(xy, nc, c);
   double U[2][NL], V[2][NL];
   load_local<NL>(ui, nu, cdu, nc, c, 2, U);
-  load_local<NL>(v, nu, cdu, nc, c, 2, V);
+  load_local<NL>(v, nv, cdu, nc, c, 2, V);
   const int mask = bfmask[c];
   const double ci = -prm.dt / prm.rho * prm.theta_i;
   const double hr = 0.5 * prm.rho;
@@ -482,12 +489,18 @@ __global__ __launch_bounds__(kBlock) void momentum_jvp_kernel(
       scratch[static_cast<size_t>(a * NL + i) * nc + c] = acc[a][i];
 }
 
-// out[d] = v[d] on the Dirichlet dofs (identity rows)
-__global__ void bc_copy_kernel(int nbc, const int* __restrict__ dofs,
-                               const double* __restrict__ v,
-                               double* __restrict__ out) {
+// out[d] = v[d] on the Dirichlet dofs (identity rows) whose row lies in
+// [r0, r1); d = a*n + row, the vectors have component strides vs / os
+__global__ void bc_copy_kernel(int nbc, const int* __restrict__ dofs, int n,
+                               int r0, int r1, const double* __restrict__ v,
+                               int vs, double* __restrict__ out, int os) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < nbc) out[dofs[k]] = v[dofs[k]];
+  if (k >= nbc) return;
+  const int d = dofs[k];
+  const int a = d / n;
+  const int row = d - a * n;
+  if (row >= r0 && row < r1)
+    out[static_cast<size_t>(a) * os + row] = v[static_cast<size_t>(a) * vs + row];
 }
 
 // ---------------------------------------------------------------------------
@@ -502,7 +515,7 @@ struct BasisTab {
 
 template <int DEG>
 __global__ __launch_bounds__(kBlock) void momentum_jacobian_kernel(
-    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    int nc, int cb, int ce, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
     const int* __restrict__ bfmask, const double* __restrict__ ui,
     flow_ns_params prm, double* __restrict__ scratch) {
   constexpr int NL = Elem<DEG>::NL;
@@ -515,9 +528,9 @@ __global__ __launch_bounds__(kBlock) void momentum_jacobian_kernel(
 
   const int lane = threadIdx.x & 63;
   const int grp = threadIdx.x >> 6;          // wavefront id: wave-uniform
-  const int c = blockIdx.x * 64 + lane;
-  const bool active = c < nc;
-  const int cc = active ? c : nc - 1;
+  const int c = cb + blockIdx.x * 64 + lane;
+  const bool active = c < ce;
+  const int cc = active ? c : ce - 1;
 
   // basis tables: one (q, i) entry per thread
   for (int t = threadIdx.x; t < NQ * NL; t += kBlock) {
@@ -646,13 +659,13 @@ __global__ __launch_bounds__(kBlock) void momentum_jacobian_kernel(
 // phase 2 for the Jacobian: per CSR nonzero, sum the 32-byte 2x2 blocks of its
 // contributions (src[t] = ij*nc + cell, the shared contribution map) and write
 // the four value planes
-__global__ void gather_blocks_kernel(int nnz, int nc, int np,
+__global__ void gather_blocks_kernel(int k0, int nnz, int nc, int np,
                                      const int* __restrict__ ptr,
                                      const int* __restrict__ src,
                                      const double* __restrict__ scratch,
                                      size_t out_stride,
                                      double* __restrict__ out) {
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nnz;
+  for (int k = k0 + blockIdx.x * blockDim.x + threadIdx.x; k < nnz;
        k += gridDim.x * blockDim.x) {
     const int a = ptr[k];
     const int b = ptr[k + 1];
@@ -907,12 +920,12 @@ __global__ __launch_bounds__(kBlock) void div_adjoint_kernel(
 // b_i = int m(u) phi_i, m = sqrt(ux^2+uy^2) (mode 0) or |ux|+|uy| (mode 1)
 template <int DEG>
 __global__ __launch_bounds__(kBlock) void magnitude_kernel(
-    int nc, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
+    int nc, int cb, int ce, const double* __restrict__ xy, const int* __restrict__ cdu, int nu,
     const double* __restrict__ u, int mode, double* __restrict__ scratch) {
   constexpr int NL = Elem<DEG>::NL;
   constexpr int NQ = 7;
-  const int c = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (c >= nc) return;
+  const int c = cb + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (c >= ce) return;
   const Geom g = load_geom(xy, nc, c);
   double U[2][NL];
   load_local<NL>(u, nu, cdu, nc, c, 2, U);
@@ -941,10 +954,23 @@ __global__ __launch_bounds__(kBlock) void magnitude_kernel(
 
 static int check_mesh_space(const flow_mesh* mesh, const flow_space* V) {
   FLOW_REQUIRE(mesh && mesh->nc > 0 && mesh->xy, "mesh");
+  FLOW_REQUIRE(mesh->c1 == 0 ||
+                   (0 <= mesh->c0 && mesh->c0 < mesh->c1 && mesh->c1 <= mesh->nc),
+               "mesh cell range");
   FLOW_REQUIRE(V && (V->deg == 1 || V->deg == 2) && V->n > 0 && V->cell_dofs,
                "space");
+  FLOW_REQUIRE(V->r1 == 0 || (0 <= V->r0 && V->r0 < V->r1 && V->r1 <= V->n),
+               "space row range");
   return FLOW_OK;
 }
+
+// the cells the kernels of this call run over
+struct CellRange {
+  int cb, ce;
+  explicit CellRange(const flow_mesh* m)
+      : cb(m->c1 > 0 ? m->c0 : 0), ce(m->c1 > 0 ? m->c1 : m->nc) {}
+  int count() const { return ce - cb; }
+};
 
 }  // namespace flow
 
@@ -987,10 +1013,11 @@ extern "C" int flow_assemble_pressure_rhs(const flow_mesh* mesh,
   FLOW_REQUIRE(P->deg == 1 && P->vptr && P->vsrc, "pressure space must be P1");
   FLOW_REQUIRE(u && p0 && scratch && b, "pointers");
   hipStream_t st = as_stream(stream);
-  FLOW_DISPATCH_DEG(W->deg, pressure_rhs_kernel, cell_grid(mesh->nc), st,
-                    mesh->nc, mesh->xy, W->cell_dofs, W->n, P->cell_dofs, u, p0,
-                    alpha_rho_dt, mu, rotational, scratch);
-  return gather(P->n, 1, P->vptr, P->vsrc, scratch, 0, b, st);
+  const CellRange cr(mesh);
+  FLOW_DISPATCH_DEG(W->deg, pressure_rhs_kernel, cell_grid(cr.count()), st,
+                    mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n,
+                    P->cell_dofs, u, p0, alpha_rho_dt, mu, rotational, scratch);
+  return gather(P->n, 1, P->vptr, P->vsrc, scratch, 0, b, st, 0, P->r0, P->r1);
 }
 
 extern "C" int flow_assemble_correction_rhs(
@@ -1003,12 +1030,13 @@ extern "C" int flow_assemble_correction_rhs(
   FLOW_REQUIRE(P->deg == 1 && W->vptr && W->vsrc, "spaces");
   FLOW_REQUIRE(u && p1 && p0 && scratch && b, "pointers");
   hipStream_t st = as_stream(stream);
-  FLOW_DISPATCH_DEG(W->deg, correction_rhs_kernel, cell_grid(mesh->nc), st,
-                    mesh->nc, mesh->xy, W->cell_dofs, W->n, P->cell_dofs, u, p1,
-                    p0, dt_rho, mu, rotational, scratch);
+  const CellRange cr(mesh);
+  FLOW_DISPATCH_DEG(W->deg, correction_rhs_kernel, cell_grid(cr.count()), st,
+                    mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n,
+                    P->cell_dofs, u, p1, p0, dt_rho, mu, rotational, scratch);
   const int nl = W->deg == 1 ? 3 : 6;
   return gather(W->n, 2, W->vptr, W->vsrc, scratch,
-                static_cast<size_t>(nl) * mesh->nc, b, st);
+                static_cast<size_t>(nl) * mesh->nc, b, st, 0, W->r0, W->r1);
 }
 
 static int check_coef(const flow_coef* f) {
@@ -1049,24 +1077,35 @@ extern "C" int flow_assemble_momentum(
   FLOW_REQUIRE(prm->dt > 0.0 && prm->rho > 0.0 && prm->mu > 0.0, "parameters");
   hipStream_t st = as_stream(stream);
   const int nl = W->deg == 1 ? 3 : 6;
+  const CellRange cr(mesh);
   if (F) {
     FLOW_REQUIRE(W->vptr && W->vsrc, "vector map");
-    FLOW_DISPATCH_DEG(W->deg, momentum_residual_kernel, cell_grid(mesh->nc), st,
-                      mesh->nc, mesh->xy, W->cell_dofs, W->n, P->cell_dofs,
-                      bfmask, ui, u0, p0, *f0, *f1, *prm, scratch);
+    FLOW_DISPATCH_DEG(W->deg, momentum_residual_kernel, cell_grid(cr.count()),
+                      st, mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n,
+                      P->cell_dofs, bfmask, ui, u0, p0, *f0, *f1, *prm, scratch);
     if ((rc = gather(W->n, 2, W->vptr, W->vsrc, scratch,
-                     static_cast<size_t>(nl) * mesh->nc, F, st)))
+                     static_cast<size_t>(nl) * mesh->nc, F, st, 0, W->r0,
+                     W->r1)))
       return rc;
   }
   if (Jvals) {
     FLOW_REQUIRE(W->cptr && W->csrc && W->nnz > 0, "matrix map");
     FLOW_REQUIRE(j_plane_stride >= (size_t)W->nnz, "Jacobian plane stride");
     FLOW_DISPATCH_DEG(W->deg, momentum_jacobian_kernel,
-                      dim3((mesh->nc + 63) / 64), st, mesh->nc, mesh->xy,
-                      W->cell_dofs, W->n, bfmask, ui, *prm, scratch);
+                      dim3((cr.count() + 63) / 64), st, mesh->nc, cr.cb, cr.ce,
+                      mesh->xy, W->cell_dofs, W->n, bfmask, ui, *prm, scratch);
+    // the nonzeros of the rows [r0, r1) (a host-known range: the caller
+    // passes the row pointer values through the space's row range)
+    int k0 = 0, k1 = W->nnz;
+    if (W->r1 > 0) {
+      FLOW_REQUIRE(W->nnz0 >= 0 && W->nnz0 < W->nnz1 && W->nnz1 <= W->nnz,
+                   "space nonzero range");
+      k0 = W->nnz0;
+      k1 = W->nnz1;
+    }
     hipLaunchKernelGGL(gather_blocks_kernel,
-                       dim3(grid_for(W->nnz, kBlock, 1 << 20)), dim3(kBlock), 0,
-                       st, W->nnz, mesh->nc, nl * nl, W->cptr, W->csrc, scratch,
+                       dim3(grid_for(k1 - k0, kBlock, 1 << 20)), dim3(kBlock), 0,
+                       st, k0, k1, mesh->nc, nl * nl, W->cptr, W->csrc, scratch,
                        j_plane_stride, Jvals);
     FLOW_CHECK_LAUNCH();
   }
@@ -1085,21 +1124,29 @@ int flow::momentum_jvp_check(const flow_momentum_jvp* J) {
   return FLOW_OK;
 }
 
+// v_stride / out_stride: component strides of v and out (0: W->n); both
+// pointers are indexed by GLOBAL row (callers with compact vectors shift them)
 int flow::momentum_jvp_apply(const flow_momentum_jvp* J, const double* v,
-                             double* out, hipStream_t st) {
+                             double* out, hipStream_t st, int v_stride,
+                             int out_stride) {
   const flow_mesh* mesh = J->mesh;
   const flow_space* W = J->W;
   const int nl = W->deg == 1 ? 3 : 6;
+  const int vs = v_stride ? v_stride : W->n;
+  const int os = out_stride ? out_stride : W->n;
+  const CellRange cr(mesh);
   int rc;
-  FLOW_DISPATCH_DEG(W->deg, momentum_jvp_kernel, cell_grid(mesh->nc), st,
-                    mesh->nc, mesh->xy, W->cell_dofs, W->n, J->bfmask, J->ui, v,
-                    J->prm, J->scratch);
+  FLOW_DISPATCH_DEG(W->deg, momentum_jvp_kernel, cell_grid(cr.count()), st,
+                    mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n, vs,
+                    J->bfmask, J->ui, v, J->prm, J->scratch);
   if ((rc = gather(W->n, 2, W->vptr, W->vsrc, J->scratch,
-                   static_cast<size_t>(nl) * mesh->nc, out, st)))
+                   static_cast<size_t>(nl) * mesh->nc, out, st, os, W->r0,
+                   W->r1)))
     return rc;
   if (J->nbc > 0) {
+    const int r0 = W->r1 > 0 ? W->r0 : 0, r1 = W->r1 > 0 ? W->r1 : W->n;
     hipLaunchKernelGGL(bc_copy_kernel, dim3(grid_for(J->nbc)), dim3(kBlock), 0,
-                       st, J->nbc, J->bc_dofs, v, out);
+                       st, J->nbc, J->bc_dofs, W->n, r0, r1, v, vs, out, os);
     FLOW_CHECK_LAUNCH();
   }
   return FLOW_OK;
@@ -1111,7 +1158,7 @@ extern "C" int flow_momentum_jvp_apply(const flow_momentum_jvp* J,
   int rc = momentum_jvp_check(J);
   if (rc) return rc;
   FLOW_REQUIRE(v && out && v != out, "jvp vectors");
-  return momentum_jvp_apply(J, v, out, as_stream(stream));
+  return momentum_jvp_apply(J, v, out, as_stream(stream), 0, 0);
 }
 
 extern "C" int flow_assemble_magnitude(const flow_mesh* mesh, const flow_space* W,
@@ -1123,9 +1170,10 @@ extern "C" int flow_assemble_magnitude(const flow_mesh* mesh, const flow_space* 
   FLOW_REQUIRE(mode == 0 || mode == 1, "mode");
   FLOW_REQUIRE(u && scratch && b && W->vptr && W->vsrc, "pointers");
   hipStream_t st = as_stream(stream);
-  FLOW_DISPATCH_DEG(W->deg, magnitude_kernel, cell_grid(mesh->nc), st, mesh->nc,
-                    mesh->xy, W->cell_dofs, W->n, u, mode, scratch);
-  return gather(W->n, 1, W->vptr, W->vsrc, scratch, 0, b, st);
+  const CellRange cr(mesh);
+  FLOW_DISPATCH_DEG(W->deg, magnitude_kernel, cell_grid(cr.count()), st, mesh->nc,
+                    cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n, u, mode, scratch);
+  return gather(W->n, 1, W->vptr, W->vsrc, scratch, 0, b, st, 0, W->r0, W->r1);
 }
 
 extern "C" int flow_assemble_div_adjoint(const flow_mesh* mesh,

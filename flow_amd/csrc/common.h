@@ -21,7 +21,7 @@ int ilu_check(const flow_ilu* ilu, int op_size);
 // assembly_kernels.hip: the matrix-free operator (flow_operator kind 3)
 int momentum_jvp_check(const flow_momentum_jvp* J);
 int momentum_jvp_apply(const flow_momentum_jvp* J, const double* v, double* out,
-                       hipStream_t st);
+                       hipStream_t st, int v_stride = 0, int out_stride = 0);
 
 #define FLOW_CHECK_HIP(expr)                                                 \
   do {                                                                       \

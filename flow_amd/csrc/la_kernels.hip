@@ -100,11 +100,18 @@ __device__ __forceinline__ double stream_tile_row_sum(
     v[j] = ok ? v2p[p] : make_double2(0.0, 0.0);
     c[j] = ok ? c2p[p] : make_int2(0, 0);
   }
+  // x is only gathered for the tile's OWN nonzeros [k0, k1): the alignment
+  // slack before k0, the odd element behind k1 (a column of another row, or
+  // the padding 0 behind the last nonzero) and the idle lanes must not be
+  // dereferenced -- x may be a window of a larger vector (row-sharded solves
+  // pass x shifted to global row numbering: x[0] is then far outside it)
+  const int lo = k0 - ka, hi = k1 - ka;
   double x0[kPairs], x1[kPairs];
 #pragma unroll
   for (int j = 0; j < kPairs; ++j) {   // all gathers in flight before any use
-    x0[j] = x[c[j].x];
-    x1[j] = x[c[j].y];
+    const int e = 2 * (threadIdx.x + j * kBlock);
+    x0[j] = (e >= lo && e < hi) ? x[c[j].x] : 0.0;
+    x1[j] = (e + 1 < hi) ? x[c[j].y] : 0.0;
   }
 #pragma unroll
   for (int j = 0; j < kPairs; ++j) {
@@ -223,8 +230,10 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
     if (p < npair) {
       const int2 c = c2p[p];
       const double2 axx = pxx[p], axy = pxy[p], ayx = pyx[p], ayy = pyy[p];
-      const double u0 = x[c.x], u1 = x[n + c.x];
-      const double w0 = x[c.y], w1 = x[n + c.y];
+      // (only the tile's own nonzeros are dereferenced)
+      const bool g0 = 2 * p >= k0 - ka, g1 = 2 * p + 1 < k1 - ka;
+      const double u0 = g0 ? x[c.x] : 0.0, u1 = g0 ? x[n + c.x] : 0.0;
+      const double w0 = g1 ? x[c.y] : 0.0, w1 = g1 ? x[n + c.y] : 0.0;
       prod0[2 * p] = axx.x * u0 + axy.x * u1;
       prod1[2 * p] = ayx.x * u0 + ayy.x * u1;
       prod0[2 * p + 1] = axx.y * w0 + axy.y * w1;
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
     int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals, const int* __restrict__ rowblocks,
     const unsigned char* __restrict__ mask, const double* __restrict__ x,
-    double* __restrict__ y, double* __restrict__ dpart,
+    double* __restrict__ y, int xs, double* __restrict__ dpart,
     const double* __restrict__ stop) {
   // ONE product array, used by the two components in turn (two would halve the
   // occupancy: 32 KB of LDS per workgroup)
@@ -287,13 +296,17 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
     v[j] = ok ? v2p[p] : make_double2(0.0, 0.0);
     c[j] = ok ? c2p[p] : make_int2(0, 0);
   }
+  // (only the tile's own nonzeros are dereferenced: see stream_tile_row_sum)
+  const int lo = k0 - ka, hi = k1 - ka;
   double xa[kPairs], xb[kPairs], ua[kPairs], ub[kPairs];
 #pragma unroll
   for (int j = 0; j < kPairs; ++j) {   // all gathers in flight before any use
-    xa[j] = x[c[j].x];
-    xb[j] = x[c[j].y];
-    ua[j] = x[n + c[j].x];
-    ub[j] = x[n + c[j].y];
+    const int e = 2 * (threadIdx.x + j * kBlock);
+    const bool g0 = e >= lo && e < hi, g1 = e + 1 < hi;
+    xa[j] = g0 ? x[c[j].x] : 0.0;
+    xb[j] = g1 ? x[c[j].y] : 0.0;
+    ua[j] = g0 ? x[xs + c[j].x] : 0.0;
+    ub[j] = g1 ? x[xs + c[j].y] : 0.0;
   }
 #pragma unroll
   for (int j = 0; j < kPairs; ++j) {
@@ -319,11 +332,11 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
   for (int k = a; k < b; ++k) s1 += prod[k];
   double t = 0.0;
   if (r < r1) {
-    const double x0 = x[r], x1 = x[n + r];
+    const double x0 = x[r], x1 = x[xs + r];
     if (!mask[r]) s0 = x0;
     if (!mask[n + r]) s1 = x1;
     y[r] = s0;
-    y[n + r] = s1;
+    y[xs + r] = s1;
     if (DOT) t = s0 * x0 + s1 * x1;
   }
   if (DOT) {
@@ -378,25 +391,29 @@ struct SpmvProfile {
 static SpmvProfile g_spmv_profile;
 
 // y = A x; with dpart != nullptr also the dot_parts(A) workgroup shares of x.y
+// vec_stride: component stride of x and y for the two-component kinds 3 and 4
+// (0: A->n); x and y are indexed by global row either way
 static int apply(const flow_operator* A, const double* x, double* y,
                  hipStream_t st, double* dpart = nullptr,
-                 const double* stop = nullptr) {
+                 const double* stop = nullptr, int vec_stride = 0,
+                 int out_stride = 0) {
   if (A->kind == 3) {
     FLOW_REQUIRE(dpart == nullptr, "matrix-free operators carry no fused dot");
     return momentum_jvp_apply(static_cast<const flow_momentum_jvp*>(A->matfree),
-                              x, y, st);
+                              x, y, st, vec_stride, out_stride);
   }
+  const int xs = vec_stride ? vec_stride : A->n;
   const dim3 grid(A->nblocks, A->kind == 1 ? 2 : 1);
   const double* v1 = A->kind == 1 ? A->vals[1] : A->vals[0];
   if (A->kind == 4) {
     if (dpart)
       hipLaunchKernelGGL(spmv_stream_pair_kernel<true>, grid, dim3(kBlock), 0, st,
                          A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
-                         A->rowmask, x, y, dpart, stop);
+                         A->rowmask, x, y, xs, dpart, stop);
     else
       hipLaunchKernelGGL(spmv_stream_pair_kernel<false>, grid, dim3(kBlock), 0,
                          st, A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
-                         A->rowmask, x, y, dpart, stop);
+                         A->rowmask, x, y, xs, dpart, stop);
   } else if (A->kind == 2) {
     if (dpart)
       hipLaunchKernelGGL(spmv_stream_block2_kernel<true>, grid, dim3(kBlock), 0,
@@ -622,12 +639,15 @@ __global__ __launch_bounds__(kScalarBlock) void cg_scalar_kernel(
 // (want_z = 0: z is produced afterwards by the two-level preconditioner)
 // DOTS (needs want_z, gridDim.x <= kRedBlocks): the block's shares of r.z and
 // z.z go to partial[blockIdx.x] / partial[2*kRedBlocks + blockIdx.x].
+// own != nullptr (sharded solves: the vectors cover ghost rows too): the dots
+// only count the entries with own[i] = 1
 template <bool DOTS>
 __global__ __launch_bounds__(kBlock) void cg_update_kernel(
     int n, const double* __restrict__ S, const double* __restrict__ dinv,
     const double* __restrict__ w, double* __restrict__ z, double* __restrict__ p,
     double* __restrict__ s, double* __restrict__ x, double* __restrict__ r,
-    int want_z, double* __restrict__ partial) {
+    int want_z, double* __restrict__ partial,
+    const double* __restrict__ own) {
   if (stopped(S + kDone)) return;
   const double alpha = load_scalar(S + kAlpha);
   const double beta = load_scalar(S + kBeta);
@@ -644,8 +664,8 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(
     if (want_z) {
       const double zi = dinv ? dinv[i] * ri : ri;
       z[i] = zi;
-      if (DOTS) {
-        g += ri * zi;
+      if (DOTS && (!own || own[i] != 0.0)) {   // (select, not multiply:
+        g += ri * zi;                            // ghost entries may be NaN)
         rr += zi * zi;
       }
     }
@@ -823,16 +843,20 @@ static int check_mg(const flow_mg* M, int n) {
   return FLOW_OK;
 }
 
-// z = V-cycle(r) on level 0; gpart != nullptr: the last kernel also leaves the
-// *nparts (= Ps[0].nblocks) workgroup shares of r.z in gpart and z.z in rpart
+// z = V-cycle(r) from level l0 down (l0 = 0: the whole hierarchy; the sharded
+// pressure solve runs the levels >= 1 replicated: l0 = 1, r0 = the summed
+// coarse residual).  gpart != nullptr (l0 = 0 only): the last kernel also
+// leaves the *nparts (= Ps[0].nblocks) workgroup shares of r.z in gpart and z.z
+// in rpart
 static int vcycle(const flow_mg* M, const double* r0, double* z0, hipStream_t st,
                   double* gpart = nullptr, double* rpart = nullptr,
-                  int* nparts = nullptr, const double* stop = nullptr) {
+                  int* nparts = nullptr, const double* stop = nullptr,
+                  int l0 = 0) {
   const int L = M->nlevels;
   int rc;
   double* const none = nullptr;
-  for (int l = 0; l + 1 < L; ++l) {
-    const double* r = l == 0 ? r0 : M->r[l];
+  for (int l = l0; l + 1 < L; ++l) {
+    const double* r = l == l0 ? r0 : M->r[l];
     const flow_operator* A = &M->Ah[l];
     // t = r - Ah r ; r_{l+1} = R t
     hipLaunchKernelGGL((mg_level_kernel<0, false>), dim3(A->nblocks), dim3(kBlock),
@@ -842,14 +866,14 @@ static int vcycle(const flow_mg* M, const double* r0, double* z0, hipStream_t st
       return rc;
   }
   {
-    const double* r = L == 1 ? r0 : M->r[L - 1];
-    double* x = L == 1 ? z0 : M->x[L - 1];
+    const double* r = l0 == L - 1 ? r0 : M->r[L - 1];
+    double* x = l0 == L - 1 ? z0 : M->x[L - 1];
     hipLaunchKernelGGL(coarse_gemv_kernel, dim3(grid_for(M->nc, 4, kMaxGrid)),
                        dim3(kBlock), 0, st, M->nc, M->lda, M->Ainv, r, x, stop);
   }
-  for (int l = L - 2; l >= 0; --l) {
-    const double* r = l == 0 ? r0 : M->r[l];
-    double* x = l == 0 ? z0 : M->x[l];
+  for (int l = L - 2; l >= l0; --l) {
+    const double* r = l == l0 ? r0 : M->r[l];
+    double* x = l == l0 ? z0 : M->x[l];
     const flow_operator* P = &M->Ps[l];
     // x = Ps x_{l+1} + w D^-1 (r + t)
     if (l == 0 && gpart) {
@@ -1036,16 +1060,19 @@ static int cg(const flow_operator* A, const double* dinv,
     for (int k = 0; k < todo; ++k) {
       if (C) {
         hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
-                           st, N, S, dinv, w, z, p, s, x, r, 0, partial);
+                           st, N, S, dinv, w, z, p, s, x, r, 0, partial,
+                           static_cast<const double*>(nullptr));
         if ((rc = two_level(C, dinv, r, z, crc, czc, st, partial, &np, stop)))
           return rc;
       } else if (M) {
         hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
-                           st, N, S, dinv, w, z, p, s, x, r, 0, partial);
+                           st, N, S, dinv, w, z, p, s, x, r, 0, partial,
+                           static_cast<const double*>(nullptr));
         if ((rc = vcycle(M, r, z, st, mpart, mpart + nm, &np, stop))) return rc;
       } else {
         hipLaunchKernelGGL(cg_update_kernel<true>, dim3(gu), dim3(kBlock), 0, st,
-                           N, S, dinv, w, z, p, s, x, r, 1, partial);
+                           N, S, dinv, w, z, p, s, x, r, 1, partial,
+                           static_cast<const double*>(nullptr));
         np = gu;
       }
       if ((rc = apply(A, z, w, st, dpart, stop))) return rc;
@@ -1791,7 +1818,6 @@ extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
             first_check, work, iters_host, resid_host, as_stream(stream));
 }
 
-// pieces of the two-level preconditioner for the row-sharded loop
 // z = V-cycle(r): one application of the multigrid preconditioner (tests, and
 // callers that drive their own Krylov loop)
 extern "C" int flow_mg_apply(const flow_mg* mg, int n, const double* r,
@@ -1800,62 +1826,6 @@ extern "C" int flow_mg_apply(const flow_mg* mg, int n, const double* r,
   int rc = check_mg(mg, n);
   if (rc) return rc;
   return vcycle(mg, r, z, as_stream(stream));
-}
-
-extern "C" int flow_coarse_restrict_dev(const flow_coarse* C, const double* r,
-                                        int r0, int r1, double* rc_out,
-                                        void* stream) {
-  FLOW_REQUIRE(C && r && rc_out && r0 >= 0 && r1 <= C->n && r0 < r1, "restrict");
-  hipLaunchKernelGGL(coarse_restrict_kernel, dim3(grid_for(C->nc, 4, kMaxGrid)),
-                     dim3(kBlock), 0, as_stream(stream), C->nc, C->agg_ptr,
-                     C->agg_dofs, r, r0, r1, rc_out, static_cast<const double*>(nullptr));
-  FLOW_CHECK_LAUNCH();
-  return FLOW_OK;
-}
-
-extern "C" int flow_coarse_solve_dev(const flow_coarse* C, const double* rc_in,
-                                     double* zc, void* stream) {
-  FLOW_REQUIRE(C && rc_in && zc && rc_in != zc, "coarse solve");
-  int rc = check_coarse(C, C->n);
-  if (rc) return rc;
-  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(rc_in) % 16 == 0,
-               "coarse residual must be 16-byte aligned");
-  hipLaunchKernelGGL(coarse_gemv_kernel, dim3(grid_for(C->nc, 4, kMaxGrid)),
-                     dim3(kBlock), 0, as_stream(stream), C->nc, C->lda, C->Ainv,
-                     rc_in, zc, static_cast<const double*>(nullptr));
-  FLOW_CHECK_LAUNCH();
-  return FLOW_OK;
-}
-
-// sigma = omega + beta sigma ; rc -= alpha sigma   (alpha, beta from S):
-// keeps rc = P^T r current by recurrence, so that the restriction travels in
-// the same all-reduce as the dot products (omega = P^T w, w = A z)
-__global__ void coarse_recur_kernel(int nc, const double* __restrict__ S,
-                                    const double* __restrict__ omega,
-                                    double* __restrict__ sigma,
-                                    double* __restrict__ rc) {
-  const double alpha = load_scalar(S + kAlpha);
-  const double beta = load_scalar(S + kBeta);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc;
-       i += gridDim.x * blockDim.x) {
-    const double s = load_scalar(omega + i) + beta * sigma[i];
-    sigma[i] = s;
-    rc[i] -= alpha * s;
-  }
-}
-
-extern "C" int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
-                                       const double* r, const double* zc,
-                                       double* z, int r0, int r1,
-                                       void* stream) {
-  FLOW_REQUIRE(C && dinv && r && zc && z && r0 >= 0 && r1 <= C->n && r0 < r1,
-               "prolong");
-  hipLaunchKernelGGL(coarse_prolong_kernel<false>, dim3(grid_for(r1 - r0)),
-                     dim3(kBlock), 0, as_stream(stream), r1 - r0, C->agg_of + r0,
-                     dinv + r0, r + r0, zc, z + r0,
-                     static_cast<double*>(nullptr), static_cast<const double*>(nullptr));
-  FLOW_CHECK_LAUNCH();
-  return FLOW_OK;
 }
 
 extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
@@ -1900,22 +1870,289 @@ extern "C" int flow_gmres_solve(const flow_operator* A, const double* dinv,
                iters_host, resid_host, as_stream(stream));
 }
 
+
+// ===========================================================================
+// K15: domain decomposition over the GPUs of one node (include/flow_hip.h).
+// One communication primitive -- comm->allreduce: sum of the head of comm->buf
+// over the ranks -- carries the dot products, the partial coarse residuals AND
+// the halos (own slots filled, all others zero: the sum is the concatenation).
+// ===========================================================================
+namespace flow {
+
+static int check_comm(const flow_comm* c, long long need) {
+  FLOW_REQUIRE(c != nullptr && c->allreduce != nullptr && c->buf != nullptr,
+               "communicator");
+  FLOW_REQUIRE(c->world >= 1 && c->world <= kNumSlots && c->rank >= 0 &&
+                   c->rank < c->world,
+               "communicator rank / world (at most 16 ranks)");
+  FLOW_REQUIRE(c->capacity >= need, "exchange buffer too small");
+  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(c->buf) % 16 == 0,
+               "exchange buffer must be 16-byte aligned");
+  return FLOW_OK;
+}
+
+static int check_rows(const flow_rows* R) {
+  FLOW_REQUIRE(R != nullptr, "row ranges are NULL");
+  FLOW_REQUIRE(0 <= R->e0 && R->e0 <= R->r0 && R->r0 < R->r1 && R->r1 <= R->e1 &&
+                   R->e1 <= R->n,
+               "row ranges");
+  FLOW_REQUIRE(R->nhalo >= 0, "halo size");
+  for (int i = 0; i < 2; ++i) {
+    FLOW_REQUIRE(R->send_len[i] >= 0 && R->recv_len[i] >= 0, "halo lengths");
+    FLOW_REQUIRE(R->send_len[i] == 0 ||
+                     (R->send_row[i] >= R->r0 &&
+                      R->send_row[i] + R->send_len[i] <= R->r1 &&
+                      R->send_slot[i] >= 0 &&
+                      R->send_slot[i] + R->send_len[i] <= R->nhalo),
+                 "halo send range");
+    FLOW_REQUIRE(R->recv_len[i] == 0 ||
+                     (R->recv_row[i] >= R->e0 &&
+                      R->recv_row[i] + R->recv_len[i] <= R->e1 &&
+                      (R->recv_row[i] + R->recv_len[i] <= R->r0 ||
+                       R->recv_row[i] >= R->r1) &&
+                      R->recv_slot[i] >= 0 &&
+                      R->recv_slot[i] + R->recv_len[i] <= R->nhalo),
+                 "halo receive range");
+  }
+  return FLOW_OK;
+}
+
+static int exchange(const flow_comm* c, int count) {
+  const int rc = c->allreduce(c->user, count);
+  if (rc != 0) {
+    set_error("the all-reduce callback failed (code %d, %d doubles)", rc, count);
+    return FLOW_HIP_ERROR;
+  }
+  return FLOW_OK;
+}
+
+// halo[a*nhalo + k] <- the own boundary entries of x (global row index,
+// component stride `stride`), zero in everybody else's slots
+__global__ void shard_pack_kernel(flow_rows R, int ncomp,
+                                  const double* __restrict__ x, int stride,
+                                  double* __restrict__ halo) {
+  const int total = ncomp * R.nhalo;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += gridDim.x * blockDim.x) {
+    const int a = t / R.nhalo, k = t - a * R.nhalo;
+    const double* xa = x + static_cast<size_t>(a) * stride;
+    double v = 0.0;
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd)
+      if (k >= R.send_slot[sd] && k < R.send_slot[sd] + R.send_len[sd])
+        v = xa[R.send_row[sd] + (k - R.send_slot[sd])];
+    halo[t] = v;
+  }
+}
+
+// ghost rows of x <- the neighbours' slots of the summed buffer
+__global__ void shard_unpack_kernel(flow_rows R, int ncomp,
+                                    const double* __restrict__ halo,
+                                    double* __restrict__ x, int stride) {
+  const int per = R.recv_len[0] + R.recv_len[1];
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncomp * per;
+       t += gridDim.x * blockDim.x) {
+    const int a = t / per, k = t - a * per;
+    const int sd = k < R.recv_len[0] ? 0 : 1;
+    const int j = sd == 0 ? k : k - R.recv_len[0];
+    x[static_cast<size_t>(a) * stride + R.recv_row[sd] + j] =
+        load_scalar(halo + static_cast<size_t>(a) * R.nhalo + R.recv_slot[sd] + j);
+  }
+}
+
+// x: indexed by global row (x[a*stride + row]); the halo travels at buf + off
+static int halo(const flow_comm* C, const flow_rows* R, int ncomp, double* x,
+                int stride, hipStream_t st) {
+  const int count = ncomp * R->nhalo;
+  if (count == 0) return FLOW_OK;      // a single rank
+  hipLaunchKernelGGL(shard_pack_kernel, dim3(grid_for(count)), dim3(kBlock), 0,
+                     st, *R, ncomp, x, stride, C->buf);
+  FLOW_CHECK_LAUNCH();
+  int rc = exchange(C, count);
+  if (rc) return rc;
+  const int per = R->recv_len[0] + R->recv_len[1];
+  if (per > 0) {
+    hipLaunchKernelGGL(shard_unpack_kernel, dim3(grid_for(ncomp * per)),
+                       dim3(kBlock), 0, st, *R, ncomp, C->buf, x, stride);
+    FLOW_CHECK_LAUNCH();
+  }
+  return FLOW_OK;
+}
+
+// ext-compact <- global-length field (ncomp components), and the ownership mask
+__global__ void shard_compress_kernel(int ncomp, int me, int e0, int n,
+                                      const double* __restrict__ src,
+                                      double* __restrict__ dst) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncomp * me;
+       t += gridDim.x * blockDim.x) {
+    const int a = t / me, i = t - a * me;
+    dst[t] = src[static_cast<size_t>(a) * n + e0 + i];
+  }
+}
+
+__global__ void shard_expand_kernel(int ncomp, int me, int e0, int n,
+                                    const double* __restrict__ src,
+                                    double* __restrict__ dst) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncomp * me;
+       t += gridDim.x * blockDim.x) {
+    const int a = t / me, i = t - a * me;
+    dst[static_cast<size_t>(a) * n + e0 + i] = src[t];
+  }
+}
+
+__global__ void shard_own_kernel(int ncomp, int me, int lo, int hi,
+                                 double* __restrict__ own) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncomp * me;
+       t += gridDim.x * blockDim.x) {
+    const int i = t % me;
+    own[t] = (i >= lo && i < hi) ? 1.0 : 0.0;
+  }
+}
+
+// dst (owned-compact, stride mo, ncomp comps) <-> src (other layout): generic
+// strided 2-D copy  dst[a*ds + i] = src[a*ss + i], i < m
+__global__ void shard_copy2d_kernel(int ncomp, int m, const double* __restrict__ src,
+                                    int ss, double* __restrict__ dst, int ds,
+                                    double scale, int accumulate) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncomp * m;
+       t += gridDim.x * blockDim.x) {
+    const int a = t / m, i = t - a * m;
+    const double v = scale * src[static_cast<size_t>(a) * ss + i];
+    double* d = dst + static_cast<size_t>(a) * ds + i;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+static int copy2d(int ncomp, int m, const double* src, int ss, double* dst,
+                  int ds, hipStream_t st, double scale = 1.0,
+                  int accumulate = 0) {
+  hipLaunchKernelGGL(shard_copy2d_kernel, dim3(grid_for(ncomp * m)), dim3(kBlock),
+                     0, st, ncomp, m, src, ss, dst, ds, scale, accumulate);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+// n doubles of device memory -> the host mailbox
+__global__ void mailbox_copy_kernel(int n, const double* __restrict__ src,
+                                    volatile double* __restrict__ mailbox) {
+  if (threadIdx.x < n) mailbox[threadIdx.x] = load_scalar(src + threadIdx.x);
+  __threadfence_system();
+}
+
+static int read_values(const double* dev, int n, double* host, hipStream_t st) {
+  double *mailbox = nullptr, *dev_view = nullptr;
+  int rc = mailbox_of_thread(&mailbox, &dev_view);
+  if (rc) return rc;
+  FLOW_REQUIRE(n <= kMailbox, "mailbox size");
+  hipLaunchKernelGGL(mailbox_copy_kernel, dim3(1), dim3(64), 0, st, n, dev,
+                     dev_view);
+  FLOW_CHECK_LAUNCH();
+  FLOW_CHECK_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) host[i] = static_cast<volatile double*>(mailbox)[i];
+  return FLOW_OK;
+}
+
+// buf[k] = (k == rank) ? max(v[0..nv)) : 0, k < world
+__global__ void shard_rank_slot_kernel(int world, int rank, int nv,
+                                       const double* __restrict__ v,
+                                       double* __restrict__ buf) {
+  const int k = threadIdx.x;
+  if (k >= world) return;
+  double m = 0.0;
+  if (k == rank)
+    for (int i = 0; i < nv; ++i) m = fmax(m, load_scalar(v + i));
+  buf[k] = m;
+}
+
 // ---------------------------------------------------------------------------
-// building blocks of the row-sharded (multi-GPU) CG: the same kernels, driven
-// by flow_amd/parallel.py with one all-reduce + one halo exchange per iteration
+// sharded CG (Jacobi or multigrid V-cycle), ext-compact vectors
 // ---------------------------------------------------------------------------
-// S <- Chronopoulos-Gear scalars from the (all-reduced) sums in3 =
-// (r.z, z.w, z.z)
-__global__ void cg_scalar_from_sums_kernel(int first,
-                                           const double* __restrict__ in3,
-                                           double* __restrict__ S) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double g = load_scalar(in3), d = load_scalar(in3 + 1),
-               rr = load_scalar(in3 + 2);
+// block 0: the three partial lists -> buf[0..2], buf[3] = *extra (or 0);
+// blocks >= 1: halo slots of w at buf + 4 (own boundary entries, else 0)
+__global__ __launch_bounds__(kScalarBlock) void shard_finish_pack_kernel(
+    flow_rows R, int ncomp, int np, int nd, const double* __restrict__ gpart,
+    const double* __restrict__ rpart, const double* __restrict__ dpart,
+    const double* __restrict__ extra, const double* __restrict__ w, int stride,
+    double* __restrict__ buf, const double* __restrict__ stop) {
+  if (stopped(stop)) return;
+  if (blockIdx.x > 0) {
+    const int total = ncomp * R.nhalo;
+    double* halo = buf + 4;
+    for (int t = (blockIdx.x - 1) * blockDim.x + threadIdx.x; t < total;
+         t += (gridDim.x - 1) * blockDim.x) {
+      const int a = t / R.nhalo, k = t - a * R.nhalo;
+      const double* wa = w + static_cast<size_t>(a) * stride;
+      double v = 0.0;
+#pragma unroll
+      for (int sd = 0; sd < 2; ++sd)
+        if (k >= R.send_slot[sd] && k < R.send_slot[sd] + R.send_len[sd])
+          v = wa[R.send_row[sd] + (k - R.send_slot[sd])];
+      halo[t] = v;
+    }
+    return;
+  }
+  __shared__ double wsum[3][kScalarBlock / 64];
+  double g = 0.0, rr = 0.0, d = 0.0;
+  for (int i = threadIdx.x; i < np; i += kScalarBlock) {
+    g += load_scalar(gpart + i);
+    rr += load_scalar(rpart + i);
+  }
+  for (int i = threadIdx.x; i < nd; i += kScalarBlock) d += load_scalar(dpart + i);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    g += __shfl_down(g, off, 64);
+    d += __shfl_down(d, off, 64);
+    rr += __shfl_down(rr, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    wsum[0][threadIdx.x >> 6] = g;
+    wsum[1][threadIdx.x >> 6] = d;
+    wsum[2][threadIdx.x >> 6] = rr;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    g = d = rr = 0.0;
+    for (int k = 0; k < kScalarBlock / 64; ++k) {
+      g += wsum[0][k];
+      d += wsum[1][k];
+      rr += wsum[2][k];
+    }
+    buf[0] = g;
+    buf[1] = d;
+    buf[2] = rr;
+    buf[3] = extra ? load_scalar(extra) : 0.0;
+  }
+}
+
+// thread 0 of block 0: Chronopoulos-Gear scalars + the stopping test from the
+// summed buf[0..3] (first: the target from buf[3] = |B b|^2), exactly as
+// cg_scalar_kernel; everybody: ghost rows of w <- the neighbours' slots
+__global__ void shard_scalar_unpack_kernel(flow_rows R, int ncomp, int first,
+                                           double rtol2, double atol2,
+                                           const double* __restrict__ buf,
+                                           double* __restrict__ S,
+                                           double* __restrict__ w, int stride) {
+  if (stopped(S + kDone)) return;
+  const int per = R.recv_len[0] + R.recv_len[1];
+  const double* halo = buf + 4;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncomp * per;
+       t += gridDim.x * blockDim.x) {
+    const int a = t / per, k = t - a * per;
+    const int sd = k < R.recv_len[0] ? 0 : 1;
+    const int j = sd == 0 ? k : k - R.recv_len[0];
+    w[static_cast<size_t>(a) * stride + R.recv_row[sd] + j] =
+        load_scalar(halo + static_cast<size_t>(a) * R.nhalo + R.recv_slot[sd] + j);
+  }
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const double g = load_scalar(buf), d = load_scalar(buf + 1),
+               rr = load_scalar(buf + 2);
   double alpha, beta;
   if (first) {
     beta = 0.0;
     alpha = (d != 0.0) ? g / d : 0.0;
+    store_scalar(S + kB2, load_scalar(buf + 3));
+    store_scalar(S + kTarget2, fmax(rtol2 * load_scalar(buf + 3), atol2));
+    store_scalar(S + kIter, 0.0);
   } else {
     const double g_old = load_scalar(S + kGamma);
     const double a_old = load_scalar(S + kAlpha);
@@ -1923,153 +2160,607 @@ __global__ void cg_scalar_from_sums_kernel(int first,
     const double den = (a_old != 0.0) ? d - beta * g / a_old : 0.0;
     alpha = (den != 0.0) ? g / den : 0.0;
   }
+  const double k = first ? 0.0 : load_scalar(S + kIter);
+  const double target2 =
+      first ? fmax(rtol2 * load_scalar(buf + 3), atol2) : load_scalar(S + kTarget2);
+  const bool nan = !(rr == rr);
+  if (nan || rr <= target2) {
+    store_scalar(S + kConvIt, k);
+    store_scalar(S + kDone, nan ? 2.0 : 1.0);
+    alpha = beta = 0.0;
+  }
+  store_scalar(S + kIter, k + 1.0);
   store_scalar(S + kGamma, g);
   store_scalar(S + kAlpha, alpha);
   store_scalar(S + kBeta, beta);
   store_scalar(S + kRes2, rr);
 }
 
-extern "C" int flow_residual_dev(int n, const double* b, const double* q,
-                                 const double* dinv, double* r, double* z,
-                                 void* stream) {
-  FLOW_REQUIRE(n > 0 && b && q && r, "residual");
-  hipLaunchKernelGGL(residual_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
-                     as_stream(stream), n, b, q, dinv, r, z);
+// masked dots of ext-compact vectors: sum own*a0*b0 [, own*a1*b1]
+__global__ __launch_bounds__(kBlock) void shard_dot2_kernel(
+    int n, const double* __restrict__ own, const double* __restrict__ a0,
+    const double* __restrict__ b0, const double* __restrict__ a1,
+    const double* __restrict__ b1, double* __restrict__ p0,
+    double* __restrict__ p1) {
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    if (own[i] != 0.0) {      // select, not multiply: ghost entries may be NaN
+      s0 += a0[i] * b0[i];
+      s1 += a1[i] * b1[i];
+    }
+  }
+  s0 = block_sum(s0);
+  s1 = block_sum(s1);
+  if (threadIdx.x == 0) {
+    p0[blockIdx.x] = s0;
+    p1[blockIdx.x] = s1;
+  }
+}
+
+struct ShardCg {
+  const flow_comm* C;
+  const flow_rows* R;
+  const flow_operator* A;
+  const flow_mg_shard* G;     // nullptr: Jacobi
+  int ncomp, me, m, L;
+  double *partial, *S, *r, *z, *w, *p, *s, *xc, *bc, *dc, *own, *t;
+  double *dpart, *mpart;
+  hipStream_t st;
+  template <class T>
+  T* sh(T* v) const { return v - R->e0; }   // index by global row
+};
+
+// z (owned rows) = V-cycle(r), r ext-compact with current ghosts; two
+// collectives are NOT included: the caller makes z's ghosts current.  One
+// collective here: the partial coarse residuals.  gpart/rpart as vcycle().
+static int shard_vcycle(const ShardCg& c, const double* r, double* z,
+                        double* gpart, double* rpart, int* nparts,
+                        const double* stop) {
+  const flow_mg* M = c.G->mg;
+  const flow_operator* A0 = &c.G->Ah0;
+  const flow_operator* P0 = &c.G->Ps0;
+  const flow_operator* Rg = &c.G->Rg;
+  const int n1 = Rg->n;
+  double* const none = nullptr;
+  int rc;
+  // t = r - Ah r on the owned rows
+  hipLaunchKernelGGL((mg_level_kernel<0, false>), dim3(A0->nblocks), dim3(kBlock),
+                     0, c.st, A0->rowptr, A0->cols, A0->vals[0], A0->rowblocks,
+                     c.sh(r), c.sh(r), none, none, M->omega, c.sh(c.t), none,
+                     none, stop);
+  // the rank's share of the coarse residual -> buf, summed over the ranks
+  if ((rc = apply(Rg, c.t + (c.R->r0 - c.R->e0), c.C->buf, c.st, nullptr, stop)))
+    return rc;
+  if ((rc = exchange(c.C, n1))) return rc;
+  // levels >= 1: replicated
+  if ((rc = vcycle(M, c.C->buf, M->x[1], c.st, nullptr, nullptr, nullptr, stop,
+                   1)))
+    return rc;
+  // z = Ps x_1 + w D^-1 (r + t) on the owned rows
+  if (gpart) {
+    hipLaunchKernelGGL((mg_level_kernel<1, true>), dim3(P0->nblocks), dim3(kBlock),
+                       0, c.st, P0->rowptr, P0->cols, P0->vals[0], P0->rowblocks,
+                       M->x[1], c.sh(r), c.sh(c.t), M->dinv[0], M->omega, c.sh(z),
+                       gpart, rpart, stop);
+    *nparts = P0->nblocks;
+  } else {
+    hipLaunchKernelGGL((mg_level_kernel<1, false>), dim3(P0->nblocks),
+                       dim3(kBlock), 0, c.st, P0->rowptr, P0->cols, P0->vals[0],
+                       P0->rowblocks, M->x[1], c.sh(r), c.sh(c.t), M->dinv[0],
+                       M->omega, c.sh(z), none, none, stop);
+  }
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
 
-// ---------------------------------------------------------------------------
-// One iteration of the row-sharded CG between two all-reduces (flow_cg_shard in
-// include/flow_hip.h).  The all-reduced buffer carries, in ONE collective, the
-// three dot products, the coarse restriction of w AND the boundary entries of
-// w the neighbours need: x, r, p, s and z are kept current on the ghost rows
-// too (same recurrences on identical inputs), so z never has to be exchanged
-// before the SpMV.
-// ---------------------------------------------------------------------------
-// buf halo section <- own boundary entries of w, zero elsewhere; buf[3] <- 0
-__global__ void halo_pack_kernel(int nhalo, int row0, int len0, int slot0,
-                                 int row1, int len1, int slot1,
-                                 const double* __restrict__ w,
-                                 double* __restrict__ halo,
-                                 double* __restrict__ sums) {
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nhalo;
-       k += gridDim.x * blockDim.x) {
-    double v = 0.0;
-    if (k >= slot0 && k < slot0 + len0) v = w[row0 + (k - slot0)];
-    if (k >= slot1 && k < slot1 + len1) v = w[row1 + (k - slot1)];
-    halo[k] = v;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) sums[3] = 0.0;
+static size_t shard_cg_work_len(const flow_rows* R, const flow_operator* A,
+                                const flow_mg_shard* G) {
+  const size_t ncomp = A->kind == 4 ? 2 : 1;
+  const size_t L = ncomp * (R->e1 - R->e0);
+  return FLOW_REDUCE_WORK + (G ? 11 : 10) * L + A->nblocks + 2 +
+         (G ? 2 * static_cast<size_t>(G->Ps0.nblocks) : 0);
 }
 
-// ghost entries of w <- the neighbours' slots of the reduced buffer
-__global__ void halo_unpack_kernel(int row0, int len0, int slot0, int row1,
-                                   int len1, int slot1,
-                                   const double* __restrict__ halo,
-                                   double* __restrict__ w) {
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < len0 + len1;
-       k += gridDim.x * blockDim.x) {
-    if (k < len0) w[row0 + k] = load_scalar(halo + slot0 + k);
-    else w[row1 + (k - len0)] = load_scalar(halo + slot1 + (k - len0));
-  }
-}
+static int shard_cg(const flow_comm* C, const flow_rows* R,
+                    const flow_operator* A, const double* dinv,
+                    const flow_mg_shard* G, const double* b, double* x,
+                    double rtol, double atol, int maxit, int check_every,
+                    int first_check, double* work, int* iters_host,
+                    double* resid_host, hipStream_t st) {
+  ShardCg c;
+  c.C = C;
+  c.R = R;
+  c.A = A;
+  c.G = G;
+  c.st = st;
+  c.ncomp = A->kind == 4 ? 2 : 1;
+  c.me = R->e1 - R->e0;
+  c.m = R->r1 - R->r0;
+  c.L = c.ncomp * c.me;
+  const int L = c.L, me = c.me, n = R->n, ncomp = c.ncomp;
+  c.partial = work;
+  c.S = work + 3 * kRedBlocks;
+  double* v = work + FLOW_REDUCE_WORK;
+  c.r = v;
+  c.z = c.r + L;
+  c.w = c.z + L;
+  c.p = c.w + L;
+  c.s = c.p + L;
+  c.xc = c.s + L;
+  c.bc = c.xc + L;
+  c.dc = c.bc + L;
+  c.own = c.dc + L;
+  c.t = c.own + L;                       // MG only (10 L without it)
+  double* tail = c.own + L + (G ? L : 0);
+  c.dpart = tail;
+  c.mpart = c.dpart + A->nblocks + ((L + A->nblocks) & 1);
+  const int nd = A->nblocks;
+  const int nm = G ? G->Ps0.nblocks : 0;
+  const int gl = grid_for(L);
+  const int gu = grid_for(L, kBlock, kRedBlocks);
+  const double rtol2 = rtol * rtol, atol2 = atol * atol;
+  const double* stop = c.S + kDone;
+  double* const none = nullptr;
+  int rc, np = 0;
 
-static int check_shard(const flow_cg_shard* c) {
-  FLOW_REQUIRE(c != nullptr, "shard context is NULL");
-  int rc = check_operator(c->A);
-  if (rc) return rc;
-  FLOW_REQUIRE(c->A->kind == 0 && c->A->n == c->n, "shard operator");
-  FLOW_REQUIRE(0 <= c->e0 && c->e0 <= c->r0 && c->r0 < c->r1 && c->r1 <= c->e1 &&
-                   c->e1 <= c->n,
-               "shard row ranges");
-  FLOW_REQUIRE(c->dinv && c->x && c->r && c->z && c->w && c->p && c->s && c->S &&
-                   c->buf && c->work,
-               "shard pointers");
-  FLOW_REQUIRE(c->nhalo >= 0, "shard halo size");
-  for (int i = 0; i < 2; ++i) {
-    FLOW_REQUIRE(c->send_len[i] >= 0 && c->recv_len[i] >= 0, "halo lengths");
-    FLOW_REQUIRE(c->send_len[i] == 0 ||
-                     (c->send_row[i] >= c->r0 &&
-                      c->send_row[i] + c->send_len[i] <= c->r1 &&
-                      c->send_slot[i] >= 0 &&
-                      c->send_slot[i] + c->send_len[i] <= c->nhalo),
-                 "halo send range");
-    FLOW_REQUIRE(c->recv_len[i] == 0 ||
-                     (c->recv_row[i] >= c->e0 &&
-                      c->recv_row[i] + c->recv_len[i] <= c->e1 &&
-                      c->recv_slot[i] >= 0 &&
-                      c->recv_slot[i] + c->recv_len[i] <= c->nhalo),
-                 "halo receive range");
-  }
-  if (c->coarse) {
-    if ((rc = check_coarse(c->coarse, c->n))) return rc;
-    FLOW_REQUIRE(c->rc && c->zc && c->sigma, "shard coarse vectors");
-    FLOW_REQUIRE(reinterpret_cast<uintptr_t>(c->rc) % 16 == 0,
-                 "coarse residual must be 16-byte aligned");
-  }
-  return FLOW_OK;
-}
+  // ext-compact copies; ownership mask
+  hipLaunchKernelGGL(shard_compress_kernel, dim3(gl), dim3(kBlock), 0, st, ncomp,
+                     me, R->e0, n, b, c.bc);
+  hipLaunchKernelGGL(shard_compress_kernel, dim3(gl), dim3(kBlock), 0, st, ncomp,
+                     me, R->e0, n, x, c.xc);
+  hipLaunchKernelGGL(shard_compress_kernel, dim3(gl), dim3(kBlock), 0, st, ncomp,
+                     me, R->e0, n, dinv, c.dc);
+  hipLaunchKernelGGL(shard_own_kernel, dim3(gl), dim3(kBlock), 0, st, ncomp, me,
+                     R->r0 - R->e0, R->r1 - R->e0, c.own);
+  if ((rc = fill(kNumSlots, 0.0, c.S, st))) return rc;
+  if ((rc = fill(3 * L, 0.0, c.w, st))) return rc;          // w, p, s
+  FLOW_CHECK_LAUNCH();
 
-extern "C" int flow_cg_shard_step(const flow_cg_shard* c, int phase,
-                                  void* stream) {
-  int rc = check_shard(c);
-  if (rc) return rc;
-  FLOW_REQUIRE(phase >= 0 && phase <= 2, "shard phase");
-  hipStream_t st = as_stream(stream);
-  const flow_coarse* C = c->coarse;
-  const int nc = C ? C->nc : 0;
-  double* sums = c->buf;
-  double* omega = c->buf + 4;
-  double* halo = c->buf + 4 + nc;
-  const int ne = c->e1 - c->e0;
-  if (phase > 0) {
-    // the buffer now holds the global sums, omega = P^T w and the neighbours'
-    // boundary values of w
-    if (c->recv_len[0] + c->recv_len[1] > 0)
-      hipLaunchKernelGGL(halo_unpack_kernel,
-                         dim3(grid_for(c->recv_len[0] + c->recv_len[1])),
-                         dim3(kBlock), 0, st, c->recv_row[0], c->recv_len[0],
-                         c->recv_slot[0], c->recv_row[1], c->recv_len[1],
-                         c->recv_slot[1], halo, c->w);
-    hipLaunchKernelGGL(cg_scalar_from_sums_kernel, dim3(1), dim3(64), 0, st,
-                       phase == 1 ? 1 : 0, sums, c->S);
-    if (C)   // sigma = omega + beta sigma ; rc -= alpha sigma  (rc = P^T r)
-      hipLaunchKernelGGL(coarse_recur_kernel, dim3(grid_for(nc)), dim3(kBlock), 0,
-                         st, nc, c->S, omega, c->sigma, c->rc);
-    // p, s, x, r [, z = dinv r] on the owned AND ghost rows
-    hipLaunchKernelGGL(cg_update_kernel<false>, dim3(grid_for(ne)), dim3(kBlock),
-                       0, st, ne, c->S, c->dinv + c->e0, c->w + c->e0,
-                       c->z + c->e0, c->p + c->e0, c->s + c->e0, c->x + c->e0,
-                       c->r + c->e0, C ? 0 : 1, static_cast<double*>(nullptr));
-    if (C) {
-      hipLaunchKernelGGL(coarse_gemv_kernel, dim3(grid_for(nc, 4, kMaxGrid)),
-                         dim3(kBlock), 0, st, nc, C->lda, C->Ainv, c->rc, c->zc,
-                         static_cast<const double*>(nullptr));
-      hipLaunchKernelGGL(coarse_prolong_kernel<false>, dim3(grid_for(ne)),
-                         dim3(kBlock), 0, st, ne, C->agg_of + c->e0,
-                         c->dinv + c->e0, c->r + c->e0, c->zc, c->z + c->e0,
-                         static_cast<double*>(nullptr), static_cast<const double*>(nullptr));
+  // |B b|^2 over the owned rows -> S[kB2] (this rank's share)
+  if (G) {
+    if ((rc = halo(C, R, 1, c.sh(c.bc), me, st))) return rc;
+    if ((rc = shard_vcycle(c, c.bc, c.z, none, none, nullptr, nullptr)))
+      return rc;
+  } else {
+    hipLaunchKernelGGL(vmul_kernel, dim3(gl), dim3(kBlock), 0, st, L, 1.0, c.dc,
+                       c.bc, c.z);
+  }
+  hipLaunchKernelGGL(shard_dot2_kernel, dim3(gu), dim3(kBlock), 0, st, L, c.own,
+                     c.z, c.z, c.z, c.z, c.partial, c.partial + kRedBlocks);
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, gu, 1, 0,
+                     c.partial, c.S + kB2);
+  FLOW_CHECK_LAUNCH();
+
+  // r = b - A x on the owned rows, then on the ghost rows from their owners
+  if ((rc = halo(C, R, ncomp, c.sh(c.xc), me, st))) return rc;
+  if ((rc = apply(A, c.sh(c.xc), c.sh(c.w), st, nullptr, nullptr, me))) return rc;
+  hipLaunchKernelGGL(residual_kernel, dim3(gl), dim3(kBlock), 0, st, L, c.bc, c.w,
+                     static_cast<const double*>(nullptr), c.r, none);
+  FLOW_CHECK_LAUNCH();
+  if ((rc = halo(C, R, ncomp, c.sh(c.r), me, st))) return rc;
+  // z = B r
+  if (G) {
+    if ((rc = shard_vcycle(c, c.r, c.z, none, none, nullptr, nullptr))) return rc;
+    if ((rc = halo(C, R, 1, c.sh(c.z), me, st))) return rc;
+  } else {
+    hipLaunchKernelGGL(vmul_kernel, dim3(gl), dim3(kBlock), 0, st, L, 1.0, c.dc,
+                       c.r, c.z);
+  }
+  // w = A z (owned rows, z.w partials); r.z, z.z over the owned rows
+  if ((rc = apply(A, c.sh(c.z), c.sh(c.w), st, c.dpart, nullptr, me))) return rc;
+  hipLaunchKernelGGL(shard_dot2_kernel, dim3(gu), dim3(kBlock), 0, st, L, c.own,
+                     c.r, c.z, c.z, c.z, c.partial, c.partial + 2 * kRedBlocks);
+  const int gp = 1 + grid_for(ncomp * R->nhalo > 0 ? ncomp * R->nhalo : 1,
+                              kScalarBlock, 64);
+  const int count = 4 + ncomp * R->nhalo;
+  hipLaunchKernelGGL(shard_finish_pack_kernel, dim3(gp), dim3(kScalarBlock), 0, st,
+                     *R, ncomp, gu, nd, c.partial, c.partial + 2 * kRedBlocks,
+                     c.dpart, c.S + kB2, c.sh(c.w), me, C->buf,
+                     static_cast<const double*>(nullptr));
+  FLOW_CHECK_LAUNCH();
+  if ((rc = exchange(C, count))) return rc;
+
+  const int per = R->recv_len[0] + R->recv_len[1];
+  const int gs = grid_for(ncomp * per > 0 ? ncomp * per : 1);
+  // alpha, beta and the verdict on the start; ghost rows of w
+  hipLaunchKernelGGL(shard_scalar_unpack_kernel, dim3(gs), dim3(kBlock), 0, st, *R,
+                     ncomp, 1, rtol2, atol2, C->buf, c.S, c.sh(c.w), me);
+  FLOW_CHECK_LAUNCH();
+  double state[kNumSlots];
+  int launched = 0;
+  while (true) {
+    const int batch = (launched == 0 && first_check > 0) ? first_check
+                                                         : check_every;
+    const int todo = (maxit - launched < batch) ? maxit - launched : batch;
+    for (int k = 0; k < todo; ++k) {
+      const double *gpart, *rpart;
+      if (G) {
+        hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gl), dim3(kBlock), 0, st,
+                           L, c.S, c.dc, c.w, c.z, c.p, c.s, c.xc, c.r, 0,
+                           c.partial, static_cast<const double*>(nullptr));
+        if ((rc = shard_vcycle(c, c.r, c.z, c.mpart, c.mpart + nm, &np, stop)))
+          return rc;
+        if ((rc = halo(C, R, 1, c.sh(c.z), me, st))) return rc;
+        gpart = c.mpart;
+        rpart = c.mpart + nm;
+      } else {
+        hipLaunchKernelGGL(cg_update_kernel<true>, dim3(gu), dim3(kBlock), 0, st,
+                           L, c.S, c.dc, c.w, c.z, c.p, c.s, c.xc, c.r, 1,
+                           c.partial, c.own);
+        np = gu;
+        gpart = c.partial;
+        rpart = c.partial + 2 * kRedBlocks;
+      }
+      if ((rc = apply(A, c.sh(c.z), c.sh(c.w), st, c.dpart, stop, me))) return rc;
+      hipLaunchKernelGGL(shard_finish_pack_kernel, dim3(gp), dim3(kScalarBlock), 0,
+                         st, *R, ncomp, np, nd, gpart, rpart, c.dpart,
+                         static_cast<const double*>(nullptr), c.sh(c.w), me,
+                         C->buf, stop);
+      FLOW_CHECK_LAUNCH();
+      if ((rc = exchange(C, count))) return rc;
+      hipLaunchKernelGGL(shard_scalar_unpack_kernel, dim3(gs), dim3(kBlock), 0,
+                         st, *R, ncomp, 0, rtol2, atol2, C->buf, c.S, c.sh(c.w),
+                         me);
     }
     FLOW_CHECK_LAUNCH();
+    launched += todo;
+    if ((rc = read_state(c.S, state, st))) return rc;
+    const double res2 = state[kRes2];
+    if (state[kDone] == 2.0 || !(res2 == res2)) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = res2;
+      set_error("sharded CG broke down (NaN residual) at iteration %d",
+                *iters_host);
+      return FLOW_NOT_CONVERGED;
+    }
+    if (state[kDone] == 1.0) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = sqrt(res2);
+      break;
+    }
+    if (launched >= maxit) {
+      *iters_host = launched;
+      *resid_host = sqrt(res2);
+      set_error("sharded CG did not converge in %d iterations: |B r| = %.3e > "
+                "%.3e", launched, sqrt(res2), sqrt(state[kTarget2]));
+      return FLOW_NOT_CONVERGED;
+    }
   }
-  // w = A z on the owned rows (the operator carries the owned row blocks)
-  if ((rc = apply(c->A, c->z, c->w, st))) return rc;
-  const int no = c->r1 - c->r0;
-  int np = 0;
-  if ((rc = dots(no, 3, c->r + c->r0, c->z + c->r0, c->z + c->r0, c->w + c->r0,
-                 c->z + c->r0, c->z + c->r0, c->work, &np, st)))
-    return rc;
-  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 3, 0,
-                     c->work, sums);
-  if (C)
-    hipLaunchKernelGGL(coarse_restrict_kernel, dim3(grid_for(nc, 4, kMaxGrid)),
-                       dim3(kBlock), 0, st, nc, C->agg_ptr, C->agg_dofs, c->w,
-                       c->r0, c->r1, omega, static_cast<const double*>(nullptr));
-  hipLaunchKernelGGL(halo_pack_kernel, dim3(grid_for(c->nhalo > 0 ? c->nhalo : 1)),
-                     dim3(kBlock), 0, st, c->nhalo, c->send_row[0],
-                     c->send_len[0], c->send_slot[0], c->send_row[1],
-                     c->send_len[1], c->send_slot[1], c->w, halo, sums);
+  // x on the owned AND ghost rows (the recurrences ran there too)
+  hipLaunchKernelGGL(shard_expand_kernel, dim3(gl), dim3(kBlock), 0, st, ncomp, me,
+                     R->e0, n, c.xc, x);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// sharded GMRES(m): owned-compact Krylov vectors (2 * (r1 - r0) doubles), the
+// operator's input staged ext-compact with its halo, block-Jacobi ILU(0)
+// ---------------------------------------------------------------------------
+static int shard_gmres(const flow_comm* C, const flow_rows* R,
+                       const flow_operator* A, const flow_ilu* ilu,
+                       const double* b, double* x, double rtol, double atol,
+                       int maxit, int m, int x_is_zero, double* work,
+                       int* iters_host, double* resid_host, hipStream_t st) {
+  const int mo = R->r1 - R->r0;         // owned rows
+  const int me = R->e1 - R->e0;
+  const int n = R->n;
+  const int N = 2 * mo;
+  double* V = work + FLOW_REDUCE_WORK;
+  double* Z = V + static_cast<size_t>(m + 1) * N;
+  double* iwork = Z + static_cast<size_t>(m) * N;
+  double* xc = iwork + N;
+  double* bc = xc + N;
+  double* stage = bc + N;                    // 2 * me, ext-compact
+  double* P = stage + 2 * static_cast<size_t>(me);
+  double* Pww = P + kGmresMax * kRedBlocks;
+  double* Pnn = Pww + kRedBlocks;
+  const int gv = grid_for(N);
+  const int gd = grid_for(N, kBlock, kRedBlocks);
+  int rc;
+
+  // w (owned-compact) = A v (owned-compact): stage, halo, apply on the strip
+  auto apply_owned = [&](const double* v, double* w) -> int {
+    int r;
+    if ((r = copy2d(2, mo, v, mo, stage + (R->r0 - R->e0), me, st))) return r;
+    if ((r = halo(C, R, 2, stage - R->e0, me, st))) return r;
+    return apply(A, stage - R->e0, w - R->r0, st, nullptr, nullptr, me, mo);
+  };
+  // sums of nv partial lists (list k at base + k*kRedBlocks) -> all ranks'
+  // total on the host
+  auto sums_to_host = [&](int nparts, int nd, int extra, double* host) -> int {
+    const int nv = nd + extra;
+    hipLaunchKernelGGL(gmres_finish_kernel, dim3(nv), dim3(kBlock), 0, st, nparts,
+                       nd, P, C->buf);
+    FLOW_CHECK_LAUNCH();
+    int r = exchange(C, nv);
+    if (r) return r;
+    return read_values(C->buf, nv, host, st);
+  };
+
+  if ((rc = copy2d(2, mo, b + R->r0, n, bc, mo, st))) return rc;
+  if (x_is_zero) {
+    if ((rc = fill(N, 0.0, xc, st))) return rc;
+  } else if ((rc = copy2d(2, mo, x + R->r0, n, xc, mo, st))) {
+    return rc;
+  }
+  double host[kGmresMax + 2];
+  double target = 0.0, resid = 0.0;
+  int it = 0;
+  bool have_target = false;
+  while (true) {
+    // r0 = b - A x -> V_0
+    if (x_is_zero && it == 0) {
+      hipLaunchKernelGGL(axpby_kernel, dim3(gv), dim3(kBlock), 0, st, N, 1.0, bc,
+                         0.0, V);
+    } else {
+      if ((rc = apply_owned(xc, iwork))) return rc;
+      hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(kBlock), 0, st, N, bc,
+                         iwork, static_cast<const double*>(nullptr), V,
+                         static_cast<double*>(nullptr));
+    }
+    // |b|^2 and |r0|^2 in one collective (lists 0 and 1 of P)
+    hipLaunchKernelGGL(gmres_dots_kernel<1>, dim3(gd), dim3(kBlock), 0, st, N, bc,
+                       bc, static_cast<size_t>(N), 0, P, Pww);
+    hipLaunchKernelGGL(gmres_dots_kernel<1>, dim3(gd), dim3(kBlock), 0, st, N, V,
+                       V, static_cast<size_t>(N), 0, P + kRedBlocks, Pww);
+    FLOW_CHECK_LAUNCH();
+    if ((rc = sums_to_host(gd, 2, 0, host))) return rc;
+    if (!have_target) {
+      target = fmax(rtol * sqrt(host[0]), atol);
+      have_target = true;
+    }
+    const double res2 = host[1];
+    const double beta = sqrt(res2);
+    resid = beta;
+    if (!(res2 == res2)) {
+      *iters_host = it;
+      *resid_host = res2;
+      set_error("sharded GMRES broke down (NaN residual) at iteration %d", it);
+      return FLOW_NOT_CONVERGED;
+    }
+    if (beta <= target) break;
+    if (it >= maxit) {
+      *iters_host = it;
+      *resid_host = beta;
+      set_error("sharded GMRES did not converge in %d iterations: |r| = %.3e > "
+                "%.3e", it, beta, target);
+      return FLOW_NOT_CONVERGED;
+    }
+
+    double H[kGmresMax][kGmresMax + 1] = {};
+    double nrm[kGmresMax + 1];
+    double eta[kGmresMax];
+    double y[kGmresMax], cf[kGmresMax];
+    nrm[0] = beta;
+    int j = 0;
+    bool converged = false;
+    while (j < m && it < maxit) {
+      double* w = V + static_cast<size_t>(j + 1) * N;
+      double* zj = Z + static_cast<size_t>(j) * N;
+      if ((rc = ilu_apply(ilu, V + static_cast<size_t>(j) * N, zj, iwork, st)))
+        return rc;
+      if ((rc = apply_owned(zj, w))) return rc;
+      for (int k0 = 0; k0 <= j; k0 += 8) {
+        const int chunk = j + 1 - k0 < 8 ? j + 1 - k0 : 8;
+#define FLOW_CALL(NV)                                                         \
+  hipLaunchKernelGGL(gmres_dots_kernel<NV>, dim3(gd), dim3(kBlock), 0, st, N,  \
+                     w, V + static_cast<size_t>(k0) * N,                      \
+                     static_cast<size_t>(N), k0 == 0 ? 1 : 0,                 \
+                     P + k0 * kRedBlocks, Pww)
+        FLOW_NV_SWITCH(chunk, FLOW_CALL)
+#undef FLOW_CALL
+      }
+      FLOW_CHECK_LAUNCH();
+      const int nd = j + 1;
+      if ((rc = sums_to_host(gd, nd, 1 + (j > 0 ? 1 : 0), host))) return rc;
+      if (j > 0) {
+        nrm[j] = sqrt(host[nd + 1]);
+        H[j - 1][j] = eta[j - 1] * nrm[j];
+      }
+      const double ww = host[nd] / (nrm[j] * nrm[j]);
+      double sum = 0.0;
+      const bool bad = !(ww == ww) || !(nrm[j] > 0.0);
+      for (int k = 0; k <= j; ++k) {
+        H[j][k] = host[k] / (nrm[j] * nrm[k]);
+        sum += H[j][k] * H[j][k];
+      }
+      if (bad) {
+        *iters_host = it;
+        *resid_host = resid;
+        set_error("sharded GMRES broke down (NaN) at iteration %d", it);
+        return FLOW_NOT_CONVERGED;
+      }
+      const double e2 = ww - sum;
+      const bool lucky = !(e2 > 1.0e-28 * ww);
+      eta[j] = lucky ? 0.0 : sqrt(e2);
+      H[j][j + 1] = eta[j];
+      ++it;
+      ++j;
+      resid = gmres_least_squares(H, j, beta, y);
+      if (resid <= target || lucky) {
+        converged = true;
+        break;
+      }
+      if (j < m && it < maxit) {
+        const double inv = 1.0 / eta[j - 1];
+        for (int k = 0; k < j; ++k) cf[k] = -H[j - 1][k] * inv / nrm[k];
+        if ((rc = gmres_combine(N, j, cf, inv / nrm[j - 1], w, V, w, Pnn, false,
+                                st)))
+          return rc;
+      }
+    }
+    for (int k = 0; k < j; ++k) cf[k] = y[k] / nrm[k];
+    if ((rc = gmres_combine(N, j, cf, 0.0, nullptr, Z, xc, nullptr, true, st)))
+      return rc;
+    x_is_zero = 0;
+    if (converged) break;
+  }
+  // the owned rows of x
+  if ((rc = copy2d(2, mo, xc, mo, x + R->r0, n, st))) return rc;
+  *iters_host = it;
+  *resid_host = resid;
+  return FLOW_OK;
+}
+
+}  // namespace flow
+
+extern "C" int flow_shard_halo(const flow_comm* comm, const flow_rows* rows,
+                               int ncomp, double* x, int stride, void* stream) {
+  int rc = check_rows(rows);
+  if (rc) return rc;
+  FLOW_REQUIRE(ncomp == 1 || ncomp == 2, "components");
+  if ((rc = check_comm(comm, static_cast<long long>(ncomp) * rows->nhalo)))
+    return rc;
+  FLOW_REQUIRE(x != nullptr && stride >= rows->e1 - rows->e0, "halo vector");
+  return halo(comm, rows, ncomp, x, stride, as_stream(stream));
+}
+
+extern "C" int flow_shard_reduce_host(const flow_comm* comm,
+                                      const flow_rows* rows, int ncomp,
+                                      const double* x, const double* y,
+                                      int stride, int kind, double* work,
+                                      double* result_host, void* stream) {
+  int rc = check_rows(rows);
+  if (rc) return rc;
+  if ((rc = check_comm(comm, kNumSlots))) return rc;
+  FLOW_REQUIRE(ncomp == 1 || ncomp == 2, "components");
+  FLOW_REQUIRE(x && work && result_host && (kind == 1 || y), "reduce arguments");
+  FLOW_REQUIRE(kind == 0 || kind == 1, "reduce kind");
+  hipStream_t st = as_stream(stream);
+  const int m = rows->r1 - rows->r0;
+  const double* x0 = x + rows->r0;
+  const double* x1 = x0 + (ncomp == 2 ? stride : 0);
+  double host[kNumSlots];
+  if (kind == 0) {
+    const double* y0 = y + rows->r0;
+    const double* y1 = y0 + (ncomp == 2 ? stride : 0);
+    int np = 0;
+    if ((rc = dots(m, ncomp, x0, y0, x1, y1, x0, y0, work, &np, st))) return rc;
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, ncomp, 0,
+                       work, comm->buf);
+    FLOW_CHECK_LAUNCH();
+    if ((rc = exchange(comm, ncomp))) return rc;
+    if ((rc = read_values(comm->buf, ncomp, host, st))) return rc;
+    *result_host = host[0] + (ncomp == 2 ? host[1] : 0.0);
+    return FLOW_OK;
+  }
+  double* S = work + 3 * kRedBlocks;
+  const int g = grid_for(m, kBlock * 4, kRedBlocks);
+  for (int a = 0; a < ncomp; ++a) {
+    hipLaunchKernelGGL(absmax_kernel, dim3(g), dim3(kBlock), 0, st, m,
+                       a == 0 ? x0 : x1, work);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, g, 1, 1, work,
+                       S + a);
+  }
+  hipLaunchKernelGGL(shard_rank_slot_kernel, dim3(1), dim3(64), 0, st, comm->world,
+                     comm->rank, ncomp, S, comm->buf);
+  FLOW_CHECK_LAUNCH();
+  if ((rc = exchange(comm, comm->world))) return rc;
+  if ((rc = read_values(comm->buf, comm->world, host, st))) return rc;
+  double mx = 0.0;
+  for (int k = 0; k < comm->world; ++k) mx = fmax(mx, host[k]);
+  *result_host = mx;
+  return FLOW_OK;
+}
+
+static int check_shard_solver(const flow_comm* comm, const flow_rows* rows,
+                              const flow_operator* A, const double* b,
+                              const double* x, double rtol, double atol,
+                              int maxit, const double* work,
+                              const int* iters_host, const double* resid_host) {
+  int rc = check_rows(rows);
+  if (rc) return rc;
+  if ((rc = check_operator(A))) return rc;
+  FLOW_REQUIRE(A->n == rows->n, "operator / row ranges");
+  FLOW_REQUIRE(b && x && work && iters_host && resid_host, "solver pointers");
+  FLOW_REQUIRE(rtol >= 0.0 && atol >= 0.0 && maxit >= 0, "solver tolerances");
+  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(work) % 16 == 0,
+               "solver workspace must be 16-byte aligned");
+  (void)comm;
+  return FLOW_OK;
+}
+
+extern "C" int flow_shard_cg_solve(const flow_comm* comm, const flow_rows* rows,
+                                   const flow_operator* A, const double* dinv,
+                                   const double* b, double* x, double rtol,
+                                   double atol, int maxit, int check_every,
+                                   int first_check, double* work,
+                                   size_t work_len, int* iters_host,
+                                   double* resid_host, void* stream) {
+  int rc = check_shard_solver(comm, rows, A, b, x, rtol, atol, maxit, work,
+                              iters_host, resid_host);
+  if (rc) return rc;
+  FLOW_REQUIRE(A->kind == 0 || A->kind == 4, "sharded CG: operator kind 0 or 4");
+  FLOW_REQUIRE(dinv != nullptr && check_every > 0 && first_check >= 0,
+               "sharded CG arguments");
+  const int ncomp = A->kind == 4 ? 2 : 1;
+  if ((rc = check_comm(comm, 4 + static_cast<long long>(ncomp) * rows->nhalo)))
+    return rc;
+  FLOW_REQUIRE(work_len >= shard_cg_work_len(rows, A, nullptr),
+               "sharded CG workspace too small");
+  return shard_cg(comm, rows, A, dinv, nullptr, b, x, rtol, atol, maxit,
+                  check_every, first_check, work, iters_host, resid_host,
+                  as_stream(stream));
+}
+
+extern "C" int flow_shard_mgcg_solve(
+    const flow_comm* comm, const flow_rows* rows, const flow_operator* A,
+    const double* dinv, const flow_mg_shard* mgs, const double* b, double* x,
+    double rtol, double atol, int maxit, int check_every, int first_check,
+    double* work, size_t work_len, int* iters_host, double* resid_host,
+    void* stream) {
+  int rc = check_shard_solver(comm, rows, A, b, x, rtol, atol, maxit, work,
+                              iters_host, resid_host);
+  if (rc) return rc;
+  FLOW_REQUIRE(A->kind == 0 && dinv != nullptr && check_every > 0 &&
+                   first_check >= 0,
+               "sharded multigrid CG arguments");
+  FLOW_REQUIRE(mgs && mgs->mg, "sharded hierarchy");
+  if ((rc = check_mg(mgs->mg, A->n))) return rc;
+  FLOW_REQUIRE(mgs->mg->nlevels >= 2, "multigrid: at least two levels");
+  if ((rc = check_operator(&mgs->Ah0))) return rc;
+  if ((rc = check_operator(&mgs->Ps0))) return rc;
+  if ((rc = check_operator(&mgs->Rg))) return rc;
+  FLOW_REQUIRE(mgs->Ah0.kind == 0 && mgs->Ps0.kind == 0 && mgs->Rg.kind == 0 &&
+                   mgs->Ah0.n == A->n && mgs->Ps0.n == A->n &&
+                   mgs->Rg.n == mgs->mg->R[0].n,
+               "sharded hierarchy operators");
+  long long need = 4 + rows->nhalo;
+  if (mgs->Rg.n > need) need = mgs->Rg.n;
+  if ((rc = check_comm(comm, need))) return rc;
+  FLOW_REQUIRE(work_len >= shard_cg_work_len(rows, A, mgs),
+               "sharded multigrid CG workspace too small");
+  return shard_cg(comm, rows, A, dinv, mgs, b, x, rtol, atol, maxit, check_every,
+                  first_check, work, iters_host, resid_host, as_stream(stream));
+}
+
+extern "C" int flow_shard_gmres_solve(
+    const flow_comm* comm, const flow_rows* rows, const flow_operator* A,
+    const flow_ilu* ilu, const double* b, double* x, double rtol, double atol,
+    int maxit, int restart, int x_is_zero, double* work, size_t work_len,
+    int* iters_host, double* resid_host, void* stream) {
+  int rc = check_shard_solver(comm, rows, A, b, x, rtol, atol, maxit, work,
+                              iters_host, resid_host);
+  if (rc) return rc;
+  FLOW_REQUIRE(A->kind == 3, "sharded GMRES: the matrix-free Jacobian action");
+  FLOW_REQUIRE(restart >= 1 && restart <= FLOW_GMRES_MAX_RESTART,
+               "GMRES restart length");
+  const flow_momentum_jvp* J = static_cast<const flow_momentum_jvp*>(A->matfree);
+  FLOW_REQUIRE(J->W->r0 == rows->r0 && J->W->r1 == rows->r1,
+               "the operator's row range must be the rank's owned rows");
+  const int mo = rows->r1 - rows->r0, me = rows->e1 - rows->e0;
+  FLOW_REQUIRE(ilu != nullptr, "sharded GMRES needs the block-Jacobi ILU(0)");
+  if ((rc = ilu_check(ilu, 2 * mo))) return rc;
+  long long need = 2LL * rows->nhalo;
+  if (need < FLOW_GMRES_MAX_RESTART + 2) need = FLOW_GMRES_MAX_RESTART + 2;
+  if ((rc = check_comm(comm, need))) return rc;
+  FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK +
+                               (2 * static_cast<size_t>(restart) + 4) * 2 * mo +
+                               2 * static_cast<size_t>(me) + FLOW_GMRES_PARTIALS,
+               "sharded GMRES workspace too small");
+  return shard_gmres(comm, rows, A, ilu, b, x, rtol, atol, maxit, restart,
+                     x_is_zero, work, iters_host, resid_host, as_stream(stream));
 }

@@ -61,11 +61,30 @@ class IluPlan(object):
     slice_offset + 64 k + i, fully coalesced, and sums its row in registers.
     Pad entries carry value 0 and column 0 (a finished row of colour 0).'''
 
-    def __init__(self, layout):
+    def __init__(self, layout, rows=None):
+        '''rows = (r0, r1): the plan of the diagonal block of those rows (the
+        block-Jacobi ILU(0) of a strip, flow_amd/parallel.py): local numbering
+        row - r0, couplings to columns outside the block dropped; the factor
+        still reads its entries from the FULL value planes of the layout's
+        pattern (src_pos points there).'''
         rowptr = layout.pattern('rowptr').astype(numpy.int64)
         cols = layout.pattern('cols').astype(numpy.int64)
         n = layout.N
         nnz = layout.nnz
+        src_index = None
+        if rows is not None:
+            r0, r1 = rows
+            k0, k1 = int(rowptr[r0]), int(rowptr[r1])
+            seg = cols[k0:k1]
+            keep = (seg >= r0) & (seg < r1)
+            row_of = numpy.repeat(numpy.arange(r0, r1), numpy.diff(rowptr[r0:r1 + 1]))
+            src_index = (numpy.nonzero(keep)[0] + k0).astype(numpy.int64)
+            cols = seg[keep] - r0
+            n = r1 - r0
+            rowptr = numpy.zeros(n + 1, dtype=numpy.int64)
+            numpy.cumsum(numpy.bincount(row_of[keep] - r0, minlength=n),
+                         out=rowptr[1:])
+            nnz = len(cols)
         colour, nc = colour_graph(rowptr, cols)
         rows = numpy.repeat(numpy.arange(n, dtype=numpy.int64),
                             numpy.diff(rowptr))
@@ -141,7 +160,8 @@ class IluPlan(object):
             'rowptr': p_rowptr.astype(numpy.int32),
             'cols': p_cols.astype(numpy.int32),
             'diag': diag.astype(numpy.int32),
-            'src_pos': order.astype(numpy.int32),
+            'src_pos': (order if src_index is None
+                        else src_index[order]).astype(numpy.int32),
             'old_of_new': old_of_new.astype(numpy.int32),
             'new_of_old': new_of_old.astype(numpy.int32),
             'sl_row': sl_row.astype(numpy.int32),
@@ -186,8 +206,8 @@ class Ilu0(object):
     the couplings between the velocity components are left to the Krylov
     method.  `refactor(A)` re-uses the buffers.'''
 
-    def __init__(self, A):
-        self.plan = plan_for(A.layout)
+    def __init__(self, A, plan=None):
+        self.plan = plan if plan is not None else plan_for(A.layout)
         self.planes = {0: [0], 1: [0, 1], 2: [0, 3]}[A.kind]
         self.lu = device.zeros(len(self.planes) * self.plan.lu_size)
         self.struct = _hip.IluS(
@@ -198,7 +218,6 @@ class Ilu0(object):
 
     def refactor(self, A):
         lib = _hip.lib()
-        assert plan_for(A.layout) is self.plan
         nb = len(self.planes)
         _hip.check(lib.flow_ilu0_factor(
             ctypes.byref(self.plan.struct), nb,

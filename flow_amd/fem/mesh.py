@@ -253,6 +253,12 @@ def rectangle_with_hole(
         (cen[:, 0] - centre[0])**2 + (cen[:, 1] - centre[1])**2 > radius**2
         )
     cells = cells[keep]
+    # cells in the order of their lowest vertex: x-major like the vertices, so
+    # that neighbouring threads of the cell kernels (one cell each) touch
+    # neighbouring dofs, the contribution lists of a row point to neighbouring
+    # scratch entries, and a strip of the domain is a contiguous cell range
+    # (flow_amd/parallel.py)
+    cells = cells[numpy.argsort(cells.min(axis=1), kind='stable')]
     # drop unused vertices, keeping the x-major order
     used = numpy.zeros(len(pts), dtype=bool)
     used[cells.ravel()] = True

@@ -102,6 +102,7 @@ class Multigrid(object):
         self.levels = []          # device operators Ah, Ps, R + dinv, t per level
         self.host_levels = []     # keep_host: scipy (A, D, P) for the tests
         self.sizes = [n]
+        self.R0_host = None
         rng = numpy.random.RandomState(1)
         self.fine = A
         while Ah.shape[0] > coarsest and len(self.levels) < _hip.MG_MAX_LEVELS - 1:
@@ -136,6 +137,10 @@ class Multigrid(object):
                 ))
             if keep_host:
                 self.host_levels.append((Ah, D, P))
+            if not self.levels[1:]:
+                # the finest restriction, for the strip-sharded cycle
+                # (flow_amd/parallel.py cuts it by columns)
+                self.R0_host = R
             cnt = numpy.bincount(agg[idx], minlength=nc)
             x = numpy.stack([
                 numpy.bincount(agg[idx], weights=x[idx, d], minlength=nc) / cnt

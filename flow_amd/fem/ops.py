@@ -218,17 +218,23 @@ class MomentumJacobian(object):
     assembled.  Quacks like a Matrix for krylov_solve ('bicgstab').'''
     kind = 3
 
-    def __init__(self, W, bfmask, ui, prm, bc_dofs):
+    def __init__(self, W, bfmask, ui, prm, bc_dofs, mesh_s=None, space_s=None):
+        '''mesh_s / space_s: a rank's views of the mesh and space structs
+        (cell and row ranges: flow_amd/parallel.py); default: everything.'''
         mesh = W.mesh()
         self.layout = W.layout
         self.size = W.size()
         n2 = self.size
         nc = mesh.num_cells()
+        if mesh_s is None:
+            mesh_s = mesh_struct(mesh)
+        if space_s is None:
+            space_s = space_struct(W.layout)
         self._keep = (bfmask, ui, bc_dofs,
-                      device.empty(2 * W.layout.nloc * nc))
+                      device.empty(2 * W.layout.nloc * nc), mesh_s, space_s)
         self.struct = _hip.MomentumJvp(
-            ctypes.pointer(mesh_struct(mesh)),
-            ctypes.pointer(space_struct(W.layout)),
+            ctypes.pointer(mesh_s),
+            ctypes.pointer(space_s),
             _hip.i32(bfmask, nc, 'bfmask'), _hip.f64(ui, n2, 'ui'), prm,
             _hip.f64(self._keep[3]), int(bc_dofs.numel()),
             _hip.i32(bc_dofs) if bc_dofs.numel() else None,
@@ -574,16 +580,19 @@ def project_magnitude(u, mode=0, tol=1.0e-12, initial_guess=None):
     `project(abs(ux) + abs(uy), Q)` (mode 1; tests/test_boussinesq.py:268-272)
     for a vector field u of degree k.  `initial_guess`: a previous projection
     to start the mass solve from (step-size controllers call this every step).'''
+    from .. import parallel
     lib = _hip.lib()
     W = u.function_space()
     assert W.dim == 2
     mesh = W.mesh()
     lay = W.layout
     S = W.collapse()
-    b = device.empty(lay.N)
+    strips = parallel.active()
+    b = device.zeros(lay.N)
     buf = scratch(mesh, lay.nloc * mesh.num_cells())
     _hip.check(lib.flow_assemble_magnitude(
-        ctypes.byref(mesh_struct(mesh)), ctypes.byref(space_struct(lay)),
+        ctypes.byref(parallel.mesh_view(mesh) if strips else mesh_struct(mesh)),
+        ctypes.byref(parallel.view(lay).space if strips else space_struct(lay)),
         int(mode), _hip.f64(u.data, 2 * lay.N), _hip.f64(buf), _hip.f64(b),
         _hip.stream()
         ))
@@ -594,10 +603,14 @@ def project_magnitude(u, mode=0, tol=1.0e-12, initial_guess=None):
     out = Function(S)
     if initial_guess is not None:
         out.assign(initial_guess)
-    out.solve_info = krylov_solve(
-        'cg', M, b, out.data, tol, maxit=1000, dinv=lay._dev[key],
-        check_every=2,
-        tag='project_magnitude' if initial_guess is not None else None)
+    tag = 'project_magnitude' if initial_guess is not None else None
+    if strips:
+        out.solve_info = parallel.cg(M, lay._dev[key], b, out.data, tol,
+                                     maxit=1000, check_every=2, tag=tag)
+    else:
+        out.solve_info = krylov_solve(
+            'cg', M, b, out.data, tol, maxit=1000, dinv=lay._dev[key],
+            check_every=2, tag=tag)
     return out
 
 

@@ -15,6 +15,7 @@ from __future__ import print_function
 
 from . import fem
 from . import navier_stokes
+from . import parallel
 
 X0, X1 = 0.0, 0.6
 Y0, Y1 = -0.07, 0.07
@@ -198,7 +199,11 @@ class KarmanProblem(object):
             info['projection_iterations'] = umag.solve_info.iterations
             if mode is not None:
                 self._umag_start.report(mode, umag.solve_info.iterations)
-            unorm = umag.vector().norm('linf')
+            if parallel.active():
+                unorm = parallel.norm_linf(
+                    umag.data, umag.function_space().layout)
+            else:
+                unorm = umag.vector().norm('linf')
             target_dt = 1.0 * self.hmax / unorm
             alpha = 0.5
             self.dt = min(

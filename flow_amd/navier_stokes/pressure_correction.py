@@ -22,9 +22,8 @@ to dolfin/PETSc, this module calls the HIP kernels of libflow_hip.so:
                        (K1), right-hand side kernel (K2), CG + a smoothed-
                        aggregation V-cycle instead of CG + BoomerAMG; Dirichlet
                        branch with symmetric elimination (CG from p0), Neumann
-                       branch without null-space handling, from x0 = 0 as in
-                       the reference (mode 'parity') or from p0 minus its mean
-                       (mode 'fast');
+                       branch without null-space handling, from p0 minus its
+                       mean (sum zero like the reference's x0 = 0);
   velocity correction  vector mass system (reference :436-465): cached mass
                        matrix (K3), right-hand side kernel (K4), CG + Jacobi.
 
@@ -97,7 +96,10 @@ solver_parameters = {
     # the two-level scheme below
     # 'extrapolate' (mode 'fast'): start vectors extrapolated in time
     'pressure': {'maxit': 200000, 'check_every': 10, 'two_level': True,
-                 'multigrid': True, 'coarse_size': 4096, 'extrapolate': False},
+                 'multigrid': True, 'coarse_size': 4096, 'extrapolate': False,
+                 # rows below which the multigrid hierarchy stops coarsening
+                 # (dense inverse there)
+                 'mg_coarsest': 4200},
     'correction': {'maxit': 10000, 'check_every': 2, 'extrapolate': False},
     }
 
@@ -128,6 +130,8 @@ def set_mode(name):
 
 
 def _uses_history():
+    if parallel.active():      # the strips run the parity path only
+        return False
     return (solver_parameters['newton'].get('initial_guess') == 'best'
             or solver_parameters['pressure'].get('extrapolate', False)
             or solver_parameters['correction'].get('extrapolate', False))
@@ -173,6 +177,18 @@ def _bc_arrays(bcs, size):
 _BC_UPLOADS = {}
 
 
+def _mesh_s(mesh):
+    '''flow_mesh of the whole mesh, or of the calling rank's cells when the
+    step runs on the strips of flow_amd.parallel.'''
+    return parallel.mesh_view(mesh) if parallel.active() \
+        else ops.mesh_struct(mesh)
+
+
+def _space_s(layout):
+    return parallel.view(layout).space if parallel.active() \
+        else ops.space_struct(layout)
+
+
 def _bc_mask(dofs, n, comp=None):
     '''uint8 mask of length n for the dofs of component `comp`.'''
     mask = numpy.zeros(n, dtype=numpy.uint8)
@@ -197,6 +213,9 @@ def _compute_tentative_velocity(
     assert time_step_method in _THETA, time_step_method
     theta_i, theta_e = _THETA[time_step_method]
     alpha = 1.0
+    if parallel.active():
+        return _tentative_velocity_on_strips(
+            u, p0, f, u_bcs, theta_i, theta_e, rho, mu, dt, tol), alpha
     W = u[0].function_space()
     P = p0.function_space()
     mesh = W.mesh()
@@ -425,6 +444,131 @@ def _compute_tentative_velocity(
     return ui, alpha
 
 
+def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
+                                  dt, tol):
+    '''The Newton iteration of _compute_tentative_velocity on the x-strips of
+    flow_amd.parallel: the same path (start u0, near-exact steps, stop at
+    ||F|| < tol), every rank on its cells and rows.  Residual and Jacobian
+    action are evaluated over the rank's cells and gathered for its owned
+    rows; the linear systems are solved by GMRES with the rank's own ILU(0)
+    (block Jacobi); ||F|| is the norm over all ranks.  Fields are valid on the
+    owned + ghost rows on entry and on exit.'''
+    lib = _hip.lib()
+    W = u[0].function_space()
+    P = p0.function_space()
+    mesh = W.mesh()
+    lay = W.layout
+    nc = mesh.num_cells()
+    n2 = W.size()
+    npar = solver_parameters['newton']
+    assert npar.get('preconditioner', 'ilu0') == 'ilu0' and \
+        npar.get('linear_solver', 'gmres') == 'gmres', \
+        'the strips run GMRES + block-Jacobi ILU(0)'
+    ms = parallel.mesh_view(mesh)
+    wv = parallel.view(lay)
+    pv = parallel.view(P.layout)
+    ui = Function(W)
+    ui.assign(u[0])
+    f0 = as_cell_coefficient(f[0], mesh, 2)
+    f1 = as_cell_coefficient(f[1], mesh, 2)
+    f0s, keep0 = ops.coef_struct(f0, mesh, lay.degree)
+    f1s, keep1 = ops.coef_struct(f1, mesh, lay.degree)
+    prm = _hip.NsParams(dt, rho, mu, theta_i, theta_e)
+    bc_dofs_host, bc_dofs, bc_vals = _bc_arrays(u_bcs, n2)
+    nbc = bc_dofs.numel()
+    bfmask = mesh._cache.get('bfmask_dev')
+    if bfmask is None:
+        bfmask = device.to_device(mesh.cell_bfacet_mask())
+        mesh._cache['bfmask_dev'] = bfmask
+    J = lay._dev.get('jacobian')
+    if J is None:
+        J = ops.Matrix(lay, 2)
+        lay._dev['jacobian'] = J
+    F = device.zeros(n2)
+    dx = device.zeros(n2)
+    buf = ops.scratch(mesh, max(2 * lay.nloc, 4 * lay.nloc**2) * nc)
+    st = _hip.stream()
+
+    def assemble(want_f, want_j):
+        _hip.check(lib.flow_assemble_momentum(
+            ctypes.byref(ms), ctypes.byref(wv.space), ctypes.byref(pv.space),
+            _hip.i32(bfmask, nc, 'bfmask'), _hip.f64(ui.data, n2),
+            _hip.f64(u[0].data, n2), _hip.f64(p0.data, P.size()),
+            ctypes.byref(f0s), ctypes.byref(f1s), ctypes.byref(prm),
+            _hip.f64(buf), _hip.f64(F, n2) if want_f else None,
+            _hip.f64(J.vals, 4 * J.stride) if want_j else None, J.stride, st
+            ))
+
+    history = []
+    applications = []
+    linear_its = []
+    it = 0
+    Jop = None
+    key = (rho, mu, theta_i, nbc, hash(bc_dofs_host.tobytes()),
+           parallel.comm().world)
+    while True:
+        assemble(True, False)
+        _hip.check(lib.flow_bc_residual(
+            nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(ui.data),
+            _hip.f64(F), st
+            ))
+        nrm = numpy.sqrt(parallel.dot(F, F, lay, 2))
+        history.append(nrm)
+        info('Newton iteration %d: r (abs) = %.3e (tol = %.3e)' % (it, nrm, tol))
+        if nrm < tol:
+            break
+        if it >= npar['maximum_iterations'] or not numpy.isfinite(nrm):
+            raise RuntimeError(
+                'Newton solver did not converge after %d iterations '
+                '(residual history %r)' % (it, history)
+                )
+        # lagged block-Jacobi ILU(0), refactored by the same rules as on one
+        # GPU; `stale` is decided from the iteration count, which is the same
+        # on every rank
+        pre = lay._dev.get('jacobian_ilu_strip')
+        refactored = False
+        if pre is None or pre.key != key or pre.stale or (
+                it == 0 and not (1.0 / npar['ilu_lag'] <= dt / pre.dt
+                                 <= npar['ilu_lag'])):
+            assemble(False, True)
+            _hip.check(lib.flow_bc_identity_rows(
+                ctypes.byref(J.operator()), _hip.f64(J.vals),
+                _hip.i32(lay.dev('diag_idx')), nbc, _hip.i32(bc_dofs), st
+                ))
+            if pre is None:
+                pre = parallel.local_ilu(J)
+                lay._dev['jacobian_ilu_strip'] = pre
+            else:
+                pre.refactor(J)
+            pre.dt, pre.key, pre.stale = dt, key, False
+            refactored = True
+        if Jop is None:
+            Jop = ops.MomentumJacobian(W, bfmask, ui.data, prm, bc_dofs,
+                                       mesh_s=ms, space_s=wv.space)
+        lin_atol = max(npar['linear_atol_factor'] * tol, npar['forcing'] * nrm)
+        lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
+        ops.fill(dx, 0.0)
+        sol = parallel.gmres(Jop, pre, F, dx, rtol=lin_rtol, atol=0.0,
+                             maxit=npar['linear_maxit'],
+                             restart=npar['gmres_restart'], x_is_zero=True)
+        its = (sol.iterations + 1) // 2
+        applications.append(sol.iterations)
+        linear_its.append(its)
+        if refactored:
+            pre.base_its = max(its, npar['check_every'])
+        elif its > 2 * pre.base_its:
+            pre.stale = True
+        # (dx is zero outside the owned rows)
+        ops.axpby(-1.0, dx, 1.0, ui.data)
+        parallel.halo(ui.data, lay, 2)
+        it += 1
+    del keep0, keep1
+    last_step_info['newton_residuals'] = history
+    last_step_info['newton_linear_iterations'] = linear_its
+    last_step_info['newton_linear_applications'] = applications
+    return ui
+
+
 def _bicgstab_with_restarts(A, b, x, rtol, pre, npar):
     '''BiCGStab can stagnate when its bi-orthogonality degrades: restart from
     the current iterate every `restart` iterations (x is updated in place also
@@ -452,10 +596,14 @@ def _pressure_cg(A, dinv, prec, b, x, tol, par):
     flow_amd.parallel is enabled and the system is large enough for that to pay
     (parallel.min_rows()).'''
     coarse, mg = prec
-    if parallel.active(A.size):
-        return parallel.pressure_cg(
-            A, dinv, coarse, b, x, tol, 0.0, par['maxit'], par['check_every']
-            )
+    if parallel.active():
+        if mg is not None:
+            # the same V-cycle, finest level cut into the ranks' strips
+            return parallel.mgcg(A, dinv, mg, b, x, tol, 0.0, par['maxit'],
+                                 check_every=2, tag='pressure')
+        # (a system too small to coarsen: plain Jacobi-CG on the strips)
+        return parallel.cg(A, dinv, b, x, tol, 0.0, par['maxit'],
+                           check_every=par['check_every'], tag='pressure')
     return ops.krylov_solve(
         'cg', A, b, x, rtol=tol, atol=0.0, maxit=par['maxit'], dinv=dinv,
         check_every=2 if mg is not None else par['check_every'],
@@ -470,11 +618,12 @@ def _preconditioner(lay, key, A, isbc, singular, par):
     for plain Jacobi ('two_level': False).  Built once per (operator, BC set).'''
     if not par.get('two_level', False):
         return None, None
-    if par.get('multigrid', True) and not parallel.active(A.size):
-        mkey = ('mg', key)
+    if par.get('multigrid', True):
+        mkey = ('mg', key, par.get('mg_coarsest', 4200))
         if mkey not in lay._dev:
             from ..fem.multigrid import Multigrid
-            lay._dev[mkey] = Multigrid(A, isbc, singular=singular)
+            lay._dev[mkey] = Multigrid(A, isbc, singular=singular,
+                                       coarsest=par.get('mg_coarsest', 4200))
         if lay._dev[mkey].nlevels >= 2:
             return None, lay._dev[mkey]
     ckey = ('coarse', key, par['coarse_size'])
@@ -513,16 +662,18 @@ def _compute_pressure(
     hist = _history(W.layout) if par.get('extrapolate', False) else None
     # The reference starts its Krylov solve from a fresh (zero) Function
     # (:313).  With Dirichlet conditions the solution is unique and p0 is the
-    # natural start of an incremental scheme (same stopping test
-    # ||r|| <= tol ||b||, a state of rest stays exactly at rest).  Without
-    # them the constant the singular system leaves open is the start's: zero
-    # like the reference's in mode 'parity'; p0 minus its (Euclidean) mean in
-    # mode 'fast', so that no constant accumulates from step to step.
-    if p_bcs or solver_parameters['mode'] != 'parity':
+    # natural start of an incremental scheme (same stopping test, a state of
+    # rest stays exactly at rest).  Without them the constant the singular
+    # system leaves open is the start's: p0 minus its (Euclidean) mean -- sum
+    # zero like the reference's zero start, so that no constant accumulates
+    # from step to step, and still exact on a state of rest.
+    if True:
         p1.assign(p0)
         if not p_bcs:
             one = device.zeros(P.N) + 1.0
-            ops.axpby(-ops.dot(one, p1.data) / P.N, one, 1.0, p1.data)
+            total = parallel.dot(one, p1.data, lay) if parallel.active() \
+                else ops.dot(one, p1.data)
+            ops.axpby(-total / P.N, one, 1.0, p1.data)
     if hist is not None and 'p_in' in hist and 0.7 <= dt / hist['dt'] <= 1.5:
         # ... extrapolated through the previous pressures when this call
         # continues the previous step's trajectory at a settled step size
@@ -548,12 +699,11 @@ def _compute_pressure(
             ops.axpby(r, p0.data, 1.0, p1.data)
             ops.axpby(-r, hist['p_in'], 1.0, p1.data)
     K = ops.assemble_stiffness(P)
-    b = device.empty(P.N)
+    b = device.zeros(P.N)
     buf = ops.scratch(mesh, 3 * nc)
     _hip.check(lib.flow_assemble_pressure_rhs(
-        ctypes.byref(ops.mesh_struct(mesh)),
-        ctypes.byref(ops.space_struct(W.layout)),
-        ctypes.byref(ops.space_struct(lay)), _hip.f64(ui.data, W.size()),
+        ctypes.byref(_mesh_s(mesh)), ctypes.byref(_space_s(W.layout)),
+        ctypes.byref(_space_s(lay)), _hip.f64(ui.data, W.size()),
         _hip.f64(p0.data, P.N), alpha * rho / dt, mu, int(rotational_form),
         _hip.f64(buf), _hip.f64(b, P.N), st
         ))
@@ -617,11 +767,11 @@ def _compute_velocity_correction(
     n2 = W.size()
     st = _hip.stream()
 
-    b = device.empty(n2)
+    b = device.zeros(n2)
     buf = ops.scratch(mesh, 2 * lay.nloc * nc)
     _hip.check(lib.flow_assemble_correction_rhs(
-        ctypes.byref(ops.mesh_struct(mesh)), ctypes.byref(ops.space_struct(lay)),
-        ctypes.byref(ops.space_struct(P.layout)), _hip.f64(ui.data, n2),
+        ctypes.byref(_mesh_s(mesh)), ctypes.byref(_space_s(lay)),
+        ctypes.byref(_space_s(P.layout)), _hip.f64(ui.data, n2),
         _hip.f64(p1.data, P.N), _hip.f64(p0.data, P.N), dt / rho, mu,
         int(rotational_form), _hip.f64(buf), _hip.f64(b, n2), st
         ))
@@ -669,10 +819,14 @@ def _compute_velocity_correction(
                 nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(vec), st
                 ))
     par = solver_parameters['correction']
-    sol = ops.krylov_solve(
-        'cg', Mbc, b, u1.data, rtol=tol, atol=0.0, maxit=par['maxit'],
-        dinv=dinv, check_every=par['check_every'], tag='correction'
-        )
+    if parallel.active():
+        sol = parallel.cg(Mbc, dinv, b, u1.data, tol, 0.0, par['maxit'],
+                          check_every=par['check_every'], tag='correction')
+    else:
+        sol = ops.krylov_solve(
+            'cg', Mbc, b, u1.data, rtol=tol, atol=0.0, maxit=par['maxit'],
+            dinv=dinv, check_every=par['check_every'], tag='correction'
+            )
     if verbose:
         info('velocity correction: %r' % sol)
     last_step_info['correction'] = sol

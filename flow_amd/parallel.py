@@ -1,37 +1,46 @@
 # -*- coding: utf-8 -*-
 '''
-Row-block sharding of the pressure-Poisson solve over the GPUs of one node
-(nothing in the reference: DOLFIN/PETSc would do this
-implicitly under mpirun).
+Domain decomposition of the WHOLE pressure-correction step over the GPUs of
+one node (nothing in the reference: DOLFIN/PETSc would do
+this implicitly under mpirun).
 
-One process per GPU, torch.distributed over RCCL ('nccl' backend) on xGMI.
-Rank g owns the contiguous rows [r_g, r_{g+1}) of the P1 stiffness matrix,
-balanced by nonzeros.  With the x-major vertex numbering of the channel mesh
-the matrix is banded (bandwidth ~ ny), so the columns a rank's rows reference
-(its ghost rows) belong to its left and right neighbour only.
+One process per GPU, torch.distributed over RCCL ('nccl' backend) on xGMI.  The
+channel is cut into strips along x.  With the x-major vertex numbering of the
+mesh every scalar space splits into contiguous row blocks: rank g OWNS the
+vertices [v_g, v_{g+1}), the P1 rows of those vertices, the P2 rows whose lowest
+vertex is one of them, and works on the cells that touch an owned vertex.  What
+its rows are coupled to beyond that -- matrix columns, dofs of those cells --
+are GHOST rows, a vertex column wide, owned by the left and right neighbour.
 
-Chronopoulos-Gear single-reduction CG with exactly ONE collective per
-iteration.  Every rank keeps x, r, p, s, z current on its ghost rows as well:
-their updates are pointwise, so all they need there is w = A z, which the
-owners publish.  The all-reduced buffer
+Every sub-step runs on the strips (flow_amd/navier_stokes):
+  tentative velocity   residual and matrix-free Jacobian action over the rank's
+                       cells, rows gathered for the owned dofs; GMRES with the
+                       rank's own ILU(0) (block Jacobi: the factor of the
+                       diagonal block of the owned rows, no communication)
+  pressure             CG with the SAME smoothed-aggregation V-cycle as on one
+                       GPU: finest level row-sharded, coarse residual summed
+                       over the ranks, the small levels replicated
+  velocity correction, step-size projection
+                       Jacobi-CG on the P2 mass matrix, one collective per
+                       iteration
 
-    [ r.z, z.w, r.r, 0 | omega = P^T w | boundary entries of w, rank by rank ]
+ONE communication primitive carries everything (flow_comm in
+include/flow_hip.h): an all-reduce (sum) of the head of a device buffer.  Dot
+products, the partial coarse residuals of the V-cycle and the halos travel in
+it -- for a halo every rank writes its boundary rows into its own slots and
+zeros into everybody else's, so the sum is the concatenation and the ghost
+values are bitwise the owners'.  The Krylov loops live in the library
+(flow_shard_*_solve) and call back into `Comm._allreduce` below, which hands
+the buffer to torch.distributed.all_reduce: RCCL on the stream the kernels run
+on, or -- gloo backend, for CPU tests and several-ranks-on-one-GPU rehearsals --
+staged through the host.
 
-therefore carries the dot products, the coarse restriction of the two-level
-preconditioner (P^T r is advanced by the recurrence that mirrors r -= alpha s)
-AND the halo: each rank fills its own partial sums and its own boundary slots,
-zeros elsewhere, and the sum is the concatenation.  No point-to-point traffic,
-no second synchronisation point; everything between two all-reduces is one
-library call (flow_cg_shard_step, include/flow_hip.h).  The message is a few
-tens of KB: latency bound.
-
-Every rank keeps full-length vectors (the pressure space is small: 9 MB at
-10 M DoF); the start (r = b - A x, z = M^-1 r) is computed redundantly on all
-rows, and the solution is all-gathered at the end because the other sub-steps
-are replicated.
+Fields stay global-length on every rank (memory is not the scarce resource:
+288 GB), valid on the owned + ghost rows; `gather_field` makes one whole (tests,
+output).
 '''
 import ctypes
-import os
+import traceback
 
 import numpy
 import torch
@@ -41,17 +50,17 @@ from . import _hip
 from . import device
 from .fem.space import csr_stream_rowblocks
 
-_STATE = {'group': None}
+_STATE = {'group': None, 'force': False, 'comm': None}
 
 
 def enable(group, force=False):
-    '''Shard subsequent pressure solves over `group`.  Collective: every rank
+    '''Run subsequent steps on the strips of `group`.  Collective: every rank
     of the group must call it (the first NCCL operation on a group has to
-    involve all of its ranks).
-    force: take the sharded loop even on a 1-rank group or for systems below
-    min_rows() (development / tests).'''
+    involve all of its ranks).  force: also on a 1-rank group (development /
+    tests: measures the host overhead of the sharded loops).'''
     _STATE['group'] = group
     _STATE['force'] = bool(force)
+    _STATE['comm'] = Comm(group)
     if dist.get_world_size(group) > 1:
         t = torch.zeros(1, dtype=torch.float64, device=device.get()
                         if dist.get_backend(group) != 'gloo' else 'cpu')
@@ -60,93 +69,114 @@ def enable(group, force=False):
 
 def disable():
     _STATE['group'] = None
-
-
-# Rows of the pressure system from which sharding pays.  A sharded CG iteration
-# is latency bound: one all-reduce plus ~10 stream-ordered launches whose cost
-# does not shrink with the local row count (~5 us each), and the dense coarse
-# solve is replicated; a complete single-GPU iteration on the 1.1 M-row system
-# of the headline workload takes 72 us (~65 us per million rows).  Below a few
-# million rows one GPU is as fast as eight.
-DEFAULT_MIN_ROWS = 4000000
-
-
-def min_rows():
-    return int(os.environ.get('FLOW_AMD_SHARD_MIN_ROWS', DEFAULT_MIN_ROWS))
+    _STATE['comm'] = None
 
 
 def active(nrows=None):
-    '''Is the pressure solve sharded?  nrows: size of the system about to be
-    solved -- the `auto` policy shards only from min_rows() on.'''
+    '''Does the step run on strips?  (nrows: kept for callers that ask about
+    one system; the policy no longer depends on it.)'''
     if _STATE['group'] is None:
         return False
-    if _STATE.get('force', False):
-        return True
-    if dist.get_world_size(_STATE['group']) <= 1:
-        return False
-    return nrows is None or nrows >= min_rows()
+    return _STATE['force'] or dist.get_world_size(_STATE['group']) > 1
 
 
-def describe(world, nrows):
+def comm():
+    return _STATE['comm']
+
+
+def describe(world, nrows=None):
     '''One line for bench.py's `config.parallelism`.'''
-    if active(nrows):
-        return 'pressure-poisson row-block x%d' % world
+    if active():
+        return ('x-strips x%d: every sub-step sharded (block-Jacobi ILU(0) '
+                'GMRES, row-sharded V-cycle CG, Jacobi-CG mass solves)' % world)
     if world == 1:
         return 'single GPU'
-    return ('replicated x%d (pressure system of %d rows is below the sharding '
-            'threshold of %d rows: DESIGN.md section 6; --shard always forces '
-            'it)' % (world, nrows, min_rows()))
+    return 'replicated x%d' % world
 
 
-# -- partition (pure host logic, CPU-testable) --------------------------------
-class HaloLayout(object):
-    '''What rank g puts into / takes out of the halo section of the all-reduce
-    buffer.  Index 0 = left neighbour, 1 = right neighbour; len 0 = none.'''
+# -- communicator ---------------------------------------------------------------
+class Comm(object):
+    '''The exchange buffer and the all-reduce callback of flow_comm.'''
 
-    def __init__(self):
-        self.e0 = self.e1 = 0
-        self.nhalo = 0
-        self.send_row = [0, 0]
-        self.send_len = [0, 0]
-        self.send_slot = [0, 0]
-        self.recv_row = [0, 0]
-        self.recv_len = [0, 0]
-        self.recv_slot = [0, 0]
+    def __init__(self, group, capacity=1 << 16):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.staged = dist.get_backend(group) == 'gloo'
+        self.calls = 0
+        self._cb = _hip.ALLREDUCE_FN(self._allreduce)
+        self.buf = None
+        self.struct = None
+        self.ensure(capacity)
+
+    def ensure(self, capacity):
+        '''Grow the exchange buffer to at least `capacity` doubles.'''
+        if self.buf is None or self.buf.numel() < capacity:
+            self.buf = device.zeros(int(capacity) + (int(capacity) & 1))
+            assert self.buf.data_ptr() % 16 == 0
+            # (on the CPU -- host-logic tests -- the buffer is a host tensor and
+            # the struct is only ever handed to the numpy stand-ins)
+            self.struct = _hip.CommS(
+                self.rank, self.world, ctypes.c_void_p(self.buf.data_ptr()),
+                self.buf.numel(), self._cb, None)
+        return self.struct
+
+    def _allreduce(self, _user, count):
+        # called from inside the library's solver loops (ctypes re-acquires
+        # the GIL); exceptions must not propagate through the C frames
+        try:
+            self.calls += 1
+            self.allreduce_tensor(self.buf[:count])
+            return 0
+        except Exception:                                  # noqa: BLE001
+            traceback.print_exc()
+            return 1
+
+    def allreduce_tensor(self, t):
+        if self.world == 1 and self.staged:
+            return t
+        if self.staged and t.is_cuda:
+            # gloo cannot reduce device tensors (to_host synchronises first)
+            h = device.to_host(t)
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            # RCCL: enqueued behind the kernels of the current stream by
+            # torch's event hand-over; the stream waits for its result
+            dist.all_reduce(t, group=self.group)
+        return t
 
 
-class Partition(object):
-    '''Row-block partition of a CSR pattern, balanced by nonzeros.'''
+# -- partition (pure host logic, CPU-testable) ------------------------------------
+class RowBlocks(object):
+    '''Contiguous row blocks of ONE scalar space over the ranks, with the ghost
+    ranges [lo_g, r0_g) and [r1_g, hi_g) each rank needs and the layout of the
+    halo slots in the exchange buffer: rank by rank, [to-left | to-right].'''
 
-    def __init__(self, rowptr, cols, world):
-        rowptr = numpy.asarray(rowptr, dtype=numpy.int64)
-        n = len(rowptr) - 1
-        nnz = int(rowptr[-1])
-        assert 1 <= world <= n
-        targets = (numpy.arange(1, world) * nnz) // world
-        cuts = numpy.searchsorted(rowptr, targets, side='left')
-        bounds = numpy.concatenate([[0], cuts, [n]]).astype(numpy.int64)
-        # strictly increasing (tiny problems)
-        for g in range(1, world + 1):
-            bounds[g] = max(bounds[g], bounds[g - 1] + 1)
-        bounds[world] = n
-        assert (numpy.diff(bounds) > 0).all(), 'more ranks than rows'
-        self.n = n
-        self.world = world
-        self.bounds = bounds
-        # columns referenced by each rank's rows
-        self.lo = numpy.empty(world, dtype=numpy.int64)
-        self.hi = numpy.empty(world, dtype=numpy.int64)
-        cols = numpy.asarray(cols)
-        for g in range(world):
-            seg = cols[rowptr[bounds[g]]:rowptr[bounds[g + 1]]]
-            self.lo[g] = min(seg.min(), bounds[g])
-            self.hi[g] = max(seg.max() + 1, bounds[g + 1])
-        for g in range(world):
+    def __init__(self, n, bounds, lo, hi):
+        self.n = int(n)
+        self.bounds = numpy.asarray(bounds, dtype=numpy.int64)
+        self.world = len(self.bounds) - 1
+        self.lo = numpy.asarray(lo, dtype=numpy.int64)
+        self.hi = numpy.asarray(hi, dtype=numpy.int64)
+        assert self.bounds[0] == 0 and self.bounds[-1] == n
+        assert (numpy.diff(self.bounds) > 0).all(), 'more ranks than rows'
+        for g in range(self.world):
+            r0, r1 = self.rows(g)
+            assert self.lo[g] <= r0 and self.hi[g] >= r1
             # ghost rows must belong to the immediate neighbours only
-            left = bounds[g - 1] if g > 0 else 0
-            right = bounds[g + 2] if g + 2 <= world else n
+            left = self.bounds[g - 1] if g > 0 else 0
+            right = self.bounds[g + 2] if g + 2 <= self.world else n
             assert self.lo[g] >= left and self.hi[g] <= right, \
-                'matrix bandwidth exceeds the neighbour row blocks'
+                'strips too thin: a ghost range reaches past the neighbour'
+        slot = {}
+        off = 0
+        for q in range(self.world):
+            for side, (row, ln) in enumerate(self.sends(q)):
+                slot[(q, side)] = (off, row, ln)
+                off += ln
+        self.nhalo = off
+        self._slot = slot
 
     def rows(self, g):
         return int(self.bounds[g]), int(self.bounds[g + 1])
@@ -165,237 +195,350 @@ class Partition(object):
             right = (start, max(r1 - start, 0))
         return [left, right]
 
-    def halo_layout(self, g):
-        '''Slots of the halo section: rank by rank, [to-left | to-right].'''
-        slot = {}
-        off = 0
-        for q in range(self.world):
-            for side, (row, ln) in enumerate(self.sends(q)):
-                slot[(q, side)] = (off, row, ln)
-                off += ln
-        lay = HaloLayout()
-        lay.nhalo = off
-        lay.e0, lay.e1 = int(self.lo[g]), int(self.hi[g])
-        for side in (0, 1):
-            o, row, ln = slot[(g, side)]
-            lay.send_row[side], lay.send_len[side], lay.send_slot[side] = \
-                row, ln, o
+    def struct(self, g):
+        '''flow_rows of rank g.'''
+        s = _hip.RowsS()
         r0, r1 = self.rows(g)
+        s.n, s.r0, s.r1 = self.n, r0, r1
+        s.e0, s.e1 = int(self.lo[g]), int(self.hi[g])
+        s.nhalo = self.nhalo
+        for side in (0, 1):
+            o, row, ln = self._slot[(g, side)]
+            s.send_row[side], s.send_len[side], s.send_slot[side] = row, ln, o
         if g > 0:
             # my left ghost rows = what the left neighbour sends to ITS right
-            o, row, ln = slot[(g - 1, 1)]
-            assert row == lay.e0 and row + ln == r0
-            lay.recv_row[0], lay.recv_len[0], lay.recv_slot[0] = row, ln, o
+            o, row, ln = self._slot[(g - 1, 1)]
+            assert row == s.e0 and row + ln == r0
+            s.recv_row[0], s.recv_len[0], s.recv_slot[0] = row, ln, o
         else:
-            assert lay.e0 == r0
+            assert s.e0 == r0
         if g + 1 < self.world:
-            o, row, ln = slot[(g + 1, 0)]
-            assert row == r1 and row + ln == lay.e1
-            lay.recv_row[1], lay.recv_len[1], lay.recv_slot[1] = row, ln, o
+            o, row, ln = self._slot[(g + 1, 0)]
+            assert row == r1 and row + ln == s.e1
+            s.recv_row[1], s.recv_len[1], s.recv_slot[1] = row, ln, o
         else:
-            assert lay.e1 == r1
-        return lay
+            assert s.e1 == r1
+        return s
 
 
-class Comm(object):
-    '''The collectives of the solver on a torch.distributed group.  The gloo
-    backend cannot reduce device tensors, so with gloo (CPU tests, single-GPU
-    rehearsals) buffers are staged through the host.'''
+class Strips(object):
+    '''The strip decomposition of a mesh for `world` ranks: vertex bounds,
+    per-rank cell ranges, and RowBlocks of every scalar space on the mesh.'''
 
-    def __init__(self, group):
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
-        self.staged = dist.get_backend(group) == 'gloo'
+    def __init__(self, mesh, world):
+        from .fem.space import scalar_layout
+        self.mesh = mesh
+        self.world = world
+        p1 = scalar_layout(mesh, 1)
+        nv = p1.N
+        assert 1 <= world <= nv
+        # balance the work: cells per vertex ~ nonzeros of the P1 pattern
+        rowptr = p1.pattern('rowptr').astype(numpy.int64)
+        targets = (numpy.arange(1, world) * int(rowptr[-1])) // world
+        cuts = numpy.searchsorted(rowptr, targets, side='left')
+        vb = numpy.concatenate([[0], cuts, [nv]]).astype(numpy.int64)
+        for g in range(1, world + 1):
+            vb[g] = max(vb[g], vb[g - 1] + 1)
+        vb[world] = nv
+        self.vbounds = vb
+        # cells of a rank: the index range spanned by the cells that touch one
+        # of its vertices (x-major cell numbering: hardly any cell in that
+        # range touches none)
+        cv = mesh.cell_vertices
+        owner = numpy.searchsorted(vb, cv, side='right') - 1      # (nc, 3)
+        self.cells = []
+        for g in range(world):
+            idx = numpy.nonzero((owner == g).any(axis=1))[0]
+            self.cells.append((int(idx.min()), int(idx.max()) + 1))
+        self._blocks = {}
 
-    def global_rank(self, r):
-        return dist.get_global_rank(self.group, r) \
-            if self.group is not dist.group.WORLD else r
+    def blocks(self, layout):
+        '''RowBlocks of a scalar layout (P1 or P2) on this decomposition.'''
+        key = layout.degree
+        if key not in self._blocks:
+            vb = self.vbounds
+            n = layout.N
+            if layout.degree == 1:
+                bounds = vb.copy()
+            else:
+                # P2 dofs are numbered by (lowest vertex, kind): the vertex dof
+                # of v comes first among those with lowest vertex v
+                vd = layout.vertex_dofs.astype(numpy.int64)
+                bounds = numpy.concatenate([vd[vb[:-1]], [n]])
+                bounds[0] = 0
+            rowptr = layout.pattern('rowptr').astype(numpy.int64)
+            cols = layout.pattern('cols')
+            cd = layout.cell_dofs
+            lo = numpy.empty(self.world, dtype=numpy.int64)
+            hi = numpy.empty(self.world, dtype=numpy.int64)
+            for g in range(self.world):
+                r0, r1 = int(bounds[g]), int(bounds[g + 1])
+                seg = cols[rowptr[r0]:rowptr[r1]]
+                c0, c1 = self.cells[g]
+                # everything the rank's rows are coupled to AND every dof of
+                # every cell its cell kernels visit (they index compact
+                # vectors of exactly this extent)
+                lo[g] = min(int(seg.min()), int(cd[c0:c1].min()), r0)
+                hi[g] = max(int(seg.max()), int(cd[c0:c1].max())) + 1
+                hi[g] = max(hi[g], r1)
+            self._blocks[key] = RowBlocks(n, bounds, lo, hi)
+        return self._blocks[key]
 
-    def allreduce_sum(self, t):
-        if self.staged and t.is_cuda:
-            # (to_host synchronises first: see device.to_host)
-            h = device.to_host(t)
-            dist.all_reduce(h, group=self.group)
-            t.copy_(h)
-        else:
-            # RCCL: enqueued behind the kernels of the current stream by
-            # torch's event hand-over, and the stream waits for its result
-            dist.all_reduce(t, group=self.group)
+
+_STRIPS = {}
+
+
+def strips(mesh):
+    c = comm()
+    key = (id(mesh), c.world)
+    if key not in _STRIPS:
+        # (the mesh is kept alive with its decomposition: ids are not recycled)
+        _STRIPS[key] = (Strips(mesh, c.world), mesh)
+    return _STRIPS[key][0]
+
+
+# -- per-rank views of the library's structs ---------------------------------------
+class View(object):
+    '''Everything rank-specific about one scalar layout: flow_rows, the
+    space struct with the owned row / nonzero range, owned row blocks.'''
+
+    def __init__(self, layout, st, rank):
+        from .fem import ops
+        self.layout = layout
+        self.blocks = st.blocks(layout)
+        self.rows = self.blocks.struct(rank)
+        self.r0, self.r1 = self.rows.r0, self.rows.r1
+        self.e0, self.e1 = self.rows.e0, self.rows.e1
+        base = ops.space_struct(layout)
+        s = _hip.SpaceS()
+        ctypes.memmove(ctypes.byref(s), ctypes.byref(base),
+                       ctypes.sizeof(_hip.SpaceS))
+        rowptr = layout.pattern('rowptr')
+        s.r0, s.r1 = self.r0, self.r1
+        s.nnz0, s.nnz1 = int(rowptr[self.r0]), int(rowptr[self.r1])
+        self.space = s
+        rp = rowptr.astype(numpy.int64)
+        rb = csr_stream_rowblocks(rp[self.r0:self.r1 + 1] - rp[self.r0]) \
+            + self.r0
+        self.rowblocks = device.to_device(rb.astype(numpy.int32))
+
+    def operator(self, A):
+        '''A copy of A's flow_operator that covers the owned rows only.'''
+        return owned_operator(A.operator(), self.rowblocks)
+
+
+def owned_operator(base, rowblocks):
+    op = _hip.Operator()
+    ctypes.memmove(ctypes.byref(op), ctypes.byref(base),
+                   ctypes.sizeof(_hip.Operator))
+    op.rowblocks = _hip.i32(rowblocks)
+    op.nblocks = rowblocks.numel() - 1
+    return op
+
+
+def view(layout):
+    '''The calling rank's View of a scalar layout (cached on the layout).'''
+    c = comm()
+    key = ('strip_view', c.world, c.rank)
+    if key not in layout._dev:
+        layout._dev[key] = View(layout, strips(layout.mesh), c.rank)
+    return layout._dev[key]
+
+
+def mesh_view(mesh):
+    '''flow_mesh restricted to the calling rank's cells.'''
+    from .fem import ops
+    c = comm()
+    key = ('strip_mesh', c.world, c.rank)
+    if key not in mesh._cache:
+        base = ops.mesh_struct(mesh)
+        s = _hip.MeshS(base.nc, base.xy, 0, 0)
+        s.c0, s.c1 = strips(mesh).cells[c.rank]
+        mesh._cache[key] = s
+    return mesh._cache[key]
+
+
+# -- collectives on fields ------------------------------------------------------------
+def halo(vec, layout, ncomp=1):
+    '''Make the ghost rows of a global-length field current.'''
+    c = comm()
+    v = view(layout)
+    c.ensure(ncomp * v.rows.nhalo)
+    _hip.check(_hip.lib().flow_shard_halo(
+        ctypes.byref(c.struct), ctypes.byref(v.rows), ncomp,
+        _hip.f64(vec, ncomp * layout.N), layout.N, _hip.stream()))
+    return vec
+
+
+def _reduce(x, y, layout, ncomp, kind):
+    from .fem import ops
+    c = comm()
+    v = view(layout)
+    c.ensure(16)
+    res = ctypes.c_double(0.0)
+    _hip.check(_hip.lib().flow_shard_reduce_host(
+        ctypes.byref(c.struct), ctypes.byref(v.rows), ncomp,
+        _hip.f64(x, ncomp * layout.N),
+        _hip.f64(y, ncomp * layout.N) if y is not None else None, layout.N,
+        kind, _hip.f64(ops.work(_hip.REDUCE_WORK)), ctypes.byref(res),
+        _hip.stream()))
+    return res.value
+
+
+def dot(x, y, layout, ncomp=1):
+    '''x . y over the owned rows of all ranks.'''
+    return _reduce(x, y, layout, ncomp, 0)
+
+
+def norm_linf(x, layout, ncomp=1):
+    return _reduce(x, None, layout, ncomp, 1)
+
+
+def gather_field(vec, layout, ncomp=1):
+    '''Make a field whole on every rank (tests, output): every rank keeps its
+    owned rows, zeros elsewhere, and the sum is the field.'''
+    c = comm()
+    v = view(layout)
+    n = layout.N
+    out = torch.zeros_like(vec)
+    for a in range(ncomp):
+        out[a * n + v.r0:a * n + v.r1] = vec[a * n + v.r0:a * n + v.r1]
+    device.synchronize()
+    c.allreduce_tensor(out)
+    device.synchronize()
+    vec.copy_(out)
+    return vec
+
+
+# -- solvers ------------------------------------------------------------------------
+def _solve_info(its, res, name):
+    from .fem.ops import SolveInfo
+    return SolveInfo(its, res, '%s[x-strips x%d]' % (name, comm().world))
+
+
+def cg(A, dinv, b, x, rtol, atol=0.0, maxit=1000, check_every=2, tag=None):
+    '''Jacobi-CG on the strips (operator kind 0 or 4); b valid on the owned
+    rows, x on the owned rows (start) -> owned + ghost rows (solution).'''
+    from .fem import ops
+    c = comm()
+    lay = A.layout
+    v = view(lay)
+    ncomp = 2 if A.kind == 4 else 1
+    c.ensure(4 + ncomp * v.rows.nhalo)
+    op = v.operator(A)
+    n = A.size
+    wlen = _hip.REDUCE_WORK + 10 * ncomp * (v.e1 - v.e0) + op.nblocks + 2
+    wk = ops.work(wlen)
+    history = A.__dict__.setdefault('_solve_history', {}) if tag else None
+    first = history[tag] + 1 if history is not None and tag in history else 0
+    its = ctypes.c_int(0)
+    res = ctypes.c_double(0.0)
+    _hip.check(_hip.lib().flow_shard_cg_solve(
+        ctypes.byref(c.struct), ctypes.byref(v.rows), ctypes.byref(op),
+        _hip.f64(dinv, n, 'dinv'), _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'),
+        float(rtol), float(atol), int(maxit), int(check_every), int(first),
+        _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
+        _hip.stream()))
+    if history is not None:
+        history[tag] = its.value
+    return _solve_info(its.value, res.value, 'cg')
+
+
+class MgShard(object):
+    '''The finest level of a Multigrid hierarchy cut to the calling rank's
+    strip (flow_mg_shard): Ah0 / Ps0 with the row blocks of the owned rows, the
+    restriction restricted to the owned columns.'''
+
+    def __init__(self, mg, v):
+        from .fem.multigrid import CsrOperator
+        assert mg.nlevels >= 2 and mg.R0_host is not None
+        self.mg = mg
+        self._keep = []
+        lvl = mg.levels[0]
+        Rg = mg.R0_host[:, v.r0:v.r1].tocsr()
+        assert Rg.nnz > 0
+        self.Rg = CsrOperator(Rg)
+        s = _hip.MgShardS()
+        s.mg = ctypes.pointer(mg.struct)
+        s.Ah0 = owned_operator(lvl['Ah'].op, self._blocks(lvl['Ah'], v))
+        s.Ps0 = owned_operator(lvl['Ps'].op, self._blocks(lvl['Ps'], v))
+        s.Rg = self.Rg.op
+        self.struct = s
+
+    def _blocks(self, op, v):
+        rp = device.to_host(op._rowptr).numpy().astype(numpy.int64)
+        rb = csr_stream_rowblocks(rp[v.r0:v.r1 + 1] - rp[v.r0]) + v.r0
+        t = device.to_device(rb.astype(numpy.int32))
+        self._keep.append(t)
         return t
 
-    def allgather_rows(self, vec, bounds):
-        '''Make the full vector current on every rank (owned slices -> all).'''
-        for g in range(self.world):
-            r0, r1 = int(bounds[g]), int(bounds[g + 1])
-            seg = vec[r0:r1]
-            if self.staged and vec.is_cuda:
-                h = device.to_host(seg)
-                dist.broadcast(h, self.global_rank(g), group=self.group)
-                seg.copy_(h)
-            else:
-                dist.broadcast(seg, self.global_rank(g), group=self.group)
 
-
-# -- local kernels ------------------------------------------------------------
-class HipLocal(object):
-    '''The local side of the sharded CG on the HIP path: owns the vectors and
-    the flow_cg_shard context; `step` is one library call.'''
-
-    def __init__(self, A, dinv, coarse, part, rank):
-        self.lib = _hip.lib()
-        lay = A.layout
-        n = lay.N
-        self.A = A
-        self.dinv = dinv
-        self.coarse = coarse
-        self.n = n
-        r0, r1 = part.rows(rank)
-        self.r0, self.r1 = r0, r1
-        hl = part.halo_layout(rank)
-        rowptr = lay.pattern('rowptr').astype(numpy.int64)
-        rb = csr_stream_rowblocks(rowptr[r0:r1 + 1] - rowptr[r0]) + r0
-        self.rowblocks = device.to_device(rb.astype(numpy.int32))
-        base = A.operator()
-        op = _hip.Operator()
-        ctypes.memmove(ctypes.byref(op), ctypes.byref(base),
-                       ctypes.sizeof(_hip.Operator))
-        op.rowblocks = _hip.i32(self.rowblocks)
-        op.nblocks = len(rb) - 1
-        self.op = op
-        nc = coarse.nc if coarse is not None else 0
-        lda = coarse.struct.lda if coarse is not None else 0
-        z = device.zeros
-        self.r, self.z, self.w, self.p, self.s = z(n), z(n), z(n), z(n), z(n)
-        self.S = z(16)
-        self.buf = z(4 + nc + hl.nhalo)
-        self.work = device.empty(_hip.REDUCE_WORK)
-        self.rc, self.zc, self.sigma = z(max(lda, 1)), z(max(lda, 1)), \
-            z(max(lda, 1))
-        self.x = None
-        c = _hip.CgShard()
-        c.A = ctypes.pointer(self.op)
-        c.dinv = _hip.f64(dinv, n, 'dinv')
-        if coarse is not None:
-            c.coarse = ctypes.pointer(coarse.struct)
-        c.n, c.r0, c.r1, c.e0, c.e1 = n, r0, r1, hl.e0, hl.e1
-        c.nhalo = hl.nhalo
-        for side in (0, 1):
-            c.send_row[side] = hl.send_row[side]
-            c.send_len[side] = hl.send_len[side]
-            c.send_slot[side] = hl.send_slot[side]
-            c.recv_row[side] = hl.recv_row[side]
-            c.recv_len[side] = hl.recv_len[side]
-            c.recv_slot[side] = hl.recv_slot[side]
-        for name in ('r', 'z', 'w', 'p', 's', 'rc', 'zc', 'sigma', 'S', 'buf',
-                     'work'):
-            setattr(c, name, _hip.f64(getattr(self, name)))
-        self.ctx = c
-
-    def _start(self, b, q):
-        '''r = b - q, z = B r on ALL rows (replicated).'''
-        lib, n, st = self.lib, self.n, _hip.stream()
-        _hip.check(lib.flow_residual_dev(
-            n, _hip.f64(b, n), _hip.f64(q), _hip.f64(self.dinv),
-            _hip.f64(self.r), _hip.f64(self.z), st
-            ))
-        if self.coarse is not None:
-            cs = ctypes.byref(self.coarse.struct)
-            _hip.check(lib.flow_coarse_restrict_dev(
-                cs, _hip.f64(self.r), 0, n, _hip.f64(self.rc), st
-                ))
-            _hip.check(lib.flow_coarse_solve_dev(
-                cs, _hip.f64(self.rc), _hip.f64(self.zc), st
-                ))
-            _hip.check(lib.flow_coarse_prolong_dev(
-                cs, _hip.f64(self.dinv), _hip.f64(self.r), _hip.f64(self.zc),
-                _hip.f64(self.z), 0, n, st
-                ))
-
-    def begin(self, b, x):
-        '''Replicated start on ALL rows: r = b - A x, z = B r, p = s = 0.
-        Returns |B b|^2 (the stopping test is in the preconditioned norm, as
-        in flow_cg_solve).'''
-        from .fem import ops
-        n = self.n
-        self.x = x
-        self.ctx.x = _hip.f64(x, n, 'x')
-        for v in (self.p, self.s, self.S, self.sigma, self.buf, self.w):
-            _hip.fill(v, 0.0)
-        self._start(b, self.w)
-        bb2 = ops.dot(self.z, self.z)
-        self.A.apply(x, self.w)
-        self._start(b, self.w)
-        return bb2
-
-    def step(self, phase):
-        _hip.check(self.lib.flow_cg_shard_step(
-            ctypes.byref(self.ctx), int(phase), _hip.stream()
-            ))
-
-    def res2(self):
-        return float(device.to_host(self.buf[2:3])[0])
-
-
-def sharded_cg(local, comm, part, b, x, rtol, atol, maxit, check_every):
-    '''Chronopoulos-Gear CG on the row partition `part`.  `local` provides the
-    kernels (HipLocal in the product; the CPU tests inject a numpy stand-in to
-    exercise the partition + communication logic under gloo).  Returns
-    (iterations, residual norm); raises _hip.NotConverged.'''
-    # The replicated start needs bitwise identical b and x on every rank.  The
-    # ranks compute them redundantly (deterministic kernels, so they agree),
-    # but a sharded solve must not depend on that: take every row from its
-    # owner.
-    comm.allgather_rows(b, part.bounds)
-    comm.allgather_rows(x, part.bounds)
-    b2 = local.begin(b, x)
-    local.step(0)
-    comm.allreduce_sum(local.buf)
-    res2 = local.res2()
-    target = max(rtol * numpy.sqrt(b2), atol)
-    it = 0
-    while True:
-        if res2 != res2:
-            raise _hip.NotConverged('sharded CG broke down (NaN residual)')
-        if numpy.sqrt(res2) <= target:
-            break
-        if it >= maxit:
-            raise _hip.NotConverged(
-                'sharded CG did not converge in %d iterations: |r| = %.3e > %.3e'
-                % (it, numpy.sqrt(res2), target)
-                )
-        todo = min(check_every, maxit - it)
-        for k in range(todo):
-            local.step(1 if it + k == 0 else 2)
-            comm.allreduce_sum(local.buf)
-        it += todo
-        res2 = local.res2()
-    comm.allgather_rows(x, part.bounds)
-    return it, float(numpy.sqrt(res2))
-
-
-_PART_CACHE = {}
-
-
-def pressure_cg(A, dinv, coarse, b, x, rtol, atol, maxit, check_every):
-    '''Sharded replacement of ops.krylov_solve('cg', ...) for the pressure
-    system (called from navier_stokes._compute_pressure when enabled).'''
-    from .fem.ops import SolveInfo
-    comm = Comm(_STATE['group'])
+def mgcg(A, dinv, mg, b, x, rtol, atol=0.0, maxit=1000, check_every=2,
+         tag=None):
+    '''CG + the strip-sharded V-cycle (the pressure solve).'''
+    from .fem import ops
+    c = comm()
     lay = A.layout
-    key = (id(lay), comm.world)
-    if key not in _PART_CACHE:
-        _PART_CACHE[key] = Partition(
-            lay.pattern('rowptr'), lay.pattern('cols'), comm.world
-            )
-    part = _PART_CACHE[key]
-    lkey = (id(A), id(dinv), id(coarse), comm.world, comm.rank)
-    if lkey not in _PART_CACHE:
-        # keep the keyed objects alive: ids must not be recycled
-        _PART_CACHE[lkey] = (HipLocal(A, dinv, coarse, part, comm.rank),
-                             A, dinv, coarse)
-    local = _PART_CACHE[lkey][0]
-    its, res = sharded_cg(local, comm, part, b, x, rtol, atol, maxit,
-                          check_every)
-    return SolveInfo(its, res, 'cg%s[row-sharded x%d]' % (
-        '+2level' if coarse is not None else '', comm.world))
+    v = view(lay)
+    key = ('mg_shard', c.world, c.rank)
+    if key not in mg.__dict__:
+        mg.__dict__[key] = MgShard(mg, v)
+    ms = mg.__dict__[key]
+    c.ensure(max(4 + v.rows.nhalo, ms.struct.Rg.n))
+    op = v.operator(A)
+    n = A.size
+    wlen = _hip.REDUCE_WORK + 11 * (v.e1 - v.e0) + op.nblocks \
+        + 2 * ms.struct.Ps0.nblocks + 2
+    wk = ops.work(wlen)
+    history = A.__dict__.setdefault('_solve_history', {}) if tag else None
+    first = history[tag] + 1 if history is not None and tag in history else 0
+    its = ctypes.c_int(0)
+    res = ctypes.c_double(0.0)
+    _hip.check(_hip.lib().flow_shard_mgcg_solve(
+        ctypes.byref(c.struct), ctypes.byref(v.rows), ctypes.byref(op),
+        _hip.f64(dinv, n, 'dinv'), ctypes.byref(ms.struct),
+        _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
+        int(maxit), int(check_every), int(first), _hip.f64(wk), wk.numel(),
+        ctypes.byref(its), ctypes.byref(res), _hip.stream()))
+    if history is not None:
+        history[tag] = its.value
+    return _solve_info(its.value, res.value, 'cg+mg%d' % mg.nlevels)
+
+
+def gmres(Jop, ilu, b, x, rtol, atol=0.0, maxit=1000, restart=20,
+          x_is_zero=True):
+    '''GMRES + block-Jacobi ILU(0) on the strips; Jop: a MomentumJacobian built
+    on the rank's views (kind 3).  b, x: global-length velocity fields (owned
+    rows).'''
+    from .fem import ops
+    c = comm()
+    lay = Jop.layout
+    v = view(lay)
+    c.ensure(max(2 * v.rows.nhalo, _hip.GMRES_MAX_RESTART + 2))
+    mo, me = v.r1 - v.r0, v.e1 - v.e0
+    wlen = _hip.REDUCE_WORK + (2 * restart + 4) * 2 * mo + 2 * me \
+        + _hip.GMRES_PARTIALS
+    wk = ops.work(wlen)
+    its = ctypes.c_int(0)
+    res = ctypes.c_double(0.0)
+    n2 = 2 * lay.N
+    _hip.check(_hip.lib().flow_shard_gmres_solve(
+        ctypes.byref(c.struct), ctypes.byref(v.rows),
+        ctypes.byref(Jop.operator()), ctypes.byref(ilu.struct),
+        _hip.f64(b, n2, 'b'), _hip.f64(x, n2, 'x'), float(rtol), float(atol),
+        int(maxit), int(restart), int(bool(x_is_zero)), _hip.f64(wk),
+        wk.numel(), ctypes.byref(its), ctypes.byref(res), _hip.stream()))
+    return _solve_info(its.value, res.value, 'gmres+ilu0(block)')
+
+
+def local_ilu(J):
+    '''ILU(0) of the calling rank's diagonal block of the (block-diagonal part
+    of the) Jacobian J: plan over the owned rows in local numbering.'''
+    from .fem import ilu
+    c = comm()
+    lay = J.layout
+    key = ('ilu_plan_strip', c.world, c.rank)
+    if key not in lay._dev:
+        v = view(lay)
+        lay._dev[key] = ilu.IluPlan(lay, rows=(v.r0, v.r1))
+    return ilu.Ilu0(J, plan=lay._dev[key])

@@ -284,53 +284,118 @@ int flow_gmres_solve(const flow_operator* A, const double* dinv,
                      int x_is_zero, double* work, size_t work_len,
                      int* iters_host, double* resid_host, void* stream);
 
-/* ---- K15: row-sharded multi-GPU CG ----------------------------------------
+/* ---- K15: domain decomposition over the GPUs of one node -------------------
  * (nothing in the reference: DOLFIN/PETSc would do this implicitly under
- * mpirun).  Rank g owns the rows [r0, r1) and also keeps x, r, p, s, z current
- * on its ghost rows [e0, r0) and [r1, e1) (the columns its rows reference;
- * they belong to the two neighbouring ranks): the vector updates are
- * pointwise, so all they need there is w = A z, which the owners publish.  Per
- * iteration there is exactly ONE collective -- an all-reduce (sum) of
- *   buf = [ r.z, z.w, r.r, 0 | omega = P^T w (nc) | halo (nhalo) ]
- * in which every rank fills its own partial sums and, in the halo section, its
- * own boundary entries of w (zeros elsewhere) -- and ONE library call,
- * flow_cg_shard_step, which runs everything between two all-reduces.
- * The host loop (flow_amd/parallel.py) is
- *   replicated start: r = b - A x, z = M^-1 r on all rows (entry points below)
- *   step(phase 0); allreduce(buf)
- *   repeat: step(phase 1 the first time, then 2); allreduce(buf);
- *           every check_every iterations read buf[2] = r.r
- * phase 0: w = A z (owned rows), local sums, omega, pack
- * phase 1/2: unpack ghost w, alpha/beta from the sums (1: first iteration),
- *   rc -= alpha (omega + beta sigma), update on [e0, e1), z = M^-1 r on
- *   [e0, e1) (replicated dense coarse solve), then as phase 0.
- * send/recv index 0 = left neighbour, 1 = right; len 0 = none. */
+ * mpirun).  One process per GPU.  The mesh is cut into strips along the channel:
+ * with the x-major numbering every scalar space splits into contiguous row
+ * blocks, rank g OWNS the rows [r0, r1) and needs, for anything its rows are
+ * coupled to (matrix columns, dofs of incident cells), the GHOST rows [e0, r0)
+ * and [r1, e1) -- owned by its left and right neighbour.
+ *
+ * The library needs ONE communication primitive, handed in as a callback:
+ *   allreduce(user, count): sum the first `count` doubles of comm->buf over the
+ *   ranks, in stream order (kernels enqueued before it have written buf, kernels
+ *   enqueued after it see the sums).
+ * The host binds it to torch.distributed.all_reduce on RCCL (flow_amd/
+ * parallel.py).  Everything travels in that buffer: dot products, the partial
+ * coarse residual of the multigrid cycle, and the halos -- every rank writes
+ * its boundary rows into its own slots and zeros into all others, so the sum
+ * is the concatenation (bitwise the owners' values: x + 0).  One kind of
+ * collective, a fixed reduction order, identical results on every rank.
+ *
+ * Vectors inside the sharded solvers are EXT-COMPACT: ncomp * (e1 - e0)
+ * doubles, entry (a, row) at a*(e1-e0) + row - e0.  Kernels that index by
+ * global row get the base pointer shifted by -e0 and the component stride
+ * e1 - e0; fields handed in by the caller (b, x, dinv, ...) are global-length
+ * (stride n), valid on the rank's owned + ghost rows. */
+typedef int (*flow_allreduce_fn)(void* user, int count);
 typedef struct {
-  const flow_operator* A;    /* kind 0, rowblocks covering the OWNED rows only */
-  const double* dinv;        /* n */
-  const flow_coarse* coarse; /* NULL: Jacobi only */
-  int n, r0, r1, e0, e1;
-  int nhalo;                 /* doubles in the halo section of buf */
-  int send_row[2], send_len[2], send_slot[2];  /* w[row..+len) -> halo[slot..) */
-  int recv_row[2], recv_len[2], recv_slot[2];  /* halo[slot..+len) -> w[row..) */
-  double *x, *r, *z, *w, *p, *s;               /* n each */
-  double *rc, *zc, *sigma;   /* coarse->lda each, rc 16-B aligned (coarse only) */
-  double* S;                 /* 16 solver scalars (alpha, beta, ...) */
-  double* buf;               /* 4 + nc + nhalo */
-  double* work;              /* FLOW_REDUCE_WORK */
-} flow_cg_shard;
-int flow_cg_shard_step(const flow_cg_shard* c, int phase, void* stream);
-/* pieces of the replicated start (and of the Stokes Schur loop): residual and
- * the two-level preconditioner on a row range [r0, r1) */
-int flow_coarse_restrict_dev(const flow_coarse* C, const double* r, int r0,
-                             int r1, double* rc_out, void* stream);
-int flow_coarse_solve_dev(const flow_coarse* C, const double* rc_in, double* zc,
-                          void* stream);
-int flow_coarse_prolong_dev(const flow_coarse* C, const double* dinv,
-                            const double* r, const double* zc, double* z, int r0,
-                            int r1, void* stream);
-int flow_residual_dev(int n, const double* b, const double* q,
-                      const double* dinv, double* r, double* z, void* stream);
+  int rank, world;
+  double* buf;               /* exchange buffer (device), `capacity` doubles */
+  int capacity;
+  flow_allreduce_fn allreduce;
+  void* user;
+} flow_comm;
+
+/* the rows of one scalar space as rank `comm->rank` sees them; index 0 = left
+ * neighbour, 1 = right neighbour, len 0 = none */
+typedef struct {
+  int n;                     /* global rows */
+  int r0, r1;                /* owned */
+  int e0, e1;                /* owned + ghost: e0 <= r0 < r1 <= e1 */
+  int nhalo;                 /* halo slots of ONE component, all ranks together */
+  int send_row[2], send_len[2], send_slot[2];  /* x[row..+len) -> slots */
+  int recv_row[2], recv_len[2], recv_slot[2];  /* slots -> x[row..+len) */
+} flow_rows;
+
+/* make the ghost rows of x current (ncomp components, x[a*stride + row] with
+ * GLOBAL row: a global-length field has stride n; for an ext-compact vector v
+ * pass x = v - e0, stride = e1 - e0).  One collective. */
+int flow_shard_halo(const flow_comm* comm, const flow_rows* rows, int ncomp,
+                    double* x, int stride, void* stream);
+/* kind 0: sum over the owned rows of x_a[row] * y_a[row], summed over the
+ * ranks; kind 1: max |x| over the owned rows and the ranks (y unused).
+ * work: FLOW_REDUCE_WORK doubles.  One collective + one read-back. */
+int flow_shard_reduce_host(const flow_comm* comm, const flow_rows* rows,
+                           int ncomp, const double* x, const double* y,
+                           int stride, int kind, double* work,
+                           double* result_host, void* stream);
+
+/* CG + Jacobi on the strips: the mass-matrix solves of the velocity correction
+ * (operator kind 4: both components, pressure_correction.py:451-464) and of the
+ * callers' step-size projection (kind 0).  A carries the CSR-stream row blocks
+ * of the OWNED rows only; b, x, dinv are global-length fields (b valid on the
+ * owned rows, x on owned rows -- its ghosts are made current on entry and on
+ * exit).  Chronopoulos-Gear recurrences on the owned AND ghost rows (pointwise
+ * given w = A z there), so ONE collective per iteration carries the three dot
+ * products and the halo of w; stopping test, device-side convergence flag and
+ * the meaning of first_check / check_every as flow_cg_solve.  Every rank runs
+ * the same number of iterations (the sums are bitwise identical).
+ * work (16-B aligned): FLOW_REDUCE_WORK + 10 * ncomp * (e1 - e0) + A->nblocks
+ * + 2 doubles, ncomp = 1 (kind 0) or 2 (kind 4). */
+int flow_shard_cg_solve(const flow_comm* comm, const flow_rows* rows,
+                        const flow_operator* A, const double* dinv,
+                        const double* b, double* x, double rtol, double atol,
+                        int maxit, int check_every, int first_check,
+                        double* work, size_t work_len, int* iters_host,
+                        double* resid_host, void* stream);
+
+/* The pressure solve on the strips: CG preconditioned with the SAME smoothed-
+ * aggregation V(1,1) cycle as flow_cg_solve (same iteration counts).  The
+ * finest level is row-sharded: Ah0 / Ps0 are mg->Ah[0] / mg->Ps[0] with the row
+ * blocks of the owned rows, Rg is mg->R[0] restricted to the owned COLUMNS
+ * (column index minus r0; all coarse rows): every rank restricts its own part
+ * of the fine residual, the partial coarse residuals are summed by the
+ * collective, and the levels below (a tenth of the rows, latency-bound on one
+ * GPU already) run replicated on every rank.  Three collectives per iteration:
+ * [dots + halo of w], [coarse residual], [halo of z].
+ * work: FLOW_REDUCE_WORK + 11 * (e1 - e0) + A->nblocks + 2 * Ps0.nblocks + 2. */
+typedef struct {
+  const flow_mg* mg;
+  flow_operator Ah0, Ps0, Rg;
+} flow_mg_shard;
+int flow_shard_mgcg_solve(const flow_comm* comm, const flow_rows* rows,
+                          const flow_operator* A, const double* dinv,
+                          const flow_mg_shard* mgs, const double* b, double* x,
+                          double rtol, double atol, int maxit, int check_every,
+                          int first_check, double* work, size_t work_len,
+                          int* iters_host, double* resid_host, void* stream);
+
+/* GMRES(restart) for the Newton systems on the strips.  The operator is the
+ * matrix-free Jacobian action (kind 3) whose flow_mesh / flow_space carry the
+ * rank's cell and row ranges (below); the preconditioner is block Jacobi: ilu
+ * factors the rank's own diagonal block (plan over the owned rows in local
+ * numbering), no communication.  The Krylov vectors hold the owned rows only
+ * (2 * (r1 - r0) doubles); per iteration one halo collective (the operator's
+ * input) and one for the dot products.  b, x: global-length fields (owned
+ * rows).  work: FLOW_REDUCE_WORK + (2*restart + 4) * 2*(r1-r0)
+ * + 2*(e1-e0) + FLOW_GMRES_PARTIALS doubles. */
+int flow_shard_gmres_solve(const flow_comm* comm, const flow_rows* rows,
+                           const flow_operator* A, const flow_ilu* ilu,
+                           const double* b, double* x, double rtol, double atol,
+                           int maxit, int restart, int x_is_zero, double* work,
+                           size_t work_len, int* iters_host, double* resid_host,
+                           void* stream);
 
 /* ---- assembly ------------------------------------------------------------
  * Two-phase, atomic-free: a cell kernel writes local tensors to `scratch`
@@ -340,6 +405,9 @@ int flow_residual_dev(int n, const double* b, const double* q,
 typedef struct {
   int nc;                  /* cells */
   const double* xy;        /* (2,3,nc): vertex coordinates */
+  int c0, c1;              /* K15: the cell kernels run over [c0, c1) only
+                              (c1 = 0: all cells) -- a rank's cells are those
+                              that touch its owned rows */
 } flow_mesh;
 
 typedef struct {
@@ -351,6 +419,10 @@ typedef struct {
   const int* csrc;
   const int* vptr;         /* n+1    vector contribution map */
   const int* vsrc;
+  int r0, r1;              /* K15: the gathers fill the rows [r0, r1) only
+                              (r1 = 0: all rows) ... */
+  int nnz0, nnz1;          /* ... and the nonzeros [nnz0, nnz1) = [rowptr[r0],
+                              rowptr[r1]) of matrix planes */
 } flow_space;
 
 /* per-cell P_k lattice values of a coefficient (Constant / Expression(degree=k)

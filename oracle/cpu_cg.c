@@ -26,6 +26,16 @@ int oracle_num_threads(void) {
 #endif
 }
 
+/* The host may be shared: use the CPUs this process may really run on (the
+ * caller reads the cgroup quota / affinity mask), not every CPU it can see. */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 void oracle_spmv_csr(int n, const int* rowptr, const int* cols,
                      const double* vals, const double* x, double* y) {
 #pragma omp parallel for schedule(static)

@@ -21,6 +21,31 @@ def build(native=False, out_dir=None):
     return out
 
 
+def usable_cores():
+    '''CPUs this process can really use: the affinity mask capped by the
+    cgroup CPU quota (a GPU box hands one tenant a share of its cores;
+    omp_get_max_threads() sees all of them and oversubscribes).'''
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max',):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != 'max':
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if quota > 0:
+            n = min(n, max(1, quota // period))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def load(path=None):
     path = path or os.path.join(_HERE, 'liboracle_cpu.so')
     if not os.path.isfile(path):
@@ -29,6 +54,10 @@ def load(path=None):
     ip = numpy.ctypeslib.ndpointer(numpy.int32, flags='C_CONTIGUOUS')
     dp = numpy.ctypeslib.ndpointer(numpy.float64, flags='C_CONTIGUOUS')
     lib.oracle_num_threads.restype = ctypes.c_int
+    lib.oracle_set_threads.restype = None
+    lib.oracle_set_threads.argtypes = [ctypes.c_int]
+    if not os.environ.get('OMP_NUM_THREADS'):
+        lib.oracle_set_threads(usable_cores())
     lib.oracle_spmv_csr.restype = None
     lib.oracle_spmv_csr.argtypes = [ctypes.c_int, ip, ip, dp, dp, dp]
     lib.oracle_jacobi_cg.restype = ctypes.c_int

@@ -1,20 +1,21 @@
 # -*- coding: utf-8 -*-
 '''
-The row-sharded pressure solve on the HIP path, rehearsed with several ranks on
-ONE GPU (gloo backend, buffers staged through the host; RCCL needs one GPU per
-rank and is only exercised by the driver's multi-GPU bench).  GPU only; at most
-4 processes touch the card.
+The strip-sharded step on the HIP path, rehearsed with 2 and 3 ranks on ONE GPU
+(gloo backend, the exchange buffer staged through the host; RCCL needs one GPU
+per rank and is only exercised by the driver's multi-GPU bench).  GPU only; at
+most 3 processes touch the card.
 
-1. The sharded CG itself (flow_cg_shard_step + the one-collective loop) on a
-   fixed linear system built identically on every rank: strict comparison with
-   the single-GPU solver and bitwise agreement between the ranks.
-2. A whole Karman step with the pressure solve sharded, against the
-   single-process step.  The ranks compute the tentative velocity redundantly;
-   this test is what exposed the stale solver scalars described in
-   flow_amd/csrc/common.h (load_scalar): replicas that ran BiCGStab along
-   different paths produced pressure right-hand sides that differed by rho/dt
-   times the Newton tolerance (~3e-5 relative at dt = 1e-5).  With the fix the
-   replicas are bitwise identical again (tools/debug_contention.py).
+Per world size one set of worker processes checks, against the single-GPU
+solvers run in the same process:
+  * halo exchange and reductions (ghost rows bitwise the owners' values),
+  * Jacobi-CG on the P2 mass matrix (scalar and two-component identity-row
+    form) -- flow_shard_cg_solve,
+  * the pressure solve with the strip-sharded V-cycle -- flow_shard_mgcg_solve:
+    same iteration count as the single-GPU V-cycle CG,
+  * two whole Karman time steps (Newton-GMRES with block-Jacobi ILU(0),
+    pressure, correction, step-size projection all on the strips) against the
+    single-process run: <= 1e-7 relative in u and p, ghost rows bitwise equal to
+    the owners' rows, the same step sizes.
 '''
 import os
 import socket
@@ -25,6 +26,8 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
+NX, NY = 120, 30
+
 
 def _free_port():
     s = socket.socket()
@@ -34,128 +37,180 @@ def _free_port():
     return port
 
 
-def _init(rank, world, port):
+def _rel(a, b):
+    return float(numpy.linalg.norm(a - b) / numpy.linalg.norm(b))
+
+
+def _karman_steps(nsteps=2):
+    from flow_amd import karman
+    import flow_amd.navier_stokes as navsto
+    # (a 3.7 k-row pressure system: let the hierarchy coarsen it all the same)
+    navsto.solver_parameters['pressure']['mg_coarsest'] = 200
+    prob = karman.KarmanProblem(NX, NY, velocity_degree=2)
+    prob.set_initial_profile()
+    infos = [prob.step(tol=1e-12) for _ in range(nsteps)]
+    return prob, infos
+
+
+def _worker(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['LOCAL_RANK'] = '0'          # every rank shares cuda:0
+    import torch
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    return dist
-
-
-# -- 1. the solver on a fixed system -------------------------------------------
-def _poisson_system(two_level):
-    '''P1 stiffness matrix of a channel mesh with a Dirichlet outlet, Jacobi
-    diagonal, optional coarse space, right-hand side; all from fixed seeds.'''
-    from flow_amd import fem, device
-    from flow_amd.fem import ops
-    mesh = fem.karman_channel(120, 30)
-    P = fem.FunctionSpace(mesh, 'CG', 1)
-    isbc = mesh.points[:, 0] > mesh.points[:, 0].max() - 1e-12
-    K = ops.assemble_stiffness(P)
-    Kbc = ops.symmetric_bc_matrix(K, device.to_device(isbc.astype(numpy.uint8)))
-    dinv = Kbc.diag_inv()
-    coarse = ops.CoarseSpace(Kbc, isbc, target_nc=64) if two_level else None
-    b = 1.0e3 * numpy.random.RandomState(3).standard_normal(P.layout.N)
-    b[isbc] = 0.0
-    return Kbc, dinv, coarse, device.to_device(b)
-
-
-def _solver_worker(rank, world, port, two_level, out):
-    dist = _init(rank, world, port)
     try:
-        from flow_amd import parallel, device
+        from flow_amd import parallel, device, fem
+        from flow_amd.fem import ops
+        from flow_amd.fem.multigrid import Multigrid
+        res = {}
+        mesh = fem.karman_channel(NX, NY)
+        W = fem.VectorFunctionSpace(mesh, 'CG', 2)
+        P = fem.FunctionSpace(mesh, 'CG', 1)
+        lay, play = W.layout, P.layout
+        n = lay.N
+        rng = numpy.random.RandomState(5)
+        full = rng.standard_normal(2 * n)
+
+        # ---- single-GPU references (parallel not enabled yet) ---------------
+        M = ops.assemble_mass(W.collapse())
+        dinv = M.diag_inv()
+        b1 = device.to_device(full[:n])
+        x1 = device.zeros(n)
+        ref1 = ops.krylov_solve('cg', M, b1, x1, 1e-11, maxit=500, dinv=dinv,
+                                check_every=2)
+        free = numpy.ones(2 * n, dtype=numpy.uint8)
+        bdofs = rng.choice(2 * n, 50, replace=False)
+        free[bdofs] = 0
+        Mrows = ops.Matrix(lay, 4, M.vals, rowmask=device.to_device(free))
+        dinv2 = Mrows.diag_inv()
+        b2 = device.to_device(full)
+        x2 = device.zeros(2 * n)
+        x2[torch.from_numpy(bdofs).to(device.get())] = b2[
+            torch.from_numpy(bdofs).to(device.get())]
+        x2s = x2.clone()
+        ref2 = ops.krylov_solve('cg', Mrows, b2, x2, 1e-11, maxit=500,
+                                dinv=dinv2, check_every=2)
+        isbc = mesh.points[:, 0] > mesh.points[:, 0].max() - 1e-12
+        K = ops.assemble_stiffness(P)
+        Kbc = ops.symmetric_bc_matrix(
+            K, device.to_device(isbc.astype(numpy.uint8)))
+        kdinv = Kbc.diag_inv()
+        mg = Multigrid(Kbc, isbc, coarsest=200)
+        assert mg.nlevels >= 3
+        bp = 1.0e3 * rng.standard_normal(play.N)
+        bp[isbc] = 0.0
+        bp = device.to_device(bp)
+        xp = device.zeros(play.N)
+        refp = ops.krylov_solve('cg', Kbc, bp, xp, 1e-11, maxit=500, dinv=kdinv,
+                                check_every=2, mg=mg)
+
+        # ---- on the strips ---------------------------------------------------
         parallel.enable(dist.group.WORLD, force=True)
-        Kbc, dinv, coarse, b = _poisson_system(two_level)
-        x = device.zeros(b.numel())
-        sol = parallel.pressure_cg(Kbc, dinv, coarse, b, x, 1e-11, 0.0, 20000, 10)
-        # second solve on the same context, warm-started: no stale state
-        x2 = device.zeros(b.numel())
-        x2[:] = 0.5 * x
-        sol2 = parallel.pressure_cg(Kbc, dinv, coarse, b, x2, 1e-11, 0.0, 20000,
-                                    10)
-        out[rank] = (device.to_host(x).numpy(), sol.iterations, sol.method,
-                     device.to_host(x2).numpy(), sol2.iterations)
+        v = parallel.view(lay)
+        res['ranges'] = (v.r0, v.r1, v.e0, v.e1, n)
+        # halo: keep the owned rows of a known field, poison the rest
+        f = device.to_device(full.copy())
+        own = numpy.zeros(2 * n, dtype=bool)
+        for a in (0, 1):
+            own[a * n + v.r0:a * n + v.r1] = True
+        f[torch.from_numpy(~own).to(device.get())] = float('nan')
+        parallel.halo(f, lay, 2)
+        got = device.to_host(f).numpy()
+        ext = numpy.zeros(2 * n, dtype=bool)
+        for a in (0, 1):
+            ext[a * n + v.e0:a * n + v.e1] = True
+        res['halo_exact'] = bool(numpy.array_equal(got[ext], full[ext]))
+        res['halo_untouched'] = bool(numpy.isnan(got[~ext]).all())
+        g = device.to_device(full)
+        res['dot'] = parallel.dot(g, g, lay, 2) / float(full.dot(full)) - 1.0
+        res['linf'] = parallel.norm_linf(g, lay, 2) - float(abs(full).max())
+
+        y1 = device.zeros(n)
+        s1 = parallel.cg(M, dinv, b1, y1, 1e-11, maxit=500, check_every=2)
+        res['cg1'] = (s1.iterations, ref1.iterations,
+                      _rel(device.to_host(parallel.gather_field(y1.clone(), lay))
+                           .numpy(), device.to_host(x1).numpy()))
+        # ghost rows of the solution equal the owners' (gathered) values
+        whole = device.to_host(parallel.gather_field(y1.clone(), lay)).numpy()
+        res['cg1_ghosts'] = bool(numpy.array_equal(
+            device.to_host(y1).numpy()[v.e0:v.e1], whole[v.e0:v.e1]))
+
+        y2 = x2s.clone()
+        s2 = parallel.cg(Mrows, dinv2, b2, y2, 1e-11, maxit=500, check_every=2)
+        res['cg2'] = (s2.iterations, ref2.iterations,
+                      _rel(device.to_host(parallel.gather_field(
+                          y2.clone(), lay, 2)).numpy(),
+                          device.to_host(x2).numpy()))
+
+        yp = device.zeros(play.N)
+        sp = parallel.mgcg(Kbc, kdinv, mg, bp, yp, 1e-11, maxit=500)
+        res['mgcg'] = (sp.iterations, refp.iterations,
+                       _rel(device.to_host(parallel.gather_field(
+                           yp.clone(), play)).numpy(),
+                           device.to_host(xp).numpy()))
+
+        # ---- two whole time steps on the strips -----------------------------
+        prob, infos = _karman_steps()
+        u_loc = device.to_host(prob.u0.data).numpy().copy()
+        p_loc = device.to_host(prob.p0.data).numpy().copy()
+        u = device.to_host(parallel.gather_field(
+            prob.u0.data.clone(), lay, 2)).numpy()
+        p = device.to_host(parallel.gather_field(
+            prob.p0.data.clone(), play)).numpy()
+        pv = parallel.view(play)
+        res['step'] = dict(
+            u=u, p=p, dt=[i['dt'] for i in infos], t=prob.t,
+            newton=[len(i['newton_residuals']) - 1 for i in infos],
+            pressure=[i['pressure'].iterations for i in infos],
+            method=infos[-1]['pressure'].method,
+            ghosts_u=bool(numpy.array_equal(u_loc[ext], u[ext])),
+            ghosts_p=bool(numpy.array_equal(p_loc[pv.e0:pv.e1],
+                                            p[pv.e0:pv.e1])),
+            calls=parallel.comm().calls,
+            )
+        out[rank] = res
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,two_level', [(2, True), (3, False), (3, True)])
-def test_sharded_cg_matches_single_gpu_solver(hip, world, two_level):
-    from flow_amd import device
-    from flow_amd.fem import ops
-    Kbc, dinv, coarse, b = _poisson_system(two_level)
-    x_ref = device.zeros(b.numel())
-    ref = ops.krylov_solve('cg', Kbc, b, x_ref, rtol=1e-11, maxit=20000,
-                           dinv=dinv, check_every=10, coarse=coarse)
-    x_ref = device.to_host(x_ref).numpy()
+@pytest.mark.parametrize('world', [2, 3])
+def test_strip_sharded_solvers_and_step(hip, world):
+    # the single-process run of the same two steps
+    prob, infos = _karman_steps()
+    u_ref = prob.u0.vector().get_local().copy()
+    p_ref = prob.p0.vector().get_local().copy()
     manager = mp.get_context('spawn').Manager()
     out = manager.dict()
-    mp.spawn(_solver_worker, args=(world, _free_port(), two_level, out),
-             nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    covered = 0
     for r in range(world):
-        x, its, method, x2, its2 = out[r]
-        assert 'row-sharded x%d' % world in method
-        assert ('2level' in method) == two_level
-        # different summation order of the dot products: agreement to solver
-        # accuracy (rtol 1e-11 on a kappa ~ 1e4..1e5 system)
-        e = numpy.linalg.norm(x - x_ref) / numpy.linalg.norm(x_ref)
-        assert e <= 1e-7, e
-        e2 = numpy.linalg.norm(x2 - x_ref) / numpy.linalg.norm(x_ref)
-        assert e2 <= 1e-7, e2
-        # the stopping test is evaluated every check_every iterations
-        assert abs(its - ref.iterations) <= 30, (its, ref.iterations)
-        assert its2 <= its
-        # every rank holds the same solution, bit for bit
-        assert numpy.array_equal(x, out[0][0])
-        assert numpy.array_equal(x2, out[0][3])
-        assert its == out[0][1]
-
-
-# -- 2. inside a time step -----------------------------------------------------
-def _karman_step(two_level):
-    from flow_amd import karman
-    import flow_amd.navier_stokes as navsto
-    navsto.solver_parameters['pressure']['two_level'] = two_level
-    prob = karman.KarmanProblem(96, 24, velocity_degree=2)
-    prob.set_initial_profile()
-    infos = [prob.step(tol=1e-12) for _ in range(2)]
-    return prob.u0.array(), prob.p0.array(), infos
-
-
-def _step_worker(rank, world, port, two_level, out):
-    dist = _init(rank, world, port)
-    try:
-        from flow_amd import parallel
-        # force: the auto policy would not shard a system this small
-        parallel.enable(dist.group.WORLD, force=True)
-        u, p, infos = _karman_step(two_level)
-        out[rank] = (u, p, [i['pressure'].iterations for i in infos],
-                     infos[-1]['pressure'].method)
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize('world,two_level', [(2, True), (3, False)])
-def test_sharded_pressure_solve_inside_a_step(hip, world, two_level):
-    u_ref, p_ref, infos = _karman_step(two_level)
-    its_ref = [i['pressure'].iterations for i in infos]
-    manager = mp.get_context('spawn').Manager()
-    out = manager.dict()
-    mp.spawn(_step_worker, args=(world, _free_port(), two_level, out),
-             nprocs=world, join=True)
-    for r in range(world):
-        u, p, its, method = out[r]
-        assert 'row-sharded x%d' % world in method
-        assert ('2level' in method) == two_level
-        ep = numpy.linalg.norm(p - p_ref) / numpy.linalg.norm(p_ref)
-        eu = numpy.linalg.norm(u - u_ref) / numpy.linalg.norm(u_ref)
-        # different summation order across ranks: agreement to solver accuracy
-        # (tol 1e-12 on a kappa ~ 1e5 system; bar: 1e-6)
-        assert ep <= 5e-7, ep
-        assert eu <= 5e-7, eu
-        # the pressure is the solution of ONE global system on every rank
-        assert numpy.array_equal(p, out[0][1])
-        for a, b in zip(its, its_ref):
-            # the stopping test is evaluated every check_every iterations
-            assert abs(a - b) <= 60, (its, its_ref)
+        res = out[r]
+        r0, r1, e0, e1, n = res['ranges']
+        covered += r1 - r0
+        assert res['halo_exact'] and res['halo_untouched']
+        assert abs(res['dot']) < 1e-13 and res['linf'] == 0.0
+        for key, slack in (('cg1', 1), ('cg2', 1), ('mgcg', 1)):
+            its, its_ref, err = res[key]
+            assert abs(its - its_ref) <= slack, (key, its, its_ref)
+            assert err < 1e-9, (key, err)
+        assert res['cg1_ghosts']
+        st = res['step']
+        assert 'x-strips x%d' % world in st['method']
+        assert st['ghosts_u'] and st['ghosts_p']
+        # block-Jacobi ILU: other GMRES iterates, the same Newton path
+        assert st['newton'] == [len(i['newton_residuals']) - 1 for i in infos]
+        for a, b in zip(st['pressure'],
+                        [i['pressure'].iterations for i in infos]):
+            assert abs(a - b) <= 1, (st['pressure'], infos)
+        assert abs(st['t'] - prob.t) <= 1e-9 * prob.t
+        eu, ep = _rel(st['u'], u_ref), _rel(st['p'], p_ref)
+        assert eu < 1e-7 and ep < 1e-7, (eu, ep)
+        # every rank holds the same gathered fields, bit for bit
+        assert numpy.array_equal(st['u'], out[0]['step']['u'])
+        assert numpy.array_equal(st['p'], out[0]['step']['p'])
+    assert covered == out[0]['ranges'][4]
+    print('world %d: step vs single GPU: du %.2e dp %.2e, collectives per '
+          'rank %d' % (world, _rel(out[0]['step']['u'], u_ref),
+                       _rel(out[0]['step']['p'], p_ref),
+                       out[0]['step']['calls']))
