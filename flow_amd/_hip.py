@@ -201,6 +201,7 @@ SYMBOLS = {
     'flow_cg_solve': [_P(Operator), _VP, _P(CoarseS), _P(MgS), _VP, _VP, _D, _D,
                       _I, _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_mg_apply': [_P(MgS), _I, _VP, _VP, _VP],
+    'flow_two_level_apply': [_P(CoarseS), _VP, _VP, _VP, _VP, _VP],
     'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
                             _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_gmres_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I, _I,
@@ -240,6 +241,8 @@ SYMBOLS = {
     'flow_bc_symmetric_matrix': [_I, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_assemble_heat': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _D, _D, _I,
                            _VP, _VP, _VP, _VP, _VP, _VP],
+    'flow_assemble_heat_supg_source': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP,
+                                       _D, _D, _P(CoefS), _VP, _VP, _VP, _VP],
     }
 
 _LIB = None

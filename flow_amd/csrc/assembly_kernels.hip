@@ -872,6 +872,72 @@ __global__ __launch_bounds__(kBlock) void heat_kernel(
   }
 }
 
+// SUPG part of the heat load vector (flow/heat.py:79-86, the `source / rho_cp`
+// term of R2):  b_i = int (source / rho_cp) tau (conv . grad v_i).  The source
+// is a P_k interpolant per cell, k = 0, 1, 2 (f.nl = 1, 3, 6 lattice values in
+// the local dof order); degree k + 1 + 2 + 1 <= 6: the 16-point rule is exact.
+template <int DEGQ, int DEGW>
+__global__ __launch_bounds__(kBlock) void heat_supg_source_kernel(
+    int nc, const double* __restrict__ xy, const int* __restrict__ cdw, int nw,
+    const double* __restrict__ conv, double kappa, double rho_cp, flow_coef f,
+    double* __restrict__ scratch, int* __restrict__ status) {
+  constexpr int NL = Elem<DEGQ>::NL;
+  constexpr int NW = Elem<DEGW>::NL;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const Geom g = load_geom(xy, nc, c);
+  double Cv[2][NW];
+  load_local<NW>(conv, nw, cdw, nc, c, 2, Cv);
+  const double px[3] = {xy[0 * nc + c], xy[1 * nc + c], xy[2 * nc + c]};
+  const double py[3] = {xy[3 * nc + c], xy[4 * nc + c], xy[5 * nc + c]};
+  double tau_v[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+    tau_v[m] = supg_tau(px, py, 0.5 * g.adet, Cv[0][m], Cv[1][m], kappa, DEGQ,
+                        status);
+  const size_t nce = f.cell_stride ? static_cast<size_t>(nc) : 1;
+  const size_t cc = f.cell_stride ? static_cast<size_t>(c) : 0;
+  double Sv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int l = 0; l < f.nl; ++l) Sv[l] = f.values[static_cast<size_t>(l) * nce + cc];
+  double acc[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) acc[i] = 0.0;
+  for (int q = 0; q < 16; ++q) {
+    const double L[3] = {kQ16L[q][0], kQ16L[q][1], kQ16L[q][2]};
+    const double w = 0.5 * kQ16W[q] * g.adet;
+    double phi[NL], dphi[NL][3], gphi[NL][2];
+    basis<DEGQ>(L, phi, dphi);
+    phys_grad<NL>(g, dphi, gphi);
+    double wphi[NW], wd[NW][3];
+    basis<DEGW>(L, wphi, wd);
+    double b[2] = {0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      b[0] += Cv[0][t] * wphi[t];
+      b[1] += Cv[1][t] * wphi[t];
+    }
+    double sq;
+    if (f.nl == 1) {
+      sq = Sv[0];
+    } else if (f.nl == 3) {
+      sq = Sv[0] * L[0] + Sv[1] * L[1] + Sv[2] * L[2];
+    } else {
+      double p2[6], d2[6][3];
+      basis<2>(L, p2, d2);
+      sq = 0.0;
+#pragma unroll
+      for (int l = 0; l < 6; ++l) sq += Sv[l] * p2[l];
+    }
+    const double tq = tau_v[0] * L[0] + tau_v[1] * L[1] + tau_v[2] * L[2];
+    const double fac = w * sq / rho_cp * tq;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      acc[i] += fac * (b[0] * gphi[i][0] + b[1] * gphi[i][1]);
+  }
+#pragma unroll
+  for (int i = 0; i < NL; ++i) scratch[static_cast<size_t>(i) * nc + c] = acc[i];
+}
+
 // ---------------------------------------------------------------------------
 // Stokes (flow/stokes.py:40-42): adjoint of the divergence coupling,
 // out_(a,i) = - int p d_a phi_i   (the term  - p * div(v) * dx)
@@ -1290,4 +1356,34 @@ extern "C" int flow_assemble_heat(const flow_mesh* mesh, const flow_space* Q,
   if (supg)
     return gather(Q->nnz, 1, Q->cptr, Q->csrc, scratch + plane, 0, Msupg_vals, st);
   return FLOW_OK;
+}
+
+extern "C" int flow_assemble_heat_supg_source(
+    const flow_mesh* mesh, const flow_space* Q, const flow_space* W,
+    const double* conv, double kappa, double rho_cp, const flow_coef* source,
+    double* scratch, double* b, int* status_dev, void* stream) {
+  int rc = check_mesh_space(mesh, Q);
+  if (rc) return rc;
+  if ((rc = check_mesh_space(mesh, W))) return rc;
+  FLOW_REQUIRE(source && source->values &&
+                   (source->nl == 1 || source->nl == 3 || source->nl == 6),
+               "SUPG source: a P0, P1 or P2 interpolant per cell");
+  FLOW_REQUIRE(source->cell_stride == 0 || source->cell_stride == 1,
+               "coefficient stride");
+  FLOW_REQUIRE(conv && scratch && b && status_dev && Q->vptr && Q->vsrc,
+               "pointers");
+  FLOW_REQUIRE(kappa > 0.0 && rho_cp > 0.0, "coefficients");
+  hipStream_t st = as_stream(stream);
+  const dim3 grid = cell_grid(mesh->nc);
+#define FLOW_HEAT(DQ, DW)                                                        \
+  hipLaunchKernelGGL((heat_supg_source_kernel<DQ, DW>), grid, dim3(kBlock), 0,   \
+                     st, mesh->nc, mesh->xy, W->cell_dofs, W->n, conv, kappa,    \
+                     rho_cp, *source, scratch, status_dev)
+  if (Q->deg == 1 && W->deg == 1) FLOW_HEAT(1, 1);
+  else if (Q->deg == 1 && W->deg == 2) FLOW_HEAT(1, 2);
+  else if (Q->deg == 2 && W->deg == 1) FLOW_HEAT(2, 1);
+  else FLOW_HEAT(2, 2);
+#undef FLOW_HEAT
+  FLOW_CHECK_LAUNCH();
+  return gather(Q->n, 1, Q->vptr, Q->vsrc, scratch, 0, b, st);
 }

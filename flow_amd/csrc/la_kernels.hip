@@ -105,13 +105,21 @@ __device__ __forceinline__ double stream_tile_row_sum(
   // the padding 0 behind the last nonzero) and the idle lanes must not be
   // dereferenced -- x may be a window of a larger vector (row-sharded solves
   // pass x shifted to global row numbering: x[0] is then far outside it)
+  // Those entries gather the tile's first column instead (an index select,
+  // the loads themselves stay unconditional and all in flight).
   const int lo = k0 - ka, hi = k1 - ka;
+  const int safe = cols[k0 < k1 ? k0 : (k0 > 0 ? k0 - 1 : 0)];
   double x0[kPairs], x1[kPairs];
+  if (k0 < k1) {                       // (block-uniform)
 #pragma unroll
-  for (int j = 0; j < kPairs; ++j) {   // all gathers in flight before any use
-    const int e = 2 * (threadIdx.x + j * kBlock);
-    x0[j] = (e >= lo && e < hi) ? x[c[j].x] : 0.0;
-    x1[j] = (e + 1 < hi) ? x[c[j].y] : 0.0;
+    for (int j = 0; j < kPairs; ++j) {   // all gathers in flight before any use
+      const int e = 2 * (threadIdx.x + j * kBlock);
+      x0[j] = x[(e >= lo && e < hi) ? c[j].x : safe];
+      x1[j] = x[(e + 1 < hi) ? c[j].y : safe];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kPairs; ++j) x0[j] = x1[j] = 0.0;
   }
 #pragma unroll
   for (int j = 0; j < kPairs; ++j) {
@@ -230,10 +238,11 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
     if (p < npair) {
       const int2 c = c2p[p];
       const double2 axx = pxx[p], axy = pxy[p], ayx = pyx[p], ayy = pyy[p];
-      // (only the tile's own nonzeros are dereferenced)
-      const bool g0 = 2 * p >= k0 - ka, g1 = 2 * p + 1 < k1 - ka;
-      const double u0 = g0 ? x[c.x] : 0.0, u1 = g0 ? x[n + c.x] : 0.0;
-      const double w0 = g1 ? x[c.y] : 0.0, w1 = g1 ? x[n + c.y] : 0.0;
+      // (only the tile's own columns are dereferenced)
+      const int cx = 2 * p >= k0 - ka ? c.x : cols[k0];
+      const int cy = 2 * p + 1 < k1 - ka ? c.y : cols[k0];
+      const double u0 = x[cx], u1 = x[n + cx];
+      const double w0 = x[cy], w1 = x[n + cy];
       prod0[2 * p] = axx.x * u0 + axy.x * u1;
       prod1[2 * p] = ayx.x * u0 + ayy.x * u1;
       prod0[2 * p + 1] = axx.y * w0 + axy.y * w1;
@@ -296,17 +305,20 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
     v[j] = ok ? v2p[p] : make_double2(0.0, 0.0);
     c[j] = ok ? c2p[p] : make_int2(0, 0);
   }
-  // (only the tile's own nonzeros are dereferenced: see stream_tile_row_sum)
+  // (only the tile's own columns are dereferenced: see stream_tile_row_sum;
+  // a block of this square operator is never empty)
   const int lo = k0 - ka, hi = k1 - ka;
+  const int safe = cols[k0];
   double xa[kPairs], xb[kPairs], ua[kPairs], ub[kPairs];
 #pragma unroll
   for (int j = 0; j < kPairs; ++j) {   // all gathers in flight before any use
     const int e = 2 * (threadIdx.x + j * kBlock);
-    const bool g0 = e >= lo && e < hi, g1 = e + 1 < hi;
-    xa[j] = g0 ? x[c[j].x] : 0.0;
-    xb[j] = g1 ? x[c[j].y] : 0.0;
-    ua[j] = g0 ? x[xs + c[j].x] : 0.0;
-    ub[j] = g1 ? x[xs + c[j].y] : 0.0;
+    const int cx = (e >= lo && e < hi) ? c[j].x : safe;
+    const int cy = (e + 1 < hi) ? c[j].y : safe;
+    xa[j] = x[cx];
+    xb[j] = x[cy];
+    ua[j] = x[xs + cx];
+    ub[j] = x[xs + cy];
   }
 #pragma unroll
   for (int j = 0; j < kPairs; ++j) {
@@ -1826,6 +1838,20 @@ extern "C" int flow_mg_apply(const flow_mg* mg, int n, const double* r,
   int rc = check_mg(mg, n);
   if (rc) return rc;
   return vcycle(mg, r, z, as_stream(stream));
+}
+
+// z = D^-1 r + P Ac^-1 P^T r: one application of the two-level preconditioner
+// (callers that drive their own Krylov loop: the Stokes MINRES)
+extern "C" int flow_two_level_apply(const flow_coarse* coarse,
+                                    const double* dinv, const double* r,
+                                    double* z, double* work, void* stream) {
+  FLOW_REQUIRE(coarse && dinv && r && z && work && r != z, "two-level apply");
+  int rc = check_coarse(coarse, coarse->n);
+  if (rc) return rc;
+  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(work) % 16 == 0,
+               "two-level workspace must be 16-byte aligned");
+  return two_level(coarse, dinv, r, z, work, work + coarse->lda,
+                   as_stream(stream));
 }
 
 extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,

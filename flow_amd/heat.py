@@ -16,7 +16,8 @@ All operators are assembled by the HIP kernels of libflow_hip.so (K13/K14):
   A  matrix of f = -kappa grad(u).grad(v/(rho cp)) - (conv.grad u) v
      (reference :54-58) [+ SUPG terms, :60-86];
   b  rhs(f) = -int source v (UFL's rhs() negates; reference :88).
-The reference solves with sparse LU (:117-121); here BiCGStab + Jacobi.
+The reference solves with sparse LU (:117-121); here BiCGStab + ILU(0) on the
+row-equilibrated system.
 '''
 import ctypes
 
@@ -24,7 +25,9 @@ import torch
 
 from .fem import ops
 from .fem.bcs import collect
-from .fem.function import Constant, Function, Vector
+from .fem.function import (
+    Constant, Function, Vector, as_cell_coefficient,
+    )
 from . import _hip
 from . import device
 from . import stabilization
@@ -95,7 +98,8 @@ class Heat(object):
         else:
             self.M = lumped
 
-        # b = rhs(f) = - int source v  [SUPG source term only for source = 0]
+        # b = rhs(f) = - int source v  [- int (source / rho_cp) tau conv.grad(v)
+        # with SUPG: the source term of R2, reference :79-86]
         if isinstance(source, (int, float)):
             source = Constant(source)
         zero_source = isinstance(source, Constant) and \
@@ -103,11 +107,23 @@ class Heat(object):
         if zero_source:
             self.b = Vector(device.zeros(V.N))
         else:
-            if supg_stabilization:
-                raise NotImplementedError(
-                    'SUPG with a non-zero source is outside the hot path'
-                    )
             self.b = Vector(-ops.assemble_source(V, source))
+            if supg_stabilization:
+                coef = as_cell_coefficient(source, mesh, 1)
+                assert coef.nl in (1, 3, 6), \
+                    'SUPG source: Constant or Expression of degree <= 2'
+                cs, keep = ops.coef_struct(coef, mesh, lay.degree)
+                bs = device.empty(V.N)
+                _hip.check(lib.flow_assemble_heat_supg_source(
+                    ctypes.byref(ops.mesh_struct(mesh)),
+                    ctypes.byref(ops.space_struct(lay)),
+                    ctypes.byref(ops.space_struct(W.layout)),
+                    _hip.f64(conv.data, W.size()), kappa, rho_cp,
+                    ctypes.byref(cs), _hip.f64(buf), _hip.f64(bs),
+                    _hip.i32(status), _hip.stream()
+                    ))
+                del keep
+                ops.axpby(-1.0, bs, 1.0, self.b.data)
         return
 
     # pylint: disable=unused-argument

@@ -61,10 +61,12 @@ def enable(group, force=False):
     _STATE['group'] = group
     _STATE['force'] = bool(force)
     _STATE['comm'] = Comm(group)
-    if dist.get_world_size(group) > 1:
-        t = torch.zeros(1, dtype=torch.float64, device=device.get()
-                        if dist.get_backend(group) != 'gloo' else 'cpu')
-        dist.all_reduce(t, group=group)
+    # the first collective brings the communicator up: here, not inside a
+    # solver loop
+    t = torch.zeros(1, dtype=torch.float64, device=device.get()
+                    if dist.get_backend(group) != 'gloo' else 'cpu')
+    dist.all_reduce(t, group=group)
+    device.synchronize()
 
 
 def disable():

@@ -167,6 +167,13 @@ typedef struct {
   const float* Ainv;                      /* nc rows of lda floats, as flow_coarse */
   double omega;                           /* Jacobi damping w (0.8) */
 } flow_mg;
+/* z = D^-1 r + P Ac^-1 P^T r: one application of the two-level preconditioner
+ * (for callers that drive their own Krylov loop: the preconditioned MINRES of
+ * flow_amd/stokes.py).  work: 2*coarse->lda doubles, 16-byte aligned. */
+int flow_two_level_apply(const flow_coarse* coarse, const double* dinv,
+                         const double* r, double* z, double* work,
+                         void* stream);
+
 /* z = V-cycle(r) on level 0 (n = its size): one preconditioner application */
 int flow_mg_apply(const flow_mg* mg, int n, const double* r, double* z,
                   void* stream);
@@ -556,6 +563,17 @@ int flow_assemble_heat(const flow_mesh* mesh, const flow_space* Q,
                        double rho_cp, int supg, double* scratch, double* Avals,
                        double* Msupg_vals, double* tau_out, int* status_dev,
                        void* stream);
+
+/* SUPG part of the heat load vector with a non-zero source (heat.py:79-86:
+ * the `source / rho_cp` term of R2 times tau conv.grad(v)):
+ *   b_i = int (source / rho_cp) tau (conv . grad v_i);
+ * source: a scalar P0/P1/P2 interpolant per cell (nl = 1, 3, 6; G unused).
+ * scratch: nloc*nc. */
+int flow_assemble_heat_supg_source(const flow_mesh* mesh, const flow_space* Q,
+                                   const flow_space* W, const double* conv,
+                                   double kappa, double rho_cp,
+                                   const flow_coef* source, double* scratch,
+                                   double* b, int* status_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,40 @@ def test_heat_operators(hip, qdeg, wdeg, supg):
             assert (d[Q.layout.vertex_dofs] > 0.0).all()
 
 
+@pytest.mark.parametrize('qdeg,wdeg', [(1, 2), (2, 2)])
+def test_heat_load_vector_with_source(hip, qdeg, wdeg):
+    '''b = rhs(f) with a non-zero source: - int s v, and with SUPG also
+    - int (s / rho_cp) tau conv.grad(v) (reference flow/heat.py:54-58, 79-86),
+    against the oracle for a constant source; a source handed in as a
+    degree-1 / degree-2 Expression of the same constant gives the same vector
+    (the P_k interpolation per cell is exact for it).'''
+    # (rho cp = 1: the SUPG part, which carries a factor 1 / (rho cp), is then
+    # as large as - int s v and cannot hide in the tolerance)
+    kappa, rho, cp = 1.0e-3, 1.0, 1.0
+    src = 3.0
+    mesh, Q, W, conv, Qo, Wo, bcs = _setup(qdeg, wdeg, 0.5)
+    got = {}
+    for supg in (False, True):
+        _, _, bo = orc.heat_operators(Qo, Wo, conv.array(), kappa, rho, cp, src,
+                                      supg)
+        H = heat.Heat(Q, conv, kappa, rho, cp, bcs, fem.Constant(src),
+                      supg_stabilization=supg)
+        b = H.b.get_local()
+        got[supg] = (b, bo)
+        assert abs(b - bo).max() < 1e-11 * abs(bo).max(), supg
+        for k in (1, 2):
+            Hk = heat.Heat(Q, conv, kappa, rho, cp, bcs,
+                           fem.Expression('s + 0.0 * x[0]', degree=k, s=src),
+                           supg_stabilization=supg)
+            assert abs(Hk.b.get_local() - bo).max() < 1e-11 * abs(bo).max()
+    # the SUPG part on its own (it is small next to - int s v: a missing term
+    # could hide in the tolerance above)
+    part = got[True][0] - got[False][0]
+    part_o = got[True][1] - got[False][1]
+    assert abs(part_o).max() > 1e-2 * abs(got[False][1]).max()
+    assert abs(part - part_o).max() < 1e-9 * abs(part_o).max()
+
+
 def test_supg_tau_kernel(hip):
     mesh, Q, W, conv, Qo, Wo, _ = _setup(2, 2, 2.0)
     eps = 1.4e-4
