@@ -44,8 +44,12 @@ class CoolBoundary(fem.SubDomain):
 
 
 def compute_boussinesq(target_time, nx=16, supg=False, verbose=False,
-                       dt0=1.0e-2):
-    mesh = fem.heater_box(nx)
+                       dt0=1.0e-2, mesh=None):
+    '''mesh: default the structured heater box with nx cells across;
+    fem.heater_box_coarse() is the counterpart of the reference's
+    `lcar = 0.1` gmsh mesh (tests/test_boussinesq.py:84-97).'''
+    if mesh is None:
+        mesh = fem.heater_box(nx)
     hot_boundary = HotBoundary()
     cool_boundary = CoolBoundary()
 

@@ -285,3 +285,40 @@ def heater_box(nx, ny=None, diagonal='right'):
     return rectangle_with_hole(
         0.0, 0.1, 0.0, 0.2, (0.05, 0.05), 0.02, nx, ny, diagonal
         )
+
+
+def heater_box_coarse(nsides=9, side_points=1):
+    '''The heater box as gmsh meshes it at `lcar = 0.1` -- the setting of the
+    reference's golden norms (tests/test_boussinesq.py:84-97): the box is only
+    one `lcar` wide, so its short sides stay one segment and its long sides
+    get `side_points` interior points; the circle, three arcs with gmsh's
+    minimum of points per arc, becomes a polygon of `nsides` = 9 sides (area
+    2.8925 r^2: the reference's ||theta|| = 40.2258 = 293 sqrt(|Omega|) up to
+    the heating fits that to 1e-4).  Delaunay triangulation (scipy) of those
+    points with the polygon cut out.  The reference's exact triangulation
+    (gmsh version dependent, not stored anywhere) cannot be reproduced: this
+    is the same geometry at the same resolution, for a like-with-like look at
+    its goldens, not a pin.'''
+    from scipy.spatial import Delaunay
+    x0, x1, y0, y1 = 0.0, 0.1, 0.0, 0.2
+    cx, cy, r = 0.05, 0.05, 0.02
+    pts = [(x0, y0), (x1, y0), (x1, y1), (x0, y1)]
+    for k in range(1, side_points + 1):
+        y = y0 + (y1 - y0) * k / (side_points + 1.0)
+        pts += [(x0, y), (x1, y)]
+    ang = 2.0 * numpy.pi * numpy.arange(nsides) / nsides
+    pts += [(cx + r * numpy.cos(a), cy + r * numpy.sin(a)) for a in ang]
+    pts = numpy.array(pts)
+    tri = Delaunay(pts).simplices
+    cen = pts[tri].mean(axis=1)
+    # inside the polygon: a triangle of polygon vertices only
+    first = 4 + 2 * side_points
+    inside = (tri >= first).all(axis=1)
+    assert (numpy.hypot(cen[inside, 0] - cx, cen[inside, 1] - cy) < r).all()
+    cells = tri[~inside]
+    # counter-clockwise
+    p = pts[cells]
+    det = (p[:, 1, 0] - p[:, 0, 0]) * (p[:, 2, 1] - p[:, 0, 1]) \
+        - (p[:, 2, 0] - p[:, 0, 0]) * (p[:, 1, 1] - p[:, 0, 1])
+    cells[det < 0] = cells[det < 0][:, [0, 2, 1]]
+    return Mesh(pts, cells.astype(numpy.int32))

@@ -17,7 +17,7 @@ All operators are assembled by the HIP kernels of libflow_hip.so (K13/K14):
      (reference :54-58) [+ SUPG terms, :60-86];
   b  rhs(f) = -int source v (UFL's rhs() negates; reference :88).
 The reference solves with sparse LU (:117-121); here BiCGStab + ILU(0) on the
-row-equilibrated system.
+row-equilibrated system (GMRES(30) first, BiCGStab as the second try).
 '''
 import ctypes
 
@@ -32,7 +32,7 @@ from . import _hip
 from . import device
 from . import stabilization
 
-solver_parameters = {'rtol': 1.0e-13, 'maxit': 20000, 'check_every': 10,
+solver_parameters = {'rtol': 1.0e-13, 'maxit': 2000, 'check_every': 10,
                      'preconditioner': 'ilu0'}     # 'ilu0' | 'jacobi'
 last_solve_info = {}
 
@@ -190,9 +190,20 @@ class Heat(object):
             # a poor preconditioner; the reference solves with LU (:116-121).
             from .fem import ilu
             pre = ilu.Ilu0(A)
-        info = ops.krylov_solve(
-            'bicgstab', A, bvec, u.data, rtol=par['rtol'], atol=0.0,
-            maxit=par['maxit'], check_every=par['check_every'], ilu=pre
-            )
+        # GMRES(30) + ILU(0) (minimises the residual monotonically; BiCGStab
+        # stagnates on very coarse meshes, where most rows are zero-mass edge
+        # rows), BiCGStab as the second try
+        try:
+            info = ops.krylov_solve(
+                'gmres', A, bvec, u.data, rtol=par['rtol'], atol=0.0,
+                maxit=par['maxit'], ilu=pre, restart=30, x_is_zero=True,
+                dinv='jacobi' if pre is None else None
+                )
+        except _hip.NotConverged:
+            ops.fill(u.data, 0.0)
+            info = ops.krylov_solve(
+                'bicgstab', A, bvec, u.data, rtol=par['rtol'], atol=0.0,
+                maxit=par['maxit'], check_every=par['check_every'], ilu=pre
+                )
         last_solve_info['heat'] = info
         return u
