@@ -191,6 +191,7 @@ SYMBOLS = {
     'flow_operator_apply': [_P(Operator), _VP, _VP, _VP],
     'flow_profile_spmv_begin': [_I, _I],
     'flow_profile_spmv_end': [_P(_D), _P(_I)],
+    'flow_profile_event_overhead': [_P(_D), _VP],
     'flow_operator_diag_inv': [_P(Operator), _VP, _VP, _VP],
     'flow_dot_host': [_I, _VP, _VP, _VP, _P(_D), _VP],
     'flow_norm_host': [_I, _VP, _I, _VP, _P(_D), _VP],

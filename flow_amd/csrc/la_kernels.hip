@@ -1337,6 +1337,54 @@ extern "C" int flow_profile_spmv_begin(int rows, int max_launches) {
   return FLOW_OK;
 }
 
+__global__ void profile_null_kernel() {}
+
+// keeps the chip busy for ~20 us (constant 100 MHz counter; bounded loop), so
+// that the launch behind it is dispatched while it runs -- as inside a solver
+__global__ void profile_busy_kernel() {
+  const unsigned long long t0 = wall_clock64();
+  for (int i = 0; i < 100000; ++i) {
+    if (wall_clock64() - t0 > 2000ull) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+// What an event pair measures around NOTHING: the dispatch latency that every
+// bracketed launch above includes on top of the kernel's own execution time
+// (rocprofv3's kernel duration does not).  Median of 33 null launches, each
+// behind a kernel that is still running when it is enqueued, microseconds.
+extern "C" int flow_profile_event_overhead(double* overhead_us, void* stream) {
+  FLOW_REQUIRE(overhead_us != nullptr, "overhead result");
+  hipStream_t st = as_stream(stream);
+  constexpr int kN = 33;
+  hipEvent_t ev[2 * kN];
+  for (int i = 0; i < 2 * kN; ++i) FLOW_CHECK_HIP(hipEventCreate(&ev[i]));
+  for (int i = 0; i < kN; ++i) {
+    // (a running kernel in front, as in the solver: the stream is never idle
+    // and the bracketed launch is dispatched while its predecessor executes)
+    hipLaunchKernelGGL(profile_busy_kernel, dim3(256), dim3(64), 0, st);
+    FLOW_CHECK_HIP(hipEventRecord(ev[2 * i], st));
+    hipLaunchKernelGGL(profile_null_kernel, dim3(1), dim3(64), 0, st);
+    FLOW_CHECK_HIP(hipEventRecord(ev[2 * i + 1], st));
+  }
+  FLOW_CHECK_HIP(hipStreamSynchronize(st));
+  double t[kN];
+  for (int i = 0; i < kN; ++i) {
+    float ms = 0.0f;
+    FLOW_CHECK_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    t[i] = 1.0e3 * ms;
+  }
+  for (int i = 0; i < 2 * kN; ++i) (void)hipEventDestroy(ev[i]);
+  for (int i = 1; i < kN; ++i)          // insertion sort, median
+    for (int j = i; j > 0 && t[j] < t[j - 1]; --j) {
+      const double tmp = t[j];
+      t[j] = t[j - 1];
+      t[j - 1] = tmp;
+    }
+  *overhead_us = t[kN / 2];
+  return FLOW_OK;
+}
+
 extern "C" int flow_profile_spmv_end(double* total_us, int* launches) {
   SpmvProfile& pf = g_spmv_profile;
   FLOW_REQUIRE(total_us && launches, "profile results");

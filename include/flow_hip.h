@@ -99,6 +99,10 @@ int flow_operator_diag_inv(const flow_operator* A, const int* diag_idx,
  * time, not thread safe: a measuring aid for bench.py. */
 int flow_profile_spmv_begin(int rows, int max_launches);
 int flow_profile_spmv_end(double* total_us, int* launches);
+/* What such an event pair reads around a NULL kernel (median of 33, behind a
+ * busy stream): the dispatch latency every bracketed launch includes on top of
+ * the kernel's execution time -- a profiler's kernel duration does not. */
+int flow_profile_event_overhead(double* overhead_us, void* stream);
 
 /* ---- K9: BLAS-1 (PETSc VecDot/VecAXPY/VecNorm) -------------------------- */
 int flow_dot_host(int n, const double* x, const double* y, double* work,

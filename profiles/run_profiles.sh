@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline --spmv-reps 50"
+ARGS="--steps 10 --warmup 20 --no-cpu-baseline --no-hbm-resident --no-fast-leg --spmv-reps 50"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 echo trace done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
@@ -18,6 +18,10 @@ echo fetch done
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
 echo write done
 python3 $R/profiles/summarize.py stats $OUT/trace $R/gpurun_out/kernel_stats_$TAG.md
+python3 $R/profiles/summarize.py gaps $OUT/trace $R/gpurun_out/gaps_$TAG.md
+# warm replay (spmv_stream_kernel<false>, back-to-back) and the in-solver launches
+# (spmv_stream_kernel<true> on the pressure matrix: dispatch size 1923072)
 python3 $R/profiles/summarize.py pmc $OUT/fetch $OUT/write $R/gpurun_out/spmv_traffic_$TAG.json
+python3 $R/profiles/summarize.py pmc $OUT/fetch $OUT/write $R/gpurun_out/spmv_traffic_${TAG}_in_solver.json "flow::spmv_stream_kernel<true>" 1923072
 # keep the merge-back small: drop the raw traces
 rm -rf $OUT/trace $OUT/fetch $OUT/write

@@ -3,7 +3,7 @@
 Summarise rocprofv3 CSV output into the small files committed under profiles/.
 
   python profiles/summarize.py stats  <dir> <out.md>     kernel-trace summary
-  python profiles/summarize.py pmc    <fetch_dir> <write_dir> <out.json>
+  python profiles/summarize.py pmc    <fetch_dir> <write_dir> <out.json> [kernel] [grid]
   python profiles/summarize.py gaps   <dir> <out.md>     idle time between kernels
 
 The PMC summary follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
@@ -109,7 +109,7 @@ def gaps(directory, out, threshold_us=8.0):
     print('\n'.join(lines[:30]))
 
 
-def _counter(directory, counter, kernel):
+def _counter(directory, counter, kernel, grid=None):
     '''Counter values of the dispatches of `kernel` on the pressure matrix: the
     same kernel also serves the (smaller) multigrid levels and, a few times,
     the (larger) velocity operators -- keep the largest grid that was
@@ -120,19 +120,24 @@ def _counter(directory, counter, kernel):
             for r in csv.DictReader(fh):
                 if r['Counter_Name'] == counter and \
                         kernel in r['Kernel_Name']:
-                    grid = int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0)
-                    by_grid.setdefault(grid, []).append(float(r['Counter_Value']))
+                    g = int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0)
+                    by_grid.setdefault(g, []).append(float(r['Counter_Value']))
+    if grid is not None:
+        return by_grid.get(int(grid), [])
     grids = [g for g, v in by_grid.items() if len(v) >= 20]
     if not grids:
         return []
     return by_grid[max(grids)]
 
 
-def pmc(fetch_dir, write_dir, out, kernel='flow::spmv_stream_kernel<false>'):
+def pmc(fetch_dir, write_dir, out, kernel='flow::spmv_stream_kernel<false>',
+        grid=None):
     # group by dispatch size: keep the dispatches of the pressure matrix
-    # (the most frequent value set is the CG loop + the timed roofline launches)
-    f = _counter(fetch_dir, 'FETCH_SIZE', kernel)
-    w = _counter(write_dir, 'WRITE_SIZE', kernel)
+    # (the most frequent value set is the CG loop + the timed roofline launches;
+    # `grid`: the dispatch size to keep, e.g. 1923072 for the pressure matrix
+    # of the headline workload)
+    f = _counter(fetch_dir, 'FETCH_SIZE', kernel, grid)
+    w = _counter(write_dir, 'WRITE_SIZE', kernel, grid)
     if not f or not w:
         raise SystemExit('no counter rows for %s' % kernel)
     f.sort()
@@ -160,4 +165,4 @@ if __name__ == '__main__':
     elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(*sys.argv[2:7])
