@@ -92,3 +92,24 @@ def guermond2():
         lambda X, Y, t: sympy.sin(X - Y + t),
         ((0.0, 0.0), (1.0, 1.0)), 'crossed', MAX_DEGREE, MAX_DEGREE
         )
+
+
+def channel():
+    '''Time-dependent Poiseuille flow in the unit square, posed like the
+    reference's Karman driver (tests/test_karman_vortex_street.py:190-203):
+    no-slip walls top and bottom, ONLY the x-velocity prescribed on the left
+    and right sides, p = 0 on the right.  The y-velocity rows on the two sides
+    are free, so the exterior-facet terms of `_rhs_weak`
+    (pressure_correction.py:142-143) act on them -- with a non-zero value:
+    mu d_y u_x n_x -- and the scheme is only consistent with this solution if
+    those terms carry the right sign and factor: after partial integration the
+    form leaves the natural condition  mu d_n u_y = 0  on the free component,
+    which u = (g(t) y (1 - y), 0) satisfies, as it does (u.n) u_y = 0 for the
+    skew-symmetric convection term.  Velocity and pressure are exactly
+    representable (P2 / P1): the errors are those of the time discretisation.'''
+    return Problem(
+        'channel',
+        lambda X, Y, t: ((1 + sympy.sin(t)) * Y * (1 - Y), 0 * X),
+        lambda X, Y, t: (2 + sympy.cos(t)) * (1 - X),
+        ((0.0, 0.0), (1.0, 1.0)), 'crossed', 2, 1, mu=0.7, rho=1.3
+        )

@@ -37,6 +37,34 @@ def make_mesh(problem, n):
         )
 
 
+def channel_bcs(problem, mesh, dt):
+    '''Component-wise conditions of the Karman driver on the problem's box:
+    no-slip top and bottom, x-velocity on the left and right sides, p = 0 on
+    the right (tests/test_karman_vortex_street.py:190-203).'''
+    (x0, y0), (x1, y1) = problem.domain
+    eps = 1e-12
+
+    class TopBottom(fem.SubDomain):
+        def inside(self, x, on_boundary):
+            return on_boundary & ((x[1] < y0 + eps) | (x[1] > y1 - eps))
+
+    class Sides(fem.SubDomain):
+        def inside(self, x, on_boundary):
+            return on_boundary & ((x[0] < x0 + eps) | (x[0] > x1 - eps))
+
+    class Right(fem.SubDomain):
+        def inside(self, x, on_boundary):
+            return on_boundary & (x[0] > x1 - eps)
+
+    Wv = fem.VectorFunctionSpace(mesh, 'CG', 2)
+    Pv = fem.FunctionSpace(mesh, 'CG', 1)
+    ux = fem.Expression(lambda x: problem.u(x, dt)[0], degree=problem.u_degree)
+    u_bcs = [fem.DirichletBC(Wv, (0.0, 0.0), TopBottom()),
+             fem.DirichletBC(Wv.sub(0), ux, Sides())]
+    p_bcs = [fem.DirichletBC(Pv, 0.0, Right())]
+    return collect(u_bcs, Wv.size()), collect(p_bcs, Pv.N)
+
+
 def initial_data(problem, mesh, dt):
     '''Inputs of one step from exact data: L2-projected u0, p0
     (tests/test_navier_stokes.py:290-308), boundary data at t = dt (:305),
@@ -74,7 +102,9 @@ def errors_after_step(problem, mesh, W, P, u1, p1, dt):
     return err_u, err_p
 
 
-def oracle_time_errors(problem, scheme, method, mesh_sizes, Dt):
+def oracle_time_errors(problem, scheme, method, mesh_sizes, Dt, bc='all'):
+    '''bc 'all': velocity data on the whole boundary, Neumann pressure (the
+    reference harness); 'channel': channel_bcs above.'''
     errors = {
         'u': numpy.empty((len(mesh_sizes), len(Dt))),
         'p': numpy.empty((len(mesh_sizes), len(Dt))),
@@ -83,8 +113,11 @@ def oracle_time_errors(problem, scheme, method, mesh_sizes, Dt):
         mesh = make_mesh(problem, n)
         for j, dt in enumerate(Dt):
             W, P, u0, p0, u_bc, f0, f1 = initial_data(problem, mesh, dt)
+            p_bc = None
+            if bc == 'channel':
+                u_bc, p_bc = channel_bcs(problem, mesh, dt)
             u1, p1, _ = orc.step(
-                W, P, u0, p0, f0, f1, u_bc, None, problem.rho, problem.mu, dt,
+                W, P, u0, p0, f0, f1, u_bc, p_bc, problem.rho, problem.mu, dt,
                 scheme=scheme, method=method
                 )
             errors['u'][k][j], errors['p'][k][j] = errors_after_step(

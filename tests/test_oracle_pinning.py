@@ -11,7 +11,10 @@ known-answer tests -- the reference itself cannot run offline (no dolfin):
     (reference tests/test_sealed_box.py:84-141);
   * SUPG tau closed form incl. the small-Pe Taylor branch
     (reference flow/stabilization.py:116-140);
-  * the order-of-convergence formula (reference tests/helpers.py:10-14).
+  * the order-of-convergence formula (reference tests/helpers.py:10-14);
+  * (not a reference test, but its thresholds) the exterior-facet terms,
+    component-wise velocity conditions and the Dirichlet pressure branch
+    through a manufactured channel flow with free boundary rows.
 CPU only.
 '''
 import numpy
@@ -58,6 +61,46 @@ def test_rotational_order():
     _assert_time_order(mms.guermond1(), 'rotational',
                        {'velocity': 2.0, 'pressure': 1.5}, [32],
                        [1.0e-2, 0.5e-2])
+
+
+@pytest.mark.parametrize('scheme,order', [
+    ('ipcs', {'velocity': 2.0, 'pressure': 1.0}),
+    ('rotational', {'velocity': 2.0, 'pressure': 1.5}),
+    ])
+def test_orders_with_free_boundary_rows(scheme, order):
+    '''The exterior-facet terms of `_rhs_weak` (pressure_correction.py:142-143),
+    component-wise velocity conditions and the Dirichlet pressure branch
+    (:325-339) -- the setting of the Karman driver, which none of the
+    reference's all-Dirichlet known-answer tests reaches.  mms.channel() is a
+    manufactured Poiseuille flow whose free y-velocity rows on the left and
+    right sides only see a consistent scheme if those terms carry the right
+    sign and factor: with them the single-step errors fall at the schemes'
+    orders (thresholds of pressure_correction.py:556-559, 588-591, -0.1 as in
+    tests/test_navier_stokes.py:444-445) ...'''
+    Dt = [0.1, 0.05, 0.025]
+    errors = H.oracle_time_errors(mms.channel(), scheme, 'backward euler', [8],
+                                  Dt, bc='channel')
+    o = H.orders(Dt, errors)
+    assert (o['u'][:, 0] > order['velocity'] - 0.1).all(), o
+    assert (o['p'][:, 0] > order['pressure'] - 0.1).all(), o
+    assert errors['u'][0][-1] < 1e-5 and errors['p'][0][-1] < 1e-3
+
+
+def test_free_boundary_rows_need_the_facet_terms(monkeypatch):
+    '''... and without them they do not fall at all (velocity order 0.3, the
+    pressure error grows): the pin above does see these terms.'''
+    facets = orc.boundary_facets
+
+    def no_facets(S):
+        c, lf = facets(S)
+        return c[:0], lf[:0]
+    monkeypatch.setattr(orc, 'boundary_facets', no_facets)
+    Dt = [0.1, 0.05]
+    errors = H.oracle_time_errors(mms.channel(), 'ipcs', 'backward euler', [8],
+                                  Dt, bc='channel')
+    o = H.orders(Dt, errors)
+    assert o['u'][0, 0] < 0.5 and o['p'][0, 0] < 0.0, o
+    assert errors['u'][0][-1] > 1e-3
 
 
 def test_sealed_box_stays_at_rest():

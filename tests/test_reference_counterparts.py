@@ -23,7 +23,22 @@ import mms
 pytestmark = pytest.mark.gpu
 
 
-def compute_time_errors(problem, method, mesh_sizes, Dt):
+class _TopBottom(fem.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary & ((x[1] < 1e-12) | (x[1] > 1.0 - 1e-12))
+
+
+class _Sides(fem.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary & ((x[0] < 1e-12) | (x[0] > 1.0 - 1e-12))
+
+
+class _Right(fem.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary & (x[0] > 1.0 - 1e-12)
+
+
+def compute_time_errors(problem, method, mesh_sizes, Dt, bc='all'):
     errors = {'u': numpy.empty((len(mesh_sizes), len(Dt))),
               'p': numpy.empty((len(mesh_sizes), len(Dt)))}
     (x0, y0), (x1, y1) = problem.domain
@@ -51,6 +66,14 @@ def compute_time_errors(problem, method, mesh_sizes, Dt):
             sol_u.t = dt
             u_bcs = [fem.DirichletBC(W, sol_u, 'on_boundary')]
             p_bcs = []
+            if bc == 'channel':
+                # the conditions of the Karman driver on the unit square
+                # (tests/test_karman_vortex_street.py:190-203): mms.channel()
+                sol_ux = fem.Expression(lambda x: problem.u(x, dt)[0],
+                                        degree=problem.u_degree)
+                u_bcs = [fem.DirichletBC(W, (0.0, 0.0), _TopBottom()),
+                         fem.DirichletBC(W.sub(0), sol_ux, _Sides())]
+                p_bcs = [fem.DirichletBC(P, 0.0, _Right())]
             u1, p1 = method.step(
                 fem.Constant(dt),
                 {-1: u_1, 0: u0}, p0,
@@ -71,8 +94,8 @@ def compute_time_errors(problem, method, mesh_sizes, Dt):
     return errors
 
 
-def assert_time_order(problem, method, mesh_sizes, Dt):
-    errors = compute_time_errors(problem, method, mesh_sizes, Dt)
+def assert_time_order(problem, method, mesh_sizes, Dt, bc='all'):
+    errors = compute_time_errors(problem, method, mesh_sizes, Dt, bc)
     orders = {
         key: numpy.array([
             numpy.log(row[:-1] / row[1:]) / numpy.log(
@@ -99,6 +122,16 @@ def test_rotational(hip):
     assert_time_order(mms.guermond1(),
                       navsto.Rotational(time_step_method='backward euler'),
                       [32, 64], [1.0e-2, 0.5e-2])
+
+
+@pytest.mark.parametrize('scheme', ['ipcs', 'rotational'])
+def test_orders_with_free_boundary_rows(hip, scheme):
+    '''The HIP path on mms.channel(): exterior-facet terms on free rows,
+    component-wise velocity conditions, Dirichlet pressure branch (the oracle's
+    pin of the same name: tests/test_oracle_pinning.py).'''
+    method = navsto.IPCS() if scheme == 'ipcs' else navsto.Rotational()
+    assert_time_order(mms.channel(), method, [8], [0.1, 0.05, 0.025],
+                      bc='channel')
 
 
 def test_sealed_box(hip, num_steps=2):
