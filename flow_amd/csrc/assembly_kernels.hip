@@ -443,39 +443,39 @@ __global__ __launch_bounds__(kBlock) void momentum_jvp_kernel(
   for (int q = 0; q < NQ; ++q) {
     const double L[3] = {qpoint<DEG>(q, 0), qpoint<DEG>(q, 1), qpoint<DEG>(q, 2)};
     const double w = 0.5 * qweight<DEG>(q) * g.adet;
-    double phi[NL], dphi[NL][3], gphi[NL][2];
-    basis<DEG>(L, phi, dphi);
-    phys_grad<NL>(g, dphi, gphi);
-    double uq[2] = {0.0, 0.0}, vq[2] = {0.0, 0.0};
-    double gu[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, gv[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    // fields and their gradients at the point, gradients via barycentric sums
+    // (fem_device.h: ref_gradient / test_accumulate)
+    double uq[2], vq[2], gu[2][2], gv[2][2];
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
+    for (int a = 0; a < 2; ++a) {
+      uq[a] = eval_at<DEG>(U[a], L);
+      vq[a] = eval_at<DEG>(V[a], L);
+      double gur[3], gvr[3];
+      ref_gradient<DEG>(U[a], L, gur);
+      ref_gradient<DEG>(V[a], L, gvr);
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        uq[a] += U[a][j] * phi[j];
-        vq[a] += V[a][j] * phi[j];
-        gu[a][0] += U[a][j] * gphi[j][0];
-        gu[a][1] += U[a][j] * gphi[j][1];
-        gv[a][0] += V[a][j] * gphi[j][0];
-        gv[a][1] += V[a][j] * gphi[j][1];
+      for (int d = 0; d < 2; ++d) {
+        gu[a][d] = gur[0] * g.gl[0][d] + gur[1] * g.gl[1][d] + gur[2] * g.gl[2][d];
+        gv[a][d] = gvr[0] * g.gl[0][d] + gvr[1] * g.gl[1][d] + gvr[2] * g.gl[2][d];
       }
     }
-    double dconv[2];
+    // acc[a][i] += phi_i S0[a] + sum_d d_d(phi_i) S1[a][d]  with
+    //   S0 = w (v - ci rho/2 dconv),  dconv = (grad v) u + (grad u) v,
+    //   S1[a][d] = w ci (rho/2 (v_d u_a + u_d v_a) - mu (d_d v_a + d_a v_d))
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-      dconv[a] = gv[a][0] * uq[0] + gv[a][1] * uq[1] + gu[a][0] * vq[0] +
-                 gu[a][1] * vq[1];
+    for (int a = 0; a < 2; ++a) {
+      const double dconv = gv[a][0] * uq[0] + gv[a][1] * uq[1] +
+                           gu[a][0] * vq[0] + gu[a][1] * vq[1];
+      const double s0 = w * (vq[a] - ci * hr * dconv);
+      double S1[2];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const double ugp = uq[0] * gphi[i][0] + uq[1] * gphi[i][1];
-      const double vgp = vq[0] * gphi[i][0] + vq[1] * gphi[i][1];
+      for (int d = 0; d < 2; ++d)
+        S1[d] = w * ci * (hr * (vq[d] * uq[a] + uq[d] * vq[a]) -
+                          mu * (gv[a][d] + gv[d][a]));
+      double T[3];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        double r = -hr * (dconv[a] * phi[i] - vgp * uq[a] - ugp * vq[a]);
-        r -= mu * ((gv[a][0] + gv[0][a]) * gphi[i][0] +
-                   (gv[a][1] + gv[1][a]) * gphi[i][1]);
-        acc[a][i] += w * (vq[a] * phi[i] + ci * r);
-      }
+      for (int k = 0; k < 3; ++k) T[k] = g.gl[k][0] * S1[0] + g.gl[k][1] * S1[1];
+      test_accumulate<DEG>(L, s0, T, acc[a]);
     }
   }
   if (mask && ci != 0.0) {

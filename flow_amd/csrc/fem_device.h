@@ -155,6 +155,63 @@ __device__ __forceinline__ void phys_grad(const Geom& g, const double dphi[NL][3
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same basis through its STRUCTURE, for the flop-bound cell kernels: the
+// derivative of basis function i with respect to lambda_k is zero for most
+// (i, k) -- vertex function i only depends on lambda_i, edge function e on the
+// two barycentric coordinates of its end points -- so gradients are summed in
+// barycentric ("reference") coordinates first and mapped with the 3 x 2 matrix
+// gl once per quadrature point, instead of mapping every basis gradient:
+//   grad u_a = sum_k gur[a][k] grad(lambda_k),  gur[a][k] = sum_j U_aj dphi_j/dlambda_k
+//   sum_d S[d] dphi_i/dx_d = sum_k dphi_i/dlambda_k T[k],  T[k] = sum_d gl[k][d] S[d]
+// ---------------------------------------------------------------------------
+// gur[k] = sum_j U[j] dphi_j / dlambda_k
+template <int DEG>
+__device__ __forceinline__ void ref_gradient(const double U[Elem<DEG>::NL],
+                                             const double L[3], double gur[3]) {
+  if constexpr (DEG == 1) {
+    gur[0] = U[0];
+    gur[1] = U[1];
+    gur[2] = U[2];
+  } else {
+    // edges: e = 0: (1, 2), e = 1: (0, 2), e = 2: (0, 1)
+    gur[0] = U[0] * (4.0 * L[0] - 1.0) + 4.0 * (U[4] * L[2] + U[5] * L[1]);
+    gur[1] = U[1] * (4.0 * L[1] - 1.0) + 4.0 * (U[3] * L[2] + U[5] * L[0]);
+    gur[2] = U[2] * (4.0 * L[2] - 1.0) + 4.0 * (U[3] * L[1] + U[4] * L[0]);
+  }
+}
+
+// acc[i] += phi_i * s0 + sum_k (dphi_i / dlambda_k) T[k]
+template <int DEG>
+__device__ __forceinline__ void test_accumulate(const double L[3], double s0,
+                                                const double T[3],
+                                                double acc[Elem<DEG>::NL]) {
+  if constexpr (DEG == 1) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] += L[i] * s0 + T[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      acc[i] += L[i] * (2.0 * L[i] - 1.0) * s0 + (4.0 * L[i] - 1.0) * T[i];
+    acc[3] += 4.0 * (L[1] * L[2] * s0 + L[2] * T[1] + L[1] * T[2]);
+    acc[4] += 4.0 * (L[0] * L[2] * s0 + L[2] * T[0] + L[0] * T[2]);
+    acc[5] += 4.0 * (L[0] * L[1] * s0 + L[1] * T[0] + L[0] * T[1]);
+  }
+}
+
+// value at L: sum_j U[j] phi_j
+template <int DEG>
+__device__ __forceinline__ double eval_at(const double U[Elem<DEG>::NL],
+                                          const double L[3]) {
+  if constexpr (DEG == 1) {
+    return U[0] * L[0] + U[1] * L[1] + U[2] * L[2];
+  } else {
+    return U[0] * L[0] * (2.0 * L[0] - 1.0) + U[1] * L[1] * (2.0 * L[1] - 1.0) +
+           U[2] * L[2] * (2.0 * L[2] - 1.0) +
+           4.0 * (U[3] * L[1] * L[2] + U[4] * L[0] * L[2] + U[5] * L[0] * L[1]);
+  }
+}
+
 // div(u) at the three cell vertices (P1 per cell for P2 u, constant for P1 u)
 template <int DEG>
 __device__ __forceinline__ void div_at_vertices(

@@ -277,9 +277,12 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
     const unsigned char* __restrict__ mask, const double* __restrict__ x,
     double* __restrict__ y, int xs, double* __restrict__ dpart,
     const double* __restrict__ stop) {
-  // ONE product array, used by the two components in turn (two would halve the
-  // occupancy: 32 KB of LDS per workgroup)
-  __shared__ double prod[kTile];
+  // the products of the two components side by side (double2): 16 KB of LDS
+  // per workgroup -- with the 1022-nonzero tile that still leaves the 8
+  // workgroups per CU the wave limit allows, and both row sums come out of ONE
+  // pass over the segment (the single array used twice cost two barriers
+  // more: 166 -> see DESIGN.md)
+  __shared__ double2 prod[kTile];
   if (stopped(stop)) return;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int r0 = rowblocks[tile];
@@ -324,24 +327,17 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
   for (int j = 0; j < kPairs; ++j) {
     const int p = threadIdx.x + j * kBlock;
     if (p < npair) {
-      prod[2 * p] = v[j].x * xa[j];
-      prod[2 * p + 1] = v[j].y * xb[j];
+      prod[2 * p] = make_double2(v[j].x * xa[j], v[j].x * ua[j]);
+      prod[2 * p + 1] = make_double2(v[j].y * xb[j], v[j].y * ub[j]);
     }
   }
   __syncthreads();
   double s0 = 0.0, s1 = 0.0;
-  for (int k = a; k < b; ++k) s0 += prod[k];
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < kPairs; ++j) {
-    const int p = threadIdx.x + j * kBlock;
-    if (p < npair) {
-      prod[2 * p] = v[j].x * ua[j];
-      prod[2 * p + 1] = v[j].y * ub[j];
-    }
+  for (int k = a; k < b; ++k) {
+    const double2 q = prod[k];
+    s0 += q.x;
+    s1 += q.y;
   }
-  __syncthreads();
-  for (int k = a; k < b; ++k) s1 += prod[k];
   double t = 0.0;
   if (r < r1) {
     const double x0 = x[r], x1 = x[xs + r];
