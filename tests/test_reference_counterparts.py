@@ -161,6 +161,13 @@ def test_sealed_box(hip, num_steps=2):
         p0.assign(p1)
     unorm = fem.project_magnitude(u0).vector().norm('linf')
     assert unorm < 1.0e-13
+    # pure Neumann pressure: the constant the singular system leaves open does
+    # not accumulate -- every solve starts from p0 minus its mean and CG stays
+    # in the space orthogonal to the constants (sum p = 0 up to what the
+    # V-cycle leaks), while the pressure itself is O(g * height)
+    pa = p0.array()
+    assert abs(pa.sum()) <= 1.0e-6 * len(pa) * abs(pa).max(), pa.sum()
+    assert abs(pa).max() > 0.5
 
 
 def test_karman(hip, num_steps=2):
