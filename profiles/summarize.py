@@ -57,9 +57,12 @@ def stats(directory, out):
     print('\n'.join(lines[:14]))
 
 
-def gaps(directory, out, threshold_us=8.0):
+def gaps(directory, out, threshold_us=8.0, window=None):
     '''Where the GPU waits for the host: idle intervals between consecutive
-    kernels of the trace, grouped by (kernel before -> kernel after).'''
+    kernels of the trace, grouped by (kernel before -> kernel after).
+    window = "a:b": only the kernels that start between a and b milliseconds
+    before the END of the trace (the timed steps of bench.py sit there, behind
+    the setup and the Stokes start).'''
     ev = []
     for path in _find(directory, 'kernel_trace.csv'):
         with open(path) as fh:
@@ -67,6 +70,10 @@ def gaps(directory, out, threshold_us=8.0):
                 ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']),
                            r['Kernel_Name'].split('(')[0].replace('void ', '')))
     ev.sort()
+    if window:
+        a, b = [float(v) * 1.0e6 for v in window.split(':')]
+        t_end = ev[-1][1]
+        ev = [e for e in ev if t_end - a >= e[0] >= t_end - b]
     busy = sum(e - s for s, e, _ in ev) * 1e-3
     span = (ev[-1][1] - ev[0][0]) * 1e-3
     sites = defaultdict(lambda: [0, 0.0])
@@ -161,7 +168,8 @@ def pmc(fetch_dir, write_dir, out, kernel='flow::spmv_stream_kernel<false>',
 
 if __name__ == '__main__':
     if sys.argv[1] == 'gaps':
-        gaps(sys.argv[2], sys.argv[3])
+        gaps(sys.argv[2], sys.argv[3],
+             window=sys.argv[4] if len(sys.argv) > 4 else None)
     elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
     else:
