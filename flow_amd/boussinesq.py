@@ -17,6 +17,7 @@ from . import fem
 from . import heat
 from . import materials
 from . import navier_stokes
+from . import parallel
 from . import time_steppers
 from .message import begin, end, info
 
@@ -146,6 +147,11 @@ def compute_boussinesq(target_time, nx=16, supg=False, verbose=False,
                     verbose=False,
                     tol=1.0e-10
                     )
+                if parallel.active():
+                    # the Navier-Stokes step ran on the ranks' strips; the
+                    # heat operator is assembled replicated: whole fields
+                    parallel.gather_field(u1.data, W.layout, 2)
+                    parallel.gather_field(p1.data, P.layout)
             except RuntimeError:
                 info('Navier--Stokes solver failed to converge. '
                      'Decrease time step from %e to %e and try again.' %

@@ -41,12 +41,12 @@ def _rel(a, b):
     return float(numpy.linalg.norm(a - b) / numpy.linalg.norm(b))
 
 
-def _karman_steps(nsteps=2):
+def _karman_steps(nsteps=2, velocity_degree=2):
     from flow_amd import karman
     import flow_amd.navier_stokes as navsto
     # (a 3.7 k-row pressure system: let the hierarchy coarsen it all the same)
     navsto.solver_parameters['pressure']['mg_coarsest'] = 200
-    prob = karman.KarmanProblem(NX, NY, velocity_degree=2)
+    prob = karman.KarmanProblem(NX, NY, velocity_degree=velocity_degree)
     prob.set_initial_profile()
     infos = [prob.step(tol=1e-12) for _ in range(nsteps)]
     return prob, infos
@@ -169,6 +169,14 @@ def _worker(rank, world, port, out):
                                             p[pv.e0:pv.e1])),
             calls=parallel.comm().calls,
             )
+        # ---- the same with P1-P1 (BASELINE config 2's element pair) --------
+        prob1, infos1 = _karman_steps(velocity_degree=1)
+        res['step_p1'] = dict(
+            u=device.to_host(parallel.gather_field(
+                prob1.u0.data.clone(), prob1.W.layout, 2)).numpy(),
+            p=device.to_host(parallel.gather_field(
+                prob1.p0.data.clone(), prob1.P.layout)).numpy(),
+            newton=[len(i['newton_residuals']) - 1 for i in infos1])
         out[rank] = res
     finally:
         dist.destroy_process_group()
@@ -180,6 +188,9 @@ def test_strip_sharded_solvers_and_step(hip, world):
     prob, infos = _karman_steps()
     u_ref = prob.u0.vector().get_local().copy()
     p_ref = prob.p0.vector().get_local().copy()
+    prob1, infos1 = _karman_steps(velocity_degree=1)
+    u1_ref = prob1.u0.vector().get_local().copy()
+    p1_ref = prob1.p0.vector().get_local().copy()
     manager = mp.get_context('spawn').Manager()
     out = manager.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
@@ -209,6 +220,9 @@ def test_strip_sharded_solvers_and_step(hip, world):
         # every rank holds the same gathered fields, bit for bit
         assert numpy.array_equal(st['u'], out[0]['step']['u'])
         assert numpy.array_equal(st['p'], out[0]['step']['p'])
+        s1 = res['step_p1']
+        assert s1['newton'] == [len(i['newton_residuals']) - 1 for i in infos1]
+        assert _rel(s1['u'], u1_ref) < 1e-7 and _rel(s1['p'], p1_ref) < 1e-7
     assert covered == out[0]['ranges'][4]
     print('world %d: step vs single GPU: du %.2e dp %.2e, collectives per '
           'rank %d' % (world, _rel(out[0]['step']['u'], u_ref),
