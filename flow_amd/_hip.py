@@ -149,6 +149,11 @@ class CommS(ctypes.Structure):
         ]
 
 
+class RcclBinding(ctypes.Structure):
+    _fields_ = [('comm', ctypes.c_void_p), ('buf', ctypes.c_void_p),
+                ('stream', ctypes.c_void_p)]
+
+
 class RowsS(ctypes.Structure):
     _fields_ = [
         ('n', ctypes.c_int), ('r0', ctypes.c_int), ('r1', ctypes.c_int),
@@ -210,6 +215,11 @@ SYMBOLS = {
     'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],
     'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],
     'flow_ilu0_solve': [_P(IluS), _VP, _VP, _VP, _VP],
+    'flow_rccl_load': [ctypes.c_char_p],
+    'flow_rccl_unique_id': [_VP],
+    'flow_rccl_comm_create': [_VP, _I, _I, _P(_VP)],
+    'flow_rccl_comm_destroy': [_VP],
+    'flow_rccl_allreduce': [_VP, _I],
     'flow_shard_halo': [_P(CommS), _P(RowsS), _I, _VP, _I, _VP],
     'flow_shard_reduce_host': [_P(CommS), _P(RowsS), _I, _VP, _VP, _I, _I, _VP,
                                _P(_D), _VP],

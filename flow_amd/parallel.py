@@ -40,6 +40,7 @@ Fields stay global-length on every rank (memory is not the scarce resource:
 output).
 '''
 import ctypes
+import os
 import traceback
 
 import numpy
@@ -90,7 +91,12 @@ def describe(world, nrows=None):
     '''One line for bench.py's `config.parallelism`.'''
     if active():
         return ('x-strips x%d: every sub-step sharded (block-Jacobi ILU(0) '
-                'GMRES, row-sharded V-cycle CG, Jacobi-CG mass solves)' % world)
+                'GMRES, row-sharded V-cycle CG, Jacobi-CG mass solves); '
+                'collectives: %s' % (
+                    world, 'ncclAllReduce issued by the library on its stream'
+                    if comm().direct is not None else
+                    'torch.distributed.all_reduce (%s)' % (
+                        'gloo, host-staged' if comm().staged else 'RCCL')))
     if world == 1:
         return 'single GPU'
     return 'replicated x%d' % world
@@ -109,7 +115,11 @@ class Comm(object):
         self._cb = _hip.ALLREDUCE_FN(self._allreduce)
         self.buf = None
         self.struct = None
+        self.direct = None          # RcclBinding when the library calls RCCL
         self.ensure(capacity)
+        if not self.staged and device.on_gpu() and \
+                os.environ.get('FLOW_AMD_RCCL_DIRECT', '1') != '0':
+            self._bind_rccl()
 
     def ensure(self, capacity):
         '''Grow the exchange buffer to at least `capacity` doubles.'''
@@ -121,7 +131,76 @@ class Comm(object):
             self.struct = _hip.CommS(
                 self.rank, self.world, ctypes.c_void_p(self.buf.data_ptr()),
                 self.buf.numel(), self._cb, None)
+            if self.direct is not None:
+                self._point_struct_at_rccl()
         return self.struct
+
+    # -- the all-reduce issued by the library itself (csrc/rccl_direct.hip) -----
+    def _bind_rccl(self):
+        '''Create a communicator of the library's own on the RCCL instance
+        torch has loaded and bind flow_comm's callback to ncclAllReduce on the
+        solvers' stream: no Python, no event hand-over per collective.  Every
+        rank tries; the binding is only used if EVERY rank succeeded (agreed
+        on through torch's all-reduce), otherwise all stay on the torch path.'''
+        lib = _hip.lib()
+
+        def all_ok(ok):
+            flag = torch.tensor([float(ok)], dtype=torch.float64,
+                                device=device.get())
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return float(flag.item()) >= 1.0
+
+        # 1. everybody loads the library, rank 0 draws the unique id; nobody
+        #    goes on unless everybody got this far (a rank that dropped out
+        #    here would leave the others waiting in the steps below)
+        ok = 1
+        raw = ctypes.create_string_buffer(128)
+        try:
+            path = os.path.join(os.path.dirname(torch.__file__), 'lib',
+                                'librccl.so')
+            _hip.check(lib.flow_rccl_load(path.encode()))
+            if self.rank == 0:
+                _hip.check(lib.flow_rccl_unique_id(
+                    ctypes.cast(raw, ctypes.c_void_p)))
+        except Exception:                                  # noqa: BLE001
+            traceback.print_exc()
+            ok = 0
+        if not all_ok(ok):
+            return
+        # 2. the id travels through torch.distributed
+        dev_id = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8) \
+            .to(device.get())
+        src = dist.get_global_rank(self.group, 0) \
+            if self.group is not dist.group.WORLD else 0
+        dist.broadcast(dev_id, src, group=self.group)
+        raw = ctypes.create_string_buffer(
+            bytes(dev_id.cpu().numpy().tobytes()), 128)
+        # 3. the communicator (collective)
+        comm = ctypes.c_void_p(None)
+        try:
+            _hip.check(lib.flow_rccl_comm_create(
+                ctypes.cast(raw, ctypes.c_void_p), self.rank, self.world,
+                ctypes.byref(comm)))
+        except Exception:                                  # noqa: BLE001
+            traceback.print_exc()
+            ok = 0
+        if not all_ok(ok):
+            if ok:
+                lib.flow_rccl_comm_destroy(comm)
+            return
+        self._rccl_comm = comm
+        self.direct = _hip.RcclBinding(
+            comm, ctypes.c_void_p(self.buf.data_ptr()),
+            ctypes.c_void_p(device.stream_handle()))
+        self._point_struct_at_rccl()
+
+    def _point_struct_at_rccl(self):
+        lib = _hip.load_library()
+        self.direct.buf = ctypes.c_void_p(self.buf.data_ptr())
+        self.struct.allreduce = ctypes.cast(lib.flow_rccl_allreduce,
+                                            _hip.ALLREDUCE_FN)
+        self.struct.user = ctypes.cast(ctypes.pointer(self.direct),
+                                       ctypes.c_void_p)
 
     def _allreduce(self, _user, count):
         # called from inside the library's solver loops (ctypes re-acquires

@@ -328,6 +328,24 @@ typedef struct {
   void* user;
 } flow_comm;
 
+/* The same primitive issued by the library itself: ncclAllReduce on `stream`,
+ * on a communicator of its own (flow_amd/csrc/rccl_direct.hip).  The RCCL
+ * shared object is dlopen'ed by path (the instance the host already loaded),
+ * the 128-byte unique id of rank 0 is distributed by the host.  Set
+ * comm->allreduce = flow_rccl_allreduce and comm->user = &binding. */
+#define FLOW_RCCL_ID_BYTES 128
+typedef struct {
+  void* comm;                /* from flow_rccl_comm_create */
+  double* buf;               /* = flow_comm.buf */
+  void* stream;              /* hipStream_t of the solvers */
+} flow_rccl_binding;
+int flow_rccl_load(const char* librccl_path);
+int flow_rccl_unique_id(char* id_host);                      /* 128 bytes out */
+int flow_rccl_comm_create(const char* id_host, int rank, int world,
+                          void** comm_out);                  /* collective */
+int flow_rccl_comm_destroy(void* comm);
+int flow_rccl_allreduce(void* user, int count);              /* flow_allreduce_fn */
+
 /* the rows of one scalar space as rank `comm->rank` sees them; index 0 = left
  * neighbour, 1 = right neighbour, len 0 = none */
 typedef struct {

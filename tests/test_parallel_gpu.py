@@ -228,3 +228,45 @@ def test_strip_sharded_solvers_and_step(hip, world):
           'rank %d' % (world, _rel(out[0]['step']['u'], u_ref),
                        _rel(out[0]['step']['p'], p_ref),
                        out[0]['step']['calls']))
+
+
+def _rccl_worker(rank, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LOCAL_RANK'] = '0'
+    import torch.distributed as dist
+    from flow_amd import device, parallel
+    dist.init_process_group('nccl', rank=0, world_size=1,
+                            device_id=device.get())
+    try:
+        parallel.enable(dist.group.WORLD, force=True)
+        comm = parallel.comm()
+        prob, infos = _karman_steps()
+        out[0] = dict(
+            direct=comm.direct is not None, staged=comm.staged,
+            u=prob.u0.vector().get_local().copy(),
+            p=prob.p0.vector().get_local().copy(),
+            newton=[len(i['newton_residuals']) - 1 for i in infos],
+            method=infos[-1]['pressure'].method)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_issued_by_the_library(hip):
+    '''The RCCL branch of the communicator on a 1-rank group (all one GPU
+    allows: RCCL refuses two ranks on one device): flow_comm's callback is
+    ncclAllReduce issued by the library on its own stream
+    (csrc/rccl_direct.hip; communicator created beside torch's from an id
+    broadcast through torch.distributed), and two whole time steps through the
+    sharded loops reproduce the single-GPU run.'''
+    prob, infos = _karman_steps()
+    manager = mp.get_context('spawn').Manager()
+    out = manager.dict()
+    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+    res = out[0]
+    assert res['direct'] and not res['staged']
+    assert 'x-strips x1' in res['method']
+    assert res['newton'] == [len(i['newton_residuals']) - 1 for i in infos]
+    assert _rel(res['u'], prob.u0.vector().get_local()) < 1e-9
+    assert _rel(res['p'], prob.p0.vector().get_local()) < 1e-9
+
