@@ -21,7 +21,7 @@ python3 $R/profiles/summarize.py stats $OUT/trace $R/gpurun_out/kernel_stats_$TA
 python3 $R/profiles/summarize.py gaps $OUT/trace $R/gpurun_out/gaps_$TAG.md
 # warm replay (spmv_stream_kernel<false>, back-to-back) and the in-solver launches
 # (spmv_stream_kernel<true> on the pressure matrix: dispatch size 1923072)
-python3 $R/profiles/summarize.py pmc $OUT/fetch $OUT/write $R/gpurun_out/spmv_traffic_$TAG.json
+python3 $R/profiles/summarize.py pmc $OUT/fetch $OUT/write $R/gpurun_out/spmv_traffic_$TAG.json "flow::spmv_stream_kernel<false>" 1923072
 python3 $R/profiles/summarize.py pmc $OUT/fetch $OUT/write $R/gpurun_out/spmv_traffic_${TAG}_in_solver.json "flow::spmv_stream_kernel<true>" 1923072
 # keep the merge-back small: drop the raw traces
 rm -rf $OUT/trace $OUT/fetch $OUT/write
