@@ -361,6 +361,9 @@ class CellCoefficient(object):
         self.nl = reference.nloc(k)
 
 
+_CONSTANT_COEFFICIENTS = {}
+
+
 def as_cell_coefficient(f, mesh, dim):
     '''Convert Constant / Expression / Function / NodalExpression / tuple of
     numbers to a CellCoefficient with `dim` components.'''
@@ -372,9 +375,15 @@ def as_cell_coefficient(f, mesh, dim):
     if isinstance(f, Constant):
         vals = f.values()
         assert len(vals) == dim, (len(vals), dim)
-        return CellCoefficient(
-            0, dim, device.to_device(vals.reshape(dim, 1, 1).copy()), 0
-            )
+        # (uploaded once per value: an upload drains the stream, and time
+        # loops pass the same forcing constants every step)
+        key = (tuple(float(v) for v in vals), str(device.get()))
+        if key not in _CONSTANT_COEFFICIENTS:
+            if len(_CONSTANT_COEFFICIENTS) >= 64:
+                _CONSTANT_COEFFICIENTS.clear()
+            _CONSTANT_COEFFICIENTS[key] = device.to_device(
+                vals.reshape(dim, 1, 1).copy())
+        return CellCoefficient(0, dim, _CONSTANT_COEFFICIENTS[key], 0)
     if isinstance(f, Expression):
         assert f.value_dim() == dim
         k = int(f.degree)
