@@ -383,7 +383,11 @@ def main():
             'substep_s': tim,
             }
 
+    # everything that is built once and cached (operators, hierarchy, ILU
+    # plan, ...), then the start state: all of it setup, outside the windows
+    prob.prepare()
     initial_state()
+    barrier()
     setup_s = time.perf_counter() - t_setup
     infos, elapsed = window(args.mode)
     head = summary(infos, elapsed)
