@@ -98,6 +98,7 @@ class IluS(ctypes.Structure):
         ('plan', ctypes.POINTER(IluPlanS)),
         ('nblocks', ctypes.c_int),
         ('lu', ctypes.c_void_p),
+        ('packed', ctypes.c_void_p),
         ]
 
 
@@ -214,6 +215,7 @@ SYMBOLS = {
                          _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],
     'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],
+    'flow_ilu0_pack': [_P(IluS), _VP, _VP],
     'flow_ilu0_solve': [_P(IluS), _VP, _VP, _VP, _VP],
     'flow_rccl_load': [ctypes.c_char_p],
     'flow_rccl_unique_id': [_VP],

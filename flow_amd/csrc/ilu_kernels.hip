@@ -18,7 +18,8 @@
 //    length of the dependent-load chain of a wavefront, not only the bytes.
 //    Both diagonal blocks of a two-field operator go through the same launch
 //    (blockIdx.y).
-// HBM-bound: 12 B per factor entry and application.
+// HBM-bound: 12 B per factor entry, block and application (packed streams,
+// below: 12 B for two blocks).
 #include "common.h"
 
 namespace flow {
@@ -277,6 +278,136 @@ __global__ __launch_bounds__(kBlock) void ilu_sweep_kernel(
   if (live) y[row] = (rhs - s) * di;
 }
 
+// ---- packed sweep streams ---------------------------------------------------
+// The sweeps are bound by the bytes of the factor: 12 B per entry, block and
+// application above.  A preconditioner does not need its entries to 16 digits:
+// with flow_ilu.packed the two streams are kept a second time as fp32, the
+// NB blocks of an entry interleaved (one index + one NB*4-byte value load per
+// entry, 12 B for both velocity blocks together instead of 24), and the sweep
+// vector is interleaved the same way (one NB*8-byte gather per entry).  All
+// arithmetic stays fp64: the sweeps apply the exact inverse of the ROUNDED
+// factors -- a fixed linear operator, as good a preconditioner as the unrounded
+// one (ILU(0) itself is off by far more than 6e-8), and the Krylov method
+// around it converges to the same tolerance.
+template <int NB>
+struct PackT;
+template <>
+struct PackT<1> {
+  using val = float;
+  using vec = double;
+};
+template <>
+struct PackT<2> {
+  using val = float2;
+  using vec = double2;
+};
+__device__ __forceinline__ void fma_pack(double& s, float v, double y) { s += v * y; }
+__device__ __forceinline__ void fma_pack(double2& s, float2 v, double2 y) {
+  s.x += v.x * y.x;
+  s.y += v.y * y.y;
+}
+__device__ __forceinline__ double zero_of(double) { return 0.0; }
+__device__ __forceinline__ double2 zero_of(double2) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ float fzero_of(float) { return 0.f; }
+__device__ __forceinline__ float2 fzero_of(float2) { return make_float2(0.f, 0.f); }
+
+template <int NB>
+__global__ void ilu_pack_kernel(int count, size_t lu_size,
+                                const double* __restrict__ vals,
+                                float* __restrict__ packed) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count;
+       k += gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int m = 0; m < NB; ++m)
+      packed[static_cast<size_t>(k) * NB + m] = static_cast<float>(vals[m * lu_size + k]);
+  }
+}
+
+template <int NB>
+__global__ void ilu_permute_packed_kernel(int n, const int* __restrict__ new_of_old,
+                                          const double* __restrict__ r,
+                                          double* __restrict__ y) {
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n;
+       o += gridDim.x * blockDim.x) {
+    const size_t i = new_of_old[o];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) y[i * NB + m] = r[static_cast<size_t>(m) * n + o];
+  }
+}
+
+template <int NB>
+__global__ void ilu_unpermute_packed_kernel(int n, const int* __restrict__ new_of_old,
+                                            const double* __restrict__ y,
+                                            double* __restrict__ z) {
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n;
+       o += gridDim.x * blockDim.x) {
+    const size_t i = new_of_old[o];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) z[static_cast<size_t>(m) * n + o] = y[i * NB + m];
+  }
+}
+
+// as ilu_sweep_kernel, all NB blocks in one lane
+template <bool BWD, int NB>
+__global__ __launch_bounds__(kBlock) void ilu_sweep_packed_kernel(
+    size_t lu_size, int nslices, int row_end, const int* __restrict__ slice_off,
+    const int* __restrict__ slice_row, const int* __restrict__ cols,
+    const typename PackT<NB>::val* __restrict__ vals,
+    const double* __restrict__ dinv, typename PackT<NB>::vec* __restrict__ y) {
+  using V = typename PackT<NB>::val;
+  using Y = typename PackT<NB>::vec;
+  const int sl = xcd_tile(blockIdx.x, gridDim.x) * (kBlock / kSlice) +
+                 (threadIdx.x >> 6);
+  if (sl >= nslices) return;
+  const int lane = threadIdx.x & 63;
+  const int off = slice_off[sl];
+  const int width = (slice_off[sl + 1] - off) >> 6;
+  const int row = slice_row[sl] + lane;
+  const bool live = row < row_end;
+  Y rhs = zero_of(Y());
+  double di[NB];
+#pragma unroll
+  for (int m = 0; m < NB; ++m) di[m] = 1.0;
+  if (live) {
+    rhs = y[row];
+    if (BWD) {
+#pragma unroll
+      for (int m = 0; m < NB; ++m) di[m] = dinv[m * lu_size + row];
+    }
+  }
+  const V* __restrict__ v = vals + off + lane;
+  const int* __restrict__ c = cols + off + lane;
+  // batches of 4 (12 in the fp64 kernel): an entry costs NB*3 registers here,
+  // and with 8560 slices per colour what counts is that ALL of them are
+  // resident at once (8 waves per SIMD) -- measured per application at
+  // 2 x 4.3 M rows: batch 12: 449 us, 8: 374, 6: 355, 4: 346 (fp64 streams: 432)
+  constexpr int kBatch = 4;
+  Y s = zero_of(Y());
+  for (int k0 = 0; k0 < width; k0 += kBatch) {
+    int cc[kBatch];
+    V vv[kBatch];
+    Y yy[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      const bool ok = k0 + j < width;
+      cc[j] = ok ? c[(k0 + j) * kSlice] : 0;
+      vv[j] = ok ? v[(k0 + j) * kSlice] : fzero_of(V());
+    }
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j)
+      yy[j] = (k0 + j < width) ? y[cc[j]] : zero_of(Y());
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) fma_pack(s, vv[j], yy[j]);
+  }
+  if (live) {
+    if constexpr (NB == 1) {
+      y[row] = (rhs - s) * di[0];
+    } else {
+      y[row] = make_double2((rhs.x - s.x) * di[0], (rhs.y - s.y) * di[1]);
+    }
+  }
+}
+
 static int check_plan(const flow_ilu_plan* P) {
   FLOW_REQUIRE(P && P->n > 0 && P->nnz > 0 && P->ncolors > 0, "ilu plan sizes");
   FLOW_REQUIRE(P->color_ptr_host && P->slice_ptr_host, "ilu plan host arrays");
@@ -347,12 +478,54 @@ static int factor(const flow_ilu_plan* P, int nblocks, const double* avals0,
   return FLOW_OK;
 }
 
+template <int NB>
+static int apply_packed(const flow_ilu* ilu, const double* in, double* out,
+                        double* work, hipStream_t st) {
+  using V = typename PackT<NB>::val;
+  using Y = typename PackT<NB>::vec;
+  const flow_ilu_plan* P = ilu->plan;
+  const size_t lus = static_cast<size_t>(P->lu_size);
+  constexpr int per_block = kBlock / kSlice;
+  const V* lvals = reinterpret_cast<const V*>(ilu->packed);
+  const V* uvals = lvals + P->nnz_l;
+  Y* y = reinterpret_cast<Y*>(work);
+  hipLaunchKernelGGL((ilu_permute_packed_kernel<NB>), dim3(grid_for(P->n)),
+                     dim3(kBlock), 0, st, P->n, P->new_of_old, in, work);
+  for (int c = 1; c < P->ncolors; ++c) {   // colour 0: y = r already
+    const int s0 = P->slice_ptr_host[c];
+    const int ns = P->slice_ptr_host[c + 1] - s0;
+    if (ns <= 0) continue;
+    hipLaunchKernelGGL((ilu_sweep_packed_kernel<false, NB>),
+                       dim3((ns + per_block - 1) / per_block), dim3(kBlock), 0,
+                       st, lus, ns, P->color_ptr_host[c + 1], P->l_slice_off + s0,
+                       P->slice_row + s0, P->l_cols, lvals,
+                       static_cast<const double*>(nullptr), y);
+  }
+  for (int c = P->ncolors - 1; c >= 0; --c) {
+    const int s0 = P->slice_ptr_host[c];
+    const int ns = P->slice_ptr_host[c + 1] - s0;
+    if (ns <= 0) continue;
+    hipLaunchKernelGGL((ilu_sweep_packed_kernel<true, NB>),
+                       dim3((ns + per_block - 1) / per_block), dim3(kBlock), 0,
+                       st, lus, ns, P->color_ptr_host[c + 1], P->u_slice_off + s0,
+                       P->slice_row + s0, P->u_cols, uvals, ilu->lu + P->off_d, y);
+  }
+  hipLaunchKernelGGL((ilu_unpermute_packed_kernel<NB>), dim3(grid_for(P->n)),
+                     dim3(kBlock), 0, st, P->n, P->new_of_old, work, out);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
 // out = blockdiag(LU_0[, LU_1])^-1 in ; work: nblocks * n doubles
 int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
               hipStream_t st) {
   const flow_ilu_plan* P = ilu->plan;
   const size_t lus = static_cast<size_t>(P->lu_size);
   constexpr int per_block = kBlock / kSlice;
+  if (ilu->packed) {
+    if (ilu->nblocks == 1) return apply_packed<1>(ilu, in, out, work, st);
+    return apply_packed<2>(ilu, in, out, work, st);
+  }
   hipLaunchKernelGGL(ilu_permute_kernel, dim3(grid_for(P->n)), dim3(kBlock), 0,
                      st, P->n, ilu->nblocks, P->new_of_old, in, work);
   for (int c = 1; c < P->ncolors; ++c) {   // colour 0: y = r already
@@ -390,6 +563,8 @@ int ilu_check(const flow_ilu* ilu, int op_size) {
   FLOW_REQUIRE(ilu->nblocks == 1 || ilu->nblocks == 2, "ilu blocks");
   FLOW_REQUIRE(ilu->nblocks * ilu->plan->n == op_size, "ilu size");
   FLOW_REQUIRE((reinterpret_cast<size_t>(ilu->lu) & 15) == 0, "lu alignment");
+  FLOW_REQUIRE((reinterpret_cast<size_t>(ilu->packed) & 15) == 0,
+               "packed alignment");
   return FLOW_OK;
 }
 
@@ -434,6 +609,31 @@ extern "C" int flow_ilu0_factor(const flow_ilu_plan* plan, int nblocks,
   FLOW_REQUIRE(nblocks == 1 || nblocks == 2, "ilu blocks");
   FLOW_REQUIRE(avals0 && lu && (nblocks == 1 || avals1), "ilu factor pointers");
   return factor(plan, nblocks, avals0, avals1, lu, as_stream(stream));
+}
+
+extern "C" int flow_ilu0_pack(const flow_ilu* ilu, float* packed, void* stream) {
+  FLOW_REQUIRE(ilu && ilu->plan && packed, "ilu pack pointers");
+  int rc = ilu_check(ilu, ilu->nblocks * ilu->plan->n);
+  if (rc) return rc;
+  FLOW_REQUIRE((reinterpret_cast<size_t>(packed) & 15) == 0, "packed alignment");
+  const flow_ilu_plan* P = ilu->plan;
+  // the L and U streams lie back to back in the packed buffer; in lu they are
+  // separated by alignment padding
+  const size_t lus = static_cast<size_t>(P->lu_size);
+  hipStream_t st = as_stream(stream);
+  for (int part = 0; part < 2; ++part) {
+    const int count = part == 0 ? P->nnz_l : P->nnz_u;
+    const double* src = ilu->lu + (part == 0 ? P->off_l : P->off_u);
+    float* dst = packed + (part == 0 ? 0 : static_cast<size_t>(P->nnz_l) * ilu->nblocks);
+    if (ilu->nblocks == 1)
+      hipLaunchKernelGGL((ilu_pack_kernel<1>), dim3(grid_for(count)), dim3(kBlock),
+                         0, st, count, lus, src, dst);
+    else
+      hipLaunchKernelGGL((ilu_pack_kernel<2>), dim3(grid_for(count)), dim3(kBlock),
+                         0, st, count, lus, src, dst);
+  }
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
 }
 
 extern "C" int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,

@@ -1312,7 +1312,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 16; }
+extern "C" int flow_abi_version(void) { return 17; }
 
 // the workgroup -> tile mapping of the CSR-stream kernels, for host-side tests
 extern "C" int flow_xcd_tile_host(int block, int nblocks) {

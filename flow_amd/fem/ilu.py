@@ -204,16 +204,26 @@ class Ilu0(object):
     '''ILU(0) factors of the diagonal blocks of a Matrix: one factor for a
     scalar operator, two (the (0,0) and (1,1) blocks) for block operators --
     the couplings between the velocity components are left to the Krylov
-    method.  `refactor(A)` re-uses the buffers.'''
+    method.  `refactor(A)` re-uses the buffers.  `packed`: the sweeps read the
+    factors rounded to fp32, the blocks interleaved (half the bytes per
+    application, fp64 arithmetic; include/flow_hip.h: flow_ilu.packed).'''
 
-    def __init__(self, A, plan=None):
+    def __init__(self, A, plan=None, packed=False):
+        import torch
         self.plan = plan if plan is not None else plan_for(A.layout)
         self.planes = {0: [0], 1: [0, 1], 2: [0, 3]}[A.kind]
-        self.lu = device.zeros(len(self.planes) * self.plan.lu_size)
+        nb = len(self.planes)
+        self.lu = device.zeros(nb * self.plan.lu_size)
         self.struct = _hip.IluS(
-            ctypes.pointer(self.plan.struct), len(self.planes),
-            _hip.f64(self.lu, len(self.planes) * self.plan.lu_size),
+            ctypes.pointer(self.plan.struct), nb,
+            _hip.f64(self.lu, nb * self.plan.lu_size), None,
             )
+        self.packed = None
+        if packed:
+            self.packed = torch.zeros(
+                (self.plan.nnz_l + self.plan.nnz_u) * nb + 4,
+                dtype=torch.float32, device=self.lu.device)
+            assert self.packed.data_ptr() % 16 == 0
         self.refactor(A)
 
     def refactor(self, A):
@@ -225,6 +235,13 @@ class Ilu0(object):
             _hip.f64(A.plane(self.planes[-1]), self.plan.nnz),
             _hip.f64(self.lu, nb * self.plan.lu_size), _hip.stream()
             ))
+        if self.packed is not None:
+            self.struct.packed = None
+            _hip.check(lib.flow_ilu0_pack(
+                ctypes.byref(self.struct), self.packed.data_ptr(),
+                _hip.stream()
+                ))
+            self.struct.packed = self.packed.data_ptr()
         return self
 
     def factor_values(self, k=0):

@@ -223,6 +223,11 @@ typedef struct {
   const flow_ilu_plan* plan;
   int nblocks;               /* 1 (scalar) or 2 (diagonal blocks of a 2-field op) */
   const double* lu;          /* nblocks * lu_size */
+  const float* packed;       /* NULL, or (nnz_l + nnz_u) * nblocks floats filled
+                                by flow_ilu0_pack: the sweep streams rounded to
+                                fp32, blocks interleaved -- half the bytes per
+                                application (fp64 arithmetic throughout; a
+                                preconditioner only) */
 } flow_ilu;
 /* HOST routine (setup, no GPU needed): first-fit greedy colouring of the graph
  * of a CSR pattern in row order; colour: n ints out, *ncolors <= 63 */
@@ -233,6 +238,9 @@ int flow_color_greedy_host(int n, const int* rowptr, const int* cols,
 int flow_ilu0_factor(const flow_ilu_plan* plan, int nblocks,
                      const double* avals0, const double* avals1, double* lu,
                      void* stream);
+/* fill `packed` (16-byte aligned) from the factors in ilu->lu; ilu->packed may
+ * point at it from then on.  Call again after every flow_ilu0_factor. */
+int flow_ilu0_pack(const flow_ilu* ilu, float* packed, void* stream);
 /* z = blockdiag(LU)^-1 r in the ORIGINAL numbering; r, z, work: nblocks*n */
 int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
                     double* work, void* stream);

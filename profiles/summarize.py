@@ -2,7 +2,7 @@
 '''
 Summarise rocprofv3 CSV output into the small files committed under profiles/.
 
-  python profiles/summarize.py stats  <dir> <out.md>     kernel-trace summary
+  python profiles/summarize.py stats  <dir> <out.md> [a:b]  kernel-trace summary
   python profiles/summarize.py pmc    <fetch_dir> <write_dir> <out.json> [kernel] [grid]
   python profiles/summarize.py gaps   <dir> <out.md>     idle time between kernels
 
@@ -30,11 +30,23 @@ def _find(directory, suffix):
     return hits
 
 
-def stats(directory, out):
+def stats(directory, out, window=None):
+    '''window = "a:b" as in gaps(): only kernels that start between a and b
+    milliseconds before the end of the trace.'''
     rows = defaultdict(lambda: [0, 0.0])
+    t_end = 0
+    if window:
+        a, b = [float(v) * 1.0e6 for v in window.split(':')]
+        for path in _find(directory, 'kernel_trace.csv'):
+            with open(path) as fh:
+                for r in csv.DictReader(fh):
+                    t_end = max(t_end, int(r['End_Timestamp']))
     for path in _find(directory, 'kernel_trace.csv'):
         with open(path) as fh:
             for r in csv.DictReader(fh):
+                if window and not (
+                        t_end - a >= int(r['Start_Timestamp']) >= t_end - b):
+                    continue
                 name = r['Kernel_Name'].split('(')[0]
                 if 'spmv_stream' in name and 'Grid_Size_X' in r:
                     # one row per matrix: the same kernel serves the pressure
@@ -171,6 +183,7 @@ if __name__ == '__main__':
         gaps(sys.argv[2], sys.argv[3],
              window=sys.argv[4] if len(sys.argv) > 4 else None)
     elif sys.argv[1] == 'stats':
-        stats(sys.argv[2], sys.argv[3])
+        stats(sys.argv[2], sys.argv[3],
+              window=sys.argv[4] if len(sys.argv) > 4 else None)
     else:
         pmc(*sys.argv[2:7])

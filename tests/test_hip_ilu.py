@@ -92,6 +92,62 @@ def test_factor_and_sweeps_match_host_ilu0(hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('kind', [0, 1])
+def test_packed_sweeps_apply_the_rounded_factors(hip, kind):
+    '''flow_ilu.packed: the sweeps read the factors rounded to fp32 (blocks
+    interleaved) and compute in fp64 -- the result is the EXACT inverse of the
+    rounded factors (a fixed linear operator), to fp64 round-off, and close to
+    that of the unrounded ones.'''
+    from flow_amd import device
+    from flow_amd.fem import ops
+    import torch
+    rng = numpy.random.RandomState(3)
+    mesh = fem.karman_channel(24, 7)
+    V = fem.FunctionSpace(mesh, 'CG', 2)
+    lay = V.layout
+    n = lay.N
+    M = ops.assemble_mass(V)
+    K = ops.assemble_stiffness(V)
+    scale = float(M.vals.abs().max())
+    planes = []
+    for _ in range(kind + 1):
+        pert = device.to_device(0.1 * rng.standard_normal(M.vals.numel())) * scale
+        planes.append(M.vals + 0.002 * K.vals + pert * (M.vals != 0))
+    A = ops.Matrix(lay, kind, planes[0] if kind == 0 else torch.cat(planes))
+    full = ilu.Ilu0(A)
+    packed = ilu.Ilu0(A, packed=True)
+    plan = packed.plan
+    nb = kind + 1
+    r = rng.standard_normal(nb * n)
+    z64 = device.zeros(nb * n)
+    z32 = device.zeros(nb * n)
+    full.solve(device.to_device(r), z64)
+    packed.solve(device.to_device(r), z32)
+    z64 = device.to_host(z64).numpy()
+    z32 = device.to_host(z32).numpy()
+    ip, ix = plan.host['rowptr'], plan.host['cols']
+    diag = plan.host['diag']
+    perm = plan.host['old_of_new']
+    for b in range(nb):
+        lu = packed.factor_values(b)
+        rounded = lu.astype(numpy.float32).astype(numpy.float64)
+        rounded[diag] = 1.0 / (1.0 / lu[diag])      # pivots stay fp64 (1/d)
+        LU = sp.csr_matrix((rounded, ix, ip), shape=(n, n))
+        L = sp.tril(LU, -1) + sp.identity(n)
+        U = sp.triu(LU)
+        rp = r[b * n:(b + 1) * n][perm]
+        zp = spla.spsolve_triangular(
+            U.tocsr(), spla.spsolve_triangular(L.tocsr(), rp, lower=True),
+            lower=False)
+        zref = numpy.empty(n)
+        zref[perm] = zp
+        zb = z32[b * n:(b + 1) * n]
+        assert abs(zb - zref).max() < 1e-11 * abs(zref).max()
+        d = abs(zb - z64[b * n:(b + 1) * n]).max() / abs(zref).max()
+        assert 0.0 < d < 1e-5
+
+
+@pytest.mark.gpu
 def test_bicgstab_ilu0_on_convection_dominated_heat(hip):
     '''The regime where Jacobi fails (tests/test_hip_heat.py keeps to the
     diffusion-resolved one): cell Peclet number ~ 600.'''
