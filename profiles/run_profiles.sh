@@ -19,6 +19,10 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench
 echo write done
 python3 $R/profiles/summarize.py stats $OUT/trace $R/gpurun_out/kernel_stats_$TAG.md
 python3 $R/profiles/summarize.py gaps $OUT/trace $R/gpurun_out/gaps_$TAG.md
+# the timed steps only: the last 10 steps before the 3 in-solver measurement
+# steps and the replay at the end of the trace (kernel budget of one step)
+python3 $R/profiles/summarize.py stats $OUT/trace $R/gpurun_out/kernel_stats_${TAG}_timed_steps.md 90:340 > /dev/null
+python3 $R/profiles/summarize.py gaps $OUT/trace $R/gpurun_out/gaps_${TAG}_timed_steps.md 90:340 > /dev/null
 # warm replay (spmv_stream_kernel<false>, back-to-back) and the in-solver launches
 # (spmv_stream_kernel<true> on the pressure matrix: dispatch size 1923072)
 python3 $R/profiles/summarize.py pmc $OUT/fetch $OUT/write $R/gpurun_out/spmv_traffic_$TAG.json "flow::spmv_stream_kernel<false>" 1923072
