@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libflow_hip.so')
 REDUCE_WORK = 4096
 GMRES_MAX_RESTART = 30
 GMRES_PARTIALS = (GMRES_MAX_RESTART + 2) * 1024
+GMRES_STATE = 1280
 SPMV_ROWS_PER_BLOCK = 256
 SPMV_NNZ_PER_BLOCK = 1022
 
@@ -212,7 +213,7 @@ SYMBOLS = {
     'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
                             _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_gmres_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I, _I,
-                         _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
+                         _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],
     'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],
     'flow_ilu0_pack': [_P(IluS), _VP, _VP],

@@ -29,7 +29,8 @@ template <int NP>
 __global__ __launch_bounds__(kBlock) void gather_kernel(
     int nout, const int* __restrict__ ptr, const int* __restrict__ src,
     const double* __restrict__ scratch, size_t plane_stride, size_t out_stride,
-    double* __restrict__ out) {
+    double* __restrict__ out, const double* __restrict__ stop) {
+  if (stopped(stop)) return;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nout;
        k += gridDim.x * blockDim.x) {
     const int a = ptr[k];
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(
 // rows [r0, r1) of the nout (r1 = 0: all); out_stride = 0: nout
 static int gather(int nout, int nplanes, const int* ptr, const int* src,
                   const double* scratch, size_t plane_stride, double* out,
-                  hipStream_t st, size_t out_stride = 0, int r0 = 0, int r1 = 0) {
+                  hipStream_t st, size_t out_stride = 0, int r0 = 0, int r1 = 0,
+                  const double* stop = nullptr) {
   const size_t os = out_stride ? out_stride : static_cast<size_t>(nout);
   if (r1 > 0) {
     ptr += r0;
@@ -71,10 +73,10 @@ static int gather(int nout, int nplanes, const int* ptr, const int* src,
   FLOW_REQUIRE(nplanes == 1 || nplanes == 2, "gather: 1 or 2 planes");
   if (nplanes == 1)
     hipLaunchKernelGGL(gather_kernel<1>, grid, dim3(kBlock), 0, st, nout, ptr,
-                       src, scratch, plane_stride, os, out);
+                       src, scratch, plane_stride, os, out, stop);
   else
     hipLaunchKernelGGL(gather_kernel<2>, grid, dim3(kBlock), 0, st, nout, ptr,
-                       src, scratch, plane_stride, os, out);
+                       src, scratch, plane_stride, os, out, stop);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -420,9 +422,10 @@ __global__ __launch_bounds__(kBlock) void momentum_jvp_kernel(
     const int* __restrict__ cdu, int nu, int nv,
     const int* __restrict__ bfmask, const double* __restrict__ ui,
     const double* __restrict__ v, flow_ns_params prm,
-    double* __restrict__ scratch) {
+    double* __restrict__ scratch, const double* __restrict__ stop) {
   constexpr int NL = Elem<DEG>::NL;
   constexpr int NQ = Elem<DEG>::NQ;
+  if (stopped(stop)) return;
   const int c = cb + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (c >= ce) return;
   const Geom g = load_geom(xy, nc, c);
@@ -493,7 +496,9 @@ __global__ __launch_bounds__(kBlock) void momentum_jvp_kernel(
 // [r0, r1); d = a*n + row, the vectors have component strides vs / os
 __global__ void bc_copy_kernel(int nbc, const int* __restrict__ dofs, int n,
                                int r0, int r1, const double* __restrict__ v,
-                               int vs, double* __restrict__ out, int os) {
+                               int vs, double* __restrict__ out, int os,
+                               const double* __restrict__ stop) {
+  if (stopped(stop)) return;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nbc) return;
   const int d = dofs[k];
@@ -1194,7 +1199,7 @@ int flow::momentum_jvp_check(const flow_momentum_jvp* J) {
 // pointers are indexed by GLOBAL row (callers with compact vectors shift them)
 int flow::momentum_jvp_apply(const flow_momentum_jvp* J, const double* v,
                              double* out, hipStream_t st, int v_stride,
-                             int out_stride) {
+                             int out_stride, const double* stop) {
   const flow_mesh* mesh = J->mesh;
   const flow_space* W = J->W;
   const int nl = W->deg == 1 ? 3 : 6;
@@ -1204,15 +1209,15 @@ int flow::momentum_jvp_apply(const flow_momentum_jvp* J, const double* v,
   int rc;
   FLOW_DISPATCH_DEG(W->deg, momentum_jvp_kernel, cell_grid(cr.count()), st,
                     mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n, vs,
-                    J->bfmask, J->ui, v, J->prm, J->scratch);
+                    J->bfmask, J->ui, v, J->prm, J->scratch, stop);
   if ((rc = gather(W->n, 2, W->vptr, W->vsrc, J->scratch,
                    static_cast<size_t>(nl) * mesh->nc, out, st, os, W->r0,
-                   W->r1)))
+                   W->r1, stop)))
     return rc;
   if (J->nbc > 0) {
     const int r0 = W->r1 > 0 ? W->r0 : 0, r1 = W->r1 > 0 ? W->r1 : W->n;
     hipLaunchKernelGGL(bc_copy_kernel, dim3(grid_for(J->nbc)), dim3(kBlock), 0,
-                       st, J->nbc, J->bc_dofs, W->n, r0, r1, v, vs, out, os);
+                       st, J->nbc, J->bc_dofs, W->n, r0, r1, v, vs, out, os, stop);
     FLOW_CHECK_LAUNCH();
   }
   return FLOW_OK;
@@ -1224,7 +1229,7 @@ extern "C" int flow_momentum_jvp_apply(const flow_momentum_jvp* J,
   int rc = momentum_jvp_check(J);
   if (rc) return rc;
   FLOW_REQUIRE(v && out && v != out, "jvp vectors");
-  return momentum_jvp_apply(J, v, out, as_stream(stream), 0, 0);
+  return momentum_jvp_apply(J, v, out, as_stream(stream), 0, 0, nullptr);
 }
 
 extern "C" int flow_assemble_magnitude(const flow_mesh* mesh, const flow_space* W,

@@ -14,14 +14,17 @@ void set_error(const char* fmt, ...);
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
 // ilu_kernels.hip
+// stop: a solver's sticky "done" flag (la_kernels.hip) -- every kernel returns
+// at once when it is set
 int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
-              hipStream_t st);
+              hipStream_t st, const double* stop = nullptr);
 int ilu_check(const flow_ilu* ilu, int op_size);
 
 // assembly_kernels.hip: the matrix-free operator (flow_operator kind 3)
 int momentum_jvp_check(const flow_momentum_jvp* J);
 int momentum_jvp_apply(const flow_momentum_jvp* J, const double* v, double* out,
-                       hipStream_t st, int v_stride = 0, int out_stride = 0);
+                       hipStream_t st, int v_stride = 0, int out_stride = 0,
+                       const double* stop = nullptr);
 
 #define FLOW_CHECK_HIP(expr)                                                 \
   do {                                                                       \
@@ -73,6 +76,12 @@ __device__ __forceinline__ double load_scalar(const double* p) {
 }
 __device__ __forceinline__ void store_scalar(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// a solver's sticky "done" flag (la_kernels.hip: convergence is decided on the
+// device); nullptr: none
+__device__ __forceinline__ bool stopped(const double* stop) {
+  return stop != nullptr && load_scalar(stop) != 0.0;
 }
 
 // block-wide sum, result valid in thread 0 (blockDim.x == 256)

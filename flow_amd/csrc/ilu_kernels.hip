@@ -202,7 +202,9 @@ __global__ void ilu_split_kernel(int n, int nnz_l, int nnz_u,
 __global__ void ilu_permute_kernel(int n, int nblocks,
                                    const int* __restrict__ new_of_old,
                                    const double* __restrict__ r,
-                                   double* __restrict__ y) {
+                                   double* __restrict__ y,
+                                   const double* __restrict__ stop) {
+  if (stopped(stop)) return;
   for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n;
        o += gridDim.x * blockDim.x) {
     const int i = new_of_old[o];
@@ -214,7 +216,9 @@ __global__ void ilu_permute_kernel(int n, int nblocks,
 __global__ void ilu_unpermute_kernel(int n, int nblocks,
                                      const int* __restrict__ new_of_old,
                                      const double* __restrict__ y,
-                                     double* __restrict__ z) {
+                                     double* __restrict__ z,
+                                     const double* __restrict__ stop) {
+  if (stopped(stop)) return;
   for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n;
        o += gridDim.x * blockDim.x) {
     const int i = new_of_old[o];
@@ -234,7 +238,12 @@ __global__ __launch_bounds__(kBlock) void ilu_sweep_kernel(
     int n, size_t lu_size, int nslices, int row_end,
     const int* __restrict__ slice_off, const int* __restrict__ slice_row,
     const int* __restrict__ cols, const double* __restrict__ vals,
-    const double* __restrict__ dinv, double* __restrict__ y) {
+    const double* __restrict__ dinv, double* __restrict__ y,
+    const double* __restrict__ stop) {
+  // the done flag is only looked at before the store: a sweep launch is short
+  // (the latency of three dependent loads), an early exit on the flag would
+  // put a fourth in front of them
+  const double halt = stop ? load_scalar(stop) : 0.0;
   // (XCD-aware: neighbouring slices gather from neighbouring windows of y)
   const int sl = xcd_tile(blockIdx.x, gridDim.x) * (kBlock / kSlice) +
                  (threadIdx.x >> 6);
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void ilu_sweep_kernel(
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) s += vv[j] * yy[j];
   }
-  if (live) y[row] = (rhs - s) * di;
+  if (live && halt == 0.0) y[row] = (rhs - s) * di;
 }
 
 // ---- packed sweep streams ---------------------------------------------------
@@ -326,7 +335,9 @@ __global__ void ilu_pack_kernel(int count, size_t lu_size,
 template <int NB>
 __global__ void ilu_permute_packed_kernel(int n, const int* __restrict__ new_of_old,
                                           const double* __restrict__ r,
-                                          double* __restrict__ y) {
+                                          double* __restrict__ y,
+                                          const double* __restrict__ stop) {
+  if (stopped(stop)) return;
   for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n;
        o += gridDim.x * blockDim.x) {
     const size_t i = new_of_old[o];
@@ -338,7 +349,9 @@ __global__ void ilu_permute_packed_kernel(int n, const int* __restrict__ new_of_
 template <int NB>
 __global__ void ilu_unpermute_packed_kernel(int n, const int* __restrict__ new_of_old,
                                             const double* __restrict__ y,
-                                            double* __restrict__ z) {
+                                            double* __restrict__ z,
+                                            const double* __restrict__ stop) {
+  if (stopped(stop)) return;
   for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n;
        o += gridDim.x * blockDim.x) {
     const size_t i = new_of_old[o];
@@ -353,9 +366,11 @@ __global__ __launch_bounds__(kBlock) void ilu_sweep_packed_kernel(
     size_t lu_size, int nslices, int row_end, const int* __restrict__ slice_off,
     const int* __restrict__ slice_row, const int* __restrict__ cols,
     const typename PackT<NB>::val* __restrict__ vals,
-    const double* __restrict__ dinv, typename PackT<NB>::vec* __restrict__ y) {
+    const double* __restrict__ dinv, typename PackT<NB>::vec* __restrict__ y,
+    const double* __restrict__ stop) {
   using V = typename PackT<NB>::val;
   using Y = typename PackT<NB>::vec;
+  const double halt = stop ? load_scalar(stop) : 0.0;   // (see ilu_sweep_kernel)
   const int sl = xcd_tile(blockIdx.x, gridDim.x) * (kBlock / kSlice) +
                  (threadIdx.x >> 6);
   if (sl >= nslices) return;
@@ -399,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void ilu_sweep_packed_kernel(
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) fma_pack(s, vv[j], yy[j]);
   }
-  if (live) {
+  if (live && halt == 0.0) {
     if constexpr (NB == 1) {
       y[row] = (rhs - s) * di[0];
     } else {
@@ -480,7 +495,7 @@ static int factor(const flow_ilu_plan* P, int nblocks, const double* avals0,
 
 template <int NB>
 static int apply_packed(const flow_ilu* ilu, const double* in, double* out,
-                        double* work, hipStream_t st) {
+                        double* work, hipStream_t st, const double* stop) {
   using V = typename PackT<NB>::val;
   using Y = typename PackT<NB>::vec;
   const flow_ilu_plan* P = ilu->plan;
@@ -490,7 +505,7 @@ static int apply_packed(const flow_ilu* ilu, const double* in, double* out,
   const V* uvals = lvals + P->nnz_l;
   Y* y = reinterpret_cast<Y*>(work);
   hipLaunchKernelGGL((ilu_permute_packed_kernel<NB>), dim3(grid_for(P->n)),
-                     dim3(kBlock), 0, st, P->n, P->new_of_old, in, work);
+                     dim3(kBlock), 0, st, P->n, P->new_of_old, in, work, stop);
   for (int c = 1; c < P->ncolors; ++c) {   // colour 0: y = r already
     const int s0 = P->slice_ptr_host[c];
     const int ns = P->slice_ptr_host[c + 1] - s0;
@@ -499,7 +514,7 @@ static int apply_packed(const flow_ilu* ilu, const double* in, double* out,
                        dim3((ns + per_block - 1) / per_block), dim3(kBlock), 0,
                        st, lus, ns, P->color_ptr_host[c + 1], P->l_slice_off + s0,
                        P->slice_row + s0, P->l_cols, lvals,
-                       static_cast<const double*>(nullptr), y);
+                       static_cast<const double*>(nullptr), y, stop);
   }
   for (int c = P->ncolors - 1; c >= 0; --c) {
     const int s0 = P->slice_ptr_host[c];
@@ -508,26 +523,27 @@ static int apply_packed(const flow_ilu* ilu, const double* in, double* out,
     hipLaunchKernelGGL((ilu_sweep_packed_kernel<true, NB>),
                        dim3((ns + per_block - 1) / per_block), dim3(kBlock), 0,
                        st, lus, ns, P->color_ptr_host[c + 1], P->u_slice_off + s0,
-                       P->slice_row + s0, P->u_cols, uvals, ilu->lu + P->off_d, y);
+                       P->slice_row + s0, P->u_cols, uvals, ilu->lu + P->off_d, y,
+                       stop);
   }
   hipLaunchKernelGGL((ilu_unpermute_packed_kernel<NB>), dim3(grid_for(P->n)),
-                     dim3(kBlock), 0, st, P->n, P->new_of_old, work, out);
+                     dim3(kBlock), 0, st, P->n, P->new_of_old, work, out, stop);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
 
 // out = blockdiag(LU_0[, LU_1])^-1 in ; work: nblocks * n doubles
 int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
-              hipStream_t st) {
+              hipStream_t st, const double* stop) {
   const flow_ilu_plan* P = ilu->plan;
   const size_t lus = static_cast<size_t>(P->lu_size);
   constexpr int per_block = kBlock / kSlice;
   if (ilu->packed) {
-    if (ilu->nblocks == 1) return apply_packed<1>(ilu, in, out, work, st);
-    return apply_packed<2>(ilu, in, out, work, st);
+    if (ilu->nblocks == 1) return apply_packed<1>(ilu, in, out, work, st, stop);
+    return apply_packed<2>(ilu, in, out, work, st, stop);
   }
   hipLaunchKernelGGL(ilu_permute_kernel, dim3(grid_for(P->n)), dim3(kBlock), 0,
-                     st, P->n, ilu->nblocks, P->new_of_old, in, work);
+                     st, P->n, ilu->nblocks, P->new_of_old, in, work, stop);
   for (int c = 1; c < P->ncolors; ++c) {   // colour 0: y = r already
     const int s0 = P->slice_ptr_host[c];
     const int ns = P->slice_ptr_host[c + 1] - s0;
@@ -537,7 +553,7 @@ int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
                        dim3(kBlock), 0, st, P->n, lus, ns,
                        P->color_ptr_host[c + 1], P->l_slice_off + s0,
                        P->slice_row + s0, P->l_cols, ilu->lu + P->off_l,
-                       static_cast<const double*>(nullptr), work);
+                       static_cast<const double*>(nullptr), work, stop);
   }
   for (int c = P->ncolors - 1; c >= 0; --c) {
     const int s0 = P->slice_ptr_host[c];
@@ -548,10 +564,10 @@ int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
                        dim3(kBlock), 0, st, P->n, lus, ns,
                        P->color_ptr_host[c + 1], P->u_slice_off + s0,
                        P->slice_row + s0, P->u_cols, ilu->lu + P->off_u,
-                       ilu->lu + P->off_d, work);
+                       ilu->lu + P->off_d, work, stop);
   }
   hipLaunchKernelGGL(ilu_unpermute_kernel, dim3(grid_for(P->n)), dim3(kBlock), 0,
-                     st, P->n, ilu->nblocks, P->new_of_old, work, out);
+                     st, P->n, ilu->nblocks, P->new_of_old, work, out, stop);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }

@@ -50,9 +50,7 @@ static_assert(3 * kRedBlocks + kNumSlots <= FLOW_REDUCE_WORK, "work size");
 // level is not harmless: measured on the P2 mass matrix, 8 iterations past
 // convergence moved the solution by 1.8e-4 relative), and the iteration count
 // it reports is the exact one.
-__device__ __forceinline__ bool stopped(const double* stop) {
-  return stop != nullptr && load_scalar(stop) != 0.0;
-}
+// (stopped(): common.h)
 
 // ---------------------------------------------------------------------------
 // SpMV
@@ -408,7 +406,7 @@ static int apply(const flow_operator* A, const double* x, double* y,
   if (A->kind == 3) {
     FLOW_REQUIRE(dpart == nullptr, "matrix-free operators carry no fused dot");
     return momentum_jvp_apply(static_cast<const flow_momentum_jvp*>(A->matfree),
-                              x, y, st, vec_stride, out_stride);
+                              x, y, st, vec_stride, out_stride, stop);
   }
   const int xs = vec_stride ? vec_stride : A->n;
   const dim3 grid(A->nblocks, A->kind == 1 ? 2 : 1);
@@ -543,7 +541,8 @@ static int fill(int n, double value, double* y, hipStream_t st) {
 
 // out = a * x .* y  (masks, diagonal scalings; out may alias x or y)
 __global__ void vmul_kernel(int n, double a, const double* x, const double* y,
-                            double* out) {
+                            double* out, const double* stop = nullptr) {
+  if (stopped(stop)) return;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x)
     out[i] = a * x[i] * y[i];
@@ -1312,7 +1311,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 17; }
+extern "C" int flow_abi_version(void) { return 18; }
 
 // the workgroup -> tile mapping of the CSR-stream kernels, for host-side tests
 extern "C" int flow_xcd_tile_host(int block, int nblocks) {
@@ -1511,12 +1510,22 @@ extern "C" int flow_vmul(int n, double a, const double* x, const double* y,
 
 // ---------------------------------------------------------------------------
 // GMRES(m), right-preconditioned (Saad & Schultz 1986), classical Gram-Schmidt
-// with ONE read-back per Arnoldi step:
-//   w = A M^-1 V_j ; the dots w.V_k (k <= j), w.w and |V_j|^2 go to the host in
-//   one mailbox read; h_{j+1,j} follows from Pythagoras, the new basis vector is
+// with ONE reduction per Arnoldi step:
+//   w = A M^-1 V_j ; the dots w.V_k (k <= j), w.w and |V_j|^2 are summed
+//   together; h_{j+1,j} follows from Pythagoras, the new basis vector is
 //   formed (and scaled with that estimate) in one fused pass that also leaves
-//   the partial sums of its true norm -- read with the next step's dots and
-//   put into H then.  The small least-squares problem lives on the host.
+//   the partial sums of its true norm -- summed with the next step's dots and
+//   put into H then.
+// The Hessenberg matrix, the least-squares problem and the stopping test live
+// ON THE DEVICE (gmres_step_kernel, one workgroup): the kernel that sums the
+// dots also extends H, solves min |beta e1 - H y|, writes the coefficients of
+// the next basis vector and of the solution update into device memory, and
+// sets the solver's sticky done flag -- the Arnoldi steps are enqueued without
+// the host in between (round 1 read every step's dots back: ~25 us of idle GPU
+// per step), as many as the caller expects the solve to need; everything
+// enqueued behind the accepted iterate returns at once.  (The sharded variant
+// further down keeps this algebra on the host: its sums come out of a
+// collective it has to wait for anyway.)
 // Basis vectors are handled eight at a time (compile-time unrolled).
 // ---------------------------------------------------------------------------
 constexpr int kGmresMax = FLOW_GMRES_MAX_RESTART;
@@ -1531,7 +1540,8 @@ template <int NV>
 __global__ __launch_bounds__(kBlock) void gmres_dots_kernel(
     int n, const double* __restrict__ w, const double* __restrict__ V,
     size_t stride, int with_ww, double* __restrict__ partial,
-    double* __restrict__ ww_partial) {
+    double* __restrict__ ww_partial, const double* __restrict__ stop = nullptr) {
+  if (stopped(stop)) return;
   double acc[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) acc[k] = 0.0;
@@ -1593,6 +1603,190 @@ __global__ __launch_bounds__(kBlock) void gmres_finish_kernel(
   }
 }
 
+// gmres_combine_kernel with the coefficients in device memory: coef[k] (k < NV)
+// and, for the w term, *cw
+template <int NV>
+__global__ __launch_bounds__(kBlock) void gmres_combine_dev_kernel(
+    int n, const double* __restrict__ coef, const double* __restrict__ cw,
+    int first, const double* w, const double* __restrict__ V, size_t stride,
+    double* out, double* __restrict__ nn_partial,
+    const double* __restrict__ stop) {
+  if (stopped(stop)) return;
+  double c[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) c[k] = load_scalar(coef + k);
+  const double c_w = (first && w) ? load_scalar(cw) : 0.0;
+  double nn = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    double acc = first ? (w ? c_w * w[i] : 0.0) : out[i];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc += c[k] * V[k * stride + i];
+    out[i] = acc;
+    nn += acc * acc;
+  }
+  if (nn_partial) {
+    nn = block_sum(nn);
+    if (threadIdx.x == 0) nn_partial[blockIdx.x] = nn;
+  }
+}
+
+// device-resident state of one GMRES cycle (doubles, behind the partials)
+constexpr int kGH = 0;                                   // H[col][row]
+constexpr int kGNrm = kGH + kGmresMax * (kGmresMax + 1);  // |V_k|
+constexpr int kGEta = kGNrm + kGmresMax + 1;              // h_{k+1,k} estimates
+constexpr int kGCoef = kGEta + kGmresMax;                 // next vector: c_k
+constexpr int kGCw = kGCoef + kGmresMax;                  //   and the w factor
+constexpr int kGYc = kGCw + 1;                            // update: y_k / |V_k|
+constexpr int kGRot = kGYc + kGmresMax;                   // Givens (cs, sn)[k]
+constexpr int kGRhs = kGRot + 2 * kGmresMax;              // rotated beta e1
+constexpr int kGState = kGRhs + kGmresMax + 1;
+static_assert(kGState <= FLOW_GMRES_STATE, "gmres device state");
+
+// Arnoldi step j of a cycle, the part round 1 did on the host: sums of the
+// partials of w.V_k (k <= j), w.w and |V_j|^2 -> column j of H, the
+// least-squares problem, the stopping test.  One workgroup; the wavefronts sum
+// the value lists, thread 0 does the (tiny, serial) algebra -- O(j) per step:
+// H is kept in its rotated (triangular) form R; a step re-rotates column j-1
+// (its sub-diagonal has just been corrected with the true norm of V_j) and
+// column j with the rotations kept from before; the triangular solve for y
+// only runs behind the step that ends the cycle (`last`) or the solve.
+//   S[kConvIt] = columns of this cycle that are final, S[kRes2] = the residual
+//   estimate, S[kDone] = 1 converged (or invariant subspace) / 2 not a number
+__global__ __launch_bounds__(kBlock) void gmres_step_kernel(
+    int nparts, int j, int last, double beta, double target,
+    const double* __restrict__ partial, double* __restrict__ G,
+    double* __restrict__ S) {
+  constexpr int ld = kGmresMax + 1;
+  __shared__ double val[kGmresMax + 2];
+  // columns < j: rows <= col-1 rotated (R), column j-1 as H left it
+  __shared__ double Hs[kGmresMax * ld];
+  __shared__ double nrm[kGmresMax + 1], eta[kGmresMax];
+  __shared__ double g[kGmresMax + 1], cs[kGmresMax], sn[kGmresMax], y[kGmresMax];
+  if (stopped(S + kDone)) return;
+  const int nd = j + 1;
+  const int nval = nd + 1 + (j > 0 ? 1 : 0);
+  const int lane = threadIdx.x & 63;
+  // the value lists, a wavefront each (per-lane loads, four in flight)
+  for (int v = threadIdx.x >> 6; v < nval; v += kBlock / 64) {
+    const int list = v < nd ? v : kGmresMax + (v - nd);
+    const double* __restrict__ p = partial + list * kRedBlocks;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = lane;
+    for (; i + 192 < nparts; i += 256) {
+      s0 += p[i];
+      s1 += p[i + 64];
+      s2 += p[i + 128];
+      s3 += p[i + 192];
+    }
+    for (; i < nparts; i += 64) s0 += p[i];
+    double s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) val[v] = s;
+  }
+  // the state earlier steps of the cycle left (per-lane loads as well)
+  for (int i = threadIdx.x; i < j * ld; i += kBlock) Hs[i] = G[kGH + i];
+  if (threadIdx.x < j) {
+    nrm[threadIdx.x] = G[kGNrm + threadIdx.x];
+    eta[threadIdx.x] = G[kGEta + threadIdx.x];
+    cs[threadIdx.x] = G[kGRot + 2 * threadIdx.x];
+    sn[threadIdx.x] = G[kGRot + 2 * threadIdx.x + 1];
+    g[threadIdx.x] = G[kGRhs + threadIdx.x];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  // G holds, for every finished column c: rows 0..c-1 of R (rotated) and, in
+  // rows c and c+1, the UNROTATED pair (h_cc after the earlier rotations, the
+  // sub-diagonal) -- the rotation c is formed from them when column c+1 comes
+  // (then the sub-diagonal is final) or at the end of this step
+  if (j == 0) {
+    nrm[0] = beta;
+    g[0] = beta;
+  }
+  if (j > 0) {
+    // the true norm of V_j (it was scaled with the Pythagoras estimate eta)
+    nrm[j] = sqrt(val[nd + 1]);
+    const int c = j - 1;
+    Hs[c * ld + j] = eta[c] * nrm[j];
+    // rotation c, now final
+    const double a = Hs[c * ld + c], bsub = Hs[c * ld + c + 1];
+    const double d = hypot(a, bsub);
+    cs[c] = d > 0.0 ? a / d : 1.0;
+    sn[c] = d > 0.0 ? bsub / d : 0.0;
+    Hs[c * ld + c] = d;
+    G[kGH + c * ld + c] = d;
+    G[kGRot + 2 * c] = cs[c];
+    G[kGRot + 2 * c + 1] = sn[c];
+    const double gc = g[c];           // (unrotated so far)
+    g[c + 1] = -sn[c] * gc;
+    g[c] = cs[c] * gc;
+    G[kGRhs + c] = g[c];
+  }
+  const double nj = nrm[j];
+  G[kGNrm + j] = nj;
+  const double ww = val[nd] / (nj * nj);
+  double sum = 0.0;
+  double* col = Hs + j * ld;
+  for (int k = 0; k <= j; ++k) {
+    const double h = val[k] / (nj * nrm[k]);
+    y[k] = h;                         // (H[j][k], for the coefficients below)
+    col[k] = h;
+    sum += h * h;
+  }
+  if (!(ww == ww) || !(nj > 0.0)) {
+    store_scalar(S + kConvIt, static_cast<double>(j));
+    store_scalar(S + kDone, 2.0);
+    return;
+  }
+  const double e2 = ww - sum;
+  // (nearly) invariant subspace: the least-squares residual is then zero
+  const bool lucky = !(e2 > 1.0e-28 * ww);
+  const double et = lucky ? 0.0 : sqrt(e2);
+  G[kGEta + j] = et;
+  // the coefficients of V_{j+1} = (w / nrm_j - sum_k H[j][k] V_k / nrm_k) / eta_j
+  // (unused when the step ends the solve)
+  if (!lucky) {
+    const double inv = 1.0 / et;
+    for (int k = 0; k <= j; ++k)
+      store_scalar(G + kGCoef + k, -y[k] * inv / nrm[k]);
+    store_scalar(G + kGCw, inv / nj);
+  }
+  // column j through the rotations 0 .. j-1
+  for (int i = 0; i < j; ++i) {
+    const double t = cs[i] * col[i] + sn[i] * col[i + 1];
+    col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1];
+    col[i] = t;
+  }
+  col[j + 1] = et;
+  for (int r = 0; r <= j + 1; ++r) G[kGH + j * ld + r] = col[r];
+  G[kGRhs + j] = g[j];                // (before its own rotation)
+  // residual estimate with the Pythagoras sub-diagonal: |g_{j+1}| after
+  // rotation j
+  const double dj = hypot(col[j], et);
+  const double csj = dj > 0.0 ? col[j] / dj : 1.0;
+  const double snj = dj > 0.0 ? et / dj : 0.0;
+  const double resid = fabs(snj * g[j]);
+  store_scalar(S + kRes2, resid);
+  store_scalar(S + kConvIt, static_cast<double>(j + 1));
+  const bool done = resid <= target || lucky;
+  if (done || last) {
+    // y from the triangular system R y = g over the j+1 columns
+    const int nc = j + 1;
+    col[j] = dj;
+    g[j] = csj * g[j];
+    for (int i = nc - 1; i >= 0; --i) {
+      double t = g[i];
+      for (int c = i + 1; c < nc; ++c) t -= Hs[c * ld + i] * y[c];
+      const double rii = Hs[i * ld + i];
+      y[i] = rii != 0.0 ? t / rii : 0.0;
+    }
+    // (read by the update kernel with load_scalar: wave-uniform there)
+    for (int k = 0; k < nc; ++k) store_scalar(G + kGYc + k, y[k] / nrm[k]);
+    if (done) store_scalar(S + kDone, 1.0);
+  }
+}
+
 #define FLOW_NV_SWITCH(nv, CALL) \
   switch (nv) {                  \
     case 1: CALL(1); break;      \
@@ -1635,6 +1829,27 @@ static int gmres_combine(int N, int nv, const double* c, double cw,
   return FLOW_OK;
 }
 
+// the same with the coefficients in device memory (coef[0, nv), *cw)
+static int gmres_combine_dev(int N, int nv, const double* coef, const double* cw,
+                             const double* w, const double* V, double* out,
+                             double* nn_partial, bool accumulate,
+                             const double* stop, hipStream_t st) {
+  const int g = grid_for(N, kBlock, kRedBlocks);
+  for (int k0 = 0; k0 < nv; k0 += 8) {
+    const int chunk = nv - k0 < 8 ? nv - k0 : 8;
+    double* nnp = (k0 + 8 >= nv) ? nn_partial : nullptr;
+#define FLOW_CALL(NV)                                                           \
+  hipLaunchKernelGGL(gmres_combine_dev_kernel<NV>, dim3(g), dim3(kBlock), 0, st, \
+                     N, coef + k0, cw, (k0 == 0 && !accumulate) ? 1 : 0, w,     \
+                     V + static_cast<size_t>(k0) * N, static_cast<size_t>(N),   \
+                     out, nnp, stop)
+    FLOW_NV_SWITCH(chunk, FLOW_CALL)
+#undef FLOW_CALL
+  }
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
 // least squares  min | beta e1 - H y |  for the (j+1) x j Hessenberg matrix H
 // (column-major H[col][row]); returns the residual norm
 static double gmres_least_squares(const double (*H)[kGmresMax + 1], int j,
@@ -1665,13 +1880,17 @@ static double gmres_least_squares(const double (*H)[kGmresMax + 1], int j,
   return fabs(g[j]);
 }
 
-// work: [reductions | V_0 .. V_m | Z_0 .. Z_{m-1} | sweep buffer | partials];
-// Z_j = M^-1 V_j is kept, so that the update x += sum_j y_j Z_j needs no
-// further preconditioner application (memory is not the scarce resource)
+// work: [reductions | V_0 .. V_m | Z_0 .. Z_{m-1} | sweep buffer | partials |
+// device state]; Z_j = M^-1 V_j is kept, so that the update x += sum_j y_j Z_j
+// needs no further preconditioner application (memory is not the scarce
+// resource).  expected: operator applications the caller expects the solve to
+// need (0: unknown) -- that many Arnoldi steps are enqueued before the host
+// looks at the state for the first time, then one at a time; the result does
+// not depend on it.
 static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu,
                  const double* b, double* x, double rtol, double atol, int maxit,
-                 int m, int x_is_zero, double* work, int* iters_host,
-                 double* resid_host, hipStream_t st) {
+                 int m, int x_is_zero, int expected, double* work,
+                 int* iters_host, double* resid_host, hipStream_t st) {
   const int N = op_size(A);
   double* partial = work;
   double* S = work + 3 * kRedBlocks;
@@ -1681,11 +1900,11 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
   double* P = iwork + N;                    // (kGmresMax + 2) x kRedBlocks
   double* Pww = P + kGmresMax * kRedBlocks;
   double* Pnn = Pww + kRedBlocks;
+  double* G = P + FLOW_GMRES_PARTIALS;      // device state of the cycle
+  const double* stop = S + kDone;
   const int gv = grid_for(N);
   const int gd = grid_for(N, kBlock, kRedBlocks);
-  double *mailbox = nullptr, *mailbox_dev = nullptr;
   int np = 0, rc;
-  if ((rc = mailbox_of_thread(&mailbox, &mailbox_dev))) return rc;
 
   // Z_j = M^-1 V_j (without a preconditioner Z_j is V_j itself)
   const bool precond = ilu || dinv;
@@ -1693,10 +1912,38 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
   auto precondition = [&](int j) -> int {
     const double* in = V + static_cast<size_t>(j) * N;
     double* out = Z + static_cast<size_t>(j) * N;
-    if (ilu) return ilu_apply(ilu, in, out, iwork, st);
+    if (ilu) return ilu_apply(ilu, in, out, iwork, st, stop);
     if (dinv)
       hipLaunchKernelGGL(vmul_kernel, dim3(gv), dim3(kBlock), 0, st, N, 1.0, dinv,
-                         in, out);
+                         in, out, stop);
+    return FLOW_OK;
+  };
+  // Arnoldi step j of the cycle, enqueued without a read-back
+  auto arnoldi = [&](int j, double beta, double target, bool last) -> int {
+    int r;
+    double* w = V + static_cast<size_t>(j + 1) * N;
+    if ((r = precondition(j))) return r;
+    if ((r = apply(A, Zbase + static_cast<size_t>(j) * N, w, st, nullptr, stop)))
+      return r;
+    for (int k0 = 0; k0 <= j; k0 += 8) {
+      const int chunk = j + 1 - k0 < 8 ? j + 1 - k0 : 8;
+#define FLOW_CALL(NV)                                                         \
+  hipLaunchKernelGGL(gmres_dots_kernel<NV>, dim3(gd), dim3(kBlock), 0, st, N,  \
+                     w, V + static_cast<size_t>(k0) * N,                      \
+                     static_cast<size_t>(N), k0 == 0 ? 1 : 0,                 \
+                     P + k0 * kRedBlocks, Pww, stop)
+      FLOW_NV_SWITCH(chunk, FLOW_CALL)
+#undef FLOW_CALL
+    }
+    hipLaunchKernelGGL(gmres_step_kernel, dim3(1), dim3(kBlock), 0, st, gd, j,
+                       last ? 1 : 0, beta, target, P, G, S);
+    FLOW_CHECK_LAUNCH();
+    // the next basis vector, in place on w (skipped by the flag when the step
+    // kernel has just accepted the iterate; not needed behind the last column)
+    if (!last &&
+        (r = gmres_combine_dev(N, j + 1, G + kGCoef, G + kGCw, w, V, w, Pnn, false,
+                               stop, st)))
+      return r;
     return FLOW_OK;
   };
 
@@ -1746,75 +1993,42 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
       return FLOW_NOT_CONVERGED;
     }
 
-    double H[kGmresMax][kGmresMax + 1] = {};   // H[column][row]
-    double nrm[kGmresMax + 1];                 // true norms of the stored V_k
-    double eta[kGmresMax];                     // h_{j+1,j} used to scale V_{j+1}
-    double y[kGmresMax], c[kGmresMax];
-    nrm[0] = beta;
-    int j = 0;
+    // one cycle: up to m columns; `cols` of them are known to be final
+    const int it0 = it;
+    int enq = 0, cols = 0;
     bool converged = false;
-    while (j < m && it < maxit) {
-      double* w = V + static_cast<size_t>(j + 1) * N;
-      if ((rc = precondition(j))) return rc;
-      if ((rc = apply(A, Zbase + static_cast<size_t>(j) * N, w, st))) return rc;
-      for (int k0 = 0; k0 <= j; k0 += 8) {
-        const int chunk = j + 1 - k0 < 8 ? j + 1 - k0 : 8;
-#define FLOW_CALL(NV)                                                         \
-  hipLaunchKernelGGL(gmres_dots_kernel<NV>, dim3(gd), dim3(kBlock), 0, st, N,  \
-                     w, V + static_cast<size_t>(k0) * N,                      \
-                     static_cast<size_t>(N), k0 == 0 ? 1 : 0,                 \
-                     P + k0 * kRedBlocks, Pww)
-        FLOW_NV_SWITCH(chunk, FLOW_CALL)
-#undef FLOW_CALL
+    double state[kNumSlots];
+    while (true) {
+      const int room = (m < maxit - it0 ? m : maxit - it0) - enq;
+      if (room <= 0) break;
+      int plan = expected - (it0 + enq);
+      if (plan < 1) plan = 1;
+      if (plan > room) plan = room;
+      for (int k = 0; k < plan; ++k, ++enq) {
+        const bool last = enq + 1 >= m || it0 + enq + 1 >= maxit;
+        if ((rc = arnoldi(enq, beta, target, last))) return rc;
       }
-      const int nd = j + 1;
-      hipLaunchKernelGGL(gmres_finish_kernel, dim3(nd + 1 + (j > 0 ? 1 : 0)),
-                         dim3(kBlock), 0, st, gd, nd, P, mailbox_dev);
-      FLOW_CHECK_LAUNCH();
-      FLOW_CHECK_HIP(hipStreamSynchronize(st));
-      const volatile double* mb = mailbox;
-      if (j > 0) {
-        // the true norm of V_j (scaled with the Pythagoras estimate eta)
-        nrm[j] = sqrt(mb[nd + 1]);
-        H[j - 1][j] = eta[j - 1] * nrm[j];
-      }
-      const double ww = mb[nd] / (nrm[j] * nrm[j]);
-      double sum = 0.0;
-      bool bad = !(ww == ww) || !(nrm[j] > 0.0);
-      for (int k = 0; k <= j; ++k) {
-        H[j][k] = mb[k] / (nrm[j] * nrm[k]);
-        sum += H[j][k] * H[j][k];
-      }
-      if (bad) {
-        *iters_host = it;
+      if ((rc = read_state(S, state, st))) return rc;
+      cols = static_cast<int>(state[kConvIt]);
+      if (state[kDone] == 2.0) {
+        *iters_host = it0 + cols;
         *resid_host = resid;
-        set_error("GMRES broke down (NaN) at iteration %d", it);
+        set_error("GMRES broke down (NaN) at iteration %d", it0 + cols);
         return FLOW_NOT_CONVERGED;
       }
-      const double e2 = ww - sum;
-      // (nearly) invariant subspace: the least-squares residual is then zero
-      const bool lucky = !(e2 > 1.0e-28 * ww);
-      eta[j] = lucky ? 0.0 : sqrt(e2);
-      H[j][j + 1] = eta[j];
-      ++it;
-      ++j;
-      resid = gmres_least_squares(H, j, beta, y);
-      if (resid <= target || lucky) {
+      resid = state[kRes2];
+      if (state[kDone] != 0.0) {
         converged = true;
         break;
       }
-      if (j < m && it < maxit) {
-        // V_j = (w / nrm_{j-1} - sum_k H[j-1][k] V_k / nrm_k) / eta, in place
-        const double inv = 1.0 / eta[j - 1];
-        for (int k = 0; k < j; ++k) c[k] = -H[j - 1][k] * inv / nrm[k];
-        if ((rc = gmres_combine(N, j, c, inv / nrm[j - 1], w, V, w, Pnn, false,
-                                st)))
-          return rc;
-      }
     }
-    // x += sum_k y_k Z_k / nrm_k
-    for (int k = 0; k < j; ++k) c[k] = y[k] / nrm[k];
-    if ((rc = gmres_combine(N, j, c, 0.0, nullptr, Zbase, x, nullptr, true, st)))
+    it = it0 + cols;
+    // x += sum_k y_k Z_k / nrm_k (coefficients left by the last step kernel
+    // that ran); the flag is taken down first: it has done its work
+    if ((rc = fill(1, 0.0, S + kDone, st))) return rc;
+    if (cols > 0 &&
+        (rc = gmres_combine_dev(N, cols, G + kGYc, nullptr, nullptr, Zbase, x,
+                                nullptr, true, nullptr, st)))
       return rc;
     x_is_zero = 0;
     if (converged) break;
@@ -1921,23 +2135,24 @@ extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
 extern "C" int flow_gmres_solve(const flow_operator* A, const double* dinv,
                                 const flow_ilu* ilu, const double* b, double* x,
                                 double rtol, double atol, int maxit, int restart,
-                                int x_is_zero, double* work, size_t work_len,
-                                int* iters_host, double* resid_host,
-                                void* stream) {
+                                int x_is_zero, int expected_its, double* work,
+                                size_t work_len, int* iters_host,
+                                double* resid_host, void* stream) {
   int rc = check_solver_args(A, b, x, rtol, atol, maxit, 1, 0, work, work_len, 0,
                              iters_host, resid_host);
   if (rc) return rc;
   FLOW_REQUIRE(restart >= 1 && restart <= FLOW_GMRES_MAX_RESTART,
                "GMRES restart length");
+  FLOW_REQUIRE(expected_its >= 0, "expected iterations");
   FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK +
                                (2 * static_cast<size_t>(restart) + 2) *
                                    op_size(A) +
-                               FLOW_GMRES_PARTIALS,
+                               FLOW_GMRES_PARTIALS + FLOW_GMRES_STATE,
                "solver workspace too small (FLOW_REDUCE_WORK + (2 restart + 2) N "
-               "+ FLOW_GMRES_PARTIALS)");
+               "+ FLOW_GMRES_PARTIALS + FLOW_GMRES_STATE)");
   if (ilu && (rc = ilu_check(ilu, op_size(A)))) return rc;
-  return gmres(A, dinv, ilu, b, x, rtol, atol, maxit, restart, x_is_zero, work,
-               iters_host, resid_host, as_stream(stream));
+  return gmres(A, dinv, ilu, b, x, rtol, atol, maxit, restart, x_is_zero,
+               expected_its, work, iters_host, resid_host, as_stream(stream));
 }
 
 

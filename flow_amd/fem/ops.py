@@ -477,7 +477,8 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     iteration after the count the previous call (kept on A) needed.
     method 'gmres': GMRES(restart); x_is_zero promises x = 0 on entry;
     `iterations` then counts operator applications (a BiCGStab iteration is
-    two).'''
+    two); first_check = the applications the caller expects the solve to need
+    (that many Arnoldi steps are enqueued before the first read-back).'''
     lib = _hip.lib()
     n = A.size
     if isinstance(dinv, str):
@@ -491,7 +492,8 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
               + (2 * coarse.struct.lda if coarse else 0)
               + (2 * mg.struct.Ps[0].nblocks if mg is not None else 0)
               + (n if ilu is not None and method == 'bicgstab' else 0)
-              + (_hip.GMRES_PARTIALS if method == 'gmres' else 0))
+              + (_hip.GMRES_PARTIALS + _hip.GMRES_STATE
+                 if method == 'gmres' else 0))
     if device._POISON:      # debugging aid: stale workspace reads become NaNs
         _hip.fill(wk, float('nan'))
     if check_every is None:
@@ -519,8 +521,9 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
             ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
             ctypes.byref(ilu.struct) if ilu is not None else None,
             _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
-            int(maxit), int(restart), int(bool(x_is_zero)), _hip.f64(wk),
-            wk.numel(), ctypes.byref(its), ctypes.byref(res), _hip.stream()
+            int(maxit), int(restart), int(bool(x_is_zero)), int(first_check),
+            _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
+            _hip.stream()
             )
     else:
         assert coarse is None and mg is None

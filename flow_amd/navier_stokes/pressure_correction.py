@@ -422,12 +422,18 @@ def _compute_tentative_velocity(
         if npar.get('linear_solver', 'gmres') == 'gmres':
             # GMRES(restart): one Jacobian action + one preconditioner
             # application per iteration, the least of the Krylov methods here
+            # (how many Arnoldi steps to enqueue before the first read-back:
+            # what Newton iteration `it` of the previous call needed -- a
+            # scheduling hint, the accepted iterate does not depend on it)
+            expected = lay._dev.setdefault('gmres_expected', {})
             sol = ops.krylov_solve(
                 'gmres', operator, F, dx, rtol=lin_rtol, atol=0.0,
                 maxit=npar['linear_maxit'], ilu=pre,
                 restart=npar['gmres_restart'], x_is_zero=True,
-                dinv='jacobi' if pre is None else None
+                dinv='jacobi' if pre is None else None,
+                first_check=expected.get(it, 0)
                 )
+            expected[it] = sol.iterations
             # counted like BiCGStab iterations (two applications each) for the
             # staleness test of the lagged factors below
             its = (sol.iterations + 1) // 2

@@ -287,21 +287,29 @@ int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
  * != NULL) or nothing: the Newton systems of the tentative velocity
  * (pressure_correction.py:224-254) -- one operator + preconditioner application
  * per iteration, ~15 % fewer of them than BiCGStab needs there.  Classical
- * Gram-Schmidt with one host read-back per iteration (the dot products of the
- * step); the small least-squares problem is solved on the host.  Stops on the
- * least-squares residual estimate, `iters_host` = operator applications.
+ * Gram-Schmidt with one reduction per iteration; the Hessenberg matrix, the
+ * small least-squares problem and the stopping test live on the device (one
+ * workgroup behind the dot products), so the Arnoldi steps are enqueued
+ * without the host in between: expected_its of them (what the caller expects
+ * the solve to need -- the count of the previous solve in a time loop; 0:
+ * unknown) before the host looks for the first time, then one at a time.  The
+ * accepted iterate does not depend on it: everything enqueued behind it returns
+ * at once.  Stops on the least-squares residual estimate, `iters_host` =
+ * operator applications.
  * x_is_zero != 0: the caller guarantees x = 0 on entry (Newton increments), the
  * initial residual is then b without an operator application.
- * work: FLOW_REDUCE_WORK + (2*restart + 2)*N + FLOW_GMRES_PARTIALS doubles
- * (the preconditioned basis vectors are kept: no extra preconditioner
- * application for the solution update). */
+ * work: FLOW_REDUCE_WORK + (2*restart + 2)*N + FLOW_GMRES_PARTIALS +
+ * FLOW_GMRES_STATE doubles (the preconditioned basis vectors are kept: no extra
+ * preconditioner application for the solution update). */
 #define FLOW_GMRES_MAX_RESTART 30
 #define FLOW_GMRES_PARTIALS ((FLOW_GMRES_MAX_RESTART + 2) * 1024)
+#define FLOW_GMRES_STATE 1280
 int flow_gmres_solve(const flow_operator* A, const double* dinv,
                      const flow_ilu* ilu, const double* b, double* x,
                      double rtol, double atol, int maxit, int restart,
-                     int x_is_zero, double* work, size_t work_len,
-                     int* iters_host, double* resid_host, void* stream);
+                     int x_is_zero, int expected_its, double* work,
+                     size_t work_len, int* iters_host, double* resid_host,
+                     void* stream);
 
 /* ---- K15: domain decomposition over the GPUs of one node -------------------
  * (nothing in the reference: DOLFIN/PETSc would do this implicitly under

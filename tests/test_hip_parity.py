@@ -256,6 +256,23 @@ def test_bicgstab_matches_direct_solve(hip):
         ig = ops.krylov_solve('gmres', A, _dev(b), xg, rtol=1e-13, maxit=4000,
                               **kw)
         assert cases.rel_l2(xg.cpu().numpy(), ref) < 1e-9, (kw, ig)
+    # the Arnoldi steps are enqueued ahead of the host's read-backs (the
+    # stopping test runs on the device): however many the caller announces --
+    # none, the exact count, far too many -- the accepted iterate and the
+    # reported count are the same
+    for restart in (30, 6):
+        outcomes = []
+        for hint in (0, None, 3, 500):
+            xg = _dev(numpy.zeros(2 * V.N))
+            if hint is None:
+                hint = outcomes[0][0]
+            ig = ops.krylov_solve('gmres', A, _dev(b), xg, rtol=1e-11,
+                                  maxit=4000, restart=restart, x_is_zero=True,
+                                  first_check=hint)
+            outcomes.append((ig.iterations, ig.residual, xg.clone()))
+        for o in outcomes[1:]:
+            assert o[0] == outcomes[0][0] and o[1] == outcomes[0][1]
+            assert torch.equal(o[2], outcomes[0][2])
     # fewer operator applications than BiCGStab (two per iteration) needs
     xg = _dev(numpy.zeros(2 * V.N))
     ig = ops.krylov_solve('gmres', A, _dev(b), xg, rtol=1e-13, maxit=4000,
