@@ -248,6 +248,32 @@ class MomentumJacobian(object):
     def operator(self):
         return self._op
 
+    def rebind(self, bfmask, ui, prm, bc_dofs):
+        '''Point the operator at another linearisation state (a time loop
+        builds one per Newton iteration: the 0.2 GB scratch buffer and the
+        structs stay).'''
+        nc = self.layout.mesh.num_cells()
+        self._keep = (bfmask, ui, bc_dofs) + self._keep[3:]
+        s = self.struct
+        s.bfmask = _hip.i32(bfmask, nc, 'bfmask')
+        s.ui = _hip.f64(ui, self.size, 'ui')
+        s.prm = prm
+        s.nbc = int(bc_dofs.numel())
+        s.bc_dofs = _hip.i32(bc_dofs) if bc_dofs.numel() else None
+        return self
+
+    @classmethod
+    def cached(cls, W, bfmask, ui, prm, bc_dofs, mesh_s=None, space_s=None):
+        '''The operator of W's layout, created on first use and re-pointed
+        afterwards.'''
+        key = ('jvp_operator', id(mesh_s), id(space_s))
+        held = W.layout._dev.get(key)
+        if held is None:
+            held = cls(W, bfmask, ui, prm, bc_dofs, mesh_s, space_s)
+            W.layout._dev[key] = held
+            return held
+        return held.rebind(bfmask, ui, prm, bc_dofs)
+
     def apply(self, x, y):
         lib = _hip.lib()
         assert x.data_ptr() != y.data_ptr()

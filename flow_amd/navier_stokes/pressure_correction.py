@@ -402,7 +402,7 @@ def _compute_tentative_velocity(
                 pre.dt, pre.key, pre.stale = dt, key, False
                 refactored = True
         if matfree and Jop is None:
-            Jop = ops.MomentumJacobian(W, bfmask, ui.data, prm, bc_dofs)
+            Jop = ops.MomentumJacobian.cached(W, bfmask, ui.data, prm, bc_dofs)
         # Inexact Newton: the linear residual only has to get below what the
         # quadratic term leaves anyway (forcing term 1e-4 ||F||), and below a
         # fraction of the Newton tolerance so that one more step is never
@@ -558,8 +558,8 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
             pre.dt, pre.key, pre.stale = dt, key, False
             refactored = True
         if Jop is None:
-            Jop = ops.MomentumJacobian(W, bfmask, ui.data, prm, bc_dofs,
-                                       mesh_s=ms, space_s=wv.space)
+            Jop = ops.MomentumJacobian.cached(W, bfmask, ui.data, prm, bc_dofs,
+                                              mesh_s=ms, space_s=wv.space)
         lin_atol = max(npar['linear_atol_factor'] * tol, npar['forcing'] * nrm)
         lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
         ops.fill(dx, 0.0)

@@ -5,6 +5,7 @@ Summarise rocprofv3 CSV output into the small files committed under profiles/.
   python profiles/summarize.py stats  <dir> <out.md> [a:b]  kernel-trace summary
   python profiles/summarize.py pmc    <fetch_dir> <write_dir> <out.json> [kernel] [grid]
   python profiles/summarize.py gaps   <dir> <out.md>     idle time between kernels
+  python profiles/summarize.py sequence <dir> <out.txt> a:b   launch order of a window
 
 The PMC summary follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
 FETCH_SIZE and WRITE_SIZE come from separate passes, are in KiB, and on gfx950
@@ -178,10 +179,51 @@ def pmc(fetch_dir, write_dir, out, kernel='flow::spmv_stream_kernel<false>',
     print(json.dumps(res))
 
 
+def sequence(directory, out, window, min_gap_us=15.0):
+    '''The kernels of a window "a:b" (ms before the end of the trace) in launch
+    order, runs of equal names folded, every idle interval >= min_gap_us shown:
+    where in a time step the GPU waits for the host.'''
+    ev = []
+    for path in _find(directory, 'kernel_trace.csv'):
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']),
+                           r['Kernel_Name'].split('(')[0].replace('void ', '')
+                           .replace('flow::', '')))
+    ev.sort()
+    a, b = [float(v) * 1.0e6 for v in window.split(':')]
+    t_end = ev[-1][1]
+    ev = [e for e in ev if t_end - a >= e[0] >= t_end - b]
+    lines = []
+    run_name, run_count, run_us = None, 0, 0.0
+    end = ev[0][0]
+
+    def flush():
+        if run_name is not None:
+            lines.append('%5d x %-60s %9.1f us' % (run_count, run_name[:60], run_us))
+    for s0, e0, name in ev:
+        gap = (s0 - end) * 1e-3
+        if gap >= min_gap_us:
+            flush()
+            run_name, run_count, run_us = None, 0, 0.0
+            lines.append('        ---- idle %.0f us ----' % gap)
+        if name != run_name:
+            flush()
+            run_name, run_count, run_us = name, 0, 0.0
+        run_count += 1
+        run_us += (e0 - s0) * 1e-3
+        end = max(end, e0)
+    flush()
+    with open(out, 'w') as fh:
+        fh.write('\n'.join(lines) + '\n')
+
+
 if __name__ == '__main__':
     if sys.argv[1] == 'gaps':
         gaps(sys.argv[2], sys.argv[3],
              window=sys.argv[4] if len(sys.argv) > 4 else None)
+    elif sys.argv[1] == 'sequence':
+        sequence(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3],
               window=sys.argv[4] if len(sys.argv) > 4 else None)
