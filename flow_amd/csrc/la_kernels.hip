@@ -1657,6 +1657,8 @@ __global__ __launch_bounds__(kBlock) void gmres_step_kernel(
     int nparts, int j, int last, double beta, double target,
     const double* __restrict__ partial, double* __restrict__ G,
     double* __restrict__ S) {
+  // nparts = 0: `partial` holds the nd + 1 [+ 1] values themselves, one after
+  // the other (the sharded solver: summed over the ranks by the collective)
   constexpr int ld = kGmresMax + 1;
   __shared__ double val[kGmresMax + 2];
   // columns < j: rows <= col-1 rotated (R), column j-1 as H left it
@@ -1668,7 +1670,8 @@ __global__ __launch_bounds__(kBlock) void gmres_step_kernel(
   const int nval = nd + 1 + (j > 0 ? 1 : 0);
   const int lane = threadIdx.x & 63;
   // the value lists, a wavefront each (per-lane loads, four in flight)
-  for (int v = threadIdx.x >> 6; v < nval; v += kBlock / 64) {
+  if (nparts == 0 && threadIdx.x < nval) val[threadIdx.x] = partial[threadIdx.x];
+  for (int v = threadIdx.x >> 6; nparts > 0 && v < nval; v += kBlock / 64) {
     const int list = v < nd ? v : kGmresMax + (v - nd);
     const double* __restrict__ p = partial + list * kRedBlocks;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -2727,8 +2730,9 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
 static int shard_gmres(const flow_comm* C, const flow_rows* R,
                        const flow_operator* A, const flow_ilu* ilu,
                        const double* b, double* x, double rtol, double atol,
-                       int maxit, int m, int x_is_zero, double* work,
-                       int* iters_host, double* resid_host, hipStream_t st) {
+                       int maxit, int m, int x_is_zero, int expected,
+                       double* work, int* iters_host, double* resid_host,
+                       hipStream_t st) {
   const int mo = R->r1 - R->r0;         // owned rows
   const int me = R->e1 - R->e0;
   const int n = R->n;
@@ -2742,16 +2746,21 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
   double* P = stage + 2 * static_cast<size_t>(me);
   double* Pww = P + kGmresMax * kRedBlocks;
   double* Pnn = Pww + kRedBlocks;
+  double* G = P + FLOW_GMRES_PARTIALS;      // device state of the cycle
+  double* S = work + 3 * kRedBlocks;
+  const double* stop = S + kDone;
   const int gv = grid_for(N);
   const int gd = grid_for(N, kBlock, kRedBlocks);
   int rc;
 
   // w (owned-compact) = A v (owned-compact): stage, halo, apply on the strip
-  auto apply_owned = [&](const double* v, double* w) -> int {
+  // (the collective inside runs whatever the flag says: every rank issues the
+  // same sequence)
+  auto apply_owned = [&](const double* v, double* w, const double* flag) -> int {
     int r;
     if ((r = copy2d(2, mo, v, mo, stage + (R->r0 - R->e0), me, st))) return r;
     if ((r = halo(C, R, 2, stage - R->e0, me, st))) return r;
-    return apply(A, stage - R->e0, w - R->r0, st, nullptr, nullptr, me, mo);
+    return apply(A, stage - R->e0, w - R->r0, st, nullptr, flag, me, mo);
   };
   // sums of nv partial lists (list k at base + k*kRedBlocks) -> all ranks'
   // total on the host
@@ -2771,6 +2780,42 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
   } else if ((rc = copy2d(2, mo, x + R->r0, n, xc, mo, st))) {
     return rc;
   }
+  if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
+  // Arnoldi step j of the cycle without a read-back: the sums come out of the
+  // collective summed over the ranks, the step kernel takes them from there
+  // (every rank computes the same H, the same verdict)
+  auto arnoldi = [&](int j, double beta, double target, bool last) -> int {
+    int r;
+    double* w = V + static_cast<size_t>(j + 1) * N;
+    double* zj = Z + static_cast<size_t>(j) * N;
+    if ((r = ilu_apply(ilu, V + static_cast<size_t>(j) * N, zj, iwork, st, stop)))
+      return r;
+    if ((r = apply_owned(zj, w, stop))) return r;
+    for (int k0 = 0; k0 <= j; k0 += 8) {
+      const int chunk = j + 1 - k0 < 8 ? j + 1 - k0 : 8;
+#define FLOW_CALL(NV)                                                         \
+  hipLaunchKernelGGL(gmres_dots_kernel<NV>, dim3(gd), dim3(kBlock), 0, st, N,  \
+                     w, V + static_cast<size_t>(k0) * N,                      \
+                     static_cast<size_t>(N), k0 == 0 ? 1 : 0,                 \
+                     P + k0 * kRedBlocks, Pww, stop)
+      FLOW_NV_SWITCH(chunk, FLOW_CALL)
+#undef FLOW_CALL
+    }
+    const int nv = j + 2 + (j > 0 ? 1 : 0);
+    hipLaunchKernelGGL(gmres_finish_kernel, dim3(nv), dim3(kBlock), 0, st, gd,
+                       j + 1, P, C->buf);
+    FLOW_CHECK_LAUNCH();
+    if ((r = exchange(C, nv))) return r;
+    hipLaunchKernelGGL(gmres_step_kernel, dim3(1), dim3(kBlock), 0, st, 0, j,
+                       last ? 1 : 0, beta, target, C->buf, G, S);
+    FLOW_CHECK_LAUNCH();
+    if (!last &&
+        (r = gmres_combine_dev(N, j + 1, G + kGCoef, G + kGCw, w, V, w, Pnn, false,
+                               stop, st)))
+      return r;
+    return FLOW_OK;
+  };
+
   double host[kGmresMax + 2];
   double target = 0.0, resid = 0.0;
   int it = 0;
@@ -2781,16 +2826,18 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
       hipLaunchKernelGGL(axpby_kernel, dim3(gv), dim3(kBlock), 0, st, N, 1.0, bc,
                          0.0, V);
     } else {
-      if ((rc = apply_owned(xc, iwork))) return rc;
+      if ((rc = apply_owned(xc, iwork, nullptr))) return rc;
       hipLaunchKernelGGL(residual_kernel, dim3(gv), dim3(kBlock), 0, st, N, bc,
                          iwork, static_cast<const double*>(nullptr), V,
                          static_cast<double*>(nullptr));
     }
     // |b|^2 and |r0|^2 in one collective (lists 0 and 1 of P)
     hipLaunchKernelGGL(gmres_dots_kernel<1>, dim3(gd), dim3(kBlock), 0, st, N, bc,
-                       bc, static_cast<size_t>(N), 0, P, Pww);
+                       bc, static_cast<size_t>(N), 0, P, Pww,
+                       static_cast<const double*>(nullptr));
     hipLaunchKernelGGL(gmres_dots_kernel<1>, dim3(gd), dim3(kBlock), 0, st, N, V,
-                       V, static_cast<size_t>(N), 0, P + kRedBlocks, Pww);
+                       V, static_cast<size_t>(N), 0, P + kRedBlocks, Pww,
+                       static_cast<const double*>(nullptr));
     FLOW_CHECK_LAUNCH();
     if ((rc = sums_to_host(gd, 2, 0, host))) return rc;
     if (!have_target) {
@@ -2815,70 +2862,40 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
       return FLOW_NOT_CONVERGED;
     }
 
-    double H[kGmresMax][kGmresMax + 1] = {};
-    double nrm[kGmresMax + 1];
-    double eta[kGmresMax];
-    double y[kGmresMax], cf[kGmresMax];
-    nrm[0] = beta;
-    int j = 0;
+    // one cycle (as gmres(): the plan only depends on numbers every rank has)
+    const int it0 = it;
+    int enq = 0, cols = 0;
     bool converged = false;
-    while (j < m && it < maxit) {
-      double* w = V + static_cast<size_t>(j + 1) * N;
-      double* zj = Z + static_cast<size_t>(j) * N;
-      if ((rc = ilu_apply(ilu, V + static_cast<size_t>(j) * N, zj, iwork, st)))
-        return rc;
-      if ((rc = apply_owned(zj, w))) return rc;
-      for (int k0 = 0; k0 <= j; k0 += 8) {
-        const int chunk = j + 1 - k0 < 8 ? j + 1 - k0 : 8;
-#define FLOW_CALL(NV)                                                         \
-  hipLaunchKernelGGL(gmres_dots_kernel<NV>, dim3(gd), dim3(kBlock), 0, st, N,  \
-                     w, V + static_cast<size_t>(k0) * N,                      \
-                     static_cast<size_t>(N), k0 == 0 ? 1 : 0,                 \
-                     P + k0 * kRedBlocks, Pww)
-        FLOW_NV_SWITCH(chunk, FLOW_CALL)
-#undef FLOW_CALL
+    double state[kNumSlots];
+    while (true) {
+      const int room = (m < maxit - it0 ? m : maxit - it0) - enq;
+      if (room <= 0) break;
+      int plan = expected - (it0 + enq);
+      if (plan < 1) plan = 1;
+      if (plan > room) plan = room;
+      for (int k = 0; k < plan; ++k, ++enq) {
+        const bool last = enq + 1 >= m || it0 + enq + 1 >= maxit;
+        if ((rc = arnoldi(enq, beta, target, last))) return rc;
       }
-      FLOW_CHECK_LAUNCH();
-      const int nd = j + 1;
-      if ((rc = sums_to_host(gd, nd, 1 + (j > 0 ? 1 : 0), host))) return rc;
-      if (j > 0) {
-        nrm[j] = sqrt(host[nd + 1]);
-        H[j - 1][j] = eta[j - 1] * nrm[j];
-      }
-      const double ww = host[nd] / (nrm[j] * nrm[j]);
-      double sum = 0.0;
-      const bool bad = !(ww == ww) || !(nrm[j] > 0.0);
-      for (int k = 0; k <= j; ++k) {
-        H[j][k] = host[k] / (nrm[j] * nrm[k]);
-        sum += H[j][k] * H[j][k];
-      }
-      if (bad) {
-        *iters_host = it;
+      if ((rc = read_state(S, state, st))) return rc;
+      cols = static_cast<int>(state[kConvIt]);
+      if (state[kDone] == 2.0) {
+        *iters_host = it0 + cols;
         *resid_host = resid;
-        set_error("sharded GMRES broke down (NaN) at iteration %d", it);
+        set_error("sharded GMRES broke down (NaN) at iteration %d", it0 + cols);
         return FLOW_NOT_CONVERGED;
       }
-      const double e2 = ww - sum;
-      const bool lucky = !(e2 > 1.0e-28 * ww);
-      eta[j] = lucky ? 0.0 : sqrt(e2);
-      H[j][j + 1] = eta[j];
-      ++it;
-      ++j;
-      resid = gmres_least_squares(H, j, beta, y);
-      if (resid <= target || lucky) {
+      resid = state[kRes2];
+      if (state[kDone] != 0.0) {
         converged = true;
         break;
       }
-      if (j < m && it < maxit) {
-        const double inv = 1.0 / eta[j - 1];
-        for (int k = 0; k < j; ++k) cf[k] = -H[j - 1][k] * inv / nrm[k];
-        if ((rc = gmres_combine(N, j, cf, inv / nrm[j - 1], w, V, w, Pnn, false,
-                                st)))
-          return rc;
-      }
     }
-    for (int k = 0; k < j; ++k) cf[k] = y[k] / nrm[k];
-    if ((rc = gmres_combine(N, j, cf, 0.0, nullptr, Z, xc, nullptr, true, st)))
+    it = it0 + cols;
+    if ((rc = fill(1, 0.0, S + kDone, st))) return rc;
+    if (cols > 0 &&
+        (rc = gmres_combine_dev(N, cols, G + kGYc, nullptr, nullptr, Z, xc,
+                                nullptr, true, nullptr, st)))
       return rc;
     x_is_zero = 0;
     if (converged) break;
@@ -3025,12 +3042,13 @@ extern "C" int flow_shard_mgcg_solve(
 extern "C" int flow_shard_gmres_solve(
     const flow_comm* comm, const flow_rows* rows, const flow_operator* A,
     const flow_ilu* ilu, const double* b, double* x, double rtol, double atol,
-    int maxit, int restart, int x_is_zero, double* work, size_t work_len,
-    int* iters_host, double* resid_host, void* stream) {
+    int maxit, int restart, int x_is_zero, int expected_its, double* work,
+    size_t work_len, int* iters_host, double* resid_host, void* stream) {
   int rc = check_shard_solver(comm, rows, A, b, x, rtol, atol, maxit, work,
                               iters_host, resid_host);
   if (rc) return rc;
   FLOW_REQUIRE(A->kind == 3, "sharded GMRES: the matrix-free Jacobian action");
+  FLOW_REQUIRE(expected_its >= 0, "expected iterations");
   FLOW_REQUIRE(restart >= 1 && restart <= FLOW_GMRES_MAX_RESTART,
                "GMRES restart length");
   const flow_momentum_jvp* J = static_cast<const flow_momentum_jvp*>(A->matfree);
@@ -3044,8 +3062,10 @@ extern "C" int flow_shard_gmres_solve(
   if ((rc = check_comm(comm, need))) return rc;
   FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK +
                                (2 * static_cast<size_t>(restart) + 4) * 2 * mo +
-                               2 * static_cast<size_t>(me) + FLOW_GMRES_PARTIALS,
+                               2 * static_cast<size_t>(me) + FLOW_GMRES_PARTIALS +
+                               FLOW_GMRES_STATE,
                "sharded GMRES workspace too small");
   return shard_gmres(comm, rows, A, ilu, b, x, rtol, atol, maxit, restart,
-                     x_is_zero, work, iters_host, resid_host, as_stream(stream));
+                     x_is_zero, expected_its, work, iters_host, resid_host,
+                     as_stream(stream));
 }

@@ -563,9 +563,14 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
         lin_atol = max(npar['linear_atol_factor'] * tol, npar['forcing'] * nrm)
         lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
         ops.fill(dx, 0.0)
+        # (the count of the previous call's Newton iteration `it`: the same
+        # number on every rank -- they all ran the same solve)
+        expected = lay._dev.setdefault('gmres_expected_strip', {})
         sol = parallel.gmres(Jop, pre, F, dx, rtol=lin_rtol, atol=0.0,
                              maxit=npar['linear_maxit'],
-                             restart=npar['gmres_restart'], x_is_zero=True)
+                             restart=npar['gmres_restart'], x_is_zero=True,
+                             expected=expected.get(it, 0))
+        expected[it] = sol.iterations
         its = (sol.iterations + 1) // 2
         applications.append(sol.iterations)
         linear_its.append(its)

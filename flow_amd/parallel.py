@@ -587,7 +587,7 @@ def mgcg(A, dinv, mg, b, x, rtol, atol=0.0, maxit=1000, check_every=2,
 
 
 def gmres(Jop, ilu, b, x, rtol, atol=0.0, maxit=1000, restart=20,
-          x_is_zero=True):
+          x_is_zero=True, expected=0):
     '''GMRES + block-Jacobi ILU(0) on the strips; Jop: a MomentumJacobian built
     on the rank's views (kind 3).  b, x: global-length velocity fields (owned
     rows).'''
@@ -598,7 +598,7 @@ def gmres(Jop, ilu, b, x, rtol, atol=0.0, maxit=1000, restart=20,
     c.ensure(max(2 * v.rows.nhalo, _hip.GMRES_MAX_RESTART + 2))
     mo, me = v.r1 - v.r0, v.e1 - v.e0
     wlen = _hip.REDUCE_WORK + (2 * restart + 4) * 2 * mo + 2 * me \
-        + _hip.GMRES_PARTIALS
+        + _hip.GMRES_PARTIALS + _hip.GMRES_STATE
     wk = ops.work(wlen)
     its = ctypes.c_int(0)
     res = ctypes.c_double(0.0)
@@ -607,8 +607,9 @@ def gmres(Jop, ilu, b, x, rtol, atol=0.0, maxit=1000, restart=20,
         ctypes.byref(c.struct), ctypes.byref(v.rows),
         ctypes.byref(Jop.operator()), ctypes.byref(ilu.struct),
         _hip.f64(b, n2, 'b'), _hip.f64(x, n2, 'x'), float(rtol), float(atol),
-        int(maxit), int(restart), int(bool(x_is_zero)), _hip.f64(wk),
-        wk.numel(), ctypes.byref(its), ctypes.byref(res), _hip.stream()))
+        int(maxit), int(restart), int(bool(x_is_zero)), int(expected),
+        _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
+        _hip.stream()))
     return _solve_info(its.value, res.value, 'gmres+ilu0(block)')
 
 

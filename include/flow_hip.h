@@ -432,15 +432,18 @@ int flow_shard_mgcg_solve(const flow_comm* comm, const flow_rows* rows,
  * factors the rank's own diagonal block (plan over the owned rows in local
  * numbering), no communication.  The Krylov vectors hold the owned rows only
  * (2 * (r1 - r0) doubles); per iteration one halo collective (the operator's
- * input) and one for the dot products.  b, x: global-length fields (owned
- * rows).  work: FLOW_REDUCE_WORK + (2*restart + 4) * 2*(r1-r0)
- * + 2*(e1-e0) + FLOW_GMRES_PARTIALS doubles. */
+ * input) and one for the dot products, whose sums the device-side step of
+ * flow_gmres_solve takes straight from the exchange buffer: no read-back per
+ * iteration here either (expected_its as there; every rank must pass the same
+ * value -- it decides how many collectives are enqueued).  b, x: global-length
+ * fields (owned rows).  work: FLOW_REDUCE_WORK + (2*restart + 4) * 2*(r1-r0)
+ * + 2*(e1-e0) + FLOW_GMRES_PARTIALS + FLOW_GMRES_STATE doubles. */
 int flow_shard_gmres_solve(const flow_comm* comm, const flow_rows* rows,
                            const flow_operator* A, const flow_ilu* ilu,
                            const double* b, double* x, double rtol, double atol,
-                           int maxit, int restart, int x_is_zero, double* work,
-                           size_t work_len, int* iters_host, double* resid_host,
-                           void* stream);
+                           int maxit, int restart, int x_is_zero,
+                           int expected_its, double* work, size_t work_len,
+                           int* iters_host, double* resid_host, void* stream);
 
 /* ---- assembly ------------------------------------------------------------
  * Two-phase, atomic-free: a cell kernel writes local tensors to `scratch`
