@@ -243,11 +243,14 @@ def main():
                          'recorded in config')
     ap.add_argument('--dt0', type=float, default=1.0e-5,
                     help='initial step size (reference driver: 1e-5)')
-    ap.add_argument('--initial', default='stokes',
+    ap.add_argument('--initial', default=None,
                     choices=['profile', 'stokes'],
                     help="initial state: 'stokes' = flow_amd.stokes.solve as "
                          "the reference driver (tests/test_karman_vortex_street"
-                         ".py:171-179); 'profile' = the inflow profile")
+                         ".py:171-179; default for the Taylor-Hood pair); "
+                         "'profile' = the inflow profile (default for P1-P1: "
+                         "the pair is not inf-sup stable, the Stokes system "
+                         "has no unique pressure to converge to)")
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="torch.distributed backend for N > 1: 'nccl' (= RCCL, "
                          "one GPU per rank); 'gloo' only to rehearse several "
@@ -260,6 +263,8 @@ def main():
     ap.add_argument('--spmv-reps', type=int, default=100)
     args = ap.parse_args()
 
+    if args.initial is None:
+        args.initial = 'stokes' if args.velocity_degree == 2 else 'profile'
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world != args.gpus:
