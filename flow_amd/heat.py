@@ -48,11 +48,9 @@ def _data(v):
 
 
 class Heat(object):
-    '''
-    Provides methods for computing
-
-        u' = F(t, u).
-    '''
+    '''The semi-discrete heat equation  M u' = A u + b  behind the two calls an
+    implicit ODE stepper makes: evaluate and solve  alpha M u + beta F(u, t),
+    F(u, t) = A u + b  (interface of the reference's flow/heat.py:12-122).'''
     def __init__(
             self, V, conv, kappa, rho, cp, bcs, source,
             supg_stabilization=False
@@ -126,10 +124,9 @@ class Heat(object):
                 ops.axpby(-1.0, bs, 1.0, self.b.data)
         return
 
-    # pylint: disable=unused-argument
     def eval_alpha_M_beta_F(self, alpha, beta, u, t):
-        '''Evaluate  alpha * M * u + beta * F(u, t).
-        '''
+        '''alpha M u + beta (A u + b) as a Vector; `t` is not used: the
+        operators do not depend on time (reference :92-101).'''
         uvec = _data(u)
         alpha = float(alpha)
         beta = float(beta)
@@ -143,8 +140,9 @@ class Heat(object):
         return Vector(out)
 
     def solve_alpha_M_beta_F(self, alpha, beta, b, t):
-        '''Solve  alpha * M * u + beta * F(u, t) = b  for u.
-        '''
+        '''u with  alpha M u + beta (A u + b) = b_in  under the boundary
+        conditions (reference :103-122; see the module docstring for the
+        solver that stands in for its sparse LU).'''
         lib = _hip.lib()
         lay = self.V.layout
         st = _hip.stream()
