@@ -1670,32 +1670,38 @@ __global__ __launch_bounds__(kBlock) void gmres_step_kernel(
   const int nval = nd + 1 + (j > 0 ? 1 : 0);
   const int lane = threadIdx.x & 63;
   // the value lists, a wavefront each (per-lane loads, four in flight)
-  if (nparts == 0 && threadIdx.x < nval) val[threadIdx.x] = partial[threadIdx.x];
+  // (everything an earlier launch wrote at these same addresses is read with
+  // load_scalar, common.h; the loads of a lane are independent: all in flight)
+  if (nparts == 0 && threadIdx.x < nval)
+    val[threadIdx.x] = load_scalar(partial + threadIdx.x);
   for (int v = threadIdx.x >> 6; nparts > 0 && v < nval; v += kBlock / 64) {
     const int list = v < nd ? v : kGmresMax + (v - nd);
     const double* __restrict__ p = partial + list * kRedBlocks;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int i = lane;
     for (; i + 192 < nparts; i += 256) {
-      s0 += p[i];
-      s1 += p[i + 64];
-      s2 += p[i + 128];
-      s3 += p[i + 192];
+      const double a0 = load_scalar(p + i), a1 = load_scalar(p + i + 64);
+      const double a2 = load_scalar(p + i + 128), a3 = load_scalar(p + i + 192);
+      s0 += a0;
+      s1 += a1;
+      s2 += a2;
+      s3 += a3;
     }
-    for (; i < nparts; i += 64) s0 += p[i];
+    for (; i < nparts; i += 64) s0 += load_scalar(p + i);
     double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) val[v] = s;
   }
   // the state earlier steps of the cycle left (per-lane loads as well)
-  for (int i = threadIdx.x; i < j * ld; i += kBlock) Hs[i] = G[kGH + i];
+  for (int i = threadIdx.x; i < j * ld; i += kBlock)
+    Hs[i] = load_scalar(G + kGH + i);
   if (threadIdx.x < j) {
-    nrm[threadIdx.x] = G[kGNrm + threadIdx.x];
-    eta[threadIdx.x] = G[kGEta + threadIdx.x];
-    cs[threadIdx.x] = G[kGRot + 2 * threadIdx.x];
-    sn[threadIdx.x] = G[kGRot + 2 * threadIdx.x + 1];
-    g[threadIdx.x] = G[kGRhs + threadIdx.x];
+    nrm[threadIdx.x] = load_scalar(G + kGNrm + threadIdx.x);
+    eta[threadIdx.x] = load_scalar(G + kGEta + threadIdx.x);
+    cs[threadIdx.x] = load_scalar(G + kGRot + 2 * threadIdx.x);
+    sn[threadIdx.x] = load_scalar(G + kGRot + 2 * threadIdx.x + 1);
+    g[threadIdx.x] = load_scalar(G + kGRhs + threadIdx.x);
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
