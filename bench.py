@@ -468,7 +468,7 @@ def main():
             'mode': args.mode,
             'mode_note': "headline = mode '%s'%s" % (
                 args.mode,
-                " (Newton from u0, linear residual <= 1e-5 of the Newton "
+                " (Newton from u0, linear residual <= 1e-6 of the Newton "
                 "tolerance: the reference's path; one step matches an exact "
                 "Newton step to < 1e-6 in u and p, "
                 "tests/test_full_size_parity.py)" if args.mode == 'parity'

@@ -35,13 +35,16 @@ Two modes (`set_mode`, `solver_parameters['mode']`):
 
   'parity' (default)  follows the reference's Newton path: start from u0
       (:220), every Newton step an (almost) exact one -- linear residual below
-      1e-5 of the Newton tolerance --, stop at the first iterate with
+      1e-6 of the Newton tolerance --, stop at the first iterate with
       ||F||_2 < 1e-10 (:230-236).  The tolerance 1e-10 is loose at 10 M DoF
       (||F|| = 1e-10 is a relative 3e-4 in the velocity there), so the iterate
       the reference stops at is a specific point, and only this path reproduces
       it: measured on the 10 M-DoF workload (tools/parity_single_step.py,
       tests/test_full_size_parity.py) the step agrees with one whose linear
-      systems are solved 1e4 times tighter to < 1e-7 relative l2 in u and p.
+      systems are solved 1e3 times tighter to < 1e-7 relative l2 in u and p
+      -- in the start-up steps, at CFL-sized steps and from the Stokes start
+      at dt = 0.024 (the bench's window: the pressure is the sensitive field
+      there, 7e-7 with the factor 1e-5, hence 1e-6).
       Nothing is carried from one call to the next except preconditioners.
   'fast'  the Newton iteration may start from the previous step's tentative
       velocity (or its extrapolation) when that leaves the smaller residual,
@@ -87,7 +90,7 @@ solver_parameters = {
     # sweeps over the basis -- 2(j+1) vectors of 69 MB in iteration j -- halve.
     'newton': {'maximum_iterations': 10, 'linear_maxit': 5000,
                'linear_solver': 'gmres', 'gmres_restart': 10,
-               'linear_rtol': 1.0e-13, 'linear_atol_factor': 1.0e-5,
+               'linear_rtol': 1.0e-13, 'linear_atol_factor': 1.0e-6,
                'forcing': 0.0, 'check_every': 1, 'restart': 400,
                'preconditioner': 'ilu0', 'ilu_lag': 8.0,
                # the sweeps read the factors rounded to fp32 (fp64 arithmetic):
@@ -112,7 +115,7 @@ solver_parameters = {
 
 _MODES = {
     'parity': {
-        'newton': {'initial_guess': 'previous', 'linear_atol_factor': 1.0e-5,
+        'newton': {'initial_guess': 'previous', 'linear_atol_factor': 1.0e-6,
                    'forcing': 0.0, 'adaptive_forcing': False},
         'pressure': {'extrapolate': False},
         'correction': {'extrapolate': False},

@@ -100,6 +100,36 @@ def test_default_step_matches_exact_newton_step(problem, warm):
     prob.dt, prob.t = state[2], state[3]
 
 
+def test_step_of_the_bench_window_matches_exact_newton_step(problem):
+    '''The regime the headline number is measured in: the flow started from
+    the Stokes solution (tests/test_karman_vortex_street.py:171-179 of the
+    reference) with the step size at its CFL plateau (dt ~ 0.024): one Newton
+    iteration of 17-18 GMRES applications per step.  Same comparison as
+    above.'''
+    import flow_amd.navier_stokes as navsto
+    prob = problem
+    prob.reset(1.0e-5)
+    prob.set_initial_stokes()
+    for _ in range(20):
+        prob.step()
+    assert prob.dt > 1.0e-2
+    state = (prob.u0.vector().get_local().copy(),
+             prob.p0.vector().get_local().copy(), prob.dt, prob.t)
+    u_y, p_y, info_y = _one_step(prob, state, 1.0e-13,
+                                 linear_atol_factor=1.0e-9)
+    assert navsto.solver_parameters['mode'] == 'parity'
+    u_d, p_d, info_d = _one_step(prob, state, 1.0e-10)
+    res_y, res_d = info_y['newton_residuals'], info_d['newton_residuals']
+    assert len(res_d) >= 2 and len(res_d) == len(res_y), (res_d, res_y)
+    assert res_d[-1] < 1.0e-10 <= res_d[-2]
+    du, dp = _rel(u_d, u_y), _rel(p_d, p_y)
+    print('Stokes start, dt %.2e: default vs exact Newton step: du %.2e dp %.2e'
+          ' (GMRES applications %r vs %r)'
+          % (state[2], du, dp, info_d['newton_linear_applications'],
+             info_y['newton_linear_applications']))
+    assert du < 0.3 * NORTH_STAR and dp < 0.3 * NORTH_STAR, (du, dp)
+
+
 def test_repeated_solves_do_not_drift(problem):
     '''The linear solvers decide convergence on the device and freeze the
     solution there: a solve asked for more iterations than it needs (the
