@@ -100,6 +100,7 @@ class IluS(ctypes.Structure):
         ('nblocks', ctypes.c_int),
         ('lu', ctypes.c_void_p),
         ('packed', ctypes.c_void_p),
+        ('single_vector', ctypes.c_int),
         ]
 
 

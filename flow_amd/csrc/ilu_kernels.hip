@@ -21,6 +21,7 @@
 // HBM-bound: 12 B per factor entry, block and application (packed streams,
 // below: 12 B for two blocks).
 #include "common.h"
+#include <type_traits>
 
 namespace flow {
 
@@ -298,18 +299,45 @@ __global__ __launch_bounds__(kBlock) void ilu_sweep_kernel(
 // factors -- a fixed linear operator, as good a preconditioner as the unrounded
 // one (ILU(0) itself is off by far more than 6e-8), and the Krylov method
 // around it converges to the same tolerance.
+// F32 (flow_ilu.single_vector): the sweep vector is kept in fp32 as well -- 8
+// instead of 16 B per gather, 20 instead of 28 B per factor entry all told; the
+// row sums still accumulate in fp64, every finished row is rounded once.  The
+// application is then no longer exactly linear in its input (rounding), which
+// only a FLEXIBLE Krylov method may use: the GMRES of la_kernels.hip is one --
+// it keeps Z_j = M^-1 V_j, multiplies THAT by A and updates x with it, so the
+// Arnoldi relation A Z = V H holds whatever produced Z_j.
 template <int NB>
 struct PackT;
 template <>
 struct PackT<1> {
   using val = float;
   using vec = double;
+  using vec32 = float;
 };
 template <>
 struct PackT<2> {
   using val = float2;
   using vec = double2;
+  using vec32 = float2;
 };
+template <int NB, bool F32>
+struct SweepVec {
+  using type = typename PackT<NB>::vec;
+};
+template <int NB>
+struct SweepVec<NB, true> {
+  using type = typename PackT<NB>::vec32;
+};
+__device__ __forceinline__ double widen(double v) { return v; }
+__device__ __forceinline__ double widen(float v) { return v; }
+__device__ __forceinline__ double2 widen(double2 v) { return v; }
+__device__ __forceinline__ double2 widen(float2 v) { return make_double2(v.x, v.y); }
+__device__ __forceinline__ void narrow(double& o, double v) { o = v; }
+__device__ __forceinline__ void narrow(float& o, double v) { o = static_cast<float>(v); }
+__device__ __forceinline__ void narrow(double2& o, double2 v) { o = v; }
+__device__ __forceinline__ void narrow(float2& o, double2 v) {
+  o = make_float2(static_cast<float>(v.x), static_cast<float>(v.y));
+}
 __device__ __forceinline__ void fma_pack(double& s, float v, double y) { s += v * y; }
 __device__ __forceinline__ void fma_pack(double2& s, float2 v, double2 y) {
   s.x += v.x * y.x;
@@ -332,23 +360,24 @@ __global__ void ilu_pack_kernel(int count, size_t lu_size,
   }
 }
 
-template <int NB>
+template <int NB, typename T>
 __global__ void ilu_permute_packed_kernel(int n, const int* __restrict__ new_of_old,
                                           const double* __restrict__ r,
-                                          double* __restrict__ y,
+                                          T* __restrict__ y,
                                           const double* __restrict__ stop) {
   if (stopped(stop)) return;
   for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n;
        o += gridDim.x * blockDim.x) {
     const size_t i = new_of_old[o];
 #pragma unroll
-    for (int m = 0; m < NB; ++m) y[i * NB + m] = r[static_cast<size_t>(m) * n + o];
+    for (int m = 0; m < NB; ++m)
+      y[i * NB + m] = static_cast<T>(r[static_cast<size_t>(m) * n + o]);
   }
 }
 
-template <int NB>
+template <int NB, typename T>
 __global__ void ilu_unpermute_packed_kernel(int n, const int* __restrict__ new_of_old,
-                                            const double* __restrict__ y,
+                                            const T* __restrict__ y,
                                             double* __restrict__ z,
                                             const double* __restrict__ stop) {
   if (stopped(stop)) return;
@@ -361,15 +390,16 @@ __global__ void ilu_unpermute_packed_kernel(int n, const int* __restrict__ new_o
 }
 
 // as ilu_sweep_kernel, all NB blocks in one lane
-template <bool BWD, int NB>
+template <bool BWD, int NB, bool F32>
 __global__ __launch_bounds__(kBlock) void ilu_sweep_packed_kernel(
     size_t lu_size, int nslices, int row_end, const int* __restrict__ slice_off,
     const int* __restrict__ slice_row, const int* __restrict__ cols,
     const typename PackT<NB>::val* __restrict__ vals,
-    const double* __restrict__ dinv, typename PackT<NB>::vec* __restrict__ y,
+    const double* __restrict__ dinv,
+    typename SweepVec<NB, F32>::type* __restrict__ y,
     const double* __restrict__ stop) {
   using V = typename PackT<NB>::val;
-  using Y = typename PackT<NB>::vec;
+  using Y = typename PackT<NB>::vec;            // arithmetic: fp64
   const double halt = stop ? load_scalar(stop) : 0.0;   // (see ilu_sweep_kernel)
   const int sl = xcd_tile(blockIdx.x, gridDim.x) * (kBlock / kSlice) +
                  (threadIdx.x >> 6);
@@ -384,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void ilu_sweep_packed_kernel(
 #pragma unroll
   for (int m = 0; m < NB; ++m) di[m] = 1.0;
   if (live) {
-    rhs = y[row];
+    rhs = widen(y[row]);
     if (BWD) {
 #pragma unroll
       for (int m = 0; m < NB; ++m) di[m] = dinv[m * lu_size + row];
@@ -410,15 +440,15 @@ __global__ __launch_bounds__(kBlock) void ilu_sweep_packed_kernel(
     }
 #pragma unroll
     for (int j = 0; j < kBatch; ++j)
-      yy[j] = (k0 + j < width) ? y[cc[j]] : zero_of(Y());
+      yy[j] = (k0 + j < width) ? widen(y[cc[j]]) : zero_of(Y());
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) fma_pack(s, vv[j], yy[j]);
   }
   if (live && halt == 0.0) {
     if constexpr (NB == 1) {
-      y[row] = (rhs - s) * di[0];
+      narrow(y[row], (rhs - s) * di[0]);
     } else {
-      y[row] = make_double2((rhs.x - s.x) * di[0], (rhs.y - s.y) * di[1]);
+      narrow(y[row], make_double2((rhs.x - s.x) * di[0], (rhs.y - s.y) * di[1]));
     }
   }
 }
@@ -493,24 +523,26 @@ static int factor(const flow_ilu_plan* P, int nblocks, const double* avals0,
   return FLOW_OK;
 }
 
-template <int NB>
+template <int NB, bool F32>
 static int apply_packed(const flow_ilu* ilu, const double* in, double* out,
                         double* work, hipStream_t st, const double* stop) {
   using V = typename PackT<NB>::val;
-  using Y = typename PackT<NB>::vec;
+  using Y = typename SweepVec<NB, F32>::type;
+  using T = std::conditional_t<F32, float, double>;
   const flow_ilu_plan* P = ilu->plan;
   const size_t lus = static_cast<size_t>(P->lu_size);
   constexpr int per_block = kBlock / kSlice;
   const V* lvals = reinterpret_cast<const V*>(ilu->packed);
   const V* uvals = lvals + P->nnz_l;
   Y* y = reinterpret_cast<Y*>(work);
-  hipLaunchKernelGGL((ilu_permute_packed_kernel<NB>), dim3(grid_for(P->n)),
-                     dim3(kBlock), 0, st, P->n, P->new_of_old, in, work, stop);
+  hipLaunchKernelGGL((ilu_permute_packed_kernel<NB, T>), dim3(grid_for(P->n)),
+                     dim3(kBlock), 0, st, P->n, P->new_of_old, in,
+                     reinterpret_cast<T*>(work), stop);
   for (int c = 1; c < P->ncolors; ++c) {   // colour 0: y = r already
     const int s0 = P->slice_ptr_host[c];
     const int ns = P->slice_ptr_host[c + 1] - s0;
     if (ns <= 0) continue;
-    hipLaunchKernelGGL((ilu_sweep_packed_kernel<false, NB>),
+    hipLaunchKernelGGL((ilu_sweep_packed_kernel<false, NB, F32>),
                        dim3((ns + per_block - 1) / per_block), dim3(kBlock), 0,
                        st, lus, ns, P->color_ptr_host[c + 1], P->l_slice_off + s0,
                        P->slice_row + s0, P->l_cols, lvals,
@@ -520,14 +552,15 @@ static int apply_packed(const flow_ilu* ilu, const double* in, double* out,
     const int s0 = P->slice_ptr_host[c];
     const int ns = P->slice_ptr_host[c + 1] - s0;
     if (ns <= 0) continue;
-    hipLaunchKernelGGL((ilu_sweep_packed_kernel<true, NB>),
+    hipLaunchKernelGGL((ilu_sweep_packed_kernel<true, NB, F32>),
                        dim3((ns + per_block - 1) / per_block), dim3(kBlock), 0,
                        st, lus, ns, P->color_ptr_host[c + 1], P->u_slice_off + s0,
                        P->slice_row + s0, P->u_cols, uvals, ilu->lu + P->off_d, y,
                        stop);
   }
-  hipLaunchKernelGGL((ilu_unpermute_packed_kernel<NB>), dim3(grid_for(P->n)),
-                     dim3(kBlock), 0, st, P->n, P->new_of_old, work, out, stop);
+  hipLaunchKernelGGL((ilu_unpermute_packed_kernel<NB, T>), dim3(grid_for(P->n)),
+                     dim3(kBlock), 0, st, P->n, P->new_of_old,
+                     reinterpret_cast<const T*>(work), out, stop);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -539,8 +572,14 @@ int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
   const size_t lus = static_cast<size_t>(P->lu_size);
   constexpr int per_block = kBlock / kSlice;
   if (ilu->packed) {
-    if (ilu->nblocks == 1) return apply_packed<1>(ilu, in, out, work, st, stop);
-    return apply_packed<2>(ilu, in, out, work, st, stop);
+    if (ilu->single_vector) {
+      if (ilu->nblocks == 1)
+        return apply_packed<1, true>(ilu, in, out, work, st, stop);
+      return apply_packed<2, true>(ilu, in, out, work, st, stop);
+    }
+    if (ilu->nblocks == 1)
+      return apply_packed<1, false>(ilu, in, out, work, st, stop);
+    return apply_packed<2, false>(ilu, in, out, work, st, stop);
   }
   hipLaunchKernelGGL(ilu_permute_kernel, dim3(grid_for(P->n)), dim3(kBlock), 0,
                      st, P->n, ilu->nblocks, P->new_of_old, in, work, stop);
@@ -581,6 +620,8 @@ int ilu_check(const flow_ilu* ilu, int op_size) {
   FLOW_REQUIRE((reinterpret_cast<size_t>(ilu->lu) & 15) == 0, "lu alignment");
   FLOW_REQUIRE((reinterpret_cast<size_t>(ilu->packed) & 15) == 0,
                "packed alignment");
+  FLOW_REQUIRE(!ilu->single_vector || ilu->packed != nullptr,
+               "single_vector needs the packed streams");
   return FLOW_OK;
 }
 

@@ -1311,7 +1311,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 18; }
+extern "C" int flow_abi_version(void) { return 19; }
 
 // the workgroup -> tile mapping of the CSR-stream kernels, for host-side tests
 extern "C" int flow_xcd_tile_host(int block, int nblocks) {
@@ -1652,7 +1652,8 @@ static_assert(kGState <= FLOW_GMRES_STATE, "gmres device state");
 // column j with the rotations kept from before; the triangular solve for y
 // only runs behind the step that ends the cycle (`last`) or the solve.
 //   S[kConvIt] = columns of this cycle that are final, S[kRes2] = the residual
-//   estimate, S[kDone] = 1 converged (or invariant subspace) / 2 not a number
+//   estimate, S[kDone] = 1 converged / 2 not a number / 3 the cycle has to end
+//   without a verdict (see below)
 __global__ __launch_bounds__(kBlock) void gmres_step_kernel(
     int nparts, int j, int last, double beta, double target,
     const double* __restrict__ partial, double* __restrict__ G,
@@ -1749,12 +1750,20 @@ __global__ __launch_bounds__(kBlock) void gmres_step_kernel(
     return;
   }
   const double e2 = ww - sum;
-  // (nearly) invariant subspace: the least-squares residual is then zero
-  const bool lucky = !(e2 > 1.0e-28 * ww);
-  const double et = lucky ? 0.0 : sqrt(e2);
+  // h_{j+1,j}^2 = |w|^2 - sum h^2 (Pythagoras: one pass over the basis instead
+  // of two) cancels when w lies in the span of the basis to more than ~6
+  // digits -- an invariant subspace, or simply a preconditioner that is nearly
+  // exact (tiny time steps: A M^-1 ~ I, the first w is parallel to V_0 to 8
+  // digits).  What is left of e2 is then rounding noise and so is the residual
+  // estimate built on it: the cycle ends here, WITHOUT a verdict -- the host
+  // applies the update, computes the true residual and either stops there or
+  // starts the next cycle from it.  (Round 1 took e2 <= 0 for convergence: a
+  // solve could return after one iteration with a true residual of 6e-9 |b|.)
+  const bool lucky = !(e2 > 1.0e-12 * ww);
+  const double et = e2 > 0.0 ? sqrt(e2) : 0.0;
   G[kGEta + j] = et;
   // the coefficients of V_{j+1} = (w / nrm_j - sum_k H[j][k] V_k / nrm_k) / eta_j
-  // (unused when the step ends the solve)
+  // (unused when the step ends the cycle)
   if (!lucky) {
     const double inv = 1.0 / et;
     for (int k = 0; k <= j; ++k)
@@ -1778,8 +1787,8 @@ __global__ __launch_bounds__(kBlock) void gmres_step_kernel(
   const double resid = fabs(snj * g[j]);
   store_scalar(S + kRes2, resid);
   store_scalar(S + kConvIt, static_cast<double>(j + 1));
-  const bool done = resid <= target || lucky;
-  if (done || last) {
+  const bool done = resid <= target && !lucky;
+  if (done || lucky || last) {
     // y from the triangular system R y = g over the j+1 columns
     const int nc = j + 1;
     col[j] = dj;
@@ -1793,6 +1802,7 @@ __global__ __launch_bounds__(kBlock) void gmres_step_kernel(
     // (read by the update kernel with load_scalar: wave-uniform there)
     for (int k = 0; k < nc; ++k) store_scalar(G + kGYc + k, y[k] / nrm[k]);
     if (done) store_scalar(S + kDone, 1.0);
+    if (lucky) store_scalar(S + kDone, 3.0);     // end of cycle, no verdict
   }
 }
 
@@ -2027,7 +2037,7 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
       }
       resid = state[kRes2];
       if (state[kDone] != 0.0) {
-        converged = true;
+        converged = state[kDone] == 1.0;   // 3: verify with the true residual
         break;
       }
     }
@@ -2893,7 +2903,7 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
       }
       resid = state[kRes2];
       if (state[kDone] != 0.0) {
-        converged = true;
+        converged = state[kDone] == 1.0;   // 3: verify with the true residual
         break;
       }
     }

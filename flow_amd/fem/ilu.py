@@ -206,9 +206,11 @@ class Ilu0(object):
     the couplings between the velocity components are left to the Krylov
     method.  `refactor(A)` re-uses the buffers.  `packed`: the sweeps read the
     factors rounded to fp32, the blocks interleaved (half the bytes per
-    application, fp64 arithmetic; include/flow_hip.h: flow_ilu.packed).'''
+    application, fp64 arithmetic; include/flow_hip.h: flow_ilu.packed);
+    `single_vector` (with packed): the sweep vector in fp32 too -- for the
+    flexible GMRES only (flow_ilu.single_vector).'''
 
-    def __init__(self, A, plan=None, packed=False):
+    def __init__(self, A, plan=None, packed=False, single_vector=False):
         import torch
         self.plan = plan if plan is not None else plan_for(A.layout)
         self.planes = {0: [0], 1: [0, 1], 2: [0, 3]}[A.kind]
@@ -217,6 +219,7 @@ class Ilu0(object):
         self.struct = _hip.IluS(
             ctypes.pointer(self.plan.struct), nb,
             _hip.f64(self.lu, nb * self.plan.lu_size), None,
+            int(bool(single_vector and packed)),
             )
         self.packed = None
         if packed:
@@ -236,12 +239,14 @@ class Ilu0(object):
             _hip.f64(self.lu, nb * self.plan.lu_size), _hip.stream()
             ))
         if self.packed is not None:
-            self.struct.packed = None
+            single = self.struct.single_vector
+            self.struct.packed, self.struct.single_vector = None, 0
             _hip.check(lib.flow_ilu0_pack(
                 ctypes.byref(self.struct), self.packed.data_ptr(),
                 _hip.stream()
                 ))
             self.struct.packed = self.packed.data_ptr()
+            self.struct.single_vector = single
         return self
 
     def factor_values(self, k=0):

@@ -96,6 +96,11 @@ solver_parameters = {
                # the sweeps read the factors rounded to fp32 (fp64 arithmetic):
                # half the bytes per application, same iteration counts
                'ilu_storage': 'fp32',
+               # ... and keep their vector in fp32 as well (fp64 row sums):
+               # the GMRES here is flexible (it stores M^-1 V_j and updates x
+               # with it), the Arnoldi relation does not care how exactly the
+               # preconditioner was applied
+               'ilu_vector': 'fp32',
                'adaptive_forcing': False, 'matrix_free': True,
                # 'previous' = always u0, the reference's choice (:204-220);
                # 'best' (mode 'fast'): see _compute_tentative_velocity
@@ -398,7 +403,8 @@ def _compute_tentative_velocity(
                     assemble_jacobian()
                 if pre is None:
                     pre = ilu.Ilu0(
-                        J, packed=npar.get('ilu_storage', 'fp32') == 'fp32')
+                        J, packed=npar.get('ilu_storage', 'fp32') == 'fp32',
+                        single_vector=npar.get('ilu_vector') == 'fp32')
                     lay._dev['jacobian_ilu'] = pre
                 else:
                     pre.refactor(J)
@@ -554,7 +560,8 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
                 ))
             if pre is None:
                 pre = parallel.local_ilu(
-                    J, packed=npar.get('ilu_storage', 'fp32') == 'fp32')
+                    J, packed=npar.get('ilu_storage', 'fp32') == 'fp32',
+                    single_vector=npar.get('ilu_vector') == 'fp32')
                 lay._dev['jacobian_ilu_strip'] = pre
             else:
                 pre.refactor(J)

@@ -613,7 +613,7 @@ def gmres(Jop, ilu, b, x, rtol, atol=0.0, maxit=1000, restart=20,
     return _solve_info(its.value, res.value, 'gmres+ilu0(block)')
 
 
-def local_ilu(J, packed=False):
+def local_ilu(J, packed=False, single_vector=False):
     '''ILU(0) of the calling rank's diagonal block of the (block-diagonal part
     of the) Jacobian J: plan over the owned rows in local numbering.'''
     from .fem import ilu
@@ -623,4 +623,5 @@ def local_ilu(J, packed=False):
     if key not in lay._dev:
         v = view(lay)
         lay._dev[key] = ilu.IluPlan(lay, rows=(v.r0, v.r1))
-    return ilu.Ilu0(J, plan=lay._dev[key], packed=packed)
+    return ilu.Ilu0(J, plan=lay._dev[key], packed=packed,
+                    single_vector=single_vector)

@@ -228,6 +228,12 @@ typedef struct {
                                 fp32, blocks interleaved -- half the bytes per
                                 application (fp64 arithmetic throughout; a
                                 preconditioner only) */
+  int single_vector;         /* with packed: the sweep vector is kept in fp32 as
+                                well (8 instead of 16 B per gather; the row
+                                sums accumulate in fp64).  The application is
+                                then not exactly linear: for FLEXIBLE Krylov
+                                methods only -- flow_gmres_solve is one (it
+                                keeps Z_j = M^-1 V_j and updates x with it) */
 } flow_ilu;
 /* HOST routine (setup, no GPU needed): first-fit greedy colouring of the graph
  * of a CSR pattern in row order; colour: n ints out, *ncolors <= 63 */

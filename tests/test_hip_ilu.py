@@ -145,6 +145,14 @@ def test_packed_sweeps_apply_the_rounded_factors(hip, kind):
         assert abs(zb - zref).max() < 1e-11 * abs(zref).max()
         d = abs(zb - z64[b * n:(b + 1) * n]).max() / abs(zref).max()
         assert 0.0 < d < 1e-5
+    # flow_ilu.single_vector: the sweep vector in fp32 too (fp64 row sums) --
+    # the same preconditioner to fp32 accuracy, for the flexible GMRES
+    single = ilu.Ilu0(A, packed=True, single_vector=True)
+    zs = device.zeros(nb * n)
+    single.solve(device.to_device(r), zs)
+    zs = device.to_host(zs).numpy()
+    d = abs(zs - z32).max() / abs(z32).max()
+    assert 0.0 < d < 2e-5, d
 
 
 @pytest.mark.gpu

@@ -283,6 +283,33 @@ def test_bicgstab_matches_direct_solve(hip):
                          rtol=1e-13, maxit=3, restart=30, x_is_zero=True)
 
 
+def test_gmres_does_not_take_cancellation_for_convergence(hip):
+    '''A nearly exact preconditioner (here: an operator within 1e-9 of the
+    identity, as the Newton systems are at tiny time steps) makes the first
+    Krylov vector parallel to the residual to 9 digits: the one-pass
+    Gram-Schmidt estimate of h_{1,0} is then rounding noise.  The solver must
+    not read that as an invariant subspace and stop (round 1 did: one
+    iteration, true residual 1e-9 |b| for a requested 1e-13) but verify with
+    the true residual and go on.'''
+    rng = numpy.random.RandomState(9)
+    mesh = fem.UnitSquareMesh(12, 12, 'crossed')
+    V = fem.FunctionSpace(mesh, 'CG', 2)
+    lay = V.layout
+    K = ops.assemble_stiffness(V)
+    vals = 1.0e-9 * K.vals / float(K.vals.abs().max())
+    vals[lay.dev('diag_idx').long()] += 1.0
+    A = ops.Matrix(lay, 0, vals.contiguous())
+    b = rng.standard_normal(V.N)
+    x = _dev(numpy.zeros(V.N))
+    info = ops.krylov_solve('gmres', A, _dev(b), x, rtol=1e-13, maxit=100,
+                            restart=10, dinv=None, x_is_zero=True)
+    t = _dev(numpy.zeros(V.N))
+    A.apply(x, t)
+    true = float((t - _dev(b)).norm())
+    assert true <= 2e-13 * numpy.linalg.norm(b), (info, true)
+    assert info.iterations >= 2
+
+
 @pytest.mark.parametrize('vdeg', [1, 2])
 @pytest.mark.parametrize('method', ['backward euler', 'crank-nicolson',
                                     'forward euler'])
