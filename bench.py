@@ -483,6 +483,16 @@ def main():
             'newton_linear_solver': navsto.solver_parameters['newton'].get(
                 'linear_solver', 'gmres') + '+ilu0',
             'newton_overrides': args.newton,
+            # every Krylov vector, matrix, dot product and update is fp64; the
+            # ILU(0) PRECONDITIONER keeps its factors (and, inside the flexible
+            # GMRES, its sweep vector) rounded to fp32 with fp64 row sums --
+            # results identical to the all-fp64 preconditioner's to 4e-14
+            # (DESIGN.md sections 3 and 4)
+            'preconditioner_storage': {
+                'ilu_factors': navsto.solver_parameters['newton'].get(
+                    'ilu_storage', 'fp64'),
+                'ilu_sweep_vector': navsto.solver_parameters['newton'].get(
+                    'ilu_vector', 'fp64')},
             },
         'roofline': {
             'kernel': 'spmv_stream_kernel<DOT> (pressure-Poisson CSR SpMV '
