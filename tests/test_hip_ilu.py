@@ -265,3 +265,30 @@ def test_start_vectors_do_not_change_the_solution(hip):
     diffs = (abs(t_a - t_b) / t_b, cases.rel_l2(u_a, u_b), cases.rel_l2(p_a, p_b))
     assert diffs[0] < 5e-5 and diffs[1] < 5e-5 and diffs[2] < 3e-4, diffs
     print('start vectors on/off: dt, u, p differences', diffs)
+
+
+@pytest.mark.gpu
+def test_prepare_builds_the_caches_and_leaves_no_trace_in_the_fields(hip):
+    '''KarmanProblem.prepare() (bench.py: one throw-away step before the timed
+    windows) creates the cached structures -- the ILU(0) plan among them -- and
+    resets fields and clock; the steps that follow agree with those of a problem
+    that was never prepared to the solvers' tolerance (caches and
+    preconditioners only change Krylov paths).'''
+    from flow_amd import karman
+    a = karman.KarmanProblem(120, 28, velocity_degree=2)
+    b = karman.KarmanProblem(120, 28, velocity_degree=2)
+    a.prepare()
+    lay = a.W.layout
+    assert 'ilu_plan' in lay._dev and lay._dev['jacobian_ilu'].stale
+    assert a.t == 0.0 and a.dt == 1.0e-5 and a.history == []
+    assert float(a.u0.data.abs().max()) == 0.0
+    assert float(a.p0.data.abs().max()) == 0.0
+    for prob in (a, b):
+        prob.set_initial_profile()
+        prob.dt = 2.0e-3
+        for _ in range(3):
+            prob.step(adapt=False)
+    ua, ub = a.u0.data.cpu().numpy(), b.u0.data.cpu().numpy()
+    pa, pb = a.p0.data.cpu().numpy(), b.p0.data.cpu().numpy()
+    assert cases.rel_l2(ua, ub) < 1e-9
+    assert cases.rel_l2(pa, pb) < 1e-7
