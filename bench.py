@@ -8,8 +8,8 @@ bench.py -- headline benchmark of the hot path (BASELINE.json):
 A "step" is one pass of the reference driver's loop body
 (tests/test_karman_vortex_street.py:219-286 of the reference): Rotational.step()
 (tentative velocity -> pressure Poisson -> velocity correction) followed by the
-CFL step-size controller, on synthetic data (structured channel mesh with a
-staircase obstacle).
+CFL step-size controller, on synthetic data (structured channel mesh pulled
+onto the cylinder: body-fitted, flow_amd/fem/mesh.py).
 
   python bench.py --gpus N --steps K --warmup W
 
@@ -457,7 +457,7 @@ def main():
         'data': 'synthetic',
         'config': {
             'workload': 'Karman vortex street %s, %d DoF '
-                        '(%d x %d structured channel, staircase obstacle), '
+                        '(%d x %d structured channel, body-fitted cylinder), '
                         '%s scheme, backward Euler, tol %.0e, mu 0.002, '
                         'rho 998.2, dt0 1e-5 + CFL controller, start: %s'
                         % ('P2-P1 Taylor-Hood' if args.velocity_degree == 2
@@ -477,6 +477,9 @@ def main():
             'cells': prob.mesh.num_cells(),
             'pressure_rows': n,
             'pressure_nnz': nnz,
+            # (dispatch size of the pressure SpMV: profiles/run_profiles.sh
+            # picks its launches out of the PMC passes by it)
+            'pressure_spmv_grid': int(Kbc.operator().nblocks) * 256,
             'parallelism': parallel.describe(world, n),
             'setup_s': setup_s,
             'stokes_start': start.get('info'),

@@ -24,8 +24,9 @@ python3 $R/profiles/summarize.py gaps $OUT/trace $R/gpurun_out/gaps_$TAG.md
 python3 $R/profiles/summarize.py stats $OUT/trace $R/gpurun_out/kernel_stats_${TAG}_timed_steps.md 90:340 > /dev/null
 python3 $R/profiles/summarize.py gaps $OUT/trace $R/gpurun_out/gaps_${TAG}_timed_steps.md 90:340 > /dev/null
 # warm replay (spmv_stream_kernel<false>, back-to-back) and the in-solver launches
-# (spmv_stream_kernel<true> on the pressure matrix: dispatch size 1923072)
-python3 $R/profiles/summarize.py pmc $OUT/fetch $OUT/write $R/gpurun_out/spmv_traffic_$TAG.json "flow::spmv_stream_kernel<false>" 1923072
-python3 $R/profiles/summarize.py pmc $OUT/fetch $OUT/write $R/gpurun_out/spmv_traffic_${TAG}_in_solver.json "flow::spmv_stream_kernel<true>" 1923072
+# (spmv_stream_kernel<true>) on the pressure matrix, picked by its dispatch size
+GRID=$(python3 -c "import json; print(json.load(open('$OUT/bench_trace.json'))['config']['pressure_spmv_grid'])")
+python3 $R/profiles/summarize.py pmc $OUT/fetch $OUT/write $R/gpurun_out/spmv_traffic_$TAG.json "flow::spmv_stream_kernel<false>" $GRID
+python3 $R/profiles/summarize.py pmc $OUT/fetch $OUT/write $R/gpurun_out/spmv_traffic_${TAG}_in_solver.json "flow::spmv_stream_kernel<true>" $GRID
 # keep the merge-back small: drop the raw traces
 rm -rf $OUT/trace $OUT/fetch $OUT/write

@@ -152,6 +152,13 @@ def _worker(rank, world, port, out):
 
         # ---- two whole time steps on the strips -----------------------------
         prob, infos = _karman_steps()
+        # (the problem's own mesh: body-fitted, not the staircase one above)
+        lay, play = prob.W.layout, prob.P.layout
+        n = lay.N
+        v = parallel.view(lay)
+        ext = numpy.zeros(2 * n, dtype=bool)
+        for a in (0, 1):
+            ext[a * n + v.e0:a * n + v.e1] = True
         u_loc = device.to_host(prob.u0.data).numpy().copy()
         p_loc = device.to_host(prob.p0.data).numpy().copy()
         u = device.to_host(parallel.gather_field(

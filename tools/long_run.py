@@ -14,7 +14,11 @@ if len(sys.argv) > 2:      # e.g. newton.linear_atol_factor=0.1
         navsto.solver_parameters[grp][name] = type(navsto.solver_parameters[grp][name])(float(val))
         print('set', grp, name, navsto.solver_parameters[grp][name])
 prob = karman.KarmanProblem(2182, 509, velocity_degree=2)
-prob.set_initial_profile(); prob.dt = 1e-5
+if os.environ.get('START', 'stokes') == 'stokes':
+    prob.set_initial_stokes()
+else:
+    prob.set_initial_profile()
+prob.dt = 1e-5
 t0 = time.time()
 worst = 0
 tot_newton = tot_lin = 0
