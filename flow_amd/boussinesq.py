@@ -46,11 +46,12 @@ class CoolBoundary(fem.SubDomain):
 
 def compute_boussinesq(target_time, nx=16, supg=False, verbose=False,
                        dt0=1.0e-2, mesh=None):
-    '''mesh: default the structured heater box with nx cells across;
+    '''mesh: default the structured heater box with nx cells across, body-
+    fitted at the heater from 12 cells on (the staircase variant below that);
     fem.heater_box_coarse() is the counterpart of the reference's
     `lcar = 0.1` gmsh mesh (tests/test_boussinesq.py:84-97).'''
     if mesh is None:
-        mesh = fem.heater_box(nx)
+        mesh = fem.heater_box(nx, fitted=nx >= 12)
     hot_boundary = HotBoundary()
     cool_boundary = CoolBoundary()
 

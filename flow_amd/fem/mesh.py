@@ -352,12 +352,18 @@ def karman_channel(nx, ny=None, diagonal='right', fitted=False):
     return make(0.0, 0.6, -0.07, 0.07, (0.1, 1.0e-2), 0.02, nx, ny, diagonal)
 
 
-def heater_box(nx, ny=None, diagonal='right'):
+def heater_box(nx, ny=None, diagonal='right', fitted=False):
     '''Box [0, 0.1] x [0, 0.2] with a circular heater of radius 0.02 at
     (0.05, 0.05): tests/test_boussinesq.py:27-30, 62-64 and
-    tests/test_sealed_box.py:35-40.'''
+    tests/test_sealed_box.py:35-40.  fitted: body-fitted heater (the blend
+    zone has to fit between heater and walls: 2.4 block half-sides; needs
+    nx >= 12).'''
     if ny is None:
         ny = 2 * nx
+    if fitted:
+        return rectangle_with_fitted_hole(
+            0.0, 0.1, 0.0, 0.2, (0.05, 0.05), 0.02, nx, ny, diagonal, blend=2.4
+            )
     return rectangle_with_hole(
         0.0, 0.1, 0.0, 0.2, (0.05, 0.05), 0.02, nx, ny, diagonal
         )
