@@ -277,6 +277,50 @@ def test_no_cpu_fallback():
         fem.project(fem.Constant(1.0), V)
 
 
+def test_body_fitted_hole():
+    '''fem.karman_channel(fitted=True): the hole's boundary vertices lie on the
+    circle, no cell is inverted or badly shaped, vertices keep their x-major
+    order, cells stay sorted by lowest vertex (what the strip decomposition and
+    the cell kernels assume), the outer boundary does not move.'''
+    import numpy
+    from flow_amd import fem
+    for nx, ny in ((60, 14), (240, 56)):
+        m = fem.karman_channel(nx, ny, fitted=True)
+        pts, cells = m.points, m.cell_vertices
+        e = m.edges[m.bfacets]
+        v = numpy.unique(e)
+        p = pts[v]
+        inner = (p[:, 0] > 1e-9) & (p[:, 0] < 0.6 - 1e-9) & \
+            (p[:, 1] > -0.07 + 1e-9) & (p[:, 1] < 0.07 - 1e-9)
+        hx, hy = 0.6 / nx, 0.14 / ny
+        c = numpy.array([round(0.1 / hx) * hx,
+                         -0.07 + round((0.01 + 0.07) / hy) * hy])
+        r = numpy.hypot(*(p[inner] - c).T)
+        assert inner.sum() >= 16 and abs(r - 0.02).max() < 1e-12
+        outer = p[~inner]
+        on_box = (abs(outer[:, 0]) < 1e-12) | (abs(outer[:, 0] - 0.6) < 1e-12) \
+            | (abs(outer[:, 1] + 0.07) < 1e-12) | (abs(outer[:, 1] - 0.07) < 1e-12)
+        assert on_box.all()
+        q = pts[cells]
+        a, b, d = q[:, 1] - q[:, 0], q[:, 2] - q[:, 0], q[:, 2] - q[:, 1]
+
+        def ang(u, w):
+            cs = (u * w).sum(1) / numpy.linalg.norm(u, axis=1) \
+                / numpy.linalg.norm(w, axis=1)
+            return numpy.degrees(numpy.arccos(numpy.clip(cs, -1, 1)))
+        angs = numpy.stack([ang(a, b), ang(-a, d), ang(-b, -d)], 1)
+        assert angs.min() > 20.0 and angs.max() < 110.0
+        area = m.cell_areas() / (0.5 * hx * hy)
+        assert 0.6 < area.min() and area.max() < 1.5
+        assert (numpy.diff(cells.min(axis=1)) >= 0).all()
+        # the fluid area: the box minus a polygon inscribed in the circle (its
+        # vertices are not equally spaced: a little less than the regular one)
+        nb = inner.sum()
+        poly = 0.5 * nb * 0.02**2 * numpy.sin(2 * numpy.pi / nb)
+        hole = 0.6 * 0.14 - m.cell_areas().sum()
+        assert 0.99 * poly < hole <= poly * (1.0 + 1e-12)
+
+
 def test_message(capsys):
     message.set_log_active(True)
     try:
