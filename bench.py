@@ -390,6 +390,12 @@ def main():
 
     # everything that is built once and cached (operators, hierarchy, ILU
     # plan, ...), then the start state: all of it setup, outside the windows
+    # (development overrides first: some of them shape those structures)
+    for kv in args.newton:
+        key, val = kv.split('=', 1)
+        old = navsto.solver_parameters['newton'][key]
+        navsto.solver_parameters['newton'][key] = \
+            val if isinstance(old, str) else type(old)(float(val))
     prob.prepare()
     initial_state()
     barrier()
