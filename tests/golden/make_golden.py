@@ -5,7 +5,12 @@ Generates the golden fixtures under tests/golden/ with the CPU oracle
 so these vectors come from the oracle, which is pinned by the reference's
 analytic known-answer tests (tests/test_oracle_pinning.py).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [--force]
+
+Existing fixtures are left alone unless --force is given: they carry their own
+mesh arrays, and the ones written before the generators numbered cells x-major
+(channel_p1, channel_p2, heat_ops) would come out with the same values in a
+different cell order.
 
 Fixtures are plain data (inputs and expected outputs):
   ns_step_<name>.npz   one pressure-correction step per scheme
@@ -28,7 +33,22 @@ import cases                                               # noqa: E402
 import mms                                                 # noqa: E402
 
 
+FORCE = '--force' in sys.argv[1:]
+
+
+def _wanted(filename):
+    path = os.path.join(HERE, filename)
+    if os.path.exists(path) and not FORCE:
+        print('kept   ', filename)
+        return None
+    print('writing', filename)
+    return path
+
+
 def ns_fixture(name, mesh, vdeg, bc_kind, dt, rho, mu, seed):
+    path = _wanted('ns_step_%s.npz' % name)
+    if path is None:
+        return
     case = cases.Case(mesh, vdeg=vdeg, dt=dt, bc_kind=bc_kind, rho=rho, mu=mu,
                       f_degree=2, seed=seed)
     u_bc, p_bc = case.bc_data()
@@ -53,11 +73,13 @@ def ns_fixture(name, mesh, vdeg, bc_kind, dt, rho, mu, seed):
         data[key + '_u1'] = u1
         data[key + '_p1'] = p1
         data[key + '_ui'] = ui
-    numpy.savez_compressed(os.path.join(HERE, 'ns_step_%s.npz' % name), **data)
+    numpy.savez_compressed(path, **data)
 
 
 def heat_fixture():
-    sys.path.insert(0, os.path.dirname(HERE))
+    path = _wanted('heat_ops.npz')
+    if path is None:
+        return
     mesh = fem.heater_box(5)
     Q = fem.FunctionSpace(mesh, 'Lagrange', 2)
     W = fem.VectorFunctionSpace(mesh, 'Lagrange', 2)
@@ -92,7 +114,7 @@ def heat_fixture():
     data['tau'] = numpy.array([
         [orc.supg_tau(pc[k], Cc[k, :, v], kappa, 2) for v in range(3)]
         for k in range(mesh.num_cells())])
-    numpy.savez_compressed(os.path.join(HERE, 'heat_ops.npz'), **data)
+    numpy.savez_compressed(path, **data)
 
 
 if __name__ == '__main__':
@@ -104,5 +126,8 @@ if __name__ == '__main__':
                0.05, 22)
     ns_fixture('channel_p1', fem.karman_channel(24, 8), 1, 'channel', 0.02, 1.5,
                0.05, 23)
+    # the body-fitted obstacle of the bench's workload (stretched triangles)
+    ns_fixture('channel_p2_fitted', fem.karman_channel(30, 10, fitted=True), 2,
+               'channel', 0.02, 1.5, 0.05, 24)
     heat_fixture()
     print('fixtures written to', HERE)

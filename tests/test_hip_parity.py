@@ -37,6 +37,11 @@ def _meshes():
         ('rect-leftright', fem.RectangleMesh(
             fem.Point(-1.0, -0.5), fem.Point(1.5, 1.0), 7, 5, 'left/right')),
         ('karman-24', fem.karman_channel(24, 8)),
+        # the body-fitted obstacle of the bench's workload (general stretched
+        # triangles, a polygonal hole with its vertices on the circle) ...
+        ('karman-30-fitted', fem.karman_channel(30, 10, fitted=True)),
+        # ... and of the Boussinesq driver's box
+        ('heater-12-fitted', fem.heater_box(12, fitted=True)),
         ]
 
 
@@ -456,12 +461,16 @@ def test_step_parity_neumann(hip, scheme, vdeg):
     assert cases.rel_l2(u1, u1o) < 1e-7
 
 
+@pytest.mark.parametrize('fitted', [False, True])
 @pytest.mark.parametrize('method', ['backward euler', 'crank-nicolson',
                                     'forward euler'])
-def test_step_parity_channel(hip, method):
+def test_step_parity_channel(hip, method, fitted):
     '''Component-wise velocity conditions + pressure Dirichlet at the outlet
-    (the Karman setting), Rotational scheme, on the channel-with-obstacle mesh.'''
-    mesh = fem.karman_channel(30, 10)
+    (the Karman setting), Rotational scheme, on the channel-with-obstacle mesh:
+    the staircase obstacle and the body-fitted one the bench runs on (stretched
+    triangles; the `ds` terms of _rhs_weak, reference :135-144, act on the
+    free rows of the two sides).'''
+    mesh = fem.karman_channel(30, 10, fitted=fitted)
     pb = mms.guermond2()
     case = cases.Case(mesh, vdeg=2, problem=pb, dt=0.02, bc_kind='channel',
                       rho=1.5, mu=0.05, seed=12)
@@ -469,6 +478,23 @@ def test_step_parity_channel(hip, method):
     u1, p1, ui = case.product_step('rotational', method)
     assert cases.rel_l2(ui, uio) < 1e-7
     assert cases.rel_l2(p1, p1o) < 1e-7
+    assert cases.rel_l2(u1, u1o) < 1e-7
+
+
+@pytest.mark.parametrize('scheme', ['chorin', 'ipcs', 'rotational'])
+def test_step_parity_fitted_box(hip, scheme):
+    '''Whole step vs oracle on the body-fitted heater box (the Boussinesq
+    driver's mesh): velocity Dirichlet everywhere -- also on the polygonal
+    heater --, Neumann pressure.'''
+    mesh = fem.heater_box(12, fitted=True)
+    case = cases.Case(mesh, vdeg=2, dt=0.03, bc_kind='all', rho=1.2, mu=0.08,
+                      seed=31)
+    u1o, p1o, uio = case.oracle_step(scheme)
+    u1, p1, ui = case.product_step(scheme)
+    W, P = case.oracle_spaces()
+    Mp = orc.mass_matrix(P)
+    assert cases.rel_l2(ui, uio) < 1e-7, 'tentative velocity'
+    assert cases.rel_l2(cases.mean_free(p1, Mp), cases.mean_free(p1o, Mp)) < 1e-7
     assert cases.rel_l2(u1, u1o) < 1e-7
 
 
