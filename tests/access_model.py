@@ -1,0 +1,89 @@
+# -*- coding: utf-8 -*-
+'''
+Host-side model of WHICH entries of the input vector `x` every CSR-stream kernel
+variant of flow_amd/csrc/la_kernels.hip dereferences, tile by tile (helper, not
+a test).  The strip-sharded solvers hand these kernels `x` as a window
+[e0, e1) of a vector, addressed by global row through a base pointer shifted
+by -e0: an index outside the window is an address outside the allocation (a
+GPU memory-access fault when it lands on an unmapped page, a silent read of
+foreign memory when it does not).  The model restates the kernels' index
+arithmetic -- tile base aligned down to an even nonzero, index PAIRS per
+lane, the trailing odd element, idle lanes, empty tiles -- so that a CPU test
+can prove the access set lies inside the window for any partition.
+
+Variants (the kernel each one restates):
+  'stream'       stream_tile_row_sum: spmv_stream_kernel, mg_level_kernel
+  'block2'       spmv_stream_block2_kernel
+  'pair'         spmv_stream_pair_kernel (both components use the same indices)
+  'stream_r2a'   stream_tile_row_sum as it was when the world-3 fault of round 2
+                 happened (every lane gathers x[col] of whatever index pair it
+                 loaded; idle lanes hold column 0) -- kept to show that the
+                 audit sees that defect
+'''
+import numpy
+
+BLOCK = 256                 # kBlock
+PAIRS = 2                   # kPairs
+LANES = BLOCK * PAIRS       # index pairs per tile
+
+
+def tile_accesses(rowptr, cols, rowblocks, variant='stream'):
+    '''(lo, hi): per tile the smallest and the largest index of x the kernel
+    dereferences in its gather phase (lo > hi: none).  cols must be readable
+    one pair past the last nonzero, as the device arrays are (padding 0).'''
+    rowptr = numpy.asarray(rowptr, dtype=numpy.int64)
+    cols = numpy.asarray(cols, dtype=numpy.int64)
+    rb = numpy.asarray(rowblocks, dtype=numpy.int64)
+    nt = len(rb) - 1
+    k0 = rowptr[rb[:-1]]
+    k1 = rowptr[rb[1:]]
+    ka = k0 & ~1
+    lo_e = (k0 - ka)[:, None]
+    hi_e = (k1 - ka)[:, None]
+    npair = ((k1 - ka + 1) >> 1)[:, None]
+    p = numpy.arange(LANES)[None, :]
+    e = 2 * p
+    pad = numpy.zeros(2 * LANES + 4, dtype=numpy.int64)
+    colsp = numpy.concatenate([cols, pad])          # (never used out of range
+    cx = colsp[ka[:, None] + e]                     #  by a kernel: see `ok`)
+    cy = colsp[ka[:, None] + e + 1]
+    ok = p < npair
+    nonempty = (k0 < k1)[:, None]
+    big = numpy.iinfo(numpy.int64).max
+    if variant == 'stream':
+        safe = colsp[numpy.where(k0 < k1, k0, numpy.maximum(k0 - 1, 0))][:, None]
+        # idle lanes hold (0, 0) and select `safe` like the slack entries
+        ix = numpy.where((e >= lo_e) & (e < hi_e), numpy.where(ok, cx, 0), safe)
+        iy = numpy.where(e + 1 < hi_e, numpy.where(ok, cy, 0), safe)
+        used = numpy.broadcast_to(nonempty, ix.shape)   # empty tile: no gather
+    elif variant == 'stream_r2a':
+        ix = numpy.where(ok, cx, 0)
+        iy = numpy.where(ok, cy, 0)
+        used = numpy.ones_like(ix, dtype=bool)
+    elif variant == 'block2':
+        first = colsp[k0][:, None]
+        ix = numpy.where(e >= lo_e, cx, first)
+        iy = numpy.where(e + 1 < hi_e, cy, first)
+        used = ok & numpy.ones_like(ix, dtype=bool)
+    elif variant == 'pair':
+        safe = colsp[k0][:, None]
+        ix = numpy.where((e >= lo_e) & (e < hi_e), numpy.where(ok, cx, 0), safe)
+        iy = numpy.where(e + 1 < hi_e, numpy.where(ok, cy, 0), safe)
+        used = numpy.ones_like(ix, dtype=bool)
+    else:
+        raise ValueError(variant)
+    lo = numpy.minimum(numpy.where(used, ix, big).min(axis=1),
+                       numpy.where(used, iy, big).min(axis=1))
+    hi = numpy.maximum(numpy.where(used, ix, -1).max(axis=1),
+                       numpy.where(used, iy, -1).max(axis=1))
+    assert len(lo) == nt
+    return lo, hi
+
+
+def window(rowptr, cols, rowblocks, variant='stream'):
+    '''[min, max] of x indices over all tiles, or None when nothing is read.'''
+    lo, hi = tile_accesses(rowptr, cols, rowblocks, variant)
+    sel = lo <= hi
+    if not sel.any():
+        return None
+    return int(lo[sel].min()), int(hi[sel].max())
