@@ -104,6 +104,28 @@ class IluS(ctypes.Structure):
         ]
 
 
+class PmgLevelS(ctypes.Structure):
+    _fields_ = [
+        ('n', ctypes.c_int), ('nnz', ctypes.c_int), ('nblocks', ctypes.c_int),
+        ('rowptr', ctypes.c_void_p), ('cols', ctypes.c_void_p),
+        ('rowblocks', ctypes.c_void_p),
+        ('vals', ctypes.c_void_p), ('dinv', ctypes.c_void_p),
+        ('lam_min', ctypes.c_double), ('lam_max', ctypes.c_double),
+        ]
+
+
+class PmgS(ctypes.Structure):
+    _fields_ = [
+        ('fine', PmgLevelS), ('coarse', PmgLevelS),
+        ('pre', ctypes.c_int), ('post', ctypes.c_int),
+        ('coarse_steps', ctypes.c_int),
+        ('ends', ctypes.c_void_p),
+        ('rptr', ctypes.c_void_p), ('rsrc', ctypes.c_void_p),
+        ('bc_fine', ctypes.c_void_p), ('bc_coarse', ctypes.c_void_p),
+        ('work', ctypes.c_void_p),
+        ]
+
+
 class MeshS(ctypes.Structure):
     _fields_ = [('nc', ctypes.c_int), ('xy', ctypes.c_void_p),
                 ('c0', ctypes.c_int), ('c1', ctypes.c_int)]
@@ -213,8 +235,13 @@ SYMBOLS = {
     'flow_two_level_apply': [_P(CoarseS), _VP, _VP, _VP, _VP, _VP],
     'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
                             _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
-    'flow_gmres_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I, _I,
-                         _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_gmres_solve': [_P(Operator), _VP, _P(IluS), _P(PmgS), _VP, _VP, _D,
+                         _D, _I, _I, _I, _I, _VP, ctypes.c_size_t, _P(_I),
+                         _P(_D), _VP],
+    'flow_pmg_pack': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP],
+    'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _P(_D), _VP],
+    'flow_pmg_apply': [_P(PmgS), _VP, _VP, _VP],
+    'flow_gather_rows': [_I, _VP, _I, _VP, _I, _VP, _I, _VP],
     'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],
     'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],
     'flow_ilu0_pack': [_P(IluS), _VP, _VP],

@@ -20,6 +20,13 @@ int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
               hipStream_t st, const double* stop = nullptr);
 int ilu_check(const flow_ilu* ilu, int op_size);
 
+// pmg_kernels.hip: the p-multigrid / Chebyshev preconditioner (flow_pmg)
+int pmg_apply(const flow_pmg* M, const double* r, double* z, hipStream_t st,
+              const double* stop = nullptr);
+int pmg_check(const flow_pmg* M, int op_size);
+// la_kernels.hip
+int sum_partials_host(double* work, int nparts, double* host, hipStream_t st);
+
 // assembly_kernels.hip: the matrix-free operator (flow_operator kind 3)
 int momentum_jvp_check(const flow_momentum_jvp* J);
 int momentum_jvp_apply(const flow_momentum_jvp* J, const double* v, double* out,

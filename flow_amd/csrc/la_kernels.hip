@@ -983,6 +983,18 @@ static int read_slot(const double* S, int slot, double* host, hipStream_t st) {
   return read_slots(S, slot, slot, host, &again, st);
 }
 
+// sum of the first nparts (<= kRedBlocks) block partials at the head of a
+// FLOW_REDUCE_WORK buffer, read back to the host (pmg_kernels.hip: the power
+// iteration of the Chebyshev setup)
+int sum_partials_host(double* work, int nparts, double* host, hipStream_t st) {
+  FLOW_REQUIRE(nparts >= 1 && nparts <= kRedBlocks, "partial count");
+  double* S = work + 3 * kRedBlocks;
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, nparts, 1, 0,
+                     work, S);
+  FLOW_CHECK_LAUNCH();
+  return read_slot(S, 0, host, st);
+}
+
 // Work of cg(): [reductions | r z w p s | z.w partials of the SpMV | rc zc |
 // r.z, z.z partials of the V-cycle's last kernel]
 static inline size_t cg_work_len(const flow_operator* A, const flow_coarse* C,
@@ -1311,7 +1323,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 19; }
+extern "C" int flow_abi_version(void) { return 20; }
 
 // the workgroup -> tile mapping of the CSR-stream kernels, for host-side tests
 extern "C" int flow_xcd_tile_host(int block, int nblocks) {
@@ -1490,6 +1502,31 @@ extern "C" int flow_axpby(int n, double a, const double* x, double b, double* y,
   FLOW_REQUIRE(n > 0 && x && y, "axpby arguments");
   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
                      as_stream(stream), n, a, x, b, y);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+// dst[a*dst_stride + k] = src[a*src_stride + idx[k]]
+__global__ void gather_rows_kernel(int ncomp, int m, const int* __restrict__ idx,
+                                   const double* __restrict__ src, int src_stride,
+                                   double* __restrict__ dst, int dst_stride) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncomp * m;
+       t += gridDim.x * blockDim.x) {
+    const int a = t / m, k = t - a * m;
+    dst[static_cast<size_t>(a) * dst_stride + k] =
+        src[static_cast<size_t>(a) * src_stride + idx[k]];
+  }
+}
+
+extern "C" int flow_gather_rows(int ncomp, const int* idx, int m,
+                                const double* src, int src_stride, double* dst,
+                                int dst_stride, void* stream) {
+  FLOW_REQUIRE(ncomp >= 1 && m > 0 && idx && src && dst && src_stride > 0 &&
+                   dst_stride >= m,
+               "gather_rows arguments");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(static_cast<long long>(ncomp) * m)),
+                     dim3(kBlock), 0, as_stream(stream), ncomp, m, idx, src,
+                     src_stride, dst, dst_stride);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -1907,7 +1944,7 @@ static double gmres_least_squares(const double (*H)[kGmresMax + 1], int j,
 // looks at the state for the first time, then one at a time; the result does
 // not depend on it.
 static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu,
-                 const double* b, double* x, double rtol, double atol, int maxit,
+                 const flow_pmg* pmg, const double* b, double* x, double rtol, double atol, int maxit,
                  int m, int x_is_zero, int expected, double* work,
                  int* iters_host, double* resid_host, hipStream_t st) {
   const int N = op_size(A);
@@ -1926,11 +1963,12 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
   int np = 0, rc;
 
   // Z_j = M^-1 V_j (without a preconditioner Z_j is V_j itself)
-  const bool precond = ilu || dinv;
+  const bool precond = pmg || ilu || dinv;
   const double* Zbase = precond ? Z : V;
   auto precondition = [&](int j) -> int {
     const double* in = V + static_cast<size_t>(j) * N;
     double* out = Z + static_cast<size_t>(j) * N;
+    if (pmg) return pmg_apply(pmg, in, out, st, stop);
     if (ilu) return ilu_apply(ilu, in, out, iwork, st, stop);
     if (dinv)
       hipLaunchKernelGGL(vmul_kernel, dim3(gv), dim3(kBlock), 0, st, N, 1.0, dinv,
@@ -2152,7 +2190,8 @@ extern "C" int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
 }
 
 extern "C" int flow_gmres_solve(const flow_operator* A, const double* dinv,
-                                const flow_ilu* ilu, const double* b, double* x,
+                                const flow_ilu* ilu, const flow_pmg* pmg,
+                                const double* b, double* x,
                                 double rtol, double atol, int maxit, int restart,
                                 int x_is_zero, int expected_its, double* work,
                                 size_t work_len, int* iters_host,
@@ -2169,8 +2208,10 @@ extern "C" int flow_gmres_solve(const flow_operator* A, const double* dinv,
                                FLOW_GMRES_PARTIALS + FLOW_GMRES_STATE,
                "solver workspace too small (FLOW_REDUCE_WORK + (2 restart + 2) N "
                "+ FLOW_GMRES_PARTIALS + FLOW_GMRES_STATE)");
+  FLOW_REQUIRE(!(ilu && pmg), "one preconditioner: ilu or pmg");
   if (ilu && (rc = ilu_check(ilu, op_size(A)))) return rc;
-  return gmres(A, dinv, ilu, b, x, rtol, atol, maxit, restart, x_is_zero,
+  if (pmg && (rc = pmg_check(pmg, op_size(A)))) return rc;
+  return gmres(A, dinv, ilu, pmg, b, x, rtol, atol, maxit, restart, x_is_zero,
                expected_its, work, iters_host, resid_host, as_stream(stream));
 }
 

@@ -492,7 +492,8 @@ class SolveInfo(object):
 
 def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
                  check_every=None, coarse=None, ilu=None, mg=None,
-                 first_check=0, tag=None, restart=20, x_is_zero=False):
+                 first_check=0, tag=None, restart=20, x_is_zero=False,
+                 pmg=None):
     '''Solve A x = b on the device; x holds the initial guess.  Raises
     _hip.NotConverged (a RuntimeError) like dolfin's
     'error_on_nonconvergence'.  first_check > 0: iterations before the first
@@ -509,7 +510,7 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     n = A.size
     if isinstance(dinv, str):
         assert dinv == 'jacobi'
-        dinv = A.diag_inv() if ilu is None else None
+        dinv = A.diag_inv() if ilu is None and pmg is None else None
     assert method in ('cg', 'bicgstab', 'gmres'), method
     nvec = {'cg': 5, 'bicgstab': 7, 'gmres': 2 * restart + 2}[method]
     nparts = A.operator().nblocks * (2 if A.kind == 1 else 1) + 2
@@ -546,6 +547,7 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
         rc = lib.flow_gmres_solve(
             ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
             ctypes.byref(ilu.struct) if ilu is not None else None,
+            ctypes.byref(pmg.struct) if pmg is not None else None,
             _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
             int(maxit), int(restart), int(bool(x_is_zero)), int(first_check),
             _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
@@ -567,7 +569,8 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     return SolveInfo(its.value, res.value,
                      method + ('+2level' if coarse is not None else '')
                      + ('+mg%d' % mg.nlevels if mg is not None else '')
-                     + ('+ilu0' if ilu is not None else ''))
+                     + ('+ilu0' if ilu is not None else '')
+                     + ('+pmg' if pmg is not None else ''))
 
 
 # -- load vectors, projection, norms -----------------------------------------

@@ -1,0 +1,209 @@
+# -*- coding: utf-8 -*-
+'''
+Host side of the p-multigrid / Chebyshev preconditioner of the Newton systems
+(`flow_pmg` in include/flow_hip.h, kernels in flow_amd/csrc/pmg_kernels.hip):
+a second stand-in -- next to the multicolour ILU(0) of flow_amd/fem/ilu.py --
+for the sparse LU behind the reference's Newton solve
+(flow/navier_stokes/pressure_correction.py:224-254), as the right
+preconditioner of the flexible GMRES.
+
+Two levels on the same mesh: the diagonal blocks of the assembled P2 Jacobian,
+smoothed with a few Chebyshev steps, and the P1 discretisation of the same
+linearised operator as the coarse problem (P1 is a subspace of P2: vertex dofs
+copy their vertex, edge dofs average their two end points), treated with
+Chebyshev steps as well.  Everything an application does is a CSR-stream
+product over a pattern that is already resident -- no dependent sweeps, no
+colouring.  Measured on the oracle's Jacobian in the regime of the 10 M-DoF
+workload (tools/precond_lab.py: CFL 1.85, diffusion number 0.85): 14-15
+GMRES iterations against 34 with the multicolour ILU(0) (natural-order ILU(0),
+which has no parallel form: 24).
+
+Setup here is index tables only (numpy, once per mesh); `refactor` packs the
+matrices and estimates the spectral radii with kernels of the library.
+'''
+import ctypes
+
+import numpy
+import torch
+
+from . import ops
+from .space import scalar_layout
+from .. import _hip
+from .. import device
+
+
+def transfer_tables(lay2):
+    '''(ends, rptr, rsrc) between the P2 layout and the P1 layout of its mesh:
+    ends[i] = the two P1 rows (= vertices) P2 dof i interpolates from (a vertex
+    dof names its vertex twice); rptr/rsrc = the transposed lists, per vertex
+    its own P2 dof FIRST, then the dofs of the edges that end there.'''
+    mesh = lay2.mesh
+    assert lay2.degree == 2
+    nv = mesh.num_vertices()
+    edges = mesh.edges.astype(numpy.int64)
+    ends = numpy.empty((lay2.N, 2), dtype=numpy.int32)
+    vd = lay2.vertex_dofs.astype(numpy.int64)
+    ed = lay2.edge_dofs.astype(numpy.int64)
+    ends[vd, 0] = numpy.arange(nv)
+    ends[vd, 1] = numpy.arange(nv)
+    ends[ed, 0] = edges[:, 0]
+    ends[ed, 1] = edges[:, 1]
+    # per vertex: [own dof | edge dofs]
+    cnt = 1 + numpy.bincount(edges.ravel(), minlength=nv)
+    rptr = numpy.zeros(nv + 1, dtype=numpy.int64)
+    numpy.cumsum(cnt, out=rptr[1:])
+    rsrc = numpy.empty(int(rptr[-1]), dtype=numpy.int32)
+    rsrc[rptr[:-1]] = vd
+    owner = numpy.concatenate([edges[:, 0], edges[:, 1]])
+    dofs = numpy.concatenate([ed, ed])
+    order = numpy.argsort(owner, kind='stable')
+    owner, dofs = owner[order], dofs[order]
+    # position inside the vertex's list: 1 + running index
+    start = numpy.zeros(nv + 1, dtype=numpy.int64)
+    numpy.cumsum(numpy.bincount(owner, minlength=nv), out=start[1:])
+    within = numpy.arange(len(owner)) - start[owner]
+    rsrc[rptr[owner] + 1 + within] = dofs
+    return ends, rptr.astype(numpy.int32), rsrc
+
+
+class _Level(object):
+    def __init__(self, lay):
+        self.lay = lay
+        n, nnz = lay.N, lay.nnz
+        # (vals readable one float2 past nnz: the kernels load value pairs)
+        self.vals = torch.zeros(2 * (nnz + 2), dtype=torch.float32,
+                                device=device.get())
+        self.dinv = torch.zeros(2 * n, dtype=torch.float32, device=device.get())
+        assert self.vals.data_ptr() % 16 == 0
+        rb = lay.dev('rowblocks')
+        s = _hip.PmgLevelS()
+        s.n, s.nnz, s.nblocks = n, nnz, rb.numel() - 1
+        s.rowptr = _hip.i32(lay.dev('rowptr'), n + 1, 'rowptr')
+        s.cols = _hip.i32(lay.dev('cols'), nnz, 'cols')
+        s.rowblocks = _hip.i32(rb, None, 'rowblocks')
+        s.vals = _hip.f32(self.vals, 2 * nnz, 'vals')
+        s.dinv = _hip.f32(self.dinv, 2 * n, 'dinv')
+        s.lam_min, s.lam_max = 0.25, 2.0
+        self.struct = s
+
+    def pack(self, J):
+        '''Diagonal blocks (planes 0 and 3) of a kind-2 Matrix on this layout.'''
+        lay = self.lay
+        assert J.layout is lay and J.kind == 2
+        _hip.check(_hip.lib().flow_pmg_pack(
+            lay.N, lay.nnz, _hip.i32(lay.dev('diag_idx'), lay.N, 'diag_idx'),
+            _hip.f64(J.plane(0), lay.nnz), _hip.f64(J.plane(3), lay.nnz),
+            _hip.f32(self.vals, 2 * lay.nnz), _hip.f32(self.dinv, 2 * lay.N),
+            _hip.stream()))
+
+    def lambda_max(self, work, iterations=25):
+        res = ctypes.c_double(0.0)
+        _hip.check(_hip.lib().flow_pmg_lambda_max(
+            ctypes.byref(self.struct), int(iterations),
+            _hip.f32(work, 6 * self.lay.N),
+            _hip.f64(ops.work(_hip.REDUCE_WORK)), ctypes.byref(res),
+            _hip.stream()))
+        return res.value
+
+
+class Pmg(object):
+    '''The preconditioner for the velocity space W (degree 2).  `refactor`
+    takes the assembled Jacobian (kind 2, Dirichlet rows already identity
+    rows) on the P2 pattern and the one of the P1 discretisation.
+
+    pre / post / coarse_steps: Chebyshev steps; ratio_fine / ratio_coarse: the
+    intervals are [lam_max / ratio, safety * lam_max] with lam_max from the
+    power method (tools/precond_lab.py: 2 / 2 / 4 steps and ratios 8 / 8 are a
+    flat optimum).'''
+
+    def __init__(self, W, pre=2, post=2, coarse_steps=4, ratio_fine=8.0,
+                 ratio_coarse=8.0, safety=1.1):
+        lay = W.layout
+        assert lay.degree == 2, 'the p-multigrid needs a P2 velocity space'
+        self.lay = lay
+        self.lay1 = scalar_layout(lay.mesh, 1)
+        self.fine = _Level(lay)
+        self.coarse = _Level(self.lay1)
+        self.ratio_fine, self.ratio_coarse = ratio_fine, ratio_coarse
+        self.safety = safety
+        ends, rptr, rsrc = transfer_tables(lay)
+        n, n1 = lay.N, self.lay1.N
+        self._keep = dict(
+            ends=device.to_device(ends.reshape(-1)),
+            rptr=device.to_device(rptr), rsrc=device.to_device(rsrc),
+            bc_fine=torch.zeros(2 * n, dtype=torch.uint8, device=device.get()),
+            bc_coarse=torch.zeros(2 * n1, dtype=torch.uint8,
+                                  device=device.get()),
+            work=torch.zeros(12 * n + 8 * n1, dtype=torch.float32,
+                             device=device.get()),
+            )
+        k = self._keep
+        s = _hip.PmgS()
+        s.fine, s.coarse = self.fine.struct, self.coarse.struct
+        s.pre, s.post, s.coarse_steps = int(pre), int(post), int(coarse_steps)
+        s.ends = _hip.i32(k['ends'], 2 * n, 'ends')
+        s.rptr = _hip.i32(k['rptr'], n1 + 1, 'rptr')
+        s.rsrc = _hip.i32(k['rsrc'], len(rsrc), 'rsrc')
+        s.bc_fine = _hip.u8(k['bc_fine'], 2 * n).value
+        s.bc_coarse = _hip.u8(k['bc_coarse'], 2 * n1).value
+        s.work = _hip.f32(k['work'], 12 * n + 8 * n1).value
+        assert k['work'].data_ptr() % 16 == 0
+        self.struct = s
+        self._bc_key = None
+        self.lam = (None, None)
+
+    # -- Dirichlet rows ----------------------------------------------------------
+    def coarse_bc_dofs(self, bc_dofs_host):
+        '''The Dirichlet dofs of the P1 level (component-blocked numbering of
+        the P1 vector space): the vertex dofs among the P2 ones.'''
+        lay, n, n1 = self.lay, self.lay.N, self.lay1.N
+        vertex_of = numpy.full(n, -1, dtype=numpy.int64)
+        vertex_of[lay.vertex_dofs] = numpy.arange(n1)
+        d = numpy.asarray(bc_dofs_host, dtype=numpy.int64)
+        comp, row = d // n, d % n
+        v = vertex_of[row]
+        sel = v >= 0
+        return numpy.sort(comp[sel] * n1 + v[sel]).astype(numpy.int32)
+
+    def set_bcs(self, bc_dofs_host):
+        '''Upload the Dirichlet masks of both levels (once per set).'''
+        key = hash(numpy.asarray(bc_dofs_host).tobytes())
+        if key == self._bc_key:
+            return self._bc1
+        n, n1 = self.lay.N, self.lay1.N
+        m0 = numpy.zeros(2 * n, dtype=numpy.uint8)
+        m0[bc_dofs_host] = 1
+        bc1 = self.coarse_bc_dofs(bc_dofs_host)
+        m1 = numpy.zeros(2 * n1, dtype=numpy.uint8)
+        m1[bc1] = 1
+        self._keep['bc_fine'].copy_(torch.from_numpy(m0))
+        self._keep['bc_coarse'].copy_(torch.from_numpy(m1))
+        device.synchronize()
+        self._bc_key = key
+        self._bc1 = (bc1, device.to_device(bc1))
+        return self._bc1
+
+    # -- numbers -------------------------------------------------------------------
+    def refactor(self, J, J1):
+        self.fine.pack(J)
+        self.coarse.pack(J1)
+        work = self._keep['work']
+        lam0 = self.fine.lambda_max(work)
+        lam1 = self.coarse.lambda_max(work)
+        self.lam = (lam0, lam1)
+        for lvl, lam, ratio in ((self.fine, lam0, self.ratio_fine),
+                                (self.coarse, lam1, self.ratio_coarse)):
+            lvl.struct.lam_max = self.safety * lam
+            lvl.struct.lam_min = lam / ratio
+        # (the level structs are embedded BY VALUE in flow_pmg)
+        self.struct.fine = self.fine.struct
+        self.struct.coarse = self.coarse.struct
+        return self
+
+    def apply(self, r, z):
+        '''z = M^-1 r (tests / direct use).'''
+        n2 = 2 * self.lay.N
+        _hip.check(_hip.lib().flow_pmg_apply(
+            ctypes.byref(self.struct), _hip.f64(r, n2, 'r'), _hip.f64(z, n2, 'z'),
+            _hip.stream()))
+        return z

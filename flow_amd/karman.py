@@ -129,7 +129,7 @@ class KarmanProblem(object):
         self.reset()
         # the factors of that step belong to another state and dt: the first
         # real Newton iteration computes its own (a few ms, no plan building)
-        for name in ('jacobian_ilu', 'jacobian_ilu_strip'):
+        for name in ('jacobian_ilu', 'jacobian_pmg', 'jacobian_ilu_strip'):
             pre = self.W.layout._dev.get(name)
             if pre is not None:
                 pre.stale = True

@@ -92,7 +92,13 @@ solver_parameters = {
                'linear_solver': 'gmres', 'gmres_restart': 10,
                'linear_rtol': 1.0e-13, 'linear_atol_factor': 1.0e-6,
                'forcing': 0.0, 'check_every': 1, 'restart': 400,
-               'preconditioner': 'ilu0', 'ilu_lag': 8.0,
+               # 'pmg' (P2 velocity spaces; falls back to 'ilu0' otherwise):
+               # two-level p-multigrid with Chebyshev smoothing, CSR-stream
+               # products only (flow_amd/fem/pmg.py) -- 14-15 applications per
+               # solve where the multicolour ILU(0) needs 33
+               'preconditioner': 'pmg', 'ilu_lag': 8.0,
+               'pmg': {'pre': 2, 'post': 2, 'coarse_steps': 4,
+                       'ratio_fine': 8.0, 'ratio_coarse': 8.0},
                # the sweeps read the factors rounded to fp32 (fp64 arithmetic):
                # half the bytes per application, same iteration counts
                'ilu_storage': 'fp32',
@@ -376,19 +382,23 @@ def _compute_tentative_velocity(
 
         ops.fill(dx, 0.0)
         pre = None
-        with_ilu = npar.get('preconditioner', 'jacobi') == 'ilu0'
+        kind = npar.get('preconditioner', 'jacobi')
+        if kind == 'pmg' and lay.degree != 2:
+            kind = 'ilu0'
+        with_ilu = kind in ('ilu0', 'pmg')
         # matrix-free Newton-Krylov: J(ui) is applied cell by cell (as cheap
         # as the assembled 2x2-block SpMV) and only assembled when the lagged
-        # ILU(0) has to be refactored
+        # preconditioner has to be rebuilt
         matfree = with_ilu and npar.get('matrix_free', True)
         if not matfree:
             assemble_jacobian()
         if with_ilu:
             from ..fem import ilu
-            pre = lay._dev.get('jacobian_ilu')
+            slot = 'jacobian_ilu' if kind == 'ilu0' else 'jacobian_pmg'
+            pre = lay._dev.get(slot)
             key = (rho, mu, theta_i, nbc, hash(bc_dofs_host.tobytes()))
             # lagged preconditioner: J = M + dt (...) changes slowly from
-            # step to step.  Refactor when the problem itself changed, when dt
+            # step to step.  Rebuild when the problem itself changed, when dt
             # has moved by more than `ilu_lag` since the last factorisation
             # (checked at the first Newton iteration of a step), or when the
             # factors have gone stale: a solve needed more than twice the
@@ -401,11 +411,18 @@ def _compute_tentative_velocity(
                                      <= npar['ilu_lag'])):
                 if matfree:
                     assemble_jacobian()
-                if pre is None:
+                if kind == 'pmg':
+                    if pre is None:
+                        from ..fem.pmg import Pmg
+                        pre = Pmg(W, **npar.get('pmg', {}))
+                        lay._dev[slot] = pre
+                    pre.refactor(J, _coarse_jacobian(
+                        pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host))
+                elif pre is None:
                     pre = ilu.Ilu0(
                         J, packed=npar.get('ilu_storage', 'fp32') == 'fp32',
                         single_vector=npar.get('ilu_vector') == 'fp32')
-                    lay._dev['jacobian_ilu'] = pre
+                    lay._dev[slot] = pre
                 else:
                     pre.refactor(J)
                 pre.dt, pre.key, pre.stale = dt, key, False
@@ -437,7 +454,9 @@ def _compute_tentative_velocity(
             expected = lay._dev.setdefault('gmres_expected', {})
             sol = ops.krylov_solve(
                 'gmres', operator, F, dx, rtol=lin_rtol, atol=0.0,
-                maxit=npar['linear_maxit'], ilu=pre,
+                maxit=npar['linear_maxit'],
+                ilu=pre if kind == 'ilu0' else None,
+                pmg=pre if kind == 'pmg' else None,
                 restart=npar['gmres_restart'], x_is_zero=True,
                 dinv='jacobi' if pre is None else None,
                 first_check=expected.get(it, 0)
@@ -448,6 +467,7 @@ def _compute_tentative_velocity(
             its = (sol.iterations + 1) // 2
             applications.append(sol.iterations)
         else:
+            assert kind != 'pmg', 'the p-multigrid needs the flexible GMRES'
             sol, its = _bicgstab_with_restarts(operator, F, dx, lin_rtol, pre, npar)
             applications.append(2 * its)
         last_linear_residual = sol.residual
@@ -467,6 +487,48 @@ def _compute_tentative_velocity(
     return ui, alpha
 
 
+def _coarse_jacobian(pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host):
+    """The Jacobian of the P1 discretisation of the same Newton system at the
+    vertex values of `ui` (the coarse level of flow_amd/fem/pmg.py): assembled
+    by the P1 instance of the momentum kernel (the P1-P1 element pair of
+    BASELINE config 2 runs through it), Dirichlet rows -> identity rows."""
+    lib = _hip.lib()
+    mesh = W.mesh()
+    lay, lay1 = W.layout, pre.lay1
+    n, n1 = lay.N, lay1.N
+    nc = mesh.num_cells()
+    st = _hip.stream()
+    hold = lay._dev.setdefault('pmg_coarse', {})
+    if 'J1' not in hold:
+        hold['J1'] = ops.Matrix(lay1, 2)
+        hold['ui1'] = device.empty(2 * n1)
+        hold['vd'] = device.to_device(lay.vertex_dofs.astype(numpy.int32))
+    J1, ui1 = hold['J1'], hold['ui1']
+    _hip.check(lib.flow_gather_rows(
+        2, _hip.i32(hold['vd'], n1), n1, _hip.f64(ui.data, 2 * n), n,
+        _hip.f64(ui1, 2 * n1), n1, st))
+    f0s, keep0 = ops.coef_struct(f0, mesh, 1)
+    f1s, keep1 = ops.coef_struct(f1, mesh, 1)
+    s1 = ops.space_struct(lay1)
+    buf = ops.scratch(mesh, 4 * lay1.nloc**2 * nc)
+    _hip.check(lib.flow_assemble_momentum(
+        ctypes.byref(ops.mesh_struct(mesh)), ctypes.byref(s1),
+        ctypes.byref(ops.space_struct(P.layout)),
+        _hip.i32(bfmask, nc, 'bfmask'), _hip.f64(ui1, 2 * n1),
+        _hip.f64(ui1, 2 * n1), _hip.f64(p0.data, P.size()),
+        ctypes.byref(f0s), ctypes.byref(f1s), ctypes.byref(prm),
+        _hip.f64(buf), None, _hip.f64(J1.vals, 4 * J1.stride), J1.stride, st
+        ))
+    del keep0, keep1
+    bc1_host, bc1 = pre.set_bcs(bc_dofs_host)
+    if len(bc1_host):
+        _hip.check(lib.flow_bc_identity_rows(
+            ctypes.byref(J1.operator()), _hip.f64(J1.vals),
+            _hip.i32(lay1.dev('diag_idx')), len(bc1_host), _hip.i32(bc1), st
+            ))
+    return J1
+
+
 def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
                                   dt, tol):
     '''The Newton iteration of _compute_tentative_velocity on the x-strips of
@@ -484,7 +546,9 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
     nc = mesh.num_cells()
     n2 = W.size()
     npar = solver_parameters['newton']
-    assert npar.get('preconditioner', 'ilu0') == 'ilu0' and \
+    # (the strips run GMRES + block-Jacobi ILU(0), whatever the single-GPU
+    # preconditioner is)
+    assert npar.get('preconditioner', 'ilu0') in ('ilu0', 'pmg') and \
         npar.get('linear_solver', 'gmres') == 'gmres', \
         'the strips run GMRES + block-Jacobi ILU(0)'
     ms = parallel.mesh_view(mesh)

@@ -121,6 +121,11 @@ int flow_axpby(int n, double a, const double* x, double b, double* y,
 int flow_vmul(int n, double a, const double* x, const double* y, double* out,
               void* stream);                        /* out = a x .* y */
 int flow_fill(int n, double value, double* y, void* stream);   /* y = value */
+/* dst[a*dst_stride + k] = src[a*src_stride + idx[k]], k < m, a < ncomp: the
+ * vertex values of a P2 field (the linearisation point of the P1 level of
+ * flow_pmg) */
+int flow_gather_rows(int ncomp, const int* idx, int m, const double* src,
+                     int src_stride, double* dst, int dst_stride, void* stream);
 #define FLOW_REDUCE_WORK 4096   /* doubles of `work` the reductions need */
 
 /* Two-level additive preconditioner  z = D^-1 r + P Ac^-1 P^T r  for scalar
@@ -251,6 +256,61 @@ int flow_ilu0_pack(const flow_ilu* ilu, float* packed, void* stream);
 int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
                     double* work, void* stream);
 
+/* ---- K17: p-multigrid / Chebyshev preconditioner ---------------------------
+ * (a second stand-in for the sparse LU of the Newton solve,
+ * pressure_correction.py:224-254, as the right preconditioner of
+ * flow_gmres_solve).  Two levels on the SAME mesh, both made of CSR-stream
+ * products only (no dependent sweeps):
+ *   fine    the two diagonal blocks of the assembled Jacobian J = dF1/dui over
+ *           the scalar P2 pattern, rounded to fp32 and interleaved (vals: nnz
+ *           float2 = (J00, J11) per nonzero), smoothed with `pre` / `post`
+ *           steps of the Chebyshev iteration for D^-1 A on [lam_min, lam_max];
+ *   coarse  the P1 discretisation of the same linearised operator (P1 is a
+ *           subspace of P2: a vertex dof copies its vertex, an edge dof
+ *           averages its two end points), packed the same way;
+ *           `coarse_steps` Chebyshev steps from a zero start.
+ * One application z = M^-1 r:
+ *   x = cheb_pre(r) ; rc = P^T (r - A x) ; xc = cheb_coarse(rc) ;
+ *   x += P xc ; x += cheb_post(r - A x).
+ * Vectors inside are fp32, both components interleaved (float2 per dof): the
+ * application is not exactly linear in r -- for FLEXIBLE Krylov methods only
+ * (flow_gmres_solve is one).  Rows of Dirichlet dofs are identity rows of J:
+ * z = r there (bc_fine); the coarse residual is zeroed on the Dirichlet rows
+ * of the coarse operator (bc_coarse), whose rows are identity rows too.
+ * Level arrays as flow_operator: cols readable at nnz, vals 16-byte aligned
+ * and readable one float2 past nnz. */
+typedef struct {
+  int n, nnz, nblocks;
+  const int* rowptr;       /* n+1 */
+  const int* cols;         /* nnz */
+  const int* rowblocks;    /* nblocks+1: CSR-stream row blocks */
+  const float* vals;       /* nnz float2 (filled by flow_pmg_pack) */
+  const float* dinv;       /* n float2: 1 / diagonal of the two blocks */
+  double lam_min, lam_max; /* Chebyshev interval for D^-1 A (flow_pmg_lambda_max
+                              gives the upper end) */
+} flow_pmg_level;
+typedef struct {
+  flow_pmg_level fine, coarse;
+  int pre, post, coarse_steps;     /* Chebyshev steps: >= 1 each */
+  const int* ends;                 /* fine.n int2: coarse rows of a fine dof */
+  const int* rptr;                 /* coarse.n+1: restriction lists ... */
+  const int* rsrc;                 /* ... of fine dofs; the FIRST entry of a list
+                                      is the vertex's own dof (weight 1), the
+                                      others are edge dofs (weight 1/2) */
+  const unsigned char* bc_fine;    /* 2*fine.n bytes (component-blocked), NULL: none */
+  const unsigned char* bc_coarse;  /* 2*coarse.n bytes, NULL: none */
+  float* work;                     /* 12*fine.n + 8*coarse.n floats, 16-B aligned */
+} flow_pmg;
+/* vals[k] = (float)(a00[k], a11[k]); dinv[i] = 1 / (a00, a11)[diag_idx[i]] */
+int flow_pmg_pack(int n, int nnz, const int* diag_idx, const double* a00,
+                  const double* a11, float* vals, float* dinv, void* stream);
+/* spectral radius of D^-1 A of a level by `iterations` (>= 2) steps of the
+ * power method.  work: 6*n floats, dwork: FLOW_REDUCE_WORK doubles. */
+int flow_pmg_lambda_max(const flow_pmg_level* level, int iterations, float* work,
+                        double* dwork, double* result_host, void* stream);
+/* z = M^-1 r (r, z: 2*fine.n doubles, component-blocked) */
+int flow_pmg_apply(const flow_pmg* pmg, const double* r, double* z, void* stream);
+
 /* ---- K12: Krylov drivers -------------------------------------------------
  * Device-resident loops.  Convergence is decided ON THE DEVICE: the kernel
  * that computes the solver scalars compares the residual norm with the target
@@ -289,8 +349,9 @@ int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
                         double rtol, double atol, int maxit, int check_every,
                         int first_check, double* work, size_t work_len,
                         int* iters_host, double* resid_host, void* stream);
-/* GMRES(restart), right-preconditioned with ILU(0) (ilu != NULL), Jacobi (dinv
- * != NULL) or nothing: the Newton systems of the tentative velocity
+/* GMRES(restart), right-preconditioned with the p-multigrid / Chebyshev cycle
+ * (pmg != NULL), ILU(0) (ilu != NULL), Jacobi (dinv != NULL) or nothing -- at
+ * most one of pmg / ilu: the Newton systems of the tentative velocity
  * (pressure_correction.py:224-254) -- one operator + preconditioner application
  * per iteration, ~15 % fewer of them than BiCGStab needs there.  Classical
  * Gram-Schmidt with one reduction per iteration; the Hessenberg matrix, the
@@ -311,7 +372,8 @@ int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
 #define FLOW_GMRES_PARTIALS ((FLOW_GMRES_MAX_RESTART + 2) * 1024)
 #define FLOW_GMRES_STATE 1280
 int flow_gmres_solve(const flow_operator* A, const double* dinv,
-                     const flow_ilu* ilu, const double* b, double* x,
+                     const flow_ilu* ilu, const flow_pmg* pmg, const double* b,
+                     double* x,
                      double rtol, double atol, int maxit, int restart,
                      int x_is_zero, int expected_its, double* work,
                      size_t work_len, int* iters_host, double* resid_host,

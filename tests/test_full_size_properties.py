@@ -226,6 +226,7 @@ def test_steps_are_reproducible(problem):
         p.dt, p.t = 1.0e-5, 0.0
         lay = p.W.layout
         lay._dev.pop('jacobian_ilu', None)
+        lay._dev.pop('jacobian_pmg', None)
         lay._dev.pop('newton_quad_C', None)
         if hasattr(p, '_umag'):
             del p._umag

@@ -270,7 +270,8 @@ def test_start_vectors_do_not_change_the_solution(hip):
 @pytest.mark.gpu
 def test_prepare_builds_the_caches_and_leaves_no_trace_in_the_fields(hip):
     '''KarmanProblem.prepare() (bench.py: one throw-away step before the timed
-    windows) creates the cached structures -- the ILU(0) plan among them -- and
+    windows) creates the cached structures -- the preconditioner of the Newton
+    systems among them -- and
     resets fields and clock; the steps that follow agree with those of a problem
     that was never prepared to the solvers' tolerance (caches and
     preconditioners only change Krylov paths).'''
@@ -279,7 +280,7 @@ def test_prepare_builds_the_caches_and_leaves_no_trace_in_the_fields(hip):
     b = karman.KarmanProblem(120, 28, velocity_degree=2)
     a.prepare()
     lay = a.W.layout
-    assert 'ilu_plan' in lay._dev and lay._dev['jacobian_ilu'].stale
+    assert lay._dev['jacobian_pmg'].stale
     assert a.t == 0.0 and a.dt == 1.0e-5 and a.history == []
     assert float(a.u0.data.abs().max()) == 0.0
     assert float(a.p0.data.abs().max()) == 0.0

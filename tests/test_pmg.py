@@ -1,0 +1,196 @@
+# -*- coding: utf-8 -*-
+'''
+The p-multigrid / Chebyshev preconditioner of the Newton systems
+(flow_amd/fem/pmg.py, flow_amd/csrc/pmg_kernels.hip): transfer tables on the
+CPU; on the GPU one application against a numpy restatement of the cycle built
+from the same matrices, the spectral-radius estimate, and GMRES with it against
+a direct solve and against the multicolour ILU(0).
+'''
+import numpy
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from flow_amd import fem
+from flow_amd.fem.pmg import transfer_tables
+from flow_amd.fem.space import scalar_layout
+
+import cases
+
+
+def _prolongation(lay2):
+    ends, rptr, rsrc = transfer_tables(lay2)
+    n, n1 = lay2.N, lay2.mesh.num_vertices()
+    rows = numpy.repeat(numpy.arange(n), 2)
+    P = sp.csr_matrix((numpy.full(2 * n, 0.5), (rows, ends.ravel())),
+                      shape=(n, n1))
+    return P, ends, rptr, rsrc
+
+
+@pytest.mark.parametrize('fitted', [False, True])
+def test_transfer_tables_embed_p1_in_p2(fitted):
+    mesh = fem.karman_channel(36, 12, fitted=fitted)
+    lay2 = scalar_layout(mesh, 2)
+    lay1 = scalar_layout(mesh, 1)
+    P, ends, rptr, rsrc = _prolongation(lay2)
+    # a P1 function is reproduced at every P2 node
+    f = lambda x: 0.3 - 1.7 * x[:, 0] + 2.9 * x[:, 1]
+    assert abs(P.dot(f(lay1.dof_coords)) - f(lay2.dof_coords)).max() < 1e-13
+    # the restriction lists are the transpose: own dof first (weight 1), then
+    # the edge dofs (weight 1/2)
+    R = P.T.tocsr()
+    n1 = lay1.N
+    assert rptr[0] == 0 and rptr[-1] == len(rsrc) and len(rptr) == n1 + 1
+    for v in (0, 1, n1 // 2, n1 - 1):
+        own, others = rsrc[rptr[v]], rsrc[rptr[v] + 1:rptr[v + 1]]
+        assert own == lay2.vertex_dofs[v]
+        row = R.getrow(v)
+        want = dict(zip(row.indices, row.data))
+        assert want.pop(own) == 1.0
+        assert sorted(want) == sorted(others)
+        assert all(w == 0.5 for w in want.values())
+    x = numpy.random.RandomState(0).standard_normal(lay2.N)
+    got = numpy.array([x[rsrc[rptr[v]]]
+                       + 0.5 * x[rsrc[rptr[v] + 1:rptr[v + 1]]].sum()
+                       for v in range(n1)])
+    assert abs(got - R.dot(x)).max() < 1e-13
+
+
+# -- numpy restatement of one application -------------------------------------------
+def _cheb(A, D, lo, hi, k, r, x=None):
+    theta, delta = 0.5 * (hi + lo), 0.5 * (hi - lo)
+    sigma = theta / delta
+    rho = 1.0 / sigma
+    if x is None:
+        x = numpy.zeros_like(r)
+        res = r.copy()
+    else:
+        res = r - A.dot(x)
+    d = res / D / theta
+    for j in range(k):
+        x = x + d
+        if j + 1 < k:
+            res = res - A.dot(d)
+            rn = 1.0 / (2.0 * sigma - rho)
+            d = rn * rho * d + 2.0 * rn / delta * res / D
+            rho = rn
+    return x
+
+
+def _cycle(pre, A, A1, P, bc0, bc1, r):
+    '''One component of flow_pmg_apply in fp64.'''
+    f, c = pre.fine.struct, pre.coarse.struct
+    s = pre.struct
+    D, D1 = A.diagonal(), A1.diagonal()
+    x = _cheb(A, D, f.lam_min, f.lam_max, s.pre, r)
+    rc = P.T.dot(r - A.dot(x))
+    rc[bc1] = 0.0
+    x = x + P.dot(_cheb(A1, D1, c.lam_min, c.lam_max, s.coarse_steps, rc))
+    x = _cheb(A, D, f.lam_min, f.lam_max, s.post, r, x)
+    x[bc0] = r[bc0]
+    return x
+
+
+@pytest.fixture(scope='module')
+def newton_system(hip):
+    '''A Karman problem after two CFL-sized steps with the p-multigrid: the
+    assembled Jacobians of both levels and the preconditioner built from
+    them.'''
+    from flow_amd import karman
+    import flow_amd.navier_stokes as navsto
+    old = navsto.solver_parameters['newton']['preconditioner']
+    navsto.solver_parameters['newton']['preconditioner'] = 'pmg'
+    try:
+        prob = karman.KarmanProblem(160, 37, mu=0.02)
+        prob.set_initial_profile()
+        prob.dt = prob.hmax / 0.016
+        infos = [prob.step(adapt=False) for _ in range(2)]
+    finally:
+        navsto.solver_parameters['newton']['preconditioner'] = old
+    lay = prob.W.layout
+    pre = lay._dev['jacobian_pmg']
+    J = lay._dev['jacobian']
+    J1 = lay._dev['pmg_coarse']['J1']
+    return prob, infos, pre, J, J1
+
+
+@pytest.mark.gpu
+def test_one_application_matches_the_numpy_cycle(newton_system):
+    from flow_amd import device
+    prob, infos, pre, J, J1 = newton_system
+    lay = prob.W.layout
+    n, n1 = lay.N, pre.lay1.N
+    Js, J1s = J.to_scipy().tocsr(), J1.to_scipy().tocsr()
+    P = _prolongation(lay)[0]
+    bc0 = device.to_host(pre._keep['bc_fine']).numpy().astype(bool)
+    bc1 = device.to_host(pre._keep['bc_coarse']).numpy().astype(bool)
+    assert bc0.sum() > 0 and bc1.sum() > 0
+    # the Dirichlet rows are identity rows on both levels
+    for M, m in ((Js, bc0), (J1s, bc1)):
+        rows = numpy.nonzero(m)[0]
+        sub = M[rows]
+        assert abs(sub.dot(numpy.ones(M.shape[1])) - 1.0).max() == 0.0
+    rng = numpy.random.RandomState(4)
+    for trial in range(2):
+        r = rng.standard_normal(2 * n)
+        if trial == 1:
+            r[bc0] = 0.0          # what the Newton systems hand it
+        z = device.zeros(2 * n)
+        pre.apply(device.to_device(r), z)
+        got = device.to_host(z).numpy()
+        ref = numpy.concatenate([
+            _cycle(pre, Js[a * n:(a + 1) * n, a * n:(a + 1) * n].tocsr(),
+                   J1s[a * n1:(a + 1) * n1, a * n1:(a + 1) * n1].tocsr(), P,
+                   bc0[a * n:(a + 1) * n], bc1[a * n1:(a + 1) * n1],
+                   r[a * n:(a + 1) * n]) for a in (0, 1)])
+        # fp32 matrices and vectors inside
+        assert cases.rel_l2(got, ref) < 2e-5, trial
+        assert numpy.array_equal(got[bc0], r[bc0].astype(numpy.float32))
+
+
+@pytest.mark.gpu
+def test_spectral_radius_estimate(newton_system):
+    prob, infos, pre, J, J1 = newton_system
+    for lvl, M, lam in ((pre.fine, J, pre.lam[0]), (pre.coarse, J1, pre.lam[1])):
+        Ms = M.to_scipy().tocsr()
+        n = lvl.lay.N
+        want = 0.0
+        for a in (0, 1):
+            B = Ms[a * n:(a + 1) * n, a * n:(a + 1) * n].tocsr()
+            DB = sp.diags(1.0 / B.diagonal()).dot(B)
+            ev = spla.eigs(DB, k=1, which='LM', return_eigenvectors=False,
+                           tol=1e-4)
+            want = max(want, abs(ev[0]))
+        # the power method from a fixed start after 25 steps: a lower bound
+        # within a few per cent (the interval adds 10 % on top)
+        assert 0.93 * want < lam <= 1.001 * want, (lam, want)
+        assert lvl.struct.lam_max >= 0.99 * want
+
+
+@pytest.mark.gpu
+def test_gmres_with_the_cycle_against_direct_solve_and_ilu(newton_system):
+    from flow_amd import device
+    from flow_amd.fem import ilu, ops
+    prob, infos, pre, J, J1 = newton_system
+    lay = prob.W.layout
+    n = lay.N
+    Js = J.to_scipy().tocsc()
+    rng = numpy.random.RandomState(8)
+    b = rng.standard_normal(2 * n)
+    ref = spla.splu(Js).solve(b)
+    counts = {}
+    for name, kw in (('pmg', dict(pmg=pre)),
+                     ('ilu0', dict(ilu=ilu.Ilu0(J, packed=True,
+                                                single_vector=True)))):
+        x = device.zeros(2 * n)
+        info = ops.krylov_solve('gmres', J, device.to_device(b), x, rtol=1e-10,
+                                maxit=400, restart=10, x_is_zero=True,
+                                dinv=None, **kw)
+        assert cases.rel_l2(device.to_host(x).numpy(), ref) < 1e-8, (name, info)
+        counts[name] = info.iterations
+    print('GMRES(10) applications to 1e-10:', counts)
+    assert counts['pmg'] < counts['ilu0'], counts
+    # the steps of the fixture converged with it, one Newton iteration each
+    for i in infos:
+        assert len(i['newton_residuals']) >= 2
+        assert i['newton_residuals'][-1] < 1e-10
