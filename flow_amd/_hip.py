@@ -23,6 +23,7 @@ GMRES_PARTIALS = (GMRES_MAX_RESTART + 2) * 1024
 GMRES_STATE = 1280
 SPMV_ROWS_PER_BLOCK = 256
 SPMV_NNZ_PER_BLOCK = 1022
+PMG_NNZ_PER_BLOCK = 2044
 
 c_double_p = ctypes.c_void_p
 c_int_p = ctypes.c_void_p
@@ -109,7 +110,8 @@ class PmgLevelS(ctypes.Structure):
         ('n', ctypes.c_int), ('nnz', ctypes.c_int), ('nblocks', ctypes.c_int),
         ('rowptr', ctypes.c_void_p), ('cols', ctypes.c_void_p),
         ('rowblocks', ctypes.c_void_p),
-        ('vals', ctypes.c_void_p), ('dinv', ctypes.c_void_p),
+        ('vals', ctypes.c_void_p), ('diag', ctypes.c_void_p),
+        ('dinv', ctypes.c_void_p),
         ('lam_min', ctypes.c_double), ('lam_max', ctypes.c_double),
         ]
 
@@ -222,6 +224,7 @@ SYMBOLS = {
     'flow_profile_spmv_begin': [_I, _I],
     'flow_profile_spmv_end': [_P(_D), _P(_I)],
     'flow_profile_event_overhead': [_P(_D), _VP],
+    'flow_profile_marker': [_I, _VP],
     'flow_operator_diag_inv': [_P(Operator), _VP, _VP, _VP],
     'flow_dot_host': [_I, _VP, _VP, _VP, _P(_D), _VP],
     'flow_norm_host': [_I, _VP, _I, _VP, _P(_D), _VP],
@@ -238,7 +241,7 @@ SYMBOLS = {
     'flow_gmres_solve': [_P(Operator), _VP, _P(IluS), _P(PmgS), _VP, _VP, _D,
                          _D, _I, _I, _I, _I, _VP, ctypes.c_size_t, _P(_I),
                          _P(_D), _VP],
-    'flow_pmg_pack': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP],
+    'flow_pmg_pack': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _P(_D), _VP],
     'flow_pmg_apply': [_P(PmgS), _VP, _VP, _VP],
     'flow_gather_rows': [_I, _VP, _I, _VP, _I, _VP, _I, _VP],
@@ -367,6 +370,10 @@ def f64(t, numel=None, name='fp64 operand'):
 
 def f32(t, numel=None, name='fp32 operand'):
     return _ptr(t, torch.float32, numel, name)
+
+
+def f16(t, numel=None, name='fp16 operand'):
+    return _ptr(t, torch.float16, numel, name)
 
 
 def i32(t, numel=None, name='int32 operand'):

@@ -7,87 +7,112 @@
 // GMRES of la_kernels.hip.  Why another one: the ILU(0) sweeps are a chain of
 // ~15 dependent launches bound by gather latency (0.30 of the HBM roofline) and
 // a multicolour factorisation is a weak one (33 applications per solve at
-// CFL-sized steps on the 10 M-DoF workload).  This preconditioner consists of
+// CFL-sized steps on the 10 M-DoF workload; this one: 13).  It consists of
 // CSR-stream products only:
 //
-//   fine level    the two diagonal blocks of the assembled P2 Jacobian, rounded
-//                 to fp32 and interleaved (ONE index + one 8-byte value load per
-//                 nonzero for both velocity components), smoothed with `pre` /
-//                 `post` steps of the Chebyshev iteration for D^-1 A;
+//   fine level    the two diagonal blocks of the assembled P2 Jacobian, row-
+//                 scaled with their diagonals (D^-1 A: entries of size <= ~1),
+//                 rounded to fp16 and interleaved -- ONE index + one 4-byte
+//                 value load per nonzero serves both velocity components, 8 B
+//                 per nonzero where the fp64 Jacobian planes have 20 --,
+//                 smoothed with `pre` / `post` steps of the Chebyshev iteration;
 //   coarse level  the P1 discretisation of the same linearised operator on the
 //                 same mesh (P1 is a subspace of P2: vertex dofs copy, edge
-//                 dofs average their end points), `coarse` Chebyshev steps
-//                 from a zero start -- at CFL-sized steps the P1 operator is
-//                 mass-dominated (condition ~10) and needs no further levels.
+//                 dofs average their end points), `coarse_steps` Chebyshev
+//                 steps from a zero start -- at CFL-sized steps the P1 operator
+//                 is mass-dominated (condition ~10) and needs no further levels.
 //
-// All vectors inside are fp32, both components interleaved (float2 per dof: one
-// 8-byte gather per nonzero serves both blocks); an application is therefore
-// not exactly linear in its input, which the flexible GMRES does not need
-// (la_kernels.hip: it keeps Z_j = M^-1 V_j and updates x with it).
-// Every kernel is HBM-bound: 12 B per nonzero + ~10 float2 vectors per cycle.
+// A smoother does not need its matrix to more than three digits (tools/
+// precond_lab.py: the same GMRES counts with fp64, fp32 and fp16 entries), and
+// the Krylov method around it is flexible: all vectors inside are fp32, both
+// components interleaved (float2 per dof: one 8-byte gather per nonzero).  The
+// iteration runs on the SCALED residual rho = D^-1 (r - A x):
+//   d_0 = rho_0 / theta;  rho_{k+1} = rho_k - (D^-1 A) d_k;
+//   d_{k+1} = c1 d_k + c2 rho_{k+1};  x = sum_k d_k
+// so that no kernel but the first reads the diagonal.  Every kernel is
+// HBM-bound: 8 B per nonzero + a few float2 vectors.
 #include "common.h"
+
+#include <hip/hip_fp16.h>
 
 namespace flow {
 
-constexpr int kPmgPairs = 2;                         // nonzero pairs per lane
-constexpr int kPmgTile = 2 * kBlock * kPmgPairs;     // LDS products per workgroup
-static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kPmgTile - 2, "tile minus alignment slack");
+constexpr int kPmgQuads = 2;                      // quads of nonzeros per lane
+constexpr int kPmgTile = kBlock * 4 * kPmgQuads;  // LDS products per workgroup
+static_assert(FLOW_PMG_NNZ_PER_BLOCK == kPmgTile - 4,
+              "tile minus alignment slack (base aligned down to a multiple of 4)");
 
 __device__ __forceinline__ float2 f2(float a, float b) { return make_float2(a, b); }
 
-// One tile of the packed stream -- rows [r0, r1) of workgroup blockIdx.x: the
-// products of both blocks with the gathered vector g go through LDS, then lane
-// i sums row r0 + i.  Same tiling, alignment rules and window safety as
+struct Half2x4 {           // four nonzeros: (block 0, block 1) each, 16 bytes
+  __half2 v[4];
+};
+static_assert(sizeof(Half2x4) == 16, "packed quad");
+
+// One tile of the packed stream -- rows [r0, r1) of workgroup blockIdx.x (at
+// most kBlock rows, kPmgTile - 4 nonzeros): every lane loads kPmgQuads 16-byte
+// quads of values and of column indices (the tile base is aligned down to a
+// multiple of four nonzeros), all of them and all gathers behind them in flight
+// before the first use -- the kernel is bound by the chain of dependent loads
+// of a tile (row blocks -> row pointers -> indices -> gathers), so a tile
+// carries as many bytes as the LDS products of a workgroup allow (16 KB: still
+// eight workgroups per CU) --, the products of both blocks with the gathered
+// vector g go through LDS, then lane i sums row r0 + i.  Window-safe like
 // stream_tile_row_sum (la_kernels.hip): g is only dereferenced for the tile's
-// own nonzeros.
+// own nonzeros (slack and idle lanes gather the tile's first column).
 __device__ __forceinline__ float2 pmg_tile_row_sum(
     const int* __restrict__ rowptr, const int* __restrict__ cols,
-    const float2* __restrict__ vals, const int* __restrict__ rowblocks,
+    const __half2* __restrict__ vals, const int* __restrict__ rowblocks,
     const float2* __restrict__ g, float2* __restrict__ prod, int& r, int& r1) {
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int r0 = rowblocks[tile];
   r1 = rowblocks[tile + 1];
   const int k0 = rowptr[r0];
   const int k1 = rowptr[r1];
-  const int ka = k0 & ~1;
+  const int ka = k0 & ~3;
   r = r0 + threadIdx.x;
   int a = 0, b = 0;
   if (r < r1) {
     a = rowptr[r] - ka;
     b = rowptr[r + 1] - ka;
   }
-  const float4* __restrict__ v4p = reinterpret_cast<const float4*>(vals + ka);
-  const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
-  const int npair = (k1 - ka + 1) >> 1;
-  float4 v[kPmgPairs];
-  int2 c[kPmgPairs];
+  const int lo = k0 - ka, hi = k1 - ka;          // hi <= kPmgTile - 1
+  const Half2x4* __restrict__ vq = reinterpret_cast<const Half2x4*>(vals + ka);
+  const int4* __restrict__ cq = reinterpret_cast<const int4*>(cols + ka);
+  Half2x4 v[kPmgQuads];
+  int4 c[kPmgQuads];
 #pragma unroll
-  for (int j = 0; j < kPmgPairs; ++j) {
-    const int p = threadIdx.x + j * kBlock;
-    const bool ok = p < npair;
-    v[j] = ok ? v4p[p] : make_float4(0.f, 0.f, 0.f, 0.f);
-    c[j] = ok ? c2p[p] : make_int2(0, 0);
-  }
-  const int lo = k0 - ka, hi = k1 - ka;
-  const int safe = cols[k0 < k1 ? k0 : (k0 > 0 ? k0 - 1 : 0)];
-  float2 g0[kPmgPairs], g1[kPmgPairs];
-  if (k0 < k1) {                       // (block-uniform)
-#pragma unroll
-    for (int j = 0; j < kPmgPairs; ++j) {   // all gathers in flight before any use
-      const int e = 2 * (threadIdx.x + j * kBlock);
-      g0[j] = g[(e >= lo && e < hi) ? c[j].x : safe];
-      g1[j] = g[(e + 1 < hi) ? c[j].y : safe];
+  for (int q = 0; q < kPmgQuads; ++q) {
+    const int p = threadIdx.x + q * kBlock;
+    c[q] = make_int4(0, 0, 0, 0);
+    if (4 * p < hi) {
+      v[q] = vq[p];
+      c[q] = cq[p];
     }
-  } else {
-#pragma unroll
-    for (int j = 0; j < kPmgPairs; ++j) g0[j] = g1[j] = f2(0.f, 0.f);
   }
+  if (k0 < k1) {                                   // (block-uniform)
+    const int safe = cols[k0];
+    float2 gg[kPmgQuads][4];
 #pragma unroll
-  for (int j = 0; j < kPmgPairs; ++j) {
-    const int p = threadIdx.x + j * kBlock;
-    if (p < npair) {
-      prod[2 * p] = f2(v[j].x * g0[j].x, v[j].y * g0[j].y);
-      prod[2 * p + 1] = f2(v[j].z * g1[j].x, v[j].w * g1[j].y);
+    for (int q = 0; q < kPmgQuads; ++q) {          // all gathers in flight
+      const int e0 = 4 * (threadIdx.x + q * kBlock);
+      const int cc[4] = {c[q].x, c[q].y, c[q].z, c[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j;
+        gg[q][j] = g[(e >= lo && e < hi) ? cc[j] : safe];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kPmgQuads; ++q) {
+      const int e0 = 4 * (threadIdx.x + q * kBlock);
+      if (e0 < hi) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float2 w = __half22float2(v[q].v[j]);
+          prod[e0 + j] = f2(w.x * gg[q][j].x, w.y * gg[q][j].y);
+        }
+      }
     }
   }
   __syncthreads();
@@ -100,175 +125,205 @@ __device__ __forceinline__ float2 pmg_tile_row_sum(
 }
 
 // One product with the packed operator plus what the Chebyshev iteration does
-// with it, row by row:
-//   res' = res - A g
-//   STEP:   d' = c1 d_own + c2 dinv res'   (d_own = nullptr: 0);   x' = x + d'
-//   FINAL:  x' goes out as fp64, component-blocked (z[a*n + row]); Dirichlet
-//           rows (bc != 0) return the input r32 there: their rows of the
-//           Jacobian are identity rows
-// res_out / d_out / x_out may be nullptr (not needed); res_out may alias
-// res_in and x_out may alias x_in (row-local); g must not be written.
-template <bool STEP, bool FINAL>
+// with it, row by row:   rho' = rho_in - (D^-1 A) g
+//   MODE 0  residual only:  rho_out = rho', times d_own[row] when that is given
+//                           (the diagonal: the unscaled residual r - A x)
+//   MODE 1  step:           d' = c1 d_own + c2 rho'  (d_own = nullptr: 0);
+//                           rho_out = rho' (nullptr: not needed), d_out = d',
+//                           x += d' (nullptr: the caller sums the d's later)
+//   MODE 2  last step:      z = x + d_own + d_extra + d'  as fp64, component-
+//                           blocked (z[a*n + row]); Dirichlet rows (bc != 0)
+//                           return the input r there: identity rows of J
+// rho_out may alias rho_in (row-local); g must not be written.
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void pmg_cheb_kernel(
     int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
-    const float2* __restrict__ vals, const int* __restrict__ rowblocks,
-    const float2* __restrict__ g, const float2* res_in, float2* res_out,
-    const float2* __restrict__ dinv, const float2* __restrict__ d_own, float c1,
-    float c2, float2* __restrict__ d_out, const float2* x_in, float2* x_out,
-    double* __restrict__ z, const unsigned char* __restrict__ bc,
-    const float2* __restrict__ r32, const double* __restrict__ stop) {
+    const __half2* __restrict__ vals, const int* __restrict__ rowblocks,
+    const float2* __restrict__ g, const float2* rho_in, float2* rho_out,
+    const float2* __restrict__ d_own, float c1, float c2,
+    float2* __restrict__ d_out, float2* __restrict__ x,
+    const float2* __restrict__ d_extra, double* __restrict__ z,
+    const unsigned char* __restrict__ bc, const double* __restrict__ rin,
+    const double* __restrict__ stop) {
   __shared__ float2 prod[kPmgTile];
   if (stopped(stop)) return;
   int r, r1;
   const float2 s = pmg_tile_row_sum(rowptr, cols, vals, rowblocks, g, prod, r, r1);
   if (r >= r1) return;
-  float2 res = res_in[r];
-  res.x -= s.x;
-  res.y -= s.y;
-  if (res_out) res_out[r] = res;
-  if (!STEP) return;
-  const float2 di = dinv[r];
-  float2 d = f2(c2 * di.x * res.x, c2 * di.y * res.y);
-  if (d_own) {
-    const float2 o = d_own[r];
-    d.x += c1 * o.x;
-    d.y += c1 * o.y;
-  }
-  if (d_out) d_out[r] = d;
-  float2 x = x_in[r];
-  x.x += d.x;
-  x.y += d.y;
-  if (FINAL) {
-    double zx = x.x, zy = x.y;
-    if (bc) {
-      const float2 in = r32[r];
-      if (bc[r]) zx = in.x;
-      if (bc[n + r]) zy = in.y;
+  float2 rho = rho_in[r];
+  rho.x -= s.x;
+  rho.y -= s.y;
+  if (MODE == 0) {
+    if (d_own) {
+      const float2 q = d_own[r];
+      rho.x *= q.x;
+      rho.y *= q.y;
     }
-    z[r] = zx;
-    z[static_cast<size_t>(n) + r] = zy;
-  } else {
-    x_out[r] = x;
+    rho_out[r] = rho;
+    return;
   }
+  float2 d = f2(c2 * rho.x, c2 * rho.y);
+  float2 own = f2(0.f, 0.f);
+  if (d_own) {
+    own = d_own[r];
+    d.x += c1 * own.x;
+    d.y += c1 * own.y;
+  }
+  if (MODE == 1) {
+    if (rho_out) rho_out[r] = rho;
+    d_out[r] = d;
+    if (x) {
+      float2 acc = x[r];
+      acc.x += d.x;
+      acc.y += d.y;
+      x[r] = acc;
+    }
+    return;
+  }
+  float2 acc = x[r];
+  acc.x += own.x + d.x;
+  acc.y += own.y + d.y;
+  if (d_extra) {
+    const float2 e = d_extra[r];
+    acc.x += e.x;
+    acc.y += e.y;
+  }
+  double zx = acc.x, zy = acc.y;
+  if (bc) {
+    if (bc[r]) zx = rin[r];
+    if (bc[n + r]) zy = rin[static_cast<size_t>(n) + r];
+  }
+  z[r] = zx;
+  z[static_cast<size_t>(n) + r] = zy;
 }
 
-// start of a Chebyshev run from x = 0 on the fine level: the fp64 component-
-// blocked input becomes r32 (kept for the post-smoothing) and res;
-// d = x = dinv res / theta
+// start of the cycle: the fp64 component-blocked input becomes the scaled
+// residual rho0 = D^-1 r (kept for the post-smoothing), rho = rho0 and
+// d0 = rho0 / theta
 __global__ __launch_bounds__(kBlock) void pmg_init_kernel(
-    int n, const double* __restrict__ r, float2* __restrict__ r32,
-    float2* __restrict__ res, const float2* __restrict__ dinv, float inv_theta,
-    float2* __restrict__ d, float2* __restrict__ x,
-    const double* __restrict__ stop) {
+    int n, const double* __restrict__ r, const float2* __restrict__ dinv,
+    float inv_theta, float2* __restrict__ rho0, float2* __restrict__ rho,
+    float2* __restrict__ d, const double* __restrict__ stop) {
   if (stopped(stop)) return;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
-    const float2 v = f2(static_cast<float>(r[i]),
-                        static_cast<float>(r[static_cast<size_t>(n) + i]));
     const float2 di = dinv[i];
-    const float2 d0 = f2(inv_theta * di.x * v.x, inv_theta * di.y * v.y);
-    r32[i] = v;
-    res[i] = v;
-    d[i] = d0;
-    x[i] = d0;
+    const float2 v = f2(static_cast<float>(r[i]) * di.x,
+                        static_cast<float>(r[static_cast<size_t>(n) + i]) * di.y);
+    rho0[i] = v;
+    rho[i] = v;
+    d[i] = f2(inv_theta * v.x, inv_theta * v.y);
   }
 }
 
-// the same on the coarse level (the input is already packed; res = the input
-// buffer itself)
-__global__ __launch_bounds__(kBlock) void pmg_init32_kernel(
-    int n, const float2* __restrict__ res, const float2* __restrict__ dinv,
-    float inv_theta, float2* __restrict__ d, float2* __restrict__ x,
-    const double* __restrict__ stop) {
-  if (stopped(stop)) return;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += gridDim.x * blockDim.x) {
-    const float2 v = res[i];
-    const float2 di = dinv[i];
-    const float2 d0 = f2(inv_theta * di.x * v.x, inv_theta * di.y * v.y);
-    d[i] = d0;
-    x[i] = d0;
-  }
-}
-
-// rc = P^T res: P1 row v collects its own P2 dof (weight 1, first in its list)
-// and the edge dofs around it (weight 1/2); Dirichlet rows of the coarse
-// operator get 0 (bcc: 2*n1 bytes, component-blocked)
+// coarse residual, scaled: rhoc = Dc^-1 P^T res -- P1 row v collects its own P2
+// dof (weight 1, first in its list) and the edge dofs around it (weight 1/2);
+// Dirichlet rows of the coarse operator get 0 (bcc: 2*n1 bytes, component-
+// blocked); xc = dc0 = rhoc / theta_c starts the coarse iteration
 __global__ __launch_bounds__(kBlock) void pmg_restrict_kernel(
     int n1, const int* __restrict__ rptr, const int* __restrict__ rsrc,
-    const float2* __restrict__ res, const unsigned char* __restrict__ bcc,
-    float2* __restrict__ rc, const double* __restrict__ stop) {
+    const float2* __restrict__ res, const float2* __restrict__ dinv_c,
+    const unsigned char* __restrict__ bcc, float inv_theta_c,
+    float2* __restrict__ rhoc, float2* __restrict__ dc, float2* __restrict__ xc,
+    const double* __restrict__ stop) {
   if (stopped(stop)) return;
+  constexpr int kAhead = 8;      // list entries in flight (a vertex has ~7)
   for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < n1;
        v += gridDim.x * blockDim.x) {
     const int a = rptr[v], b = rptr[v + 1];
-    float2 s = res[rsrc[a]];
+    int idx[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) idx[k] = rsrc[a + k < b ? a + k : a];
+    float2 t[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) t[k] = res[idx[k]];
+    float2 s = t[0];
     float2 e = f2(0.f, 0.f);
-    for (int k = a + 1; k < b; ++k) {
-      const float2 t = res[rsrc[k]];
-      e.x += t.x;
-      e.y += t.y;
+#pragma unroll
+    for (int k = 1; k < kAhead; ++k)
+      if (a + k < b) {
+        e.x += t[k].x;
+        e.y += t[k].y;
+      }
+    for (int k = a + kAhead; k < b; ++k) {
+      const float2 u = res[rsrc[k]];
+      e.x += u.x;
+      e.y += u.y;
     }
-    s.x += 0.5f * e.x;
-    s.y += 0.5f * e.y;
+    const float2 di = dinv_c[v];
+    s.x = (s.x + 0.5f * e.x) * di.x;
+    s.y = (s.y + 0.5f * e.y) * di.y;
     if (bcc) {
       if (bcc[v]) s.x = 0.f;
       if (bcc[n1 + v]) s.y = 0.f;
     }
-    rc[v] = s;
+    rhoc[v] = s;
+    const float2 d0 = f2(inv_theta_c * s.x, inv_theta_c * s.y);
+    dc[v] = d0;
+    xc[v] = d0;
   }
 }
 
-// x += P xc: ends[i] = the two P1 rows a P2 dof interpolates from (a vertex dof
-// names its vertex twice)
+// x = d_a + d_b + d_c + P (sum of the coarse corrections): ends[i] = the two P1
+// rows a P2 dof interpolates from (a vertex dof names its vertex twice);
+// nullptr terms are skipped
 __global__ __launch_bounds__(kBlock) void pmg_prolong_kernel(
-    int n, const int2* __restrict__ ends, const float2* __restrict__ xc,
-    float2* __restrict__ x, const double* __restrict__ stop) {
+    int n, const int2* __restrict__ ends, const float2* __restrict__ da,
+    const float2* __restrict__ db, const float2* __restrict__ dc,
+    const float2* __restrict__ xc, float2* __restrict__ x,
+    const double* __restrict__ stop) {
   if (stopped(stop)) return;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
     const int2 e = ends[i];
     const float2 a = xc[e.x], b = xc[e.y];
-    float2 v = x[i];
+    float2 v = da[i];
+    if (db) {
+      const float2 t = db[i];
+      v.x += t.x;
+      v.y += t.y;
+    }
+    if (dc) {
+      const float2 t = dc[i];
+      v.x += t.x;
+      v.y += t.y;
+    }
     v.x += 0.5f * (a.x + b.x);
     v.y += 0.5f * (a.y + b.y);
     x[i] = v;
   }
 }
 
-// setup: vals[k] = (a00[k], a11[k]) rounded; dinv[i] = 1 / diag
-__global__ void pmg_pack_kernel(int nnz, const double* __restrict__ a00,
-                                const double* __restrict__ a11,
-                                float2* __restrict__ vals) {
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nnz;
-       k += gridDim.x * blockDim.x)
-    vals[k] = f2(static_cast<float>(a00[k]), static_cast<float>(a11[k]));
-}
-
-__global__ void pmg_dinv_kernel(int n, const int* __restrict__ diag_idx,
+// setup: vals[k] = half2((a00, a11)[k] / their diagonals of row(k)); diag / dinv
+// per row.  A lane per row (setup only: once per refactorisation).
+__global__ void pmg_pack_kernel(int n, const int* __restrict__ rowptr,
+                                const int* __restrict__ diag_idx,
                                 const double* __restrict__ a00,
                                 const double* __restrict__ a11,
+                                __half2* __restrict__ vals,
+                                float2* __restrict__ diag,
                                 float2* __restrict__ dinv) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
-    const int k = diag_idx[i];
-    dinv[i] = f2(static_cast<float>(1.0 / a00[k]), static_cast<float>(1.0 / a11[k]));
+    const int kd = diag_idx[i];
+    const double d0 = a00[kd], d1 = a11[kd];
+    const double i0 = 1.0 / d0, i1 = 1.0 / d1;
+    diag[i] = f2(static_cast<float>(d0), static_cast<float>(d1));
+    dinv[i] = f2(static_cast<float>(i0), static_cast<float>(i1));
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      vals[k] = __floats2half2_rn(static_cast<float>(a00[k] * i0),
+                                  static_cast<float>(a11[k] * i1));
   }
 }
 
-// power iteration for the spectral radius of D^-1 A: w = dinv (A v) -- via
-// res' = 0 - A v in the product kernel -- then |w|^2 in block partials
-__global__ __launch_bounds__(kBlock) void pmg_scale_norm_kernel(
-    int n, const float2* __restrict__ dinv, float2* __restrict__ w,
-    double* __restrict__ partial) {
+// power iteration for the spectral radius of D^-1 A: |w|^2 in block partials
+// (w = -(D^-1 A) v comes out of the product kernel with rho_in = 0)
+__global__ __launch_bounds__(kBlock) void pmg_norm_kernel(
+    int n, const float2* __restrict__ w, double* __restrict__ partial) {
   double s = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
-    const float2 di = dinv[i];
-    float2 v = w[i];
-    v.x *= -di.x;
-    v.y *= -di.y;
-    w[i] = v;
+    const float2 v = w[i];
     s += static_cast<double>(v.x) * v.x + static_cast<double>(v.y) * v.y;
   }
   s = block_sum(s);
@@ -307,9 +362,12 @@ __global__ void pmg_zero_kernel(int n, float2* __restrict__ v) {
 // ---------------------------------------------------------------------------
 static int check_level(const flow_pmg_level* L, const char* which) {
   FLOW_REQUIRE(L->n > 0 && L->nnz > 0 && L->nblocks > 0, which);
-  FLOW_REQUIRE(L->rowptr && L->cols && L->rowblocks && L->vals && L->dinv, which);
-  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(L->vals) % 16 == 0,
-               "packed values must be 16-byte aligned");
+  FLOW_REQUIRE(L->rowptr && L->cols && L->rowblocks && L->vals && L->diag &&
+                   L->dinv,
+               which);
+  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(L->vals) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(L->cols) % 16 == 0,
+               "packed values and column indices must be 16-byte aligned");
   FLOW_REQUIRE(L->lam_max > L->lam_min && L->lam_min > 0.0,
                "Chebyshev interval (0 < lam_min < lam_max)");
   return FLOW_OK;
@@ -322,8 +380,8 @@ int pmg_check(const flow_pmg* M, int op_size) {
   if ((rc = check_level(&M->coarse, "coarse level of flow_pmg"))) return rc;
   FLOW_REQUIRE(2 * M->fine.n == op_size, "flow_pmg does not match the operator");
   FLOW_REQUIRE(M->pre >= 1 && M->post >= 1 && M->coarse_steps >= 1 &&
-                   M->pre <= 16 && M->post <= 16 && M->coarse_steps <= 32,
-               "Chebyshev step counts");
+                   M->pre <= 3 && M->post <= 3 && M->coarse_steps <= 32,
+               "Chebyshev step counts (pre, post: 1..3; coarse: 1..32)");
   FLOW_REQUIRE(M->ends && M->rptr && M->rsrc && M->work, "flow_pmg pointers");
   FLOW_REQUIRE(reinterpret_cast<uintptr_t>(M->work) % 16 == 0,
                "flow_pmg work must be 16-byte aligned");
@@ -338,7 +396,7 @@ struct Cheb {
       : theta(0.5 * (hi + lo)), delta(0.5 * (hi - lo)), sigma(theta / delta),
         rho(1.0 / sigma) {}
   float first() const { return static_cast<float>(1.0 / theta); }
-  // coefficients of the next step: d' = c1 d + c2 dinv res'
+  // coefficients of the next step: d' = c1 d + c2 rho'
   void next(float* c1, float* c2) {
     const double rn = 1.0 / (2.0 * sigma - rho);
     *c1 = static_cast<float>(rn * rho);
@@ -347,17 +405,17 @@ struct Cheb {
   }
 };
 
-template <bool STEP, bool FINAL>
-void launch_cheb(const flow_pmg_level* L, const float2* g, const float2* res_in,
-                 float2* res_out, const float2* d_own, float c1, float c2,
-                 float2* d_out, const float2* x_in, float2* x_out, double* z,
-                 const unsigned char* bc, const float2* r32, const double* stop,
+template <int MODE>
+void launch_cheb(const flow_pmg_level* L, const float2* g, const float2* rho_in,
+                 float2* rho_out, const float2* d_own, float c1, float c2,
+                 float2* d_out, float2* x, const float2* d_extra, double* z,
+                 const unsigned char* bc, const double* rin, const double* stop,
                  hipStream_t st) {
-  hipLaunchKernelGGL((pmg_cheb_kernel<STEP, FINAL>), dim3(L->nblocks),
-                     dim3(kBlock), 0, st, L->n, L->rowptr, L->cols,
-                     reinterpret_cast<const float2*>(L->vals), L->rowblocks, g,
-                     res_in, res_out, reinterpret_cast<const float2*>(L->dinv),
-                     d_own, c1, c2, d_out, x_in, x_out, z, bc, r32, stop);
+  hipLaunchKernelGGL((pmg_cheb_kernel<MODE>), dim3(L->nblocks), dim3(kBlock), 0,
+                     st, L->n, L->rowptr, L->cols,
+                     reinterpret_cast<const __half2*>(L->vals), L->rowblocks, g,
+                     rho_in, rho_out, d_own, c1, c2, d_out, x, d_extra, z, bc, rin,
+                     stop);
 }
 
 }  // namespace
@@ -369,16 +427,15 @@ int pmg_apply(const flow_pmg* M, const double* r, double* z, hipStream_t st,
   const flow_pmg_level* C = &M->coarse;
   const int n = F->n, n1 = C->n;
   float2* w = reinterpret_cast<float2*>(M->work);
-  float2* r32 = w;
-  float2* res = r32 + n;
-  float2* da = res + n;
-  float2* db = da + n;
-  float2* xa = db + n;
-  float2* xb = xa + n;
-  float2* crc = xb + n;
-  float2* cda = crc + n1;
-  float2* cdb = cda + n1;
-  float2* cx = cdb + n1;
+  float2* rho0 = w;
+  float2* rho = rho0 + n;
+  float2* d[3] = {rho + n, rho + 2 * static_cast<size_t>(n),
+                  rho + 3 * static_cast<size_t>(n)};
+  float2* x = rho + 4 * static_cast<size_t>(n);
+  float2* crho = x + n;
+  float2* cd[2] = {crho + n1, crho + 2 * static_cast<size_t>(n1)};
+  float2* cx = crho + 3 * static_cast<size_t>(n1);
+  const float2* fdiag = reinterpret_cast<const float2*>(F->diag);
   const float2* fdinv = reinterpret_cast<const float2*>(F->dinv);
   const float2* cdinv = reinterpret_cast<const float2*>(C->dinv);
   float2* const none = nullptr;
@@ -386,60 +443,52 @@ int pmg_apply(const flow_pmg* M, const double* r, double* z, hipStream_t st,
   const unsigned char* const nob = nullptr;
   float c1, c2;
 
-  // pre-smoothing from x = 0
+  // pre-smoothing from x = 0: d[0 .. pre-1]
   Cheb pre(F->lam_min, F->lam_max);
   hipLaunchKernelGGL(pmg_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, r,
-                     r32, res, fdinv, pre.first(), da, xa, stop);
-  float2 *dc = da, *dn = db;
+                     fdinv, pre.first(), rho0, rho, d[0], stop);
   for (int j = 1; j < M->pre; ++j) {
     pre.next(&c1, &c2);
-    launch_cheb<true, false>(F, dc, res, res, dc, c1, c2, dn, xa, xa, nod, nob,
-                             none, stop, st);
-    float2* t = dc;
-    dc = dn;
-    dn = t;
+    launch_cheb<1>(F, d[j - 1], rho, rho, d[j - 1], c1, c2, d[j], none, none, nod,
+                   nob, nod, stop, st);
   }
-  // residual behind the last correction, restricted
-  launch_cheb<false, false>(F, dc, res, res, none, 0.f, 0.f, none, none, none, nod,
-                            nob, none, stop, st);
-  hipLaunchKernelGGL(pmg_restrict_kernel, dim3(grid_for(n1)), dim3(kBlock), 0, st,
-                     n1, M->rptr, M->rsrc, res, M->bc_coarse, crc, stop);
-  // coarse level: Chebyshev from zero
+  // residual behind the last correction (unscaled: times the diagonal),
+  // restricted
+  launch_cheb<0>(F, d[M->pre - 1], rho, rho, fdiag, 0.f, 0.f, none, none, none, nod,
+                 nob, nod, stop, st);
   Cheb co(C->lam_min, C->lam_max);
-  hipLaunchKernelGGL(pmg_init32_kernel, dim3(grid_for(n1)), dim3(kBlock), 0, st,
-                     n1, crc, cdinv, co.first(), cda, cx, stop);
-  float2 *cc = cda, *cn = cdb;
+  hipLaunchKernelGGL(pmg_restrict_kernel, dim3(grid_for(n1)), dim3(kBlock), 0, st,
+                     n1, M->rptr, M->rsrc, rho, cdinv, M->bc_coarse, co.first(),
+                     crho, cd[0], cx, stop);
+  // coarse level: Chebyshev from zero, xc = sum of its corrections
   for (int j = 1; j < M->coarse_steps; ++j) {
     co.next(&c1, &c2);
-    launch_cheb<true, false>(C, cc, crc, crc, cc, c1, c2, cn, cx, cx, nod, nob,
-                             none, stop, st);
-    float2* t = cc;
-    cc = cn;
-    cn = t;
+    float2* dn = cd[j & 1];
+    const float2* dc = cd[(j - 1) & 1];
+    launch_cheb<1>(C, dc, crho, crho, dc, c1, c2, dn, cx, none, nod, nob, nod,
+                   stop, st);
   }
   hipLaunchKernelGGL(pmg_prolong_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
-                     reinterpret_cast<const int2*>(M->ends), cx, xa, stop);
-  // post-smoothing: the first step needs the residual of the corrected x
+                     reinterpret_cast<const int2*>(M->ends), d[0],
+                     M->pre > 1 ? d[1] : none, M->pre > 2 ? d[2] : none, cx, x,
+                     stop);
+  // post-smoothing: rho = rho0 - (D^-1 A) x, then `post` steps; the last one
+  // writes z = x + all its corrections
   Cheb post(F->lam_min, F->lam_max);
-  dc = da;
-  dn = db;
   if (M->post == 1) {
-    launch_cheb<true, true>(F, xa, r32, none, none, 0.f, post.first(), none, xa,
-                            none, z, M->bc_fine, r32, stop, st);
+    launch_cheb<2>(F, x, rho0, none, none, 0.f, post.first(), none, x, none, z,
+                   M->bc_fine, r, stop, st);
   } else {
-    launch_cheb<true, false>(F, xa, r32, res, none, 0.f, post.first(), dc, xa, xb,
-                             nod, nob, none, stop, st);
+    launch_cheb<1>(F, x, rho0, rho, none, 0.f, post.first(), d[0], none, none, nod,
+                   nob, nod, stop, st);
     for (int j = 1; j < M->post; ++j) {
       post.next(&c1, &c2);
       if (j + 1 == M->post)
-        launch_cheb<true, true>(F, dc, res, none, dc, c1, c2, none, xb, none, z,
-                                M->bc_fine, r32, stop, st);
+        launch_cheb<2>(F, d[j - 1], rho, none, d[j - 1], c1, c2, none, x,
+                       j == 2 ? d[0] : none, z, M->bc_fine, r, stop, st);
       else
-        launch_cheb<true, false>(F, dc, res, res, dc, c1, c2, dn, xb, xb, nod, nob,
-                                 none, stop, st);
-      float2* t = dc;
-      dc = dn;
-      dn = t;
+        launch_cheb<1>(F, d[j - 1], rho, rho, d[j - 1], c1, c2, d[j], none, none,
+                       nod, nob, nod, stop, st);
     }
   }
   FLOW_CHECK_LAUNCH();
@@ -450,18 +499,20 @@ int pmg_apply(const flow_pmg* M, const double* r, double* z, hipStream_t st,
 
 using namespace flow;
 
-extern "C" int flow_pmg_pack(int n, int nnz, const int* diag_idx,
-                             const double* a00, const double* a11, float* vals,
+extern "C" int flow_pmg_pack(int n, int nnz, const int* rowptr,
+                             const int* diag_idx, const double* a00,
+                             const double* a11, void* vals, float* diag,
                              float* dinv, void* stream) {
-  FLOW_REQUIRE(n > 0 && nnz > 0 && diag_idx && a00 && a11 && vals && dinv,
+  FLOW_REQUIRE(n > 0 && nnz > 0 && rowptr && diag_idx && a00 && a11 && vals &&
+                   diag && dinv,
                "flow_pmg_pack arguments");
   FLOW_REQUIRE(reinterpret_cast<uintptr_t>(vals) % 16 == 0,
                "packed values must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(pmg_pack_kernel, dim3(grid_for(nnz)), dim3(kBlock), 0, st, nnz,
-                     a00, a11, reinterpret_cast<float2*>(vals));
-  hipLaunchKernelGGL(pmg_dinv_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
-                     diag_idx, a00, a11, reinterpret_cast<float2*>(dinv));
+  hipLaunchKernelGGL(pmg_pack_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
+                     rowptr, diag_idx, a00, a11, reinterpret_cast<__half2*>(vals),
+                     reinterpret_cast<float2*>(diag),
+                     reinterpret_cast<float2*>(dinv));
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -470,7 +521,7 @@ extern "C" int flow_pmg_lambda_max(const flow_pmg_level* L, int iterations,
                                    float* work, double* dwork,
                                    double* result_host, void* stream) {
   FLOW_REQUIRE(L && L->n > 0 && L->rowptr && L->cols && L->rowblocks && L->vals &&
-                   L->dinv && work && dwork && result_host && iterations >= 2,
+                   work && dwork && result_host && iterations >= 2,
                "flow_pmg_lambda_max arguments");
   hipStream_t st = as_stream(stream);
   const int n = L->n;
@@ -484,16 +535,13 @@ extern "C" int flow_pmg_lambda_max(const flow_pmg_level* L, int iterations,
   hipLaunchKernelGGL(pmg_zero_kernel, dim3(g), dim3(kBlock), 0, st, n, zero);
   double lam = 0.0;
   for (int it = 0; it < iterations; ++it) {
-    // w = 0 - A v, then w = -dinv w = D^-1 A v and |w|^2
-    hipLaunchKernelGGL((pmg_cheb_kernel<false, false>), dim3(L->nblocks),
-                       dim3(kBlock), 0, st, n, L->rowptr, L->cols,
-                       reinterpret_cast<const float2*>(L->vals), L->rowblocks, v,
-                       zero, w, reinterpret_cast<const float2*>(L->dinv), none,
-                       0.f, 0.f, none, none, none, static_cast<double*>(nullptr),
-                       static_cast<const unsigned char*>(nullptr), none,
-                       static_cast<const double*>(nullptr));
-    hipLaunchKernelGGL(pmg_scale_norm_kernel, dim3(gr), dim3(kBlock), 0, st, n,
-                       reinterpret_cast<const float2*>(L->dinv), w, dwork);
+    // w = 0 - (D^-1 A) v and |w|^2
+    launch_cheb<0>(L, v, zero, w, none, 0.f, 0.f, none, none, none,
+                   static_cast<double*>(nullptr),
+                   static_cast<const unsigned char*>(nullptr),
+                   static_cast<const double*>(nullptr),
+                   static_cast<const double*>(nullptr), st);
+    hipLaunchKernelGGL(pmg_norm_kernel, dim3(gr), dim3(kBlock), 0, st, n, w, dwork);
     FLOW_CHECK_LAUNCH();
     double nrm2 = 0.0;
     int rc = flow::sum_partials_host(dwork, gr, &nrm2, st);

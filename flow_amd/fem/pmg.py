@@ -11,7 +11,8 @@ Two levels on the same mesh: the diagonal blocks of the assembled P2 Jacobian,
 smoothed with a few Chebyshev steps, and the P1 discretisation of the same
 linearised operator as the coarse problem (P1 is a subspace of P2: vertex dofs
 copy their vertex, edge dofs average their two end points), treated with
-Chebyshev steps as well.  Everything an application does is a CSR-stream
+Chebyshev steps as well.  Both matrices are kept row-scaled (D^-1 A) in fp16,
+the two velocity blocks interleaved: 8 bytes per nonzero with the index.  Everything an application does is a CSR-stream
 product over a pattern that is already resident -- no dependent sweeps, no
 colouring.  Measured on the oracle's Jacobian in the regime of the 10 M-DoF
 workload (tools/precond_lab.py: CFL 1.85, diffusion number 0.85): 14-15
@@ -27,7 +28,7 @@ import numpy
 import torch
 
 from . import ops
-from .space import scalar_layout
+from .space import scalar_layout, csr_stream_rowblocks
 from .. import _hip
 from .. import device
 
@@ -70,18 +71,26 @@ class _Level(object):
     def __init__(self, lay):
         self.lay = lay
         n, nnz = lay.N, lay.nnz
-        # (vals readable one float2 past nnz: the kernels load value pairs)
-        self.vals = torch.zeros(2 * (nnz + 2), dtype=torch.float32,
+        # (half2 per nonzero; readable three entries past nnz: the kernels load
+        # QUADS of nonzeros from a base aligned down to a multiple of four)
+        self.vals = torch.zeros(2 * (nnz + 4), dtype=torch.float16,
                                 device=device.get())
+        self.diag = torch.zeros(2 * n, dtype=torch.float32, device=device.get())
         self.dinv = torch.zeros(2 * n, dtype=torch.float32, device=device.get())
         assert self.vals.data_ptr() % 16 == 0
-        rb = lay.dev('rowblocks')
+        # row blocks of their own: at most 2044 nonzeros (the tile of 2048
+        # minus the alignment slack of a quad)
+        if 'pmg_rowblocks' not in lay._dev:
+            lay._dev['pmg_rowblocks'] = device.to_device(csr_stream_rowblocks(
+                lay.pattern('rowptr'), nnz_per_block=_hip.PMG_NNZ_PER_BLOCK))
+        rb = lay._dev['pmg_rowblocks']
         s = _hip.PmgLevelS()
         s.n, s.nnz, s.nblocks = n, nnz, rb.numel() - 1
         s.rowptr = _hip.i32(lay.dev('rowptr'), n + 1, 'rowptr')
-        s.cols = _hip.i32(lay.dev('cols'), nnz, 'cols')
+        s.cols = _hip.i32(lay.dev('cols'), nnz + 4, 'cols')
         s.rowblocks = _hip.i32(rb, None, 'rowblocks')
-        s.vals = _hip.f32(self.vals, 2 * nnz, 'vals')
+        s.vals = _hip.f16(self.vals, 2 * nnz, 'vals')
+        s.diag = _hip.f32(self.diag, 2 * n, 'diag')
         s.dinv = _hip.f32(self.dinv, 2 * n, 'dinv')
         s.lam_min, s.lam_max = 0.25, 2.0
         self.struct = s
@@ -91,10 +100,11 @@ class _Level(object):
         lay = self.lay
         assert J.layout is lay and J.kind == 2
         _hip.check(_hip.lib().flow_pmg_pack(
-            lay.N, lay.nnz, _hip.i32(lay.dev('diag_idx'), lay.N, 'diag_idx'),
+            lay.N, lay.nnz, _hip.i32(lay.dev('rowptr'), lay.N + 1, 'rowptr'),
+            _hip.i32(lay.dev('diag_idx'), lay.N, 'diag_idx'),
             _hip.f64(J.plane(0), lay.nnz), _hip.f64(J.plane(3), lay.nnz),
-            _hip.f32(self.vals, 2 * lay.nnz), _hip.f32(self.dinv, 2 * lay.N),
-            _hip.stream()))
+            _hip.f16(self.vals, 2 * lay.nnz), _hip.f32(self.diag, 2 * lay.N),
+            _hip.f32(self.dinv, 2 * lay.N), _hip.stream()))
 
     def lambda_max(self, work, iterations=25):
         res = ctypes.c_double(0.0)

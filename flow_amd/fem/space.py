@@ -149,8 +149,9 @@ class ScalarLayout(object):
             else:
                 arr = self.pattern(name)
             if name == 'cols':
-                # the SpMV loads index PAIRS: readable one entry past nnz
-                arr = numpy.concatenate([arr, numpy.zeros(1, dtype=arr.dtype)])
+                # the SpMV loads index PAIRS, the kernels of flow_pmg index
+                # QUADS: readable up to three entries past nnz
+                arr = numpy.concatenate([arr, numpy.zeros(4, dtype=arr.dtype)])
             self._dev[name] = device.to_device(arr)
         return self._dev[name]
 

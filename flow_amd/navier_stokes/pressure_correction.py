@@ -383,7 +383,10 @@ def _compute_tentative_velocity(
         ops.fill(dx, 0.0)
         pre = None
         kind = npar.get('preconditioner', 'jacobi')
-        if kind == 'pmg' and lay.degree != 2:
+        use_gmres = npar.get('linear_solver', 'gmres') == 'gmres'
+        # (the p-multigrid needs a P2 space and, its application not being
+        # exactly linear, the flexible GMRES)
+        if kind == 'pmg' and (lay.degree != 2 or not use_gmres):
             kind = 'ilu0'
         with_ilu = kind in ('ilu0', 'pmg')
         # matrix-free Newton-Krylov: J(ui) is applied cell by cell (as cheap
@@ -419,9 +422,12 @@ def _compute_tentative_velocity(
                     pre.refactor(J, _coarse_jacobian(
                         pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host))
                 elif pre is None:
+                    # (the fp32 sweep vector makes the application slightly
+                    # nonlinear: for the flexible GMRES only, flow_hip.h)
                     pre = ilu.Ilu0(
                         J, packed=npar.get('ilu_storage', 'fp32') == 'fp32',
-                        single_vector=npar.get('ilu_vector') == 'fp32')
+                        single_vector=use_gmres
+                        and npar.get('ilu_vector') == 'fp32')
                     lay._dev[slot] = pre
                 else:
                     pre.refactor(J)
@@ -445,7 +451,7 @@ def _compute_tentative_velocity(
                 lin_atol = max(lin_atol, min(0.1 * predicted, 1.0e-2 * nrm))
         lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
         operator = Jop if matfree else J
-        if npar.get('linear_solver', 'gmres') == 'gmres':
+        if use_gmres:
             # GMRES(restart): one Jacobian action + one preconditioner
             # application per iteration, the least of the Krylov methods here
             # (how many Arnoldi steps to enqueue before the first read-back:
@@ -467,7 +473,6 @@ def _compute_tentative_velocity(
             its = (sol.iterations + 1) // 2
             applications.append(sol.iterations)
         else:
-            assert kind != 'pmg', 'the p-multigrid needs the flexible GMRES'
             sol, its = _bicgstab_with_restarts(operator, F, dx, lin_rtol, pre, npar)
             applications.append(2 * its)
         last_linear_residual = sol.residual

@@ -103,6 +103,11 @@ int flow_profile_spmv_end(double* total_us, int* launches);
  * busy stream): the dispatch latency every bracketed launch includes on top of
  * the kernel's execution time -- a profiler's kernel duration does not. */
 int flow_profile_event_overhead(double* overhead_us, void* stream);
+/* Launches an empty kernel `profile_marker_kernel` with `id` workgroups (1 ..
+ * 1024) on the stream: bench.py brackets its timed steps with ids 1 and 2, and
+ * profiles/summarize.py cuts a rocprofv3 kernel trace at those launches instead
+ * of at guessed offsets. */
+int flow_profile_marker(int id, void* stream);
 
 /* ---- K9: BLAS-1 (PETSc VecDot/VecAXPY/VecNorm) -------------------------- */
 int flow_dot_host(int n, const double* x, const double* y, double* work,
@@ -262,9 +267,8 @@ int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
  * flow_gmres_solve).  Two levels on the SAME mesh, both made of CSR-stream
  * products only (no dependent sweeps):
  *   fine    the two diagonal blocks of the assembled Jacobian J = dF1/dui over
- *           the scalar P2 pattern, rounded to fp32 and interleaved (vals: nnz
- *           float2 = (J00, J11) per nonzero), smoothed with `pre` / `post`
- *           steps of the Chebyshev iteration for D^-1 A on [lam_min, lam_max];
+ *           the scalar P2 pattern, smoothed with `pre` / `post` steps of the
+ *           Chebyshev iteration for D^-1 A on [lam_min, lam_max];
  *   coarse  the P1 discretisation of the same linearised operator (P1 is a
  *           subspace of P2: a vertex dof copies its vertex, an edge dof
  *           averages its two end points), packed the same way;
@@ -272,26 +276,34 @@ int flow_ilu0_solve(const flow_ilu* ilu, const double* r, double* z,
  * One application z = M^-1 r:
  *   x = cheb_pre(r) ; rc = P^T (r - A x) ; xc = cheb_coarse(rc) ;
  *   x += P xc ; x += cheb_post(r - A x).
- * Vectors inside are fp32, both components interleaved (float2 per dof): the
- * application is not exactly linear in r -- for FLEXIBLE Krylov methods only
- * (flow_gmres_solve is one).  Rows of Dirichlet dofs are identity rows of J:
- * z = r there (bc_fine); the coarse residual is zeroed on the Dirichlet rows
- * of the coarse operator (bc_coarse), whose rows are identity rows too.
- * Level arrays as flow_operator: cols readable at nnz, vals 16-byte aligned
- * and readable one float2 past nnz. */
+ * The matrices are stored row-scaled (D^-1 A, entries of size <= ~1) in fp16,
+ * the two blocks interleaved: vals = nnz half2 (J00, J11)/diag per nonzero -- 8 B
+ * per nonzero with the index; a smoother needs no more (same GMRES counts as
+ * with fp64 entries).  Vectors inside are fp32, both components interleaved
+ * (float2 per dof): the application is not exactly linear in r -- for FLEXIBLE
+ * Krylov methods only (flow_gmres_solve is one).  Rows of Dirichlet dofs are
+ * identity rows of J: z = r there (bc_fine); the coarse residual is zeroed on
+ * the Dirichlet rows of the coarse operator (bc_coarse), whose rows are
+ * identity rows too.
+ * Level arrays: CSR-stream row blocks of at most FLOW_SPMV_ROWS_PER_BLOCK rows
+ * and FLOW_PMG_NNZ_PER_BLOCK nonzeros (a lane loads nonzeros in QUADS, 16-byte
+ * loads: the tile base is aligned down to a multiple of four); cols and
+ * vals 16-byte aligned and readable three entries past nnz. */
+#define FLOW_PMG_NNZ_PER_BLOCK 2044
 typedef struct {
   int n, nnz, nblocks;
   const int* rowptr;       /* n+1 */
   const int* cols;         /* nnz */
   const int* rowblocks;    /* nblocks+1: CSR-stream row blocks */
-  const float* vals;       /* nnz float2 (filled by flow_pmg_pack) */
-  const float* dinv;       /* n float2: 1 / diagonal of the two blocks */
+  const void* vals;        /* nnz half2 (filled by flow_pmg_pack) */
+  const float* diag;       /* n float2: diagonal of the two blocks */
+  const float* dinv;       /* n float2: 1 / diagonal */
   double lam_min, lam_max; /* Chebyshev interval for D^-1 A (flow_pmg_lambda_max
                               gives the upper end) */
 } flow_pmg_level;
 typedef struct {
   flow_pmg_level fine, coarse;
-  int pre, post, coarse_steps;     /* Chebyshev steps: >= 1 each */
+  int pre, post, coarse_steps;     /* Chebyshev steps: pre, post 1..3, coarse >= 1 */
   const int* ends;                 /* fine.n int2: coarse rows of a fine dof */
   const int* rptr;                 /* coarse.n+1: restriction lists ... */
   const int* rsrc;                 /* ... of fine dofs; the FIRST entry of a list
@@ -301,9 +313,11 @@ typedef struct {
   const unsigned char* bc_coarse;  /* 2*coarse.n bytes, NULL: none */
   float* work;                     /* 12*fine.n + 8*coarse.n floats, 16-B aligned */
 } flow_pmg;
-/* vals[k] = (float)(a00[k], a11[k]); dinv[i] = 1 / (a00, a11)[diag_idx[i]] */
-int flow_pmg_pack(int n, int nnz, const int* diag_idx, const double* a00,
-                  const double* a11, float* vals, float* dinv, void* stream);
+/* vals[k] = half2((a00, a11)[k] / their diagonal entries of row(k));
+ * diag[i] = (a00, a11)[diag_idx[i]], dinv[i] = 1 / diag[i] */
+int flow_pmg_pack(int n, int nnz, const int* rowptr, const int* diag_idx,
+                  const double* a00, const double* a11, void* vals, float* diag,
+                  float* dinv, void* stream);
 /* spectral radius of D^-1 A of a level by `iterations` (>= 2) steps of the
  * power method.  work: 6*n floats, dwork: FLOW_REDUCE_WORK doubles. */
 int flow_pmg_lambda_max(const flow_pmg_level* level, int iterations, float* work,

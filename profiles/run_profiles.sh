@@ -19,10 +19,10 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench
 echo write done
 python3 $R/profiles/summarize.py stats $OUT/trace $R/gpurun_out/kernel_stats_$TAG.md
 python3 $R/profiles/summarize.py gaps $OUT/trace $R/gpurun_out/gaps_$TAG.md
-# the timed steps only: the last 10 steps before the 3 in-solver measurement
-# steps and the replay at the end of the trace (kernel budget of one step)
-python3 $R/profiles/summarize.py stats $OUT/trace $R/gpurun_out/kernel_stats_${TAG}_timed_steps.md 90:340 > /dev/null
-python3 $R/profiles/summarize.py gaps $OUT/trace $R/gpurun_out/gaps_${TAG}_timed_steps.md 90:340 > /dev/null
+# the timed steps only (kernel budget of one step): between the marker launches
+# bench.py puts around them; fails unless exactly 10 steps lie there
+python3 $R/profiles/summarize.py stats $OUT/trace $R/gpurun_out/kernel_stats_${TAG}_timed_steps.md timed:10 > /dev/null
+python3 $R/profiles/summarize.py gaps $OUT/trace $R/gpurun_out/gaps_${TAG}_timed_steps.md timed:10 > /dev/null
 # warm replay (spmv_stream_kernel<false>, back-to-back) and the in-solver launches
 # (spmv_stream_kernel<true>) on the pressure matrix, picked by its dispatch size
 GRID=$(python3 -c "import json; print(json.load(open('$OUT/bench_trace.json'))['config']['pressure_spmv_grid'])")

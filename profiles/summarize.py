@@ -2,7 +2,9 @@
 '''
 Summarise rocprofv3 CSV output into the small files committed under profiles/.
 
-  python profiles/summarize.py stats  <dir> <out.md> [a:b]  kernel-trace summary
+  python profiles/summarize.py stats  <dir> <out.md> [a:b | timed[:K]]  kernel-trace summary
+      (a:b = ms before the end of the trace; timed = between the marker
+      launches bench.py puts around its timed steps, K = steps expected there)
   python profiles/summarize.py pmc    <fetch_dir> <write_dir> <out.json> [kernel] [grid]
   python profiles/summarize.py gaps   <dir> <out.md>     idle time between kernels
   python profiles/summarize.py sequence <dir> <out.txt> a:b   launch order of a window
@@ -24,6 +26,48 @@ import sys
 from collections import defaultdict
 
 
+def _marker_window(directory, steps=None):
+    '''(t0, t1) in trace time: from the FIRST launch of profile_marker_kernel
+    with 1 workgroup to the first one with 2 (bench.py brackets the timed steps
+    of every window with them; the headline window is the first).  steps: the number of time steps that
+    must lie in between (counted by pressure_rhs_kernel, launched once per
+    step) -- a window that silently covers something else is an error.'''
+    t = {1: None, 2: None}
+    once_per_step = []
+    for path in _find(directory, 'kernel_trace.csv'):
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                name = r['Kernel_Name']
+                if 'profile_marker_kernel' in name:
+                    g = int(r['Grid_Size_X']) // max(int(r.get(
+                        'Workgroup_Size_X', 64) or 64), 1)
+                    if g in t:
+                        # the headline window is the FIRST pair of a run
+                        if t[g] is None:
+                            t[g] = int(r['Start_Timestamp'])
+                elif 'pressure_rhs_kernel' in name:
+                    once_per_step.append(int(r['Start_Timestamp']))
+    if t[1] is None or t[2] is None or t[2] <= t[1]:
+        raise SystemExit('no marker pair in the trace under %s' % directory)
+    inside = sum(1 for x in once_per_step if t[1] <= x <= t[2])
+    if steps is not None and inside != int(steps):
+        raise SystemExit('%d time steps between the markers, expected %s'
+                         % (inside, steps))
+    return t[1], t[2], inside
+
+
+def _window(directory, window, t_end):
+    '''(lo, hi) start-time bounds of a window: "a:b" = between a and b ms
+    before the end of the trace; "timed" / "timed:K" = between bench.py's
+    markers (K: the number of steps that must lie there).'''
+    if window.startswith('timed'):
+        steps = window.split(':')[1] if ':' in window else None
+        lo, hi, _ = _marker_window(directory, steps)
+        return lo, hi
+    a, b = [float(v) * 1.0e6 for v in window.split(':')]
+    return t_end - b, t_end - a
+
+
 def _find(directory, suffix):
     hits = glob.glob(os.path.join(directory, '**', '*' + suffix), recursive=True)
     if not hits:
@@ -37,16 +81,17 @@ def stats(directory, out, window=None):
     rows = defaultdict(lambda: [0, 0.0])
     t_end = 0
     if window:
-        a, b = [float(v) * 1.0e6 for v in window.split(':')]
         for path in _find(directory, 'kernel_trace.csv'):
             with open(path) as fh:
                 for r in csv.DictReader(fh):
                     t_end = max(t_end, int(r['End_Timestamp']))
+        lo, hi = _window(directory, window, t_end)
     for path in _find(directory, 'kernel_trace.csv'):
         with open(path) as fh:
             for r in csv.DictReader(fh):
-                if window and not (
-                        t_end - a >= int(r['Start_Timestamp']) >= t_end - b):
+                if window and not (hi >= int(r['Start_Timestamp']) >= lo):
+                    continue
+                if 'profile_marker_kernel' in r['Kernel_Name']:
                     continue
                 name = r['Kernel_Name'].split('(')[0]
                 if 'spmv_stream' in name and 'Grid_Size_X' in r:
@@ -84,9 +129,9 @@ def gaps(directory, out, threshold_us=8.0, window=None):
                            r['Kernel_Name'].split('(')[0].replace('void ', '')))
     ev.sort()
     if window:
-        a, b = [float(v) * 1.0e6 for v in window.split(':')]
-        t_end = ev[-1][1]
-        ev = [e for e in ev if t_end - a >= e[0] >= t_end - b]
+        lo, hi = _window(directory, window, ev[-1][1])
+        ev = [e for e in ev if hi >= e[0] >= lo
+              and 'profile_marker_kernel' not in e[2]]
     busy = sum(e - s for s, e, _ in ev) * 1e-3
     span = (ev[-1][1] - ev[0][0]) * 1e-3
     sites = defaultdict(lambda: [0, 0.0])
@@ -191,9 +236,8 @@ def sequence(directory, out, window, min_gap_us=15.0):
                            r['Kernel_Name'].split('(')[0].replace('void ', '')
                            .replace('flow::', '')))
     ev.sort()
-    a, b = [float(v) * 1.0e6 for v in window.split(':')]
-    t_end = ev[-1][1]
-    ev = [e for e in ev if t_end - a >= e[0] >= t_end - b]
+    lo, hi = _window(directory, window, ev[-1][1])
+    ev = [e for e in ev if hi >= e[0] >= lo]
     lines = []
     run_name, run_count, run_us = None, 0, 0.0
     end = ev[0][0]

@@ -143,9 +143,9 @@ def test_one_application_matches_the_numpy_cycle(newton_system):
                    J1s[a * n1:(a + 1) * n1, a * n1:(a + 1) * n1].tocsr(), P,
                    bc0[a * n:(a + 1) * n], bc1[a * n1:(a + 1) * n1],
                    r[a * n:(a + 1) * n]) for a in (0, 1)])
-        # fp32 matrices and vectors inside
-        assert cases.rel_l2(got, ref) < 2e-5, trial
-        assert numpy.array_equal(got[bc0], r[bc0].astype(numpy.float32))
+        # fp16 matrix entries (relative 5e-4 each) and fp32 vectors inside
+        assert cases.rel_l2(got, ref) < 2e-3, trial
+        assert numpy.array_equal(got[bc0], r[bc0])
 
 
 @pytest.mark.gpu
