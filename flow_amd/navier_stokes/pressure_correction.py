@@ -99,6 +99,10 @@ solver_parameters = {
                'preconditioner': 'pmg', 'ilu_lag': 8.0,
                'pmg': {'pre': 2, 'post': 2, 'coarse_steps': 4,
                        'ratio_fine': 8.0, 'ratio_coarse': 8.0},
+               # ... used where one cycle contracts a full-spectrum vector by
+               # at least this factor (else: ILU(0)), and a GMRES that has not
+               # converged after `pmg_maxit` applications is redone with ILU(0)
+               'pmg_accept': 0.8, 'pmg_maxit': 150,
                # the sweeps read the factors rounded to fp32 (fp64 arithmetic):
                # half the bytes per application, same iteration counts
                'ilu_storage': 'fp32',
@@ -384,10 +388,16 @@ def _compute_tentative_velocity(
         pre = None
         kind = npar.get('preconditioner', 'jacobi')
         use_gmres = npar.get('linear_solver', 'gmres') == 'gmres'
-        # (the p-multigrid needs a P2 space and, its application not being
-        # exactly linear, the flexible GMRES)
-        if kind == 'pmg' and (lay.degree != 2 or not use_gmres):
-            kind = 'ilu0'
+        key = (rho, mu, theta_i, nbc, hash(bc_dofs_host.tobytes()))
+        # the p-multigrid needs a P2 space and, its application not being
+        # exactly linear, the flexible GMRES; and it is only used where its
+        # cycle contracts (see _build_preconditioner): a rejection stands until
+        # the problem changes or the step size has halved
+        if kind == 'pmg':
+            rej = lay._dev.get('pmg_rejected')
+            if lay.degree != 2 or not use_gmres or (
+                    rej is not None and rej[0] == key and dt > 0.5 * rej[1]):
+                kind = 'ilu0'
         with_ilu = kind in ('ilu0', 'pmg')
         # matrix-free Newton-Krylov: J(ui) is applied cell by cell (as cheap
         # as the assembled 2x2-block SpMV) and only assembled when the lagged
@@ -395,46 +405,66 @@ def _compute_tentative_velocity(
         matfree = with_ilu and npar.get('matrix_free', True)
         if not matfree:
             assemble_jacobian()
-        if with_ilu:
+        if matfree and Jop is None:
+            Jop = ops.MomentumJacobian.cached(W, bfmask, ui.data, prm, bc_dofs)
+        operator = Jop if matfree else J
+        refactored = False
+
+        def build(kind):
+            '''The lagged preconditioner of `kind`, rebuilt when the problem
+            itself changed, when dt has moved by more than `ilu_lag` since the
+            last factorisation (checked at the first Newton iteration of a
+            step), or when it has gone stale: a solve needed more than twice
+            the iterations the fresh one needed (while the flow spins up at
+            tiny dt the matrix is mass-dominated and old factors stay good; at
+            CFL-sized steps they do not).  Returns (kind, pre, rebuilt): a
+            p-multigrid whose cycle does not contract is replaced by the
+            ILU(0).'''
             from ..fem import ilu
             slot = 'jacobian_ilu' if kind == 'ilu0' else 'jacobian_pmg'
             pre = lay._dev.get(slot)
-            key = (rho, mu, theta_i, nbc, hash(bc_dofs_host.tobytes()))
-            # lagged preconditioner: J = M + dt (...) changes slowly from
-            # step to step.  Rebuild when the problem itself changed, when dt
-            # has moved by more than `ilu_lag` since the last factorisation
-            # (checked at the first Newton iteration of a step), or when the
-            # factors have gone stale: a solve needed more than twice the
-            # iterations the fresh factors needed (while the flow spins up at
-            # tiny dt the matrix is mass-dominated and old factors stay good;
-            # at CFL-sized steps they do not).
-            refactored = False
-            if pre is None or pre.key != key or pre.stale or (
+            if not (pre is None or pre.key != key or pre.stale or (
                     it == 0 and not (1.0 / npar['ilu_lag'] <= dt / pre.dt
-                                     <= npar['ilu_lag'])):
-                if matfree:
-                    assemble_jacobian()
-                if kind == 'pmg':
-                    if pre is None:
-                        from ..fem.pmg import Pmg
-                        pre = Pmg(W, **npar.get('pmg', {}))
-                        lay._dev[slot] = pre
-                    pre.refactor(J, _coarse_jacobian(
-                        pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host))
-                elif pre is None:
-                    # (the fp32 sweep vector makes the application slightly
-                    # nonlinear: for the flexible GMRES only, flow_hip.h)
-                    pre = ilu.Ilu0(
-                        J, packed=npar.get('ilu_storage', 'fp32') == 'fp32',
-                        single_vector=use_gmres
-                        and npar.get('ilu_vector') == 'fp32')
+                                     <= npar['ilu_lag']))):
+                return kind, pre, False
+            if matfree:
+                assemble_jacobian()
+            if kind == 'pmg':
+                if pre is None:
+                    from ..fem.pmg import Pmg
+                    pre = Pmg(W, **npar.get('pmg', {}))
                     lay._dev[slot] = pre
-                else:
-                    pre.refactor(J)
+                pre.refactor(J, _coarse_jacobian(
+                    pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host))
                 pre.dt, pre.key, pre.stale = dt, key, False
-                refactored = True
-        if matfree and Jop is None:
-            Jop = ops.MomentumJacobian.cached(W, bfmask, ui.data, prm, bc_dofs)
+                # Chebyshev smoothing assumes a spectrum near the real axis:
+                # on an under-resolved convection-dominated problem (cell
+                # Peclet number >> 1 with the Galerkin discretisation) the
+                # cycle amplifies instead.  One application on a fixed
+                # full-spectrum vector tells: |v - M^-1 J v| / |v| is ~0.3
+                # where the cycle works and > 1 where it does not.
+                pre.contraction = _contraction(pre, operator, lay, bc_dofs_host)
+                last_step_info['pmg_contraction'] = pre.contraction
+                if not pre.contraction < npar.get('pmg_accept', 0.8):
+                    lay._dev['pmg_rejected'] = (key, dt)
+                    info('p-multigrid rejected (contraction %.2f): ILU(0)'
+                         % pre.contraction)
+                    return build('ilu0')
+                return kind, pre, True
+            if pre is None:
+                # (the fp32 sweep vector makes the application slightly
+                # nonlinear: for the flexible GMRES only, flow_hip.h)
+                pre = ilu.Ilu0(
+                    J, packed=npar.get('ilu_storage', 'fp32') == 'fp32',
+                    single_vector=use_gmres and npar.get('ilu_vector') == 'fp32')
+                lay._dev[slot] = pre
+            else:
+                pre.refactor(J)
+            pre.dt, pre.key, pre.stale = dt, key, False
+            return kind, pre, True
+
+        if with_ilu:
+            kind, pre, refactored = build(kind)
         # Inexact Newton: the linear residual only has to get below what the
         # quadratic term leaves anyway (forcing term 1e-4 ||F||), and below a
         # fraction of the Newton tolerance so that one more step is never
@@ -450,7 +480,6 @@ def _compute_tentative_velocity(
             if predicted > tol:
                 lin_atol = max(lin_atol, min(0.1 * predicted, 1.0e-2 * nrm))
         lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
-        operator = Jop if matfree else J
         if use_gmres:
             # GMRES(restart): one Jacobian action + one preconditioner
             # application per iteration, the least of the Krylov methods here
@@ -458,15 +487,30 @@ def _compute_tentative_velocity(
             # what Newton iteration `it` of the previous call needed -- a
             # scheduling hint, the accepted iterate does not depend on it)
             expected = lay._dev.setdefault('gmres_expected', {})
-            sol = ops.krylov_solve(
-                'gmres', operator, F, dx, rtol=lin_rtol, atol=0.0,
-                maxit=npar['linear_maxit'],
-                ilu=pre if kind == 'ilu0' else None,
-                pmg=pre if kind == 'pmg' else None,
-                restart=npar['gmres_restart'], x_is_zero=True,
-                dinv='jacobi' if pre is None else None,
-                first_check=expected.get(it, 0)
-                )
+
+            def gmres(maxit):
+                return ops.krylov_solve(
+                    'gmres', operator, F, dx, rtol=lin_rtol, atol=0.0,
+                    maxit=maxit, ilu=pre if kind == 'ilu0' else None,
+                    pmg=pre if kind == 'pmg' else None,
+                    restart=npar['gmres_restart'], x_is_zero=True,
+                    dinv='jacobi' if pre is None else None,
+                    first_check=expected.get(it, 0))
+            if kind == 'pmg':
+                # second line of defence behind the contraction test: a solve
+                # that does not get there in `pmg_maxit` applications is redone
+                # with the ILU(0)
+                try:
+                    sol = gmres(min(npar['linear_maxit'],
+                                    npar.get('pmg_maxit', 150)))
+                except _hip.NotConverged:
+                    lay._dev['pmg_rejected'] = (key, dt)
+                    info('p-multigrid: GMRES stalled, redone with ILU(0)')
+                    ops.fill(dx, 0.0)
+                    kind, pre, refactored = build('ilu0')
+                    sol = gmres(npar['linear_maxit'])
+            else:
+                sol = gmres(npar['linear_maxit'])
             expected[it] = sol.iterations
             # counted like BiCGStab iterations (two applications each) for the
             # staleness test of the lagged factors below
@@ -490,6 +534,29 @@ def _compute_tentative_velocity(
     # operator + preconditioner applications of the linear solves
     last_step_info['newton_linear_applications'] = applications
     return ui, alpha
+
+
+def _contraction(pre, operator, lay, bc_dofs_host):
+    """|v - M^-1 J v| / |v| for the preconditioner `pre` of the operator J on a
+    fixed full-spectrum vector v that vanishes on the Dirichlet dofs (as the
+    Krylov vectors of the Newton systems do): < 1 where one application is a
+    convergent iteration, NaN / > 1 where it amplifies."""
+    n2 = 2 * lay.N
+    hold = lay._dev.setdefault('pmg_probe', {})
+    bkey = hash(bc_dofs_host.tobytes())
+    if hold.get('key') != bkey:
+        v = numpy.random.RandomState(7).standard_normal(n2)
+        v[bc_dofs_host] = 0.0
+        hold.update(key=bkey, v=device.to_device(v), w=device.empty(n2),
+                    z=device.empty(n2))
+    v, w, z = hold['v'], hold['w'], hold['z']
+    operator.apply(v, w)
+    pre.apply(w, z)
+    ops.axpby(1.0, v, -1.0, z)
+    num = ops.vector_norm(z)
+    den = ops.vector_norm(v)
+    ratio = num / den
+    return ratio if numpy.isfinite(ratio) else float('inf')
 
 
 def _coarse_jacobian(pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host):

@@ -109,9 +109,37 @@ def newton_system(hip):
         navsto.solver_parameters['newton']['preconditioner'] = old
     lay = prob.W.layout
     pre = lay._dev['jacobian_pmg']
+    # the cycle contracts here (cell Peclet number ~2, as on the 10 M-DoF
+    # workload) and was accepted
+    assert pre.contraction < 0.6 and 'pmg_rejected' not in lay._dev
     J = lay._dev['jacobian']
     J1 = lay._dev['pmg_coarse']['J1']
     return prob, infos, pre, J, J1
+
+
+@pytest.mark.gpu
+def test_falls_back_to_ilu_where_the_cycle_does_not_contract(hip):
+    '''The same channel with the physical viscosity on a coarse mesh: cell
+    Peclet number ~30 with a Galerkin discretisation.  Chebyshev smoothing
+    assumes a spectrum near the real axis; here the cycle amplifies, the
+    contraction test sees it, and the step runs with the ILU(0).'''
+    from flow_amd import karman
+    import flow_amd.navier_stokes as navsto
+    assert navsto.solver_parameters['newton']['preconditioner'] == 'pmg'
+    prob = karman.KarmanProblem(150, 35)
+    prob.set_initial_profile()
+    prob.dt = prob.hmax / 0.016
+    infos = [prob.step(adapt=False) for _ in range(2)]
+    lay = prob.W.layout
+    assert 'pmg_rejected' in lay._dev and 'jacobian_ilu' in lay._dev
+    assert not infos[0]['pmg_contraction'] < 0.8
+    for i in infos:
+        assert i['newton_residuals'][-1] < 1e-10
+    # a tiny step is mass-dominated: the rejection lapses and the cycle is
+    # accepted again
+    prob.dt = 1.0e-3 * prob.dt
+    info = prob.step(adapt=False)
+    assert info['pmg_contraction'] < 0.8
 
 
 @pytest.mark.gpu
