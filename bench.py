@@ -66,6 +66,39 @@ def measure_spmv_replay(apply, n, reps=100, warmup=10):
     return start.elapsed_time(stop) * 1.0e-3 / reps
 
 
+def measure_stream_ceilings(nbytes=1 << 30, reps=20):
+    '''What plain streaming kernels sustain on this box: own
+    16-byte-per-lane kernels (flow_profile_stream_copy / _read), `nbytes` read
+    (+ as many written for the copy) per launch -- far beyond the 256 MB
+    Infinity Cache --, HIP events on the launch stream.  Returns GB/s of the
+    bytes moved: (copy, read-only).'''
+    import torch
+    from flow_amd import device, _hip
+    n = nbytes // 8
+    src = torch.ones(n, dtype=torch.float64, device=device.get())
+    dst = device.empty(n)
+    lib = _hip.lib()
+
+    def timed(go):
+        for _ in range(3):
+            go()
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            go()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1.0e-3 / reps
+    t_copy = timed(lambda: _hip.check(lib.flow_profile_stream_copy(
+        n, _hip.f64(src), _hip.f64(dst), _hip.stream())))
+    t_read = timed(lambda: _hip.check(lib.flow_profile_stream_read(
+        n, _hip.f64(src), _hip.f64(dst), _hip.stream())))
+    del src, dst
+    return 2.0 * nbytes / t_copy / 1e9, nbytes / t_read / 1e9
+
+
 def measure_spmv_in_solver(prob, rows, steps, tol):
     '''The roofline kernel as the pressure CG runs it: `steps` more time steps
     with every launch of the fused-dot SpMV of the `rows`-row operator
@@ -123,7 +156,7 @@ def measure_spmv_hbm_resident(rows=10000000, band=1540, reps=50):
             'frac': nbytes / t / 1e9 / HBM_PEAK_GBPS}
 
 
-def cpu_baseline(Kbc, isbc, b, tol, gpu, budget_s=12.0):
+def cpu_baseline(Kbc, isbc, b, tol, gpu, ndofs, budget_s=12.0):
     '''The pressure solve of this workload on the box's host cores with the
     SAME algorithm the GPU runs: CG preconditioned with the smoothed-
     aggregation V(1,1) cycle on the same hierarchy (oracle/cpu_cg.c, OpenMP,
@@ -165,34 +198,56 @@ def cpu_baseline(Kbc, isbc, b, tol, gpu, budget_s=12.0):
     t0 = time.perf_counter()
     _, jits, _, _ = cpu_lib.jacobi_cg(lib, A, b, 1e-30, maxit=200)
     jac_rate = jits / (time.perf_counter() - t0)
+    steps, fit = oracle_step_timing(ndofs)
     out = {
-        'value': 1.0 / t_solve,
+        # whole step on the CPU: the oracle's step() -- numpy/scipy, sparse LU
+        # for every solve like the reference's dolfin defaults -- measured at
+        # the sizes it finishes in seconds and EXTRAPOLATED to this workload's
+        # size with the power law through the two largest of them
+        'value': 1.0 / fit['step_s_extrapolated'],
         'unit': 'time-steps/s',
-        'cores': cores,
+        'cores': 1,
         'kind': 'port',
-        'sample': '%d pressure solves (%.1f s) of the %d-row pressure-Poisson '
-                  'system of this workload with the algorithm the GPU runs '
-                  '(CG + smoothed-aggregation V(1,1) cycle, same hierarchy, '
-                  'same right-hand side and stopping test; oracle/cpu_cg.c, '
-                  'C/OpenMP, first-touched arrays): %d iterations, %.1f ms per '
-                  'solve; steps/s = 1 / that (pressure solve only, every other '
-                  'sub-step free: an upper bound for the CPU)'
-                  % (solves, solves * t_solve, n, its, 1e3 * t_solve),
-        'converged': bool(ok),
-        'mgcg_iterations': its,
-        'mgcg_solve_ms': 1e3 * t_solve,
-        'jacobi_cg_iterations_per_s': jac_rate,
-        'spmv_GBps': spmv_bytes(n, A.nnz) / spmv_s / 1e9,
-        'gpu_like_for_like': gpu,
+        'sample': 'oracle step() (oracle/fem_oracle.py: one Rotational step, '
+                  'sparse LU in every Newton iteration and for both linear '
+                  'systems, one core) timed on %s; EXTRAPOLATED to %d DoF with '
+                  't ~ DoF^%.2f fitted through the two largest (%.0f s per '
+                  'step, stated as an extrapolation: at 1 M DoF one such step '
+                  'already takes minutes, DESIGN.md section 5)'
+                  % (', '.join('%s (%d DoF: %.2f s)' % (
+                      o['workload'], o['dofs'], o['step_s']) for o in steps),
+                     ndofs, fit['exponent'], fit['step_s_extrapolated']),
+        'oracle_step': steps,
+        'oracle_step_fit': fit,
+        # like for like on one sub-step: the pressure solve with the GPU's
+        # algorithm on all host cores
+        'pressure_solves_per_s': 1.0 / t_solve,
+        'pressure_solve': {
+            'cores': cores,
+            'sample': '%d pressure solves (%.1f s) of the %d-row pressure-'
+                      'Poisson system of this workload with the algorithm the '
+                      'GPU runs (CG + smoothed-aggregation V(1,1) cycle, same '
+                      'hierarchy, same right-hand side and stopping test; '
+                      'oracle/cpu_cg.c, C/OpenMP, first-touched arrays): %d '
+                      'iterations, %.1f ms per solve'
+                      % (solves, solves * t_solve, n, its, 1e3 * t_solve),
+            'converged': bool(ok),
+            'mgcg_iterations': its,
+            'mgcg_solve_ms': 1e3 * t_solve,
+            'jacobi_cg_iterations_per_s': jac_rate,
+            'spmv_GBps': spmv_bytes(n, A.nnz) / spmv_s / 1e9,
+            'gpu_like_for_like': gpu,
+            },
         }
-    out['oracle_step'] = oracle_step_timing()
     return out, x_cpu
 
 
-def oracle_step_timing():
+def oracle_step_timing(target_dofs=None):
     '''Full `step()` of the CPU oracle (numpy/scipy, sparse LU for every solve:
     oracle/fem_oracle.py) at BASELINE config 1 (unit square, n = 8, P2-P1) and
-    on a Karman channel of ~56 k DoF, the largest it finishes in seconds.'''
+    on two body-fitted Karman channels, the largest it finishes in seconds;
+    plus the power law through the two channels, evaluated at `target_dofs`.'''
+    import math
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import cases
     from flow_amd import fem
@@ -200,7 +255,10 @@ def oracle_step_timing():
     for name, mesh, kind in (
             ('C1 unit square 8x8 crossed', fem.UnitSquareMesh(8, 8, 'crossed'),
              'all'),
-            ('Karman channel 160x37', fem.karman_channel(160, 37), 'channel')):
+            ('Karman channel 100x23', fem.karman_channel(100, 23, fitted=True),
+             'channel'),
+            ('Karman channel 160x37', fem.karman_channel(160, 37, fitted=True),
+             'channel')):
         case = cases.Case(mesh, vdeg=2, dt=0.01, bc_kind=kind, rho=1.0,
                           mu=0.05, seed=0)
         t0 = time.perf_counter()
@@ -209,19 +267,33 @@ def oracle_step_timing():
         ndof = case.W.size() + case.P.size()
         out.append({'workload': name, 'dofs': ndof, 'step_s': wall,
                     'dofs_per_s': ndof / wall})
-    return out
+    a, b = out[-2], out[-1]
+    expo = math.log(b['step_s'] / a['step_s']) / math.log(
+        float(b['dofs']) / a['dofs'])
+    fit = {'exponent': expo, 'through': [a['workload'], b['workload']]}
+    if target_dofs:
+        fit['target_dofs'] = target_dofs
+        fit['step_s_extrapolated'] = b['step_s'] * (
+            float(target_dofs) / b['dofs'])**expo
+    return out, fit
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    # defaults: the run starts impulsively at dt0 = 1e-5 and the controller
-    # doubles dt for 10 steps; the 20 warm-up steps cover that transient (and
-    # the one-off setup), the 30 timed ones run at CFL-sized steps -- the
-    # regime a Karman run spends its time in.  `--steps 3 --warmup 1` times the
-    # start-up transient instead (DESIGN.md section 5 reports both).
+    # The run starts at dt0 = 1e-5 and the controller at most doubles dt per
+    # step.  That ramp is SETUP here (`KarmanProblem.settle`: steps until dt
+    # has moved by < 1 % three times in a row, outside every timed region, the
+    # settled state kept): whatever --warmup / --steps the caller passes, the
+    # timed steps are CFL-sized steps with at least one Newton iteration each
+    # -- the regime a Karman run spends its time in (asserted below).
+    # `--no-settle --steps 3 --warmup 1` times the start-up transient instead.
     ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-settle', action='store_true',
+                    help='time the start-up transient: windows start at the '
+                         'initial state with dt = dt0 instead of at the '
+                         'plateau of the CFL controller')
     ap.add_argument('--nx', type=int, default=2182,
                     help='cells along the channel (2182 x 509: ~10 M DoF)')
     ap.add_argument('--ny', type=int, default=None)
@@ -325,6 +397,7 @@ def main():
                                 scheme=args.scheme)
 
     start = {}
+    settled = {}
 
     def initial_state():
         prob.reset(args.dt0)
@@ -350,7 +423,10 @@ def main():
             old = navsto.solver_parameters['newton'][key]
             navsto.solver_parameters['newton'][key] = \
                 val if isinstance(old, str) else type(old)(float(val))
-        initial_state()
+        if settled:
+            prob.restore(settled['state'])
+        else:
+            initial_state()
         for _ in range(args.warmup):
             prob.step(tol=args.tol)
         # (marker launches 1 / 2 bracket the timed steps in a kernel trace:
@@ -402,10 +478,19 @@ def main():
             val if isinstance(old, str) else type(old)(float(val))
     prob.prepare()
     initial_state()
+    if not args.no_settle:
+        navsto.set_mode(args.mode)
+        settled['steps'] = prob.settle(tol=args.tol)
+        settled['state'] = prob.snapshot()
     barrier()
     setup_s = time.perf_counter() - t_setup
     infos, elapsed = window(args.mode)
     head = summary(infos, elapsed)
+    if settled:
+        # the contract of the settle phase: plateau steps only
+        dts = head['dt']
+        assert min(head['newton_iterations']) >= 1, head['newton_iterations']
+        assert max(dts) / min(dts) < 1.2, dts
 
     # --- pressure-Poisson SpMV against the HBM roofline (dominant kernel) ---
     P = prob.P
@@ -429,14 +514,26 @@ def main():
         t_solver, bytes_solver = t_replay, bytes_alg
     achieved = bytes_solver / t_solver / 1e9
     traffic = None
-    # (PMC summary of the same in-solver dispatches: profiles/run_profiles.sh)
-    tpath = os.path.join(ROOT, 'profiles', 'spmv_traffic_in_solver.json')
+    traffic_source = None
+    # (PMC summary of the same in-solver dispatches, written by
+    # profiles/run_profiles.sh from separate --pmc passes of this command: a
+    # CITATION of the newest committed summary, not something this run measures)
+    import glob
+    tfiles = sorted(glob.glob(os.path.join(
+        ROOT, 'profiles', 'spmv_traffic_r[0-9][0-9]_in_solver.json')))
     # the committed PMC summary belongs to the headline workload only
-    if os.path.isfile(tpath) and args.nx == 2182 and args.ny is None:
+    if tfiles and args.nx == 2182 and args.ny is None:
         try:
-            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+            traffic = json.load(open(tfiles[-1])).get('hbm_bytes_per_launch')
+            traffic_source = (
+                'profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
+                'this bench command (profiles/run_profiles.sh), median over the '
+                'in-solver dispatches; committed with the round it names, not '
+                'measured by this run' % os.path.basename(tfiles[-1]))
         except Exception:                              # noqa: BLE001
             traffic = None
+    copy_ceiling, read_ceiling = measure_stream_ceilings() if world == 1 \
+        else (None, None)
     resident = None
     if world == 1 and not args.no_hbm_resident:
         resident = measure_spmv_hbm_resident()
@@ -492,16 +589,32 @@ def main():
             'pressure_spmv_grid': int(Kbc.operator().nblocks) * 256,
             'parallelism': parallel.describe(world, n),
             'setup_s': setup_s,
+            'settle': {
+                'steps': settled['steps'], 'dt': settled['state']['dt'],
+                't': settled['state']['t'],
+                'note': 'steps taken before the windows (setup) until the CFL '
+                        "controller's dt moved by < 1 % three times in a row; "
+                        'every window starts from that state'}
+            if settled else None,
+            'newton_iterations_min': min(head['newton_iterations']),
             'stokes_start': start.get('info'),
             'newton_linear_solver': navsto.solver_parameters['newton'].get(
-                'linear_solver', 'gmres') + '+ilu0',
+                'linear_solver', 'gmres') + '+' + (
+                    'ilu0' if 'jacobian_pmg' not in prob.W.layout._dev
+                    or 'pmg_rejected' in prob.W.layout._dev else
+                    'pmg (two-level p-multigrid, Chebyshev smoothing; '
+                    'contraction %.2f)'
+                    % prob.W.layout._dev['jacobian_pmg'].contraction),
             'newton_overrides': args.newton,
             # every Krylov vector, matrix, dot product and update is fp64; the
-            # ILU(0) PRECONDITIONER keeps its factors (and, inside the flexible
-            # GMRES, its sweep vector) rounded to fp32 with fp64 row sums --
-            # results identical to the all-fp64 preconditioner's to 4e-14
-            # (DESIGN.md sections 3 and 4)
+            # PRECONDITIONERS of the flexible GMRES keep their own copies of
+            # the matrix in reduced precision (p-multigrid: row-scaled fp16
+            # entries, fp32 vectors; ILU(0): fp32 factors and sweep vector,
+            # fp64 row sums) -- they only steer the Krylov path, the converged
+            # step is the same (tests/test_full_size_parity.py; DESIGN.md
+            # sections 3 and 4)
             'preconditioner_storage': {
+                'pmg_matrix': 'fp16 (row-scaled)', 'pmg_vectors': 'fp32',
                 'ilu_factors': navsto.solver_parameters['newton'].get(
                     'ilu_storage', 'fp64'),
                 'ilu_sweep_vector': navsto.solver_parameters['newton'].get(
@@ -520,6 +633,15 @@ def main():
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBPS,
             'traffic': traffic if not parallel.active() else None,
+            'traffic_source': traffic_source if not parallel.active() else None,
+            # the box's own ceilings, timed in this run: a plain
+            # streaming copy of 1 GiB in + 1 GiB out, and a kernel that only
+            # reads 1 GiB (the SpMV is read-dominated: 8 % of its bytes are
+            # stores)
+            'copy_ceiling_GBps': copy_ceiling,
+            'read_ceiling_GBps': read_ceiling,
+            'frac_of_copy': achieved / copy_ceiling if copy_ceiling else None,
+            'frac_of_read': achieved / read_ceiling if read_ceiling else None,
             'bytes_per_launch': bytes_solver,
             'us_per_launch': t_solver * 1e6,
             'launches_timed': launches,
@@ -570,7 +692,8 @@ def main():
             if name == 'mgcg':
                 x_gpu = device.to_host(xd).numpy()
         gpu['spmv_GBps_in_solver'] = achieved
-        out['cpu_baseline'], x_cpu = cpu_baseline(Kbc, isbc, b, args.tol, gpu)
+        out['cpu_baseline'], x_cpu = cpu_baseline(Kbc, isbc, b, args.tol, gpu,
+                                                  prob.num_dofs())
         out['cpu_baseline']['solution_rel_l2_gpu_vs_cpu'] = float(
             numpy.linalg.norm(x_gpu - x_cpu) / numpy.linalg.norm(x_cpu))
     print(json.dumps(out))

@@ -225,6 +225,8 @@ SYMBOLS = {
     'flow_profile_spmv_end': [_P(_D), _P(_I)],
     'flow_profile_event_overhead': [_P(_D), _VP],
     'flow_profile_marker': [_I, _VP],
+    'flow_profile_stream_copy': [ctypes.c_size_t, _VP, _VP, _VP],
+    'flow_profile_stream_read': [ctypes.c_size_t, _VP, _VP, _VP],
     'flow_operator_diag_inv': [_P(Operator), _VP, _VP, _VP],
     'flow_dot_host': [_I, _VP, _VP, _VP, _P(_D), _VP],
     'flow_norm_host': [_I, _VP, _I, _VP, _P(_D), _VP],

@@ -135,6 +135,37 @@ class KarmanProblem(object):
                 pre.stale = True
         return
 
+    def snapshot(self):
+        '''Fields, clock and step size (device copies).'''
+        from . import _hip
+        return dict(u=_hip.clone(self.u0.data), p=_hip.clone(self.p0.data),
+                    dt=self.dt, t=self.t)
+
+    def restore(self, snap):
+        '''Back to a snapshot; the controller's memory and what the steps of
+        mode 'fast' remember start afresh.'''
+        self.reset(snap['dt'])
+        fem.ops.copy(self.u0.data, snap['u'])
+        fem.ops.copy(self.p0.data, snap['p'])
+        self.t = snap['t']
+        return
+
+    def settle(self, rel=0.01, hold=3, max_steps=80, tol=1.0e-10):
+        '''Step until the CFL controller has brought the step size to its
+        plateau: `hold` consecutive steps on which dt moved by less than `rel`.
+        (From dt0 = 1e-5 the controller at most doubles dt per step: ~12 steps
+        of ramp in which the Newton systems are mass-dominated and the start
+        vector often passes the stopping test as it is -- not the regime a run
+        lives in.)  Returns the number of steps taken.'''
+        calm = 0
+        for k in range(max_steps):
+            before = self.dt
+            self.step(tol=tol)
+            calm = calm + 1 if abs(self.dt - before) <= rel * before else 0
+            if calm >= hold:
+                return k + 1
+        return max_steps
+
     def num_dofs(self):
         return self.W.size() + self.P.size()
 

@@ -181,6 +181,12 @@ _THETA = {
     }
 
 
+def _zeros(n):
+    '''A zeroed work vector; the fill is a kernel of the library on its stream
+    (no torch kernels inside a step).'''
+    return _hip.fill(device.empty(n), 0.0)
+
+
 def _bc_arrays(bcs, size):
     '''Sorted unique (dofs, values) on the device.'''
     dofs, vals = collect(bcs, size)
@@ -248,9 +254,8 @@ def _compute_tentative_velocity(
     nc = mesh.num_cells()
     n2 = W.size()
 
-    ui = Function(W)
     # initial guess: previous velocity (reference :204-220) ...
-    ui.assign(u[0])
+    ui = Function(W, _hip.clone(u[0].data))
     # ... or ('initial_guess': 'best'), when this call continues the trajectory
     # of the previous one (u[0] IS the velocity the last step returned), the
     # previous step's TENTATIVE velocity if its residual is smaller (choice (2)
@@ -626,8 +631,7 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
     ms = parallel.mesh_view(mesh)
     wv = parallel.view(lay)
     pv = parallel.view(P.layout)
-    ui = Function(W)
-    ui.assign(u[0])
+    ui = Function(W, _hip.clone(u[0].data))
     f0 = as_cell_coefficient(f[0], mesh, 2)
     f1 = as_cell_coefficient(f[1], mesh, 2)
     f0s, keep0 = ops.coef_struct(f0, mesh, lay.degree)
@@ -643,8 +647,8 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
     if J is None:
         J = ops.Matrix(lay, 2)
         lay._dev['jacobian'] = J
-    F = device.zeros(n2)
-    dx = device.zeros(n2)
+    F = _zeros(n2)
+    dx = _zeros(n2)
     buf = ops.scratch(mesh, max(2 * lay.nloc, 4 * lay.nloc**2) * nc)
     st = _hip.stream()
 
@@ -823,7 +827,7 @@ def _compute_pressure(
     st = _hip.stream()
 
     par = solver_parameters['pressure']
-    p1 = Function(P)
+    p1 = Function(P, device.empty(P.N))
     start_mode = None
     hist = _history(W.layout) if par.get('extrapolate', False) else None
     # The reference starts its Krylov solve from a fresh (zero) Function
@@ -833,13 +837,16 @@ def _compute_pressure(
     # system leaves open is the start's: p0 minus its (Euclidean) mean -- sum
     # zero like the reference's zero start, so that no constant accumulates
     # from step to step, and still exact on a state of rest.
-    if True:
-        p1.assign(p0)
-        if not p_bcs:
-            one = device.zeros(P.N) + 1.0
-            total = parallel.dot(one, p1.data, lay) if parallel.active() \
-                else ops.dot(one, p1.data)
-            ops.axpby(-total / P.N, one, 1.0, p1.data)
+    ops.copy(p1.data, p0.data)
+    if not p_bcs:
+        one = lay._dev.get('ones')
+        if one is None:
+            one = _zeros(P.N)
+            ops.fill(one, 1.0)
+            lay._dev['ones'] = one
+        total = parallel.dot(one, p1.data, lay) if parallel.active() \
+            else ops.dot(one, p1.data)
+        ops.axpby(-total / P.N, one, 1.0, p1.data)
     if hist is not None and 'p_in' in hist and 0.7 <= dt / hist['dt'] <= 1.5:
         # ... extrapolated through the previous pressures when this call
         # continues the previous step's trajectory at a settled step size
@@ -865,7 +872,8 @@ def _compute_pressure(
             ops.axpby(r, p0.data, 1.0, p1.data)
             ops.axpby(-r, hist['p_in'], 1.0, p1.data)
     K = ops.assemble_stiffness(P)
-    b = device.zeros(P.N)
+    # (the gather writes every row it owns: all of them on one GPU)
+    b = _zeros(P.N) if parallel.active() else device.empty(P.N)
     buf = ops.scratch(mesh, 3 * nc)
     _hip.check(lib.flow_assemble_pressure_rhs(
         ctypes.byref(_mesh_s(mesh)), ctypes.byref(_space_s(W.layout)),
@@ -884,7 +892,7 @@ def _compute_pressure(
                 )
             lay._dev[key] = (Kbc, Kbc.diag_inv())
         Kbc, dinv = lay._dev[key]
-        xg = device.zeros(P.N)
+        xg = _zeros(P.N)
         nbc = bc_dofs.numel()
         _hip.check(lib.flow_bc_set_values(
             nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(xg), st
@@ -933,7 +941,7 @@ def _compute_velocity_correction(
     n2 = W.size()
     st = _hip.stream()
 
-    b = device.zeros(n2)
+    b = _zeros(n2) if parallel.active() else device.empty(n2)
     buf = ops.scratch(mesh, 2 * lay.nloc * nc)
     _hip.check(lib.flow_assemble_correction_rhs(
         ctypes.byref(_mesh_s(mesh)), ctypes.byref(_space_s(lay)),
@@ -962,9 +970,8 @@ def _compute_velocity_correction(
         lay._dev[key] = (Mrows, Mrows.diag_inv())
     Mbc, dinv = lay._dev[key]
     nbc = bc_dofs.numel()
-    u1 = Function(W)
     # the tentative velocity is the natural initial guess: u1 - ui = O(dt) ...
-    ops.copy(u1.data, ui.data)
+    u1 = Function(W, _hip.clone(ui.data))
     # ... plus, when this call continues the previous one's trajectory, that
     # step's correction u1 - ui scaled with the step sizes (the correction
     # -dt/rho M^-1 grad(phi) varies slowly once the flow has settled: 6 -> 2-3

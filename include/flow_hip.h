@@ -108,6 +108,15 @@ int flow_profile_event_overhead(double* overhead_us, void* stream);
  * profiles/summarize.py cuts a rocprofv3 kernel trace at those launches instead
  * of at guessed offsets. */
 int flow_profile_marker(int id, void* stream);
+/* dst[0..n) = src[0..n) with a plain 16-byte-per-lane streaming kernel (n even,
+ * buffers 16-byte aligned): the measured copy ceiling of the box,
+ * 16 n bytes of traffic per launch; and the same for a kernel that only reads
+ * (8 n bytes; sink: one double, never written for finite data): what a
+ * read-dominated kernel like the SpMV can be held against. */
+int flow_profile_stream_copy(size_t n, const double* src, double* dst,
+                             void* stream);
+int flow_profile_stream_read(size_t n, const double* src, double* sink,
+                             void* stream);
 
 /* ---- K9: BLAS-1 (PETSc VecDot/VecAXPY/VecNorm) -------------------------- */
 int flow_dot_host(int n, const double* x, const double* y, double* work,
