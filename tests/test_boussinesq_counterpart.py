@@ -73,3 +73,66 @@ def test_boussinesq_at_the_reference_settings(hip):
           '%.6e / %.6e), |theta| %.9f / %.9f (golden %.9f / %.9f)'
           % (got[False][0], got[True][0], gold[False][0], gold[True][0],
              got[False][1], got[True][1], gold[False][1], gold[True][1]))
+
+
+def test_coupled_sweep_against_the_oracle(hip):
+    '''One fixed-point sweep of a Boussinesq time step (reference
+    tests/test_boussinesq.py:213-253: implicit Euler on Heat with the old
+    velocity, then Rotational.step with the buoyancy rho(theta) g) on the
+    body-fitted heater box, from a perturbed state, against the same two
+    solves of the CPU oracle: theta, u and p (mean-free: Neumann pressure) to
+    1e-7.  The oracle solves its linear systems exactly, so the Krylov
+    tolerance of the flow step is tightened to 1e-13 for the comparison, as in
+    tests/test_hip_parity.py: at the driver's 1e-10 -- relative to a right-hand
+    side that the hydrostatic pressure dominates -- the velocity differs from
+    the exact solve by 1.5e-6 (same Newton path: tentative velocity 2e-10).'''
+    from flow_amd.fem import reference
+    from flow_amd.fem.bcs import collect
+    from oracle import fem_oracle as orc
+    import cases
+    mesh = fem.heater_box(12, fitted=True)
+    pb = boussinesq.HeaterBox(mesh)
+    u0, p0, theta0 = pb.state_of_rest()
+    rng = numpy.random.RandomState(17)
+    xq = pb.Q.layout.dof_coords
+    xw = pb.W.layout.dof_coords
+    # a warm plume above the heater and a weak swirl that vanishes on the walls
+    th = 293.0 + 8.0 * numpy.exp(-((xq[:, 0] - 0.05)**2
+                                   + (xq[:, 1] - 0.09)**2) / 4e-4)
+    theta0.set_array(th)
+    bump = numpy.sin(numpy.pi * xw[:, 0] / 0.1) * numpy.sin(numpy.pi * xw[:, 1] / 0.2)
+    u = 1.0e-3 * numpy.concatenate([-(xw[:, 1] - 0.1) * bump,
+                                    (xw[:, 0] - 0.05) * bump])
+    d_u, v_u = collect(pb.no_slip, pb.W.size())
+    u[d_u] = v_u
+    u0.set_array(u)
+    t, dt = 12.0, 0.05
+    step = boussinesq.CoupledStep(pb, u0, p0, theta0, t, dt)
+    step.flow_tol = 1.0e-13
+    dist = step.sweep()
+    assert all(numpy.isfinite(dist)) and step.sweeps == 1
+
+    # the same sweep with the oracle
+    Qo = orc.Space(mesh.points, mesh.cell_vertices, pb.Q.layout.cell_dofs, 2, pb.Q.N)
+    Wo = orc.Space(mesh.points, mesh.cell_vertices, pb.W.layout.cell_dofs, 2, pb.W.N)
+    Po = orc.Space(mesh.points, mesh.cell_vertices, pb.P.layout.cell_dofs, 1, pb.P.N)
+    M, A, _b = orc.heat_operators(Qo, Wo, u, pb.kappa, pb.rho_room, pb.cp, 0.0,
+                                  False)
+    d_t, v_t = collect(pb.temperature_bcs(t), pb.Q.size())
+    theta_ref = orc.heat_solve(M.tocsr(), A.tocsr(), 1.0, -dt, M.dot(th), d_t, v_t)
+    # buoyancy: rho(theta) g interpolated nodally into P2 on every cell (the
+    # lattice of degree 2 is the local dof order)
+    dens = pb.rho(th)[pb.Q.layout.cell_dofs]                 # (Nc, 6)
+    f = numpy.stack([numpy.zeros_like(dens), dens * pb.gravity], axis=2)
+    lat = (reference.lattice(2), f)
+    u_ref, p_ref, _ui = orc.step(
+        Wo, Po, u, p0.array(), lat, lat, (d_u, v_u), None, pb.rho_room, pb.mu,
+        dt, scheme='rotational')
+    Mp = orc.mass_matrix(Po)
+    e_th = cases.rel_l2(step.theta.array() - 293.0, theta_ref - 293.0)
+    e_u = cases.rel_l2(step.u.array(), u_ref)
+    e_p = cases.rel_l2(cases.mean_free(step.p.array(), Mp),
+                       cases.mean_free(p_ref, Mp))
+    print('coupled sweep vs oracle: theta %.1e (of the excess over 293 K), '
+          'u %.1e, p %.1e' % (e_th, e_u, e_p))
+    assert e_th < 1e-7 and e_u < 1e-7 and e_p < 1e-7
