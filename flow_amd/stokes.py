@@ -13,11 +13,15 @@ BoomerAMG on  mu (grad u, grad v) - p q  (:40-60).
 Default here (solver_parameters['method'] = 'minres'): the same symmetric
 saddle-point system, Dirichlet values eliminated symmetrically like
 `assemble_system`, solved by preconditioned MINRES with the same block-diagonal
-preconditioner -- the viscous block replaced by ONE application of the two-level
-scheme (Jacobi + aggregate coarse space) per component, the pressure block by
-the scaled lumped pressure mass matrix.  One product with the system and one
-preconditioner application per iteration, no inner solves: 12 s of nested
-velocity solves on a 2.5 M-DoF channel become a fraction of that.
+preconditioner -- the viscous block replaced by ONE multigrid cycle per
+component (`ViscousCycle`: Chebyshev smoothing on P2, smoothed-aggregation
+V-cycle on the P1 Galerkin operator; where the reference runs BoomerAMG), the
+pressure block by the scaled lumped pressure mass matrix.  One product with the
+system and one preconditioner application per iteration, no inner solves.  On
+the 10 M-DoF Karman channel at tol 1e-13: 130 iterations, 0.4 s of iterations
+behind 3.6 s of host-side hierarchy setup (round 2, with one Jacobi +
+aggregate-coarse-space application on the viscous block instead: 8328
+iterations, 16 s).
 
 'schur': the same discrete system solved by CG on its pressure Schur complement
     S = B K^-1 B^T        (K = mu * vector Laplacian with the Dirichlet rows
@@ -52,8 +56,128 @@ last_solve_info = {}
 # hierarchy setup (scipy triple products on the P2 stiffness matrix) against
 # 0.3 s -- a one-shot solve is faster with the two-level scheme (5.5 s vs
 # 14.5 s in total); it pays when the same operator is solved with many times.
+# 'viscous_cycle' (method 'minres'): the preconditioner of the viscous block --
+# 'pmg' = ViscousCycle (Chebyshev on P2 + smoothed-aggregation V-cycle on the
+# P1 Galerkin operator), 'two_level' = one Jacobi + aggregate-coarse-space
+# application (round 2; 8328 MINRES iterations on the 10 M-DoF channel where
+# the cycle needs a few hundred)
 solver_parameters = {'multigrid': False, 'method': 'minres',
-                     'coarse_size': 4096}
+                     'coarse_size': 4096, 'viscous_cycle': 'pmg'}
+
+
+class ViscousCycle(object):
+    """Preconditioner of ONE component of the viscous block mu (grad u, grad v)
+    with its Dirichlet rows and columns eliminated -- what the reference hands
+    to BoomerAMG (flow/stokes.py:53-60, `hypre_amg` on mu inner(grad u, grad v)):
+    a symmetric two-level p-multigrid cycle
+
+        x = cheb(r);  x += P V(P^T (r - K x));  x += cheb(r - K x)
+
+    P2 level: `steps` Chebyshev steps for D^-1 K on [lam/ratio, 1.1 lam] (lam by
+    the power method) before and after; coarse level: the P1 discretisation of
+    the same form on the same mesh -- exactly the Galerkin operator P^T K P,
+    P1 being a subspace of P2 --, treated with one smoothed-aggregation V(1,1)
+    cycle (flow_amd/fem/multigrid.py, as the pressure solver: its hierarchy is
+    built on a matrix with 1/4 of the rows and 1/7 of the nonzeros of K, seconds
+    where a hierarchy on K itself takes a minute of host-side triple products).
+    Fixed, linear, symmetric positive definite (pre- and post-smoother are the
+    same polynomial in D^-1 K, the V-cycle is symmetric): fit for MINRES.
+    Everything is fp64 CSR-stream products of the library."""
+
+    def __init__(self, Kc, isbc, mu, steps=2, ratio=8.0):
+        import scipy.sparse as sp
+        from .fem.multigrid import Multigrid, CsrOperator
+        from .fem.pmg import transfer_tables
+        from .fem.space import scalar_layout
+        lay = Kc.layout
+        assert lay.degree == 2
+        lay1 = scalar_layout(lay.mesh, 1)
+        n, n1 = lay.N, lay1.N
+        self.K, self.n, self.n1 = Kc, n, n1
+        self.dinv = Kc.diag_inv()
+        self.steps = steps
+        # P1 level: mu * stiffness, Dirichlet vertices eliminated
+        isbc1 = isbc[lay.vertex_dofs]
+        K1 = ops.assemble_scalar_matrix(lay1, ops.STIFFNESS)
+        K1c = ops.symmetric_bc_matrix(
+            K1, device.to_device(isbc1.astype(numpy.uint8)))
+        ops.axpby(mu, K1c.vals, 0.0, K1c.vals)
+        if isbc1.any():
+            K1c.vals[lay1.dev('diag_idx').long()[device.to_device(isbc1)]] = 1.0
+        self.K1c = K1c
+        self.mg = Multigrid(K1c, isbc1, singular=not isbc1.any())
+        self.usable = self.mg.nlevels >= 2
+        if not self.usable:
+            return
+        # transfers between the free dofs of the two levels
+        ends, _rptr, _rsrc = transfer_tables(lay)
+        rows = numpy.repeat(numpy.arange(n), 2)
+        P = sp.csr_matrix((numpy.full(2 * n, 0.5), (rows, ends.ravel())),
+                          shape=(n, n1))
+        P = sp.diags((~isbc).astype(float)).dot(P).dot(
+            sp.diags((~isbc1).astype(float))).tocsr()
+        P.eliminate_zeros()
+        self.P = CsrOperator(P)
+        self.R = CsrOperator(P.T.tocsr())
+        self._vec = [device.empty(n) for _ in range(4)]
+        self._c = [device.empty(n1) for _ in range(2)]
+        # spectral radius of D^-1 K: power method
+        v = self._vec[0]
+        ops.copy(v, device.to_device(
+            numpy.random.RandomState(5).standard_normal(n)))
+        lam = 1.0
+        for _ in range(20):
+            Kc.apply(v, self._vec[1])
+            ops.vmul(self._vec[1], self.dinv, v)
+            lam = ops.vector_norm(v)
+            ops.axpby(0.0, v, 1.0 / lam, v)
+        self.lam = lam
+        hi, lo = 1.1 * lam, lam / ratio
+        self.theta, self.delta = 0.5 * (hi + lo), 0.5 * (hi - lo)
+
+    def _apply_csr(self, op, x, y):
+        _hip.check(_hip.lib().flow_operator_apply(
+            ctypes.byref(op.op), _hip.f64(x, op.shape[1]),
+            _hip.f64(y, op.shape[0]), _hip.stream()))
+
+    def _cheb(self, res, x, first):
+        """`steps` Chebyshev steps for K e = res, added to x (first: x = 0 on
+        entry and is overwritten).  res is overwritten."""
+        d, t = self._vec[2], self._vec[3]
+        sigma = self.theta / self.delta
+        rho = 1.0 / sigma
+        ops.vmul(res, self.dinv, d, a=1.0 / self.theta)
+        for k in range(self.steps):
+            if first and k == 0:
+                ops.copy(x, d)
+            else:
+                ops.axpby(1.0, d, 1.0, x)
+            if k + 1 < self.steps:
+                self.K.apply(d, t)
+                ops.axpby(-1.0, t, 1.0, res)
+                rn = 1.0 / (2.0 * sigma - rho)
+                ops.vmul(res, self.dinv, t, a=2.0 * rn / self.delta)
+                ops.axpby(1.0, t, rn * rho, d)
+                rho = rn
+
+    def apply(self, r, z):
+        """z = B r (r is left untouched)."""
+        res, t = self._vec[0], self._vec[1]
+        rc, xc = self._c
+        ops.copy(res, r)
+        self._cheb(res, z, True)
+        self.K.apply(z, t)
+        ops.copy(res, r)
+        ops.axpby(-1.0, t, 1.0, res)
+        self._apply_csr(self.R, res, rc)
+        self.mg.apply(rc, xc)
+        self._apply_csr(self.P, xc, t)
+        ops.axpby(1.0, t, 1.0, z)
+        self.K.apply(z, t)
+        ops.copy(res, r)
+        ops.axpby(-1.0, t, 1.0, res)
+        self._cheb(res, z, False)
+        return z
 
 
 def solve(
@@ -108,8 +232,7 @@ def solve(
     # K = mu * stiffness per component, Dirichlet rows/columns eliminated
     K = ops.assemble_scalar_matrix(lay, ops.STIFFNESS)
     planes = []
-    coarse = []
-    hierarchies = {}
+    masks = []
     for comp in range(2):
         isbc = (umask[comp * n:(comp + 1) * n] == 0.0)
         Kc = ops.symmetric_bc_matrix(
@@ -119,9 +242,29 @@ def solve(
         ops.axpby(mu, Kc.vals, 0.0, Kc.vals)
         Kc.vals[lay.dev('diag_idx').long()[device.to_device(isbc)]] = 1.0
         planes.append(Kc)
-        # preconditioner of the velocity solves: the smoothed-aggregation
-        # V-cycle (aggregates of ~3x3 dofs: half a mesh width per dof for P2),
-        # the two-level scheme for systems too small to coarsen
+        masks.append(isbc)
+    method = solver_parameters.get('method', 'minres')
+    # MINRES: the p-multigrid cycle on the viscous block (P2 spaces; systems too
+    # small to coarsen fall back to the two-level scheme)
+    cycles = None
+    if method == 'minres' and lay.degree == 2 and \
+            solver_parameters.get('viscous_cycle', 'pmg') == 'pmg':
+        made = {}
+        cycles = []
+        for comp in range(2):
+            key = masks[comp].tobytes()
+            if key not in made:
+                made[key] = ViscousCycle(planes[comp], masks[comp], mu)
+            cycles.append(made[key])
+        if not all(c.usable for c in cycles):
+            cycles = None
+    # preconditioner of the velocity solves of the other paths: the smoothed-
+    # aggregation V-cycle (aggregates of ~3x3 dofs: half a mesh width per dof
+    # for P2) or the two-level scheme
+    coarse = []
+    hierarchies = {}
+    for comp in range(2 if cycles is None else 0):
+        Kc, isbc = planes[comp], masks[comp]
         mg = None
         if multigrid:
             # both components usually carry Dirichlet data on the same dofs:
@@ -196,13 +339,6 @@ def solve(
     ops.vmul(F, umask_d, F)
     ops.axpby(1.0, ug_d, 1.0, F)
 
-    # u(p_f) = K^-1 (F - B^T p_f);  continuity on the free pressure rows:
-    #   B u(p_f) = 0   <=>   S p_f = B u(0)
-    u_hat = device.zeros(n2)
-    solve_K(F, u_hat)
-    rhs = device.empty(npr)
-    apply_B(u_hat, rhs)
-
     # preconditioner: mu / lumped pressure mass (S ~ M_p / mu)
     Mp = ops.assemble_scalar_matrix(play, ops.MASS)
     one = torch.ones(npr, dtype=torch.float64, device=device.get())
@@ -211,11 +347,19 @@ def solve(
     # minv = mu / lumped, zero on the pressure Dirichlet rows
     minv = device.to_device(mu * pmask / device.to_host(lumped).numpy())
 
-    if solver_parameters.get('method', 'minres') == 'minres':
+    if method == 'minres':
         return _minres(
             W, P, mu, tol, max_iter, verbose, planes, dinvs, coarse, F, ug_d,
-            pg_d, umask_d, pmask_d, minv, apply_B, apply_Bt
+            pg_d, umask_d, pmask_d, minv, apply_B, apply_Bt, cycles
             )
+
+    # u(p_f) = K^-1 (F - B^T p_f);  continuity on the free pressure rows:
+    #   B u(p_f) = 0   <=>   S p_f = B u(0)
+    u_hat = device.zeros(n2)
+    solve_K(F, u_hat)
+    rhs = device.empty(npr)
+    apply_B(u_hat, rhs)
+
 
     def apply_S(p, out):
         t = device.empty(n2)
@@ -273,7 +417,7 @@ def solve(
 
 
 def _minres(W, P, mu, tol, max_iter, verbose, planes, dinvs, coarse, F, ug_d,
-            pg_d, umask_d, pmask_d, minv, apply_B, apply_Bt):
+            pg_d, umask_d, pmask_d, minv, apply_B, apply_Bt, cycles=None):
     '''Preconditioned MINRES (Paige & Saunders; the form of Elman, Silvester &
     Wathen, Alg. 4.1) on the symmetric system
 
@@ -284,17 +428,20 @@ def _minres(W, P, mu, tol, max_iter, verbose, planes, dinvs, coarse, F, ug_d,
     eliminated (identity rows; F carries the lifted boundary values), Bm =
     pm B um the divergence coupling between the free rows, Ip the identity on
     the pressure Dirichlet rows -- `assemble_system(a, L, bcs)` of the
-    reference (flow/stokes.py:40-42).  Preconditioner: blockdiag(two-level
-    scheme of K per component, lumped pressure mass / mu) (:53-60, with one
-    cycle instead of BoomerAMG).  Converged when the preconditioned residual
+    reference (flow/stokes.py:40-42).  Preconditioner: blockdiag(ViscousCycle
+    of K per component -- or, cycles = None, one application of the two-level
+    scheme --, lumped pressure mass / mu) (:53-60, with one multigrid cycle
+    where the reference runs BoomerAMG).  Converged when the preconditioned residual
     has fallen by `tol` (relative_tolerance, absolute 0, :127-131).'''
     lib = _hip.lib()
     n, n2, npr = W.N, W.size(), P.N
     st = _hip.stream()
     lay = W.layout
-    for c in coarse:
-        assert c[0] is not None, "'minres' uses the two-level preconditioner"
-    cwork = device.empty(2 * max(c[0].struct.lda for c in coarse) + 2)
+    if cycles is None:
+        for c in coarse:
+            assert c[0] is not None, \
+                "'minres' without the cycle uses the two-level preconditioner"
+        cwork = device.empty(2 * max(c[0].struct.lda for c in coarse) + 2)
 
     class Vec(object):
         def __init__(self):
@@ -334,6 +481,9 @@ def _minres(W, P, mu, tol, max_iter, verbose, planes, dinvs, coarse, F, ug_d,
     def precondition(v, z):
         for comp in range(2):
             sl = slice(comp * n, (comp + 1) * n)
+            if cycles is not None:
+                cycles[comp].apply(v.u[sl], z.u[sl])
+                continue
             _hip.check(lib.flow_two_level_apply(
                 ctypes.byref(coarse[comp][0].struct),
                 _hip.f64(dinvs[comp], n), _hip.f64(v.u[sl].contiguous(), n),
@@ -412,6 +562,7 @@ def _minres(W, P, mu, tol, max_iter, verbose, planes, dinvs, coarse, F, ug_d,
     last_solve_info.clear()
     last_solve_info.update(
         outer_iterations=its, inner_iterations=0, inner_solves=0,
-        residual=abs(res) / max(gamma0, 1e-300), method='minres'
+        residual=abs(res) / max(gamma0, 1e-300), method='minres',
+        viscous_cycle='pmg' if cycles is not None else 'two_level'
         )
     return u, p
