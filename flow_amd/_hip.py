@@ -243,7 +243,7 @@ SYMBOLS = {
     'flow_gmres_solve': [_P(Operator), _VP, _P(IluS), _P(PmgS), _VP, _VP, _D,
                          _D, _I, _I, _I, _I, _VP, ctypes.c_size_t, _P(_I),
                          _P(_D), _VP],
-    'flow_pmg_pack': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
+    'flow_pmg_pack': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _P(_D), _VP],
     'flow_pmg_apply': [_P(PmgS), _VP, _VP, _VP],
     'flow_gather_rows': [_I, _VP, _I, _VP, _I, _VP, _I, _VP],
@@ -266,7 +266,7 @@ SYMBOLS = {
                               _P(MgShardS), _VP, _VP, _D, _D, _I, _I, _I, _VP,
                               ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_shard_gmres_solve': [_P(CommS), _P(RowsS), _P(Operator), _P(IluS),
-                               _VP, _VP, _D, _D, _I, _I, _I, _I, _VP,
+                               _P(PmgS), _VP, _VP, _D, _D, _I, _I, _I, _I, _VP,
                                ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_assemble_scalar_matrix': [_I, _P(MeshS), _P(SpaceS), _VP, _VP, _VP],
     'flow_assemble_pressure_rhs': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _VP,

@@ -1323,7 +1323,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 20; }
+extern "C" int flow_abi_version(void) { return 21; }
 
 // the workgroup -> tile mapping of the CSR-stream kernels, for host-side tests
 extern "C" int flow_xcd_tile_host(int block, int nblocks) {
@@ -2871,6 +2871,7 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
 // ---------------------------------------------------------------------------
 static int shard_gmres(const flow_comm* C, const flow_rows* R,
                        const flow_operator* A, const flow_ilu* ilu,
+                       const flow_pmg* pmg,
                        const double* b, double* x, double rtol, double atol,
                        int maxit, int m, int x_is_zero, int expected,
                        double* work, int* iters_host, double* resid_host,
@@ -2930,7 +2931,10 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
     int r;
     double* w = V + static_cast<size_t>(j + 1) * N;
     double* zj = Z + static_cast<size_t>(j) * N;
-    if ((r = ilu_apply(ilu, V + static_cast<size_t>(j) * N, zj, iwork, st, stop)))
+    // block Jacobi: the rank's own preconditioner on its owned rows
+    if ((r = pmg ? pmg_apply(pmg, V + static_cast<size_t>(j) * N, zj, st, stop)
+                 : ilu_apply(ilu, V + static_cast<size_t>(j) * N, zj, iwork, st,
+                             stop)))
       return r;
     if ((r = apply_owned(zj, w, stop))) return r;
     for (int k0 = 0; k0 <= j; k0 += 8) {
@@ -3183,9 +3187,10 @@ extern "C" int flow_shard_mgcg_solve(
 
 extern "C" int flow_shard_gmres_solve(
     const flow_comm* comm, const flow_rows* rows, const flow_operator* A,
-    const flow_ilu* ilu, const double* b, double* x, double rtol, double atol,
-    int maxit, int restart, int x_is_zero, int expected_its, double* work,
-    size_t work_len, int* iters_host, double* resid_host, void* stream) {
+    const flow_ilu* ilu, const flow_pmg* pmg, const double* b, double* x,
+    double rtol, double atol, int maxit, int restart, int x_is_zero,
+    int expected_its, double* work, size_t work_len, int* iters_host,
+    double* resid_host, void* stream) {
   int rc = check_shard_solver(comm, rows, A, b, x, rtol, atol, maxit, work,
                               iters_host, resid_host);
   if (rc) return rc;
@@ -3197,8 +3202,10 @@ extern "C" int flow_shard_gmres_solve(
   FLOW_REQUIRE(J->W->r0 == rows->r0 && J->W->r1 == rows->r1,
                "the operator's row range must be the rank's owned rows");
   const int mo = rows->r1 - rows->r0, me = rows->e1 - rows->e0;
-  FLOW_REQUIRE(ilu != nullptr, "sharded GMRES needs the block-Jacobi ILU(0)");
-  if ((rc = ilu_check(ilu, 2 * mo))) return rc;
+  FLOW_REQUIRE((ilu != nullptr) != (pmg != nullptr),
+               "sharded GMRES needs ONE block-Jacobi preconditioner: ilu or pmg");
+  if (ilu && (rc = ilu_check(ilu, 2 * mo))) return rc;
+  if (pmg && (rc = pmg_check(pmg, 2 * mo))) return rc;
   long long need = 2LL * rows->nhalo;
   if (need < FLOW_GMRES_MAX_RESTART + 2) need = FLOW_GMRES_MAX_RESTART + 2;
   if ((rc = check_comm(comm, need))) return rc;
@@ -3207,7 +3214,7 @@ extern "C" int flow_shard_gmres_solve(
                                2 * static_cast<size_t>(me) + FLOW_GMRES_PARTIALS +
                                FLOW_GMRES_STATE,
                "sharded GMRES workspace too small");
-  return shard_gmres(comm, rows, A, ilu, b, x, rtol, atol, maxit, restart,
+  return shard_gmres(comm, rows, A, ilu, pmg, b, x, rtol, atol, maxit, restart,
                      x_is_zero, expected_its, work, iters_host, resid_host,
                      as_stream(stream));
 }

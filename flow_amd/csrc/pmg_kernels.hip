@@ -294,12 +294,14 @@ __global__ __launch_bounds__(kBlock) void pmg_prolong_kernel(
   }
 }
 
-// setup: vals[k] = half2((a00, a11)[k] / their diagonals of row(k)); diag / dinv
+// setup: vals[k] = half2((a00, a11)[k] / their diagonals of row(k)) -- 0 where
+// keep[k] == 0 (couplings that leave a rank's diagonal block) --; diag / dinv
 // per row.  A lane per row (setup only: once per refactorisation).
 __global__ void pmg_pack_kernel(int n, const int* __restrict__ rowptr,
                                 const int* __restrict__ diag_idx,
                                 const double* __restrict__ a00,
                                 const double* __restrict__ a11,
+                                const unsigned char* __restrict__ keep,
                                 __half2* __restrict__ vals,
                                 float2* __restrict__ diag,
                                 float2* __restrict__ dinv) {
@@ -310,9 +312,12 @@ __global__ void pmg_pack_kernel(int n, const int* __restrict__ rowptr,
     const double i0 = 1.0 / d0, i1 = 1.0 / d1;
     diag[i] = f2(static_cast<float>(d0), static_cast<float>(d1));
     dinv[i] = f2(static_cast<float>(i0), static_cast<float>(i1));
-    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
-      vals[k] = __floats2half2_rn(static_cast<float>(a00[k] * i0),
-                                  static_cast<float>(a11[k] * i1));
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      const bool in = keep == nullptr || keep[k] != 0;
+      vals[k] = in ? __floats2half2_rn(static_cast<float>(a00[k] * i0),
+                                       static_cast<float>(a11[k] * i1))
+                   : __floats2half2_rn(0.f, 0.f);
+    }
   }
 }
 
@@ -501,8 +506,8 @@ using namespace flow;
 
 extern "C" int flow_pmg_pack(int n, int nnz, const int* rowptr,
                              const int* diag_idx, const double* a00,
-                             const double* a11, void* vals, float* diag,
-                             float* dinv, void* stream) {
+                             const double* a11, const unsigned char* keep,
+                             void* vals, float* diag, float* dinv, void* stream) {
   FLOW_REQUIRE(n > 0 && nnz > 0 && rowptr && diag_idx && a00 && a11 && vals &&
                    diag && dinv,
                "flow_pmg_pack arguments");
@@ -510,7 +515,8 @@ extern "C" int flow_pmg_pack(int n, int nnz, const int* rowptr,
                "packed values must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(pmg_pack_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
-                     rowptr, diag_idx, a00, a11, reinterpret_cast<__half2*>(vals),
+                     rowptr, diag_idx, a00, a11, keep,
+                     reinterpret_cast<__half2*>(vals),
                      reinterpret_cast<float2*>(diag),
                      reinterpret_cast<float2*>(dinv));
   FLOW_CHECK_LAUNCH();

@@ -67,10 +67,50 @@ def transfer_tables(lay2):
     return ends, rptr.astype(numpy.int32), rsrc
 
 
+def local_transfer_tables(lay2, rows, vrows):
+    '''The same tables for the diagonal block of a strip (flow_amd/parallel.py):
+    P2 rows [r0, r1) and P1 rows (vertices) [v0, v1) in LOCAL numbering.  An
+    end point outside the block becomes the dummy coarse row v1 - v0 (the
+    kernels read a zero there); the restriction lists hold the block's own
+    dofs only.'''
+    r0, r1 = rows
+    v0, v1 = vrows
+    ends, rptr, rsrc = transfer_tables(lay2)
+    n1 = v1 - v0
+    e = ends[r0:r1].astype(numpy.int64)
+    inside = (e >= v0) & (e < v1)
+    e_loc = numpy.where(inside, e - v0, n1).astype(numpy.int32)
+    # a vertex dof of the block names its own vertex: always inside
+    starts = rptr[v0:v1].astype(numpy.int64)
+    stops = rptr[v0 + 1:v1 + 1].astype(numpy.int64)
+    seg = rsrc[starts[0]:stops[-1]].astype(numpy.int64) if n1 else \
+        numpy.zeros(0, dtype=numpy.int64)
+    owner = numpy.repeat(numpy.arange(n1), stops - starts)
+    keep = (seg >= r0) & (seg < r1)
+    first = numpy.zeros(len(seg), dtype=bool)
+    first[starts - starts[0]] = True
+    assert keep[first].all(), 'a vertex dof outside its vertex\'s block'
+    cnt = numpy.bincount(owner[keep], minlength=n1)
+    rptr_loc = numpy.zeros(n1 + 1, dtype=numpy.int64)
+    numpy.cumsum(cnt, out=rptr_loc[1:])
+    rsrc_loc = (seg[keep] - r0).astype(numpy.int32)
+    return e_loc, rptr_loc.astype(numpy.int32), rsrc_loc
+
+
 class _Level(object):
-    def __init__(self, lay):
+    def __init__(self, lay, rows=None):
+        '''rows = (r0, r1): the diagonal block of those rows in local numbering
+        (block Jacobi on a strip).'''
         self.lay = lay
+        self.rows = rows
+        if rows is not None:
+            self._init_block(lay, rows)
+            return
+        self.offset, self.keep = 0, None
         n, nnz = lay.N, lay.nnz
+        self.n, self.nnz = n, nnz
+        self.diag_idx = lay.dev('diag_idx')
+        self.rowptr = lay.dev('rowptr')
         # (half2 per nonzero; readable three entries past nnz: the kernels load
         # QUADS of nonzeros from a base aligned down to a multiple of four)
         self.vals = torch.zeros(2 * (nnz + 4), dtype=torch.float16,
@@ -84,10 +124,14 @@ class _Level(object):
             lay._dev['pmg_rowblocks'] = device.to_device(csr_stream_rowblocks(
                 lay.pattern('rowptr'), nnz_per_block=_hip.PMG_NNZ_PER_BLOCK))
         rb = lay._dev['pmg_rowblocks']
+        self._fill_struct(lay.dev('rowptr'), lay.dev('cols'), rb)
+
+    def _fill_struct(self, rowptr, cols, rb):
+        n, nnz = self.n, self.nnz
         s = _hip.PmgLevelS()
         s.n, s.nnz, s.nblocks = n, nnz, rb.numel() - 1
-        s.rowptr = _hip.i32(lay.dev('rowptr'), n + 1, 'rowptr')
-        s.cols = _hip.i32(lay.dev('cols'), nnz + 4, 'cols')
+        s.rowptr = _hip.i32(rowptr, n + 1, 'rowptr')
+        s.cols = _hip.i32(cols, nnz + 4, 'cols')
         s.rowblocks = _hip.i32(rb, None, 'rowblocks')
         s.vals = _hip.f16(self.vals, 2 * nnz, 'vals')
         s.diag = _hip.f32(self.diag, 2 * n, 'diag')
@@ -95,22 +139,54 @@ class _Level(object):
         s.lam_min, s.lam_max = 0.25, 2.0
         self.struct = s
 
+    def _init_block(self, lay, rows):
+        r0, r1 = rows
+        rp = lay.pattern('rowptr').astype(numpy.int64)
+        k0, k1 = int(rp[r0]), int(rp[r1])
+        n, nnz = r1 - r0, k1 - k0
+        self.n, self.nnz, self.offset = n, nnz, k0
+        cols = lay.pattern('cols')[k0:k1].astype(numpy.int64)
+        row_of = numpy.repeat(numpy.arange(r0, r1), numpy.diff(rp[r0:r1 + 1]))
+        inside = (cols >= r0) & (cols < r1)
+        # couplings that leave the block: value 0 (keep mask), column = own row
+        cols_loc = numpy.where(inside, cols - r0, row_of - r0)
+        self._host = dict(
+            rowptr=(rp[r0:r1 + 1] - k0).astype(numpy.int32),
+            cols=numpy.concatenate([cols_loc, numpy.zeros(4)]).astype(numpy.int32),
+            diag_idx=(lay.pattern('diag_idx')[r0:r1].astype(numpy.int64)
+                      - k0).astype(numpy.int32),
+            keep=inside.astype(numpy.uint8))
+        self.rowptr = device.to_device(self._host['rowptr'])
+        self._cols = device.to_device(self._host['cols'])
+        self.diag_idx = device.to_device(self._host['diag_idx'])
+        self.keep = device.to_device(self._host['keep'])
+        self.vals = torch.zeros(2 * (nnz + 4), dtype=torch.float16,
+                                device=device.get())
+        self.diag = torch.zeros(2 * n, dtype=torch.float32, device=device.get())
+        self.dinv = torch.zeros(2 * n, dtype=torch.float32, device=device.get())
+        self._rb = device.to_device(csr_stream_rowblocks(
+            self._host['rowptr'], nnz_per_block=_hip.PMG_NNZ_PER_BLOCK))
+        self._fill_struct(self.rowptr, self._cols, self._rb)
+
     def pack(self, J):
         '''Diagonal blocks (planes 0 and 3) of a kind-2 Matrix on this layout.'''
         lay = self.lay
         assert J.layout is lay and J.kind == 2
+        n, nnz, k0 = self.n, self.nnz, self.offset
         _hip.check(_hip.lib().flow_pmg_pack(
-            lay.N, lay.nnz, _hip.i32(lay.dev('rowptr'), lay.N + 1, 'rowptr'),
-            _hip.i32(lay.dev('diag_idx'), lay.N, 'diag_idx'),
-            _hip.f64(J.plane(0), lay.nnz), _hip.f64(J.plane(3), lay.nnz),
-            _hip.f16(self.vals, 2 * lay.nnz), _hip.f32(self.diag, 2 * lay.N),
-            _hip.f32(self.dinv, 2 * lay.N), _hip.stream()))
+            n, nnz, _hip.i32(self.rowptr, n + 1, 'rowptr'),
+            _hip.i32(self.diag_idx, n, 'diag_idx'),
+            _hip.f64(J.plane(0)[k0:k0 + nnz], nnz),
+            _hip.f64(J.plane(3)[k0:k0 + nnz], nnz),
+            _hip.u8(self.keep, nnz) if self.keep is not None else None,
+            _hip.f16(self.vals, 2 * nnz), _hip.f32(self.diag, 2 * n),
+            _hip.f32(self.dinv, 2 * n), _hip.stream()))
 
     def lambda_max(self, work, iterations=25):
         res = ctypes.c_double(0.0)
         _hip.check(_hip.lib().flow_pmg_lambda_max(
             ctypes.byref(self.struct), int(iterations),
-            _hip.f32(work, 6 * self.lay.N),
+            _hip.f32(work, 6 * self.n),
             _hip.f64(ops.work(_hip.REDUCE_WORK)), ctypes.byref(res),
             _hip.stream()))
         return res.value
@@ -127,24 +203,33 @@ class Pmg(object):
     flat optimum).'''
 
     def __init__(self, W, pre=2, post=2, coarse_steps=4, ratio_fine=8.0,
-                 ratio_coarse=8.0, safety=1.1):
+                 ratio_coarse=8.0, safety=1.1, rows=None, vrows=None):
+        '''rows / vrows = (r0, r1) / (v0, v1): block Jacobi on a strip -- the
+        cycle on the diagonal block of those P2 / P1 rows in local numbering,
+        couplings that leave the block dropped (flow_amd/parallel.py).'''
         lay = W.layout
         assert lay.degree == 2, 'the p-multigrid needs a P2 velocity space'
         self.lay = lay
         self.lay1 = scalar_layout(lay.mesh, 1)
-        self.fine = _Level(lay)
-        self.coarse = _Level(self.lay1)
+        self.rows, self.vrows = rows, vrows
+        self.fine = _Level(lay, rows)
+        self.coarse = _Level(self.lay1, vrows)
         self.ratio_fine, self.ratio_coarse = ratio_fine, ratio_coarse
         self.safety = safety
-        ends, rptr, rsrc = transfer_tables(lay)
-        n, n1 = lay.N, self.lay1.N
+        if rows is None:
+            ends, rptr, rsrc = transfer_tables(lay)
+        else:
+            ends, rptr, rsrc = local_transfer_tables(lay, rows, vrows)
+        n, n1 = self.fine.n, self.coarse.n
         self._keep = dict(
             ends=device.to_device(ends.reshape(-1)),
             rptr=device.to_device(rptr), rsrc=device.to_device(rsrc),
             bc_fine=torch.zeros(2 * n, dtype=torch.uint8, device=device.get()),
             bc_coarse=torch.zeros(2 * n1, dtype=torch.uint8,
                                   device=device.get()),
-            work=torch.zeros(12 * n + 8 * n1, dtype=torch.float32,
+            # (+ one zero float2 behind the coarse vectors: the dummy coarse
+            # row of dofs whose partner vertex lies outside a block)
+            work=torch.zeros(12 * n + 8 * n1 + 2, dtype=torch.float32,
                              device=device.get()),
             )
         k = self._keep
@@ -156,7 +241,7 @@ class Pmg(object):
         s.rsrc = _hip.i32(k['rsrc'], len(rsrc), 'rsrc')
         s.bc_fine = _hip.u8(k['bc_fine'], 2 * n).value
         s.bc_coarse = _hip.u8(k['bc_coarse'], 2 * n1).value
-        s.work = _hip.f32(k['work'], 12 * n + 8 * n1).value
+        s.work = _hip.f32(k['work'], 12 * n + 8 * n1 + 2).value
         assert k['work'].data_ptr() % 16 == 0
         self.struct = s
         self._bc_key = None
@@ -186,6 +271,10 @@ class Pmg(object):
         bc1 = self.coarse_bc_dofs(bc_dofs_host)
         m1 = numpy.zeros(2 * n1, dtype=numpy.uint8)
         m1[bc1] = 1
+        if self.rows is not None:
+            (r0, r1), (v0, v1) = self.rows, self.vrows
+            m0 = numpy.concatenate([m0[r0:r1], m0[n + r0:n + r1]])
+            m1 = numpy.concatenate([m1[v0:v1], m1[n1 + v0:n1 + v1]])
         self._keep['bc_fine'].copy_(torch.from_numpy(m0))
         self._keep['bc_coarse'].copy_(torch.from_numpy(m1))
         device.synchronize()
@@ -211,8 +300,9 @@ class Pmg(object):
         return self
 
     def apply(self, r, z):
-        '''z = M^-1 r (tests / direct use).'''
-        n2 = 2 * self.lay.N
+        '''z = M^-1 r (tests / direct use); on a block: vectors of the block's
+        rows, component stride = its size.'''
+        n2 = 2 * self.fine.n
         _hip.check(_hip.lib().flow_pmg_apply(
             ctypes.byref(self.struct), _hip.f64(r, n2, 'r'), _hip.f64(z, n2, 'z'),
             _hip.stream()))

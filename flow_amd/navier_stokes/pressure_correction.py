@@ -526,6 +526,7 @@ def _compute_tentative_velocity(
             applications.append(2 * its)
         last_linear_residual = sol.residual
         linear_its.append(its)
+        last_step_info['newton_preconditioner'] = kind
         if pre is not None:
             if refactored:
                 pre.base_its = max(its, npar['check_every'])
@@ -564,11 +565,45 @@ def _contraction(pre, operator, lay, bc_dofs_host):
     return ratio if numpy.isfinite(ratio) else float('inf')
 
 
-def _coarse_jacobian(pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host):
+def _contraction_on_strips(pre, Jop, lay, bc_dofs_host):
+    """_contraction for the block preconditioner of the calling rank: the same
+    probe vector on every rank (seeded: its ghost rows need no exchange), the
+    Jacobian action on the rank's rows, the rank's cycle on them, and
+    |v - M^-1 J v| / |v| summed over the ranks -- every rank gets the same
+    number and takes the same decision."""
+    import torch
+    n = lay.N
+    v2 = parallel.view(lay)
+    r0, r1 = v2.r0, v2.r1
+    hold = lay._dev.setdefault('pmg_probe_strip', {})
+    bkey = (hash(bc_dofs_host.tobytes()), r0, r1)
+    if hold.get('key') != bkey:
+        v = numpy.random.RandomState(7).standard_normal(2 * n)
+        v[bc_dofs_host] = 0.0
+        own = numpy.concatenate([v[r0:r1], v[n + r0:n + r1]])
+        hold.update(key=bkey, v=device.to_device(v), w=device.empty(2 * n),
+                    vo=device.to_device(own), zo=device.empty(2 * (r1 - r0)))
+    v, w, vo, zo = hold['v'], hold['w'], hold['vo'], hold['zo']
+    Jop.apply(v, w)
+    wo = torch.cat([w[r0:r1], w[n + r0:n + r1]]).contiguous()
+    pre.apply(wo, zo)
+    ops.axpby(1.0, vo, -1.0, zo)
+    sums = torch.stack([(zo * zo).sum(), (vo * vo).sum()])
+    parallel.comm().allreduce_tensor(sums)
+    num, den = [float(x) for x in device.to_host(sums)]
+    ratio = numpy.sqrt(num / den) if den > 0.0 else float('inf')
+    return ratio if numpy.isfinite(ratio) else float('inf')
+
+
+def _coarse_jacobian(pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host,
+                     mesh_s=None, space1_s=None, pspace_s=None):
     """The Jacobian of the P1 discretisation of the same Newton system at the
     vertex values of `ui` (the coarse level of flow_amd/fem/pmg.py): assembled
     by the P1 instance of the momentum kernel (the P1-P1 element pair of
-    BASELINE config 2 runs through it), Dirichlet rows -> identity rows."""
+    BASELINE config 2 runs through it), Dirichlet rows -> identity rows.
+    mesh_s / space1_s / pspace_s: a rank's views of the mesh, the P1 velocity
+    space and the pressure space (the strips of flow_amd.parallel: its cells,
+    its rows)."""
     lib = _hip.lib()
     mesh = W.mesh()
     lay, lay1 = W.layout, pre.lay1
@@ -586,11 +621,13 @@ def _coarse_jacobian(pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host):
         _hip.f64(ui1, 2 * n1), n1, st))
     f0s, keep0 = ops.coef_struct(f0, mesh, 1)
     f1s, keep1 = ops.coef_struct(f1, mesh, 1)
-    s1 = ops.space_struct(lay1)
+    s1 = space1_s if space1_s is not None else ops.space_struct(lay1)
     buf = ops.scratch(mesh, 4 * lay1.nloc**2 * nc)
     _hip.check(lib.flow_assemble_momentum(
-        ctypes.byref(ops.mesh_struct(mesh)), ctypes.byref(s1),
-        ctypes.byref(ops.space_struct(P.layout)),
+        ctypes.byref(mesh_s if mesh_s is not None else ops.mesh_struct(mesh)),
+        ctypes.byref(s1),
+        ctypes.byref(pspace_s if pspace_s is not None
+                     else ops.space_struct(P.layout)),
         _hip.i32(bfmask, nc, 'bfmask'), _hip.f64(ui1, 2 * n1),
         _hip.f64(ui1, 2 * n1), _hip.f64(p0.data, P.size()),
         ctypes.byref(f0s), ctypes.byref(f1s), ctypes.byref(prm),
@@ -666,7 +703,7 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
     applications = []
     linear_its = []
     it = 0
-    Jop = None
+    state = {}
     key = (rho, mu, theta_i, nbc, hash(bc_dofs_host.tobytes()),
            parallel.comm().world)
     while True:
@@ -685,45 +722,95 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
                 'Newton solver did not converge after %d iterations '
                 '(residual history %r)' % (it, history)
                 )
-        # lagged block-Jacobi ILU(0), refactored by the same rules as on one
-        # GPU; `stale` is decided from the iteration count, which is the same
-        # on every rank
-        pre = lay._dev.get('jacobian_ilu_strip')
-        refactored = False
-        if pre is None or pre.key != key or pre.stale or (
-                it == 0 and not (1.0 / npar['ilu_lag'] <= dt / pre.dt
-                                 <= npar['ilu_lag'])):
+        def jacobian_action():
+            held = state.get('Jop')
+            if held is None:
+                held = state['Jop'] = ops.MomentumJacobian.cached(
+                    W, bfmask, ui.data, prm, bc_dofs, mesh_s=ms,
+                    space_s=wv.space)
+            return held
+
+        # lagged block-Jacobi preconditioner -- the rank's own two-level cycle
+        # (P2 spaces) or ILU(0) of its diagonal block --, rebuilt by the same
+        # rules as on one GPU; `stale` is decided from the iteration count,
+        # which is the same on every rank
+        kind = 'pmg' if (npar.get('preconditioner') == 'pmg'
+                         and lay.degree == 2) else 'ilu0'
+        rej = lay._dev.get('pmg_rejected_strip')
+        if kind == 'pmg' and rej is not None and rej[0] == key \
+                and dt > 0.5 * rej[1]:
+            kind = 'ilu0'
+
+        def build(kind):
+            slot = 'jacobian_%s_strip' % ('ilu' if kind == 'ilu0' else 'pmg')
+            pre = lay._dev.get(slot)
+            if not (pre is None or pre.key != key or pre.stale or (
+                    it == 0 and not (1.0 / npar['ilu_lag'] <= dt / pre.dt
+                                     <= npar['ilu_lag']))):
+                return kind, pre, False
             assemble(False, True)
             _hip.check(lib.flow_bc_identity_rows(
                 ctypes.byref(J.operator()), _hip.f64(J.vals),
                 _hip.i32(lay.dev('diag_idx')), nbc, _hip.i32(bc_dofs), st
                 ))
-            if pre is None:
+            if kind == 'pmg':
+                if pre is None:
+                    pre = parallel.local_pmg(W, **npar.get('pmg', {}))
+                    lay._dev[slot] = pre
+                pre.refactor(J, _coarse_jacobian(
+                    pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host,
+                    mesh_s=ms, space1_s=parallel.view(pre.lay1).space,
+                    pspace_s=pv.space))
+                pre.dt, pre.key, pre.stale = dt, key, False
+                # (the contraction test of the single-GPU path, summed over
+                # the ranks: the same verdict everywhere)
+                pre.contraction = _contraction_on_strips(
+                    pre, jacobian_action(), lay, bc_dofs_host)
+                last_step_info['pmg_contraction'] = pre.contraction
+                if not pre.contraction < npar.get('pmg_accept', 0.8):
+                    lay._dev['pmg_rejected_strip'] = (key, dt)
+                    return build('ilu0')
+                return 'pmg', pre, True
+            elif pre is None:
                 pre = parallel.local_ilu(
                     J, packed=npar.get('ilu_storage', 'fp32') == 'fp32',
                     single_vector=npar.get('ilu_vector') == 'fp32')
-                lay._dev['jacobian_ilu_strip'] = pre
+                lay._dev[slot] = pre
             else:
                 pre.refactor(J)
             pre.dt, pre.key, pre.stale = dt, key, False
-            refactored = True
-        if Jop is None:
-            Jop = ops.MomentumJacobian.cached(W, bfmask, ui.data, prm, bc_dofs,
-                                              mesh_s=ms, space_s=wv.space)
+            return kind, pre, True
+
+        kind, pre, refactored = build(kind)
+        Jop = jacobian_action()
         lin_atol = max(npar['linear_atol_factor'] * tol, npar['forcing'] * nrm)
         lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
         ops.fill(dx, 0.0)
         # (the count of the previous call's Newton iteration `it`: the same
         # number on every rank -- they all ran the same solve)
         expected = lay._dev.setdefault('gmres_expected_strip', {})
-        sol = parallel.gmres(Jop, pre, F, dx, rtol=lin_rtol, atol=0.0,
-                             maxit=npar['linear_maxit'],
-                             restart=npar['gmres_restart'], x_is_zero=True,
-                             expected=expected.get(it, 0))
+        def solve(maxit):
+            return parallel.gmres(Jop, pre, F, dx, rtol=lin_rtol, atol=0.0,
+                                  maxit=maxit, restart=npar['gmres_restart'],
+                                  x_is_zero=True, expected=expected.get(it, 0))
+        if kind == 'pmg':
+            # (no contraction test on the strips: a GMRES that has not
+            # converged after `pmg_maxit` applications -- the count is the same
+            # on every rank -- is redone with the block ILU(0) everywhere)
+            try:
+                sol = solve(min(npar['linear_maxit'], npar.get('pmg_maxit', 150)))
+            except _hip.NotConverged:
+                lay._dev['pmg_rejected_strip'] = (key, dt)
+                ops.fill(dx, 0.0)
+                kind, pre, refactored = build('ilu0')
+                sol = solve(npar['linear_maxit'])
+        else:
+            sol = solve(npar['linear_maxit'])
         expected[it] = sol.iterations
         its = (sol.iterations + 1) // 2
         applications.append(sol.iterations)
         linear_its.append(its)
+        last_step_info['newton_preconditioner'] = kind + ' (block Jacobi)'
         if refactored:
             pre.base_its = max(its, npar['check_every'])
         elif its > 2 * pre.base_its:

@@ -39,6 +39,7 @@ Fields stay global-length on every rank (memory is not the scarce resource:
 288 GB), valid on the owned + ghost rows; `gather_field` makes one whole (tests,
 output).
 '''
+import atexit
 import ctypes
 import os
 import traceback
@@ -71,8 +72,18 @@ def enable(group, force=False):
 
 
 def disable():
+    c = _STATE['comm']
+    if c is not None:
+        c.close()
     _STATE['group'] = None
     _STATE['comm'] = None
+
+
+@atexit.register
+def _close_at_exit():
+    c = _STATE.get('comm')
+    if c is not None:
+        c.close()
 
 
 def active(nrows=None):
@@ -116,10 +127,27 @@ class Comm(object):
         self.buf = None
         self.struct = None
         self.direct = None          # RcclBinding when the library calls RCCL
+        self._rccl_comm = None
+        self.failed = False         # a collective failed: no further ones
         self.ensure(capacity)
+        # The all-reduce issued by the library itself (no Python, no event
+        # hand-over per collective) is OPT-IN: it has only ever run on 1-rank
+        # groups (the development box has one GPU), torch.distributed's
+        # all_reduce is the path every multi-rank test goes through.
         if not self.staged and device.on_gpu() and \
-                os.environ.get('FLOW_AMD_RCCL_DIRECT', '1') != '0':
+                os.environ.get('FLOW_AMD_RCCL_DIRECT', '0') == '1':
             self._bind_rccl()
+
+    def close(self):
+        '''Destroy the library's own RCCL communicator (if one was made).'''
+        comm, self._rccl_comm = self._rccl_comm, None
+        if comm is not None:
+            self.direct = None
+            try:
+                device.synchronize()
+                _hip.load_library().flow_rccl_comm_destroy(comm)
+            except Exception:                                  # noqa: BLE001
+                traceback.print_exc()
 
     def ensure(self, capacity):
         '''Grow the exchange buffer to at least `capacity` doubles.'''
@@ -133,6 +161,14 @@ class Comm(object):
                 self.buf.numel(), self._cb, None)
             if self.direct is not None:
                 self._point_struct_at_rccl()
+        if self.direct is not None:
+            # the solvers enqueue on torch's CURRENT stream, whatever it was
+            # when the binding was made: ncclAllReduce must run on the same one
+            self.direct.stream = ctypes.c_void_p(device.stream_handle())
+        if self.failed:
+            raise _hip.HipError(
+                'a collective of this communicator failed earlier: the ranks '
+                'are no longer in step, no further collectives are issued')
         return self.struct
 
     # -- the all-reduce issued by the library itself (csrc/rccl_direct.hip) -----
@@ -211,6 +247,7 @@ class Comm(object):
             return 0
         except Exception:                                  # noqa: BLE001
             traceback.print_exc()
+            self.failed = True
             return 1
 
     def allreduce_tensor(self, t):
@@ -586,11 +623,14 @@ def mgcg(A, dinv, mg, b, x, rtol, atol=0.0, maxit=1000, check_every=2,
     return _solve_info(its.value, res.value, 'cg+mg%d' % mg.nlevels)
 
 
-def gmres(Jop, ilu, b, x, rtol, atol=0.0, maxit=1000, restart=20,
+def gmres(Jop, pre, b, x, rtol, atol=0.0, maxit=1000, restart=20,
           x_is_zero=True, expected=0):
-    '''GMRES + block-Jacobi ILU(0) on the strips; Jop: a MomentumJacobian built
-    on the rank's views (kind 3).  b, x: global-length velocity fields (owned
-    rows).'''
+    '''GMRES + a block-Jacobi preconditioner on the strips -- `pre`: the rank's
+    own ILU(0) (local_ilu) or two-level cycle (local_pmg) of its diagonal
+    block; Jop: a MomentumJacobian built on the rank's views (kind 3).  b, x:
+    global-length velocity fields (owned rows).'''
+    from .fem.pmg import Pmg
+    is_pmg = isinstance(pre, Pmg)
     from .fem import ops
     c = comm()
     lay = Jop.layout
@@ -605,12 +645,28 @@ def gmres(Jop, ilu, b, x, rtol, atol=0.0, maxit=1000, restart=20,
     n2 = 2 * lay.N
     _hip.check(_hip.lib().flow_shard_gmres_solve(
         ctypes.byref(c.struct), ctypes.byref(v.rows),
-        ctypes.byref(Jop.operator()), ctypes.byref(ilu.struct),
+        ctypes.byref(Jop.operator()),
+        None if is_pmg else ctypes.byref(pre.struct),
+        ctypes.byref(pre.struct) if is_pmg else None,
         _hip.f64(b, n2, 'b'), _hip.f64(x, n2, 'x'), float(rtol), float(atol),
         int(maxit), int(restart), int(bool(x_is_zero)), int(expected),
         _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
         _hip.stream()))
-    return _solve_info(its.value, res.value, 'gmres+ilu0(block)')
+    return _solve_info(its.value, res.value,
+                       'gmres+pmg(block)' if is_pmg else 'gmres+ilu0(block)')
+
+
+def local_pmg(W, **kw):
+    '''The two-level cycle of flow_amd/fem/pmg.py on the calling rank's
+    diagonal block: P2 rows / P1 rows (vertices) of its strip in local
+    numbering, couplings that leave the block dropped -- block Jacobi, no
+    communication inside the preconditioner.'''
+    from .fem.pmg import Pmg
+    from .fem.space import scalar_layout
+    lay = W.layout
+    v2 = view(lay)
+    v1 = view(scalar_layout(lay.mesh, 1))
+    return Pmg(W, rows=(v2.r0, v2.r1), vrows=(v1.r0, v1.r1), **kw)
 
 
 def local_ilu(J, packed=False, single_vector=False):

@@ -320,12 +320,22 @@ typedef struct {
                                       others are edge dofs (weight 1/2) */
   const unsigned char* bc_fine;    /* 2*fine.n bytes (component-blocked), NULL: none */
   const unsigned char* bc_coarse;  /* 2*coarse.n bytes, NULL: none */
-  float* work;                     /* 12*fine.n + 8*coarse.n floats, 16-B aligned */
+  float* work;                     /* 12*fine.n + 8*coarse.n + 2 floats, 16-B
+                                      aligned; the LAST float2 must be zero and
+                                      is never written (dummy coarse row) */
 } flow_pmg;
-/* vals[k] = half2((a00, a11)[k] / their diagonal entries of row(k));
- * diag[i] = (a00, a11)[diag_idx[i]], dinv[i] = 1 / diag[i] */
+/* vals[k] = half2((a00, a11)[k] / their diagonal entries of row(k)), 0 where
+ * keep[k] == 0 (keep = NULL: everything is kept);
+ * diag[i] = (a00, a11)[diag_idx[i]], dinv[i] = 1 / diag[i].
+ * K15, block Jacobi on a strip: the level is a rank's DIAGONAL BLOCK in local
+ * numbering -- rowptr / diag_idx / a00 / a11 shifted to the block's first
+ * nonzero, cols in local numbering with the couplings that leave the block
+ * pointing at their own row and marked keep = 0; `ends` of a dof whose partner
+ * vertex lies outside names the dummy coarse row coarse.n (work carries a zero
+ * there), the restriction lists hold the block's own dofs only. */
 int flow_pmg_pack(int n, int nnz, const int* rowptr, const int* diag_idx,
-                  const double* a00, const double* a11, void* vals, float* diag,
+                  const double* a00, const double* a11,
+                  const unsigned char* keep, void* vals, float* diag,
                   float* dinv, void* stream);
 /* spectral radius of D^-1 A of a level by `iterations` (>= 2) steps of the
  * power method.  work: 6*n floats, dwork: FLOW_REDUCE_WORK doubles. */
@@ -519,9 +529,10 @@ int flow_shard_mgcg_solve(const flow_comm* comm, const flow_rows* rows,
 
 /* GMRES(restart) for the Newton systems on the strips.  The operator is the
  * matrix-free Jacobian action (kind 3) whose flow_mesh / flow_space carry the
- * rank's cell and row ranges (below); the preconditioner is block Jacobi: ilu
- * factors the rank's own diagonal block (plan over the owned rows in local
- * numbering), no communication.  The Krylov vectors hold the owned rows only
+ * rank's cell and row ranges (below); the preconditioner is block Jacobi, no
+ * communication: EITHER ilu, the factors of the rank's own diagonal block (plan
+ * over the owned rows in local numbering), OR pmg, the two-level cycle of K17
+ * on that block (levels in local numbering, flow_pmg_pack).  The Krylov vectors hold the owned rows only
  * (2 * (r1 - r0) doubles); per iteration one halo collective (the operator's
  * input) and one for the dot products, whose sums the device-side step of
  * flow_gmres_solve takes straight from the exchange buffer: no read-back per
@@ -531,7 +542,8 @@ int flow_shard_mgcg_solve(const flow_comm* comm, const flow_rows* rows,
  * + 2*(e1-e0) + FLOW_GMRES_PARTIALS + FLOW_GMRES_STATE doubles. */
 int flow_shard_gmres_solve(const flow_comm* comm, const flow_rows* rows,
                            const flow_operator* A, const flow_ilu* ilu,
-                           const double* b, double* x, double rtol, double atol,
+                           const flow_pmg* pmg, const double* b, double* x,
+                           double rtol, double atol,
                            int maxit, int restart, int x_is_zero,
                            int expected_its, double* work, size_t work_len,
                            int* iters_host, double* resid_host, void* stream);

@@ -237,10 +237,11 @@ def test_strip_sharded_solvers_and_step(hip, world):
                        out[0]['step']['calls']))
 
 
-def _rccl_worker(rank, port, out):
+def _rccl_worker(rank, port, direct, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['LOCAL_RANK'] = '0'
+    os.environ['FLOW_AMD_RCCL_DIRECT'] = '1' if direct else '0'
     import torch.distributed as dist
     from flow_amd import device, parallel
     dist.init_process_group('nccl', rank=0, world_size=1,
@@ -256,22 +257,28 @@ def _rccl_worker(rank, port, out):
             newton=[len(i['newton_residuals']) - 1 for i in infos],
             method=infos[-1]['pressure'].method)
     finally:
+        parallel.disable()          # (destroys the library's own communicator)
         dist.destroy_process_group()
 
 
-def test_allreduce_issued_by_the_library(hip):
-    '''The RCCL branch of the communicator on a 1-rank group (all one GPU
-    allows: RCCL refuses two ranks on one device): flow_comm's callback is
-    ncclAllReduce issued by the library on its own stream
+@pytest.mark.parametrize('direct', [False, True])
+def test_rccl_branches_on_a_one_rank_group(hip, direct):
+    '''The two RCCL branches of the communicator on a 1-rank group (all one GPU
+    allows: RCCL refuses two ranks on one device).  direct = False (default):
+    flow_comm's callback hands the buffer to torch.distributed.all_reduce on
+    the 'nccl' backend; direct = True (FLOW_AMD_RCCL_DIRECT=1, opt-in): it is
+    ncclAllReduce issued by the library on the solvers' stream
     (csrc/rccl_direct.hip; communicator created beside torch's from an id
-    broadcast through torch.distributed), and two whole time steps through the
-    sharded loops reproduce the single-GPU run.'''
+    broadcast through torch.distributed, destroyed by parallel.disable()).
+    Either way two whole time steps through the sharded loops reproduce the
+    single-GPU run.'''
     prob, infos = _karman_steps()
     manager = mp.get_context('spawn').Manager()
     out = manager.dict()
-    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(_free_port(), direct, out), nprocs=1,
+             join=True)
     res = out[0]
-    assert res['direct'] and not res['staged']
+    assert res['direct'] == direct and not res['staged']
     assert 'x-strips x1' in res['method']
     assert res['newton'] == [len(i['newton_residuals']) - 1 for i in infos]
     assert _rel(res['u'], prob.u0.vector().get_local()) < 1e-9
@@ -340,3 +347,75 @@ def test_strips_on_a_2M_dof_channel(hip):
           'on one GPU' % (eu, ep, res['apps'], apps))
     assert eu < 1e-7 and ep < 1e-7, (eu, ep)
 
+
+
+# -- the block p-multigrid on the strips ------------------------------------------------
+PMG_MU = 0.036      # cell Peclet number ~2 on the 120 x 30 mesh, as the 10 M-DoF
+                    # workload has with the physical viscosity: the cycle is used
+
+
+def _pmg_steps(nsteps=2):
+    from flow_amd import karman
+    import flow_amd.navier_stokes as navsto
+    navsto.solver_parameters['pressure']['mg_coarsest'] = 200
+    prob = karman.KarmanProblem(NX, NY, mu=PMG_MU)
+    prob.set_initial_profile()
+    prob.dt = prob.hmax / 0.016             # a CFL-sized step from the start
+    infos = [prob.step(adapt=False) for _ in range(nsteps)]
+    return prob, infos
+
+
+def _pmg_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LOCAL_RANK'] = '0'
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from flow_amd import parallel, device
+        parallel.enable(dist.group.WORLD, force=True)
+        prob, infos = _pmg_steps()
+        lay = prob.W.layout
+        out[rank] = dict(
+            u=device.to_host(parallel.gather_field(
+                prob.u0.data.clone(), lay, 2)).numpy(),
+            p=device.to_host(parallel.gather_field(
+                prob.p0.data.clone(), prob.P.layout)).numpy(),
+            pre=[i['newton_preconditioner'] for i in infos],
+            contraction=[i.get('pmg_contraction') for i in infos],
+            applications=[i['newton_linear_applications'] for i in infos],
+            newton=[len(i['newton_residuals']) - 1 for i in infos])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_block_pmg_on_strips(hip, world):
+    '''The Newton systems on the strips with the rank-local two-level cycle as
+    the block-Jacobi preconditioner (flow_shard_gmres_solve with a flow_pmg in
+    local numbering): accepted by the contraction test summed over the ranks,
+    the same Newton path and the same fields as the single-GPU run, and not
+    many more GMRES applications than with the global cycle (the couplings
+    across the strip boundaries are all that is dropped: +16 % with two strips
+    of 60 cells, +35 % with three of 40; the wider the strips the less).'''
+    prob, infos = _pmg_steps()
+    assert [i['newton_preconditioner'] for i in infos] == ['pmg', 'pmg']
+    ref_apps = [sum(i['newton_linear_applications']) for i in infos]
+    manager = mp.get_context('spawn').Manager()
+    out = manager.dict()
+    mp.spawn(_pmg_worker, args=(world, _free_port(), out), nprocs=world,
+             join=True)
+    for r in range(world):
+        res = out[r]
+        assert res['pre'] == ['pmg (block Jacobi)'] * 2, res['pre']
+        assert res['contraction'][0] < 0.8
+        assert res['newton'] == [len(i['newton_residuals']) - 1 for i in infos]
+        apps = [sum(a) for a in res['applications']]
+        for a, b in zip(apps, ref_apps):
+            assert a <= 1.5 * b + 2, (apps, ref_apps)
+        assert _rel(res['u'], prob.u0.vector().get_local()) < 1e-7
+        assert _rel(res['p'], prob.p0.vector().get_local()) < 1e-7
+        assert numpy.array_equal(res['u'], out[0]['u'])
+    print('world %d: GMRES applications %r (single GPU %r), contraction %.2f'
+          % (world, [sum(a) for a in out[0]['applications']], ref_apps,
+             out[0]['contraction'][0]))
