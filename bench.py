@@ -313,6 +313,11 @@ def main():
                     help='override an entry of solver_parameters["newton"] '
                          '(development: e.g. linear_solver=bicgstab); '
                          'recorded in config')
+    ap.add_argument('--mu', type=float, default=0.002,
+                    help='dynamic viscosity (reference driver: 0.002); '
+                         'development: a smaller mesh with mu scaled by the '
+                         'mesh width keeps the cell Peclet number of the '
+                         'headline workload')
     ap.add_argument('--dt0', type=float, default=1.0e-5,
                     help='initial step size (reference driver: 1e-5)')
     ap.add_argument('--initial', default=None,
@@ -394,7 +399,7 @@ def main():
     ny = args.ny if args.ny else max(2, int(round(args.nx * 509.0 / 2182.0)))
     prob = karman.KarmanProblem(args.nx, ny,
                                 velocity_degree=args.velocity_degree,
-                                scheme=args.scheme)
+                                scheme=args.scheme, mu=args.mu)
 
     start = {}
     settled = {}
@@ -565,11 +570,11 @@ def main():
         'config': {
             'workload': 'Karman vortex street %s, %d DoF '
                         '(%d x %d structured channel, body-fitted cylinder), '
-                        '%s scheme, backward Euler, tol %.0e, mu 0.002, '
+                        '%s scheme, backward Euler, tol %.0e, mu %g, '
                         'rho 998.2, dt0 1e-5 + CFL controller, start: %s'
                         % ('P2-P1 Taylor-Hood' if args.velocity_degree == 2
                            else 'P1-P1', prob.num_dofs(), args.nx, ny,
-                           args.scheme, args.tol,
+                           args.scheme, args.tol, args.mu,
                            'Stokes solution' if args.initial == 'stokes'
                            else 'inflow profile'),
             'mode': args.mode,
