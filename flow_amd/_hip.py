@@ -241,7 +241,7 @@ SYMBOLS = {
     'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
                             _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_gmres_solve': [_P(Operator), _VP, _P(IluS), _P(PmgS), _VP, _VP, _D,
-                         _D, _I, _I, _I, _I, _VP, ctypes.c_size_t, _P(_I),
+                         _D, _I, _I, _I, _I, _I, _VP, ctypes.c_size_t, _P(_I),
                          _P(_D), _VP],
     'flow_pmg_pack': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _P(_D), _VP],

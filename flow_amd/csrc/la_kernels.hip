@@ -2029,9 +2029,10 @@ static double gmres_least_squares(const double (*H)[kGmresMax + 1], int j,
 // looks at the state for the first time, then one at a time; the result does
 // not depend on it.
 static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu,
-                 const flow_pmg* pmg, const double* b, double* x, double rtol, double atol, int maxit,
-                 int m, int x_is_zero, int expected, double* work,
-                 int* iters_host, double* resid_host, hipStream_t st) {
+                 const flow_pmg* pmg, const double* b, double* x, double rtol,
+                 double atol, int maxit, int m, int x_is_zero, int expected,
+                 int verify, double* work, int* iters_host, double* resid_host,
+                 hipStream_t st) {
   const int N = op_size(A);
   double* partial = work;
   double* S = work + 3 * kRedBlocks;
@@ -2096,6 +2097,7 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
   double b2 = 0.0, target = 0.0, resid = 0.0;
   int it = 0;
   bool have_target = false;
+  bool claimed = false;     // the last cycle stopped on the residual estimate
   while (true) {
     // r0 = b - A x -> V_0, beta = |r0|
     if (x_is_zero && it == 0) {
@@ -2126,7 +2128,15 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
       set_error("GMRES broke down (NaN residual) at iteration %d", it);
       return FLOW_NOT_CONVERGED;
     }
-    if (beta <= target) break;
+    // behind a cycle that stopped on the least-squares ESTIMATE this is the
+    // verification with the true residual b - A x (one operator application):
+    // the one-pass Gram-Schmidt and a reduced-precision preconditioner can
+    // leave the estimate below the target while the true residual stagnates
+    // (seen in principle at rtol 1e-13, flow/heat.py's solves); within a
+    // factor 10 of the target the iterate is accepted and the TRUE norm
+    // reported, beyond it the solve goes on from here
+    if (beta <= target || (claimed && beta <= 10.0 * target)) break;
+    claimed = false;
     if (it >= maxit) {
       *iters_host = it;
       *resid_host = beta;
@@ -2173,8 +2183,10 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
                                 nullptr, true, nullptr, st)))
       return rc;
     x_is_zero = 0;
-    if (converged) break;
-    // else: restart from the true residual (or report non-convergence there)
+    if (converged && !verify) break;
+    claimed = converged;
+    // restart from the true residual: verify a claimed convergence there, go
+    // on otherwise (or report non-convergence)
   }
   *iters_host = it;
   *resid_host = resid;
@@ -2278,8 +2290,8 @@ extern "C" int flow_gmres_solve(const flow_operator* A, const double* dinv,
                                 const flow_ilu* ilu, const flow_pmg* pmg,
                                 const double* b, double* x,
                                 double rtol, double atol, int maxit, int restart,
-                                int x_is_zero, int expected_its, double* work,
-                                size_t work_len, int* iters_host,
+                                int x_is_zero, int expected_its, int verify,
+                                double* work, size_t work_len, int* iters_host,
                                 double* resid_host, void* stream) {
   int rc = check_solver_args(A, b, x, rtol, atol, maxit, 1, 0, work, work_len, 0,
                              iters_host, resid_host);
@@ -2297,7 +2309,8 @@ extern "C" int flow_gmres_solve(const flow_operator* A, const double* dinv,
   if (ilu && (rc = ilu_check(ilu, op_size(A)))) return rc;
   if (pmg && (rc = pmg_check(pmg, op_size(A)))) return rc;
   return gmres(A, dinv, ilu, pmg, b, x, rtol, atol, maxit, restart, x_is_zero,
-               expected_its, work, iters_host, resid_host, as_stream(stream));
+               expected_its, verify, work, iters_host, resid_host,
+               as_stream(stream));
 }
 
 

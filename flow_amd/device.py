@@ -76,6 +76,11 @@ def _guarded(n, fill):
 def zeros(n, dtype=torch.float64):
     if _GUARD and dtype == torch.float64:
         return _guarded(n, 0.0)
+    if dtype == torch.float64 and int(n) > 0 and on_gpu():
+        # the fill is a kernel of the library on the stream everything else
+        # runs on (no torch kernels between the library's: _hip.fill)
+        from . import _hip
+        return _hip.fill(torch.empty(int(n), dtype=dtype, device=get()), 0.0)
     return torch.zeros(int(n), dtype=dtype, device=get())
 
 

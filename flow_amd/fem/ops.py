@@ -493,7 +493,7 @@ class SolveInfo(object):
 def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
                  check_every=None, coarse=None, ilu=None, mg=None,
                  first_check=0, tag=None, restart=20, x_is_zero=False,
-                 pmg=None):
+                 pmg=None, verify=True):
     '''Solve A x = b on the device; x holds the initial guess.  Raises
     _hip.NotConverged (a RuntimeError) like dolfin's
     'error_on_nonconvergence'.  first_check > 0: iterations before the first
@@ -505,7 +505,10 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     method 'gmres': GMRES(restart); x_is_zero promises x = 0 on entry;
     `iterations` then counts operator applications (a BiCGStab iteration is
     two); first_check = the applications the caller expects the solve to need
-    (that many Arnoldi steps are enqueued before the first read-back).'''
+    (that many Arnoldi steps are enqueued before the first read-back);
+    verify: check the accepted iterate with the true residual (one more
+    operator application; off for the Newton systems, whose outer iteration
+    recomputes the nonlinear residual anyway).'''
     lib = _hip.lib()
     n = A.size
     if isinstance(dinv, str):
@@ -550,6 +553,7 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
             ctypes.byref(pmg.struct) if pmg is not None else None,
             _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
             int(maxit), int(restart), int(bool(x_is_zero)), int(first_check),
+            int(bool(verify)),
             _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
             _hip.stream()
             )

@@ -500,7 +500,9 @@ def _compute_tentative_velocity(
                     pmg=pre if kind == 'pmg' else None,
                     restart=npar['gmres_restart'], x_is_zero=True,
                     dinv='jacobi' if pre is None else None,
-                    first_check=expected.get(it, 0))
+                    first_check=expected.get(it, 0),
+                    # (the next Newton residual is the check of this solve)
+                    verify=False)
             if kind == 'pmg':
                 # second line of defence behind the contraction test: a solve
                 # that does not get there in `pmg_maxit` applications is redone

@@ -394,8 +394,14 @@ int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
  * the solve to need -- the count of the previous solve in a time loop; 0:
  * unknown) before the host looks for the first time, then one at a time.  The
  * accepted iterate does not depend on it: everything enqueued behind it returns
- * at once.  Stops on the least-squares residual estimate, `iters_host` =
- * operator applications.
+ * at once.  A cycle stops on the least-squares residual estimate.  verify != 0:
+ * the iterate is then checked with the true residual b - A x (one more
+ * operator application and read-back, not counted): accepted within a factor
+ * 10 of the target, with the TRUE norm in *resid_host, continued otherwise --
+ * for solves nothing else checks (flow/heat.py:117-121); verify = 0: the
+ * estimate is trusted (*resid_host = the estimate) -- the Newton systems, whose
+ * outer iteration recomputes the nonlinear residual anyway.  `iters_host` =
+ * operator applications of the Arnoldi steps.
  * x_is_zero != 0: the caller guarantees x = 0 on entry (Newton increments), the
  * initial residual is then b without an operator application.
  * work: FLOW_REDUCE_WORK + (2*restart + 2)*N + FLOW_GMRES_PARTIALS +
@@ -408,7 +414,7 @@ int flow_gmres_solve(const flow_operator* A, const double* dinv,
                      const flow_ilu* ilu, const flow_pmg* pmg, const double* b,
                      double* x,
                      double rtol, double atol, int maxit, int restart,
-                     int x_is_zero, int expected_its, double* work,
+                     int x_is_zero, int expected_its, int verify, double* work,
                      size_t work_len, int* iters_host, double* resid_host,
                      void* stream);
 

@@ -315,6 +315,38 @@ def test_gmres_does_not_take_cancellation_for_convergence(hip):
     assert info.iterations >= 2
 
 
+def test_gmres_reports_the_true_residual(hip):
+    '''A cycle of flow_gmres_solve stops on the least-squares estimate of the
+    residual; the iterate it returns is then verified with b - A x, and the
+    norm handed back is that TRUE one -- also with a reduced-precision
+    preconditioner (fp32-packed ILU(0) with an fp32 sweep vector) at
+    rtol 1e-13, where the estimate alone could run ahead of the truth.'''
+    from flow_amd.fem import ilu
+    rng = numpy.random.RandomState(31)
+    mesh = fem.UnitSquareMesh(10, 10, 'crossed')
+    V = fem.FunctionSpace(mesh, 'CG', 2)
+    lay = V.layout
+    M = ops.assemble_mass(V).vals
+    K = ops.assemble_stiffness(V).vals
+    import torch
+    # (the system of test_bicgstab_matches_direct_solve)
+    pert = _dev(0.02 * rng.standard_normal(4 * M.numel()) * float(M.abs().max()))
+    base = torch.cat([M + 0.01 * K, torch.zeros_like(M), torch.zeros_like(M),
+                      M + 0.01 * K])
+    A = ops.Matrix(lay, 2, (base + pert).contiguous())
+    b = rng.standard_normal(2 * V.N)
+    for kw in (dict(ilu=ilu.Ilu0(A, packed=True, single_vector=True)),
+               dict(dinv='jacobi')):
+        x = _dev(numpy.zeros(2 * V.N))
+        info = ops.krylov_solve('gmres', A, _dev(b), x, rtol=1e-13, maxit=4000,
+                                restart=30, x_is_zero=True, **kw)
+        t = _dev(numpy.zeros(2 * V.N))
+        A.apply(x, t)
+        true = float((t - _dev(b)).norm())
+        assert abs(info.residual - true) <= 1e-2 * true + 1e-300, (info, true)
+        assert true <= 10.0 * 1e-13 * numpy.linalg.norm(b), (info, true)
+
+
 @pytest.mark.parametrize('vdeg', [1, 2])
 @pytest.mark.parametrize('method', ['backward euler', 'crank-nicolson',
                                     'forward euler'])
