@@ -220,6 +220,7 @@ _P = ctypes.POINTER
 SYMBOLS = {
     'flow_abi_version': [],
     'flow_xcd_tile_host': [_I, _I],
+    'flow_spmv_tile_nnz': [_I],
     'flow_operator_apply': [_P(Operator), _VP, _VP, _VP],
     'flow_profile_spmv_begin': [_I, _I],
     'flow_profile_spmv_end': [_P(_D), _P(_I)],
@@ -323,6 +324,12 @@ def load_library():
             fn.argtypes = argtypes
         _LIB = lib
     return _LIB
+
+
+def spmv_tile_nnz(kind=0):
+    '''Nonzeros a CSR-stream row block of an operator of `kind` may hold (a
+    build constant of the library; no GPU needed).'''
+    return int(load_library().flow_spmv_tile_nnz(int(kind)))
 
 
 def lib():

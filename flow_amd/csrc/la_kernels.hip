@@ -55,10 +55,18 @@ static_assert(3 * kRedBlocks + kNumSlots <= FLOW_REDUCE_WORK, "work size");
 // ---------------------------------------------------------------------------
 // SpMV
 // ---------------------------------------------------------------------------
-constexpr int kPairs = 2;                       // nonzero pairs per lane
+// Tiles of the kernels that park ONE product per nonzero in LDS (operator kinds
+// 0 and 1, the multigrid level kernels): kPairs index pairs per lane; tiles of
+// the kernels that park two (kinds 2 and 4): kPairs2.
+#ifndef FLOW_SPMV_PAIRS
+#define FLOW_SPMV_PAIRS 2
+#endif
+constexpr int kPairs = FLOW_SPMV_PAIRS;         // nonzero pairs per lane
 constexpr int kTile = 2 * kBlock * kPairs;      // LDS products per workgroup
+constexpr int kPairs2 = 2;
+constexpr int kTile2 = 2 * kBlock * kPairs2;
 static_assert(FLOW_SPMV_ROWS_PER_BLOCK == kBlock, "one lane per row");
-static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTile - 2, "tile minus alignment slack");
+static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTile2 - 2, "tile minus alignment slack");
 
 // scalar plane(s): blockIdx.y selects the component of a block-diagonal operator.
 // DOT: the workgroup also leaves its share of x.y (= x.Ax) in
@@ -209,8 +217,8 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
     const int* __restrict__ rowblocks, const double* __restrict__ x,
     double* __restrict__ y, double* __restrict__ dpart,
     const double* __restrict__ stop) {
-  __shared__ double prod0[kTile];
-  __shared__ double prod1[kTile];
+  __shared__ double prod0[kTile2];
+  __shared__ double prod1[kTile2];
   if (stopped(stop)) return;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int r0 = rowblocks[tile];
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
   const double2* __restrict__ pyx = reinterpret_cast<const double2*>(vyx + ka);
   const double2* __restrict__ pyy = reinterpret_cast<const double2*>(vyy + ka);
 #pragma unroll
-  for (int j = 0; j < kPairs; ++j) {
+  for (int j = 0; j < kPairs2; ++j) {
     const int p = threadIdx.x + j * kBlock;
     if (p < npair) {
       const int2 c = c2p[p];
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
   // workgroups per CU the wave limit allows, and both row sums come out of ONE
   // pass over the segment (the single array used twice cost two barriers
   // more: 166 -> see DESIGN.md)
-  __shared__ double2 prod[kTile];
+  __shared__ double2 prod[kTile2];
   if (stopped(stop)) return;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int r0 = rowblocks[tile];
@@ -297,10 +305,10 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
   const double2* __restrict__ v2p = reinterpret_cast<const double2*>(vals + ka);
   const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
   const int npair = (k1 - ka + 1) >> 1;
-  double2 v[kPairs];
-  int2 c[kPairs];
+  double2 v[kPairs2];
+  int2 c[kPairs2];
 #pragma unroll
-  for (int j = 0; j < kPairs; ++j) {
+  for (int j = 0; j < kPairs2; ++j) {
     const int p = threadIdx.x + j * kBlock;
     const bool ok = p < npair;
     v[j] = ok ? v2p[p] : make_double2(0.0, 0.0);
@@ -310,9 +318,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
   // a block of this square operator is never empty)
   const int lo = k0 - ka, hi = k1 - ka;
   const int safe = cols[k0];
-  double xa[kPairs], xb[kPairs], ua[kPairs], ub[kPairs];
+  double xa[kPairs2], xb[kPairs2], ua[kPairs2], ub[kPairs2];
 #pragma unroll
-  for (int j = 0; j < kPairs; ++j) {   // all gathers in flight before any use
+  for (int j = 0; j < kPairs2; ++j) {   // all gathers in flight before any use
     const int e = 2 * (threadIdx.x + j * kBlock);
     const int cx = (e >= lo && e < hi) ? c[j].x : safe;
     const int cy = (e + 1 < hi) ? c[j].y : safe;
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
     ub[j] = x[xs + cy];
   }
 #pragma unroll
-  for (int j = 0; j < kPairs; ++j) {
+  for (int j = 0; j < kPairs2; ++j) {
     const int p = threadIdx.x + j * kBlock;
     if (p < npair) {
       prod[2 * p] = make_double2(v[j].x * xa[j], v[j].x * ua[j]);
@@ -1324,6 +1332,12 @@ using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
 extern "C" int flow_abi_version(void) { return 21; }
+
+// nonzeros a CSR-stream row block of an operator of `kind` may hold (the host
+// builds the row blocks: flow_amd/fem/space.py)
+extern "C" int flow_spmv_tile_nnz(int kind) {
+  return (kind == 2 || kind == 4) ? kTile2 - 2 : kTile - 2;
+}
 
 // the workgroup -> tile mapping of the CSR-stream kernels, for host-side tests
 extern "C" int flow_xcd_tile_host(int block, int nblocks) {

@@ -153,7 +153,7 @@ class Matrix(object):
             op.kind = self.kind
             op.n = lay.N
             op.nnz = lay.nnz
-            rb = lay.dev('rowblocks')
+            rb = lay.dev('rowblocks2' if self.kind in (2, 4) else 'rowblocks')
             op.nblocks = rb.numel() - 1
             op.rowptr = _hip.i32(lay.dev('rowptr'), lay.N + 1, 'rowptr')
             op.cols = _hip.i32(lay.dev('cols'), lay.nnz, 'cols')

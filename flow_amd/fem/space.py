@@ -106,7 +106,11 @@ class ScalarLayout(object):
             'cptr': cptr,
             'csrc': csrc,
             'diag_idx': diag_idx,
+            # CSR-stream row blocks: for operators that park one product per
+            # nonzero in LDS (kinds 0, 1) and for those that park two (2, 4)
             'rowblocks': csr_stream_rowblocks(rowptr),
+            'rowblocks2': csr_stream_rowblocks(
+                rowptr, nnz_per_block=SPMV_NNZ_PER_BLOCK),
             }
         return
 
@@ -157,10 +161,14 @@ class ScalarLayout(object):
 
 
 def csr_stream_rowblocks(rowptr, rows_per_block=SPMV_ROWS_PER_BLOCK,
-                         nnz_per_block=SPMV_NNZ_PER_BLOCK):
+                         nnz_per_block=None):
     '''Row-block boundaries for the CSR-stream SpMV: consecutive rows are
     grouped so that a block has at most `rows_per_block` rows and at most
-    `nnz_per_block` nonzeros (the LDS tile of products).'''
+    `nnz_per_block` nonzeros (the LDS tile of products; default: what the
+    library's scalar kernels take, flow_spmv_tile_nnz(0)).'''
+    if nnz_per_block is None:
+        from .. import _hip
+        nnz_per_block = _hip.spmv_tile_nnz(0)
     n = len(rowptr) - 1
     rowptr = numpy.asarray(rowptr, dtype=numpy.int64)
     if n > 0:

@@ -436,13 +436,19 @@ class View(object):
         s.nnz0, s.nnz1 = int(rowptr[self.r0]), int(rowptr[self.r1])
         self.space = s
         rp = rowptr.astype(numpy.int64)
-        rb = csr_stream_rowblocks(rp[self.r0:self.r1 + 1] - rp[self.r0]) \
-            + self.r0
+        local = rp[self.r0:self.r1 + 1] - rp[self.r0]
+        rb = csr_stream_rowblocks(local) + self.r0
         self.rowblocks = device.to_device(rb.astype(numpy.int32))
+        # (operator kinds 2 and 4 park two products per nonzero: smaller tiles)
+        rb2 = csr_stream_rowblocks(
+            local, nnz_per_block=_hip.SPMV_NNZ_PER_BLOCK) + self.r0
+        self.rowblocks2 = device.to_device(rb2.astype(numpy.int32))
 
     def operator(self, A):
         '''A copy of A's flow_operator that covers the owned rows only.'''
-        return owned_operator(A.operator(), self.rowblocks)
+        return owned_operator(
+            A.operator(),
+            self.rowblocks2 if A.kind in (2, 4) else self.rowblocks)
 
 
 def owned_operator(base, rowblocks):

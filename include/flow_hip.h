@@ -39,9 +39,14 @@ extern "C" {
 #define FLOW_INVALID 2
 #define FLOW_HIP_ERROR 3
 
-/* CSR-stream tiling of flow_spmv (row blocks are built on the host). */
+/* CSR-stream tiling of the SpMV kernels (row blocks are built on the host): at
+ * most FLOW_SPMV_ROWS_PER_BLOCK rows and flow_spmv_tile_nnz(kind) nonzeros per
+ * block -- FLOW_SPMV_NNZ_PER_BLOCK for the kinds that park two products per
+ * nonzero in LDS (2 and 4), as many or twice as many for the others (a build
+ * constant of the library: ask). */
 #define FLOW_SPMV_ROWS_PER_BLOCK 256
 #define FLOW_SPMV_NNZ_PER_BLOCK 1022
+int flow_spmv_tile_nnz(int kind);
 
 const char* flow_last_error(void);
 int flow_abi_version(void);

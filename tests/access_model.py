@@ -22,9 +22,15 @@ Variants (the kernel each one restates):
 '''
 import numpy
 
+from flow_amd import _hip
+
 BLOCK = 256                 # kBlock
-PAIRS = 2                   # kPairs
-LANES = BLOCK * PAIRS       # index pairs per tile
+
+
+def pairs_per_lane(variant):
+    '''kPairs (kinds 0, 1: a build constant of the library) / kPairs2.'''
+    kind = 2 if variant in ('block2', 'pair') else 0
+    return (_hip.spmv_tile_nnz(kind) + 2) // (2 * BLOCK)
 
 
 def tile_accesses(rowptr, cols, rowblocks, variant='stream'):
@@ -41,9 +47,11 @@ def tile_accesses(rowptr, cols, rowblocks, variant='stream'):
     lo_e = (k0 - ka)[:, None]
     hi_e = (k1 - ka)[:, None]
     npair = ((k1 - ka + 1) >> 1)[:, None]
-    p = numpy.arange(LANES)[None, :]
+    lanes = BLOCK * pairs_per_lane(variant)      # index pairs per tile
+    assert (k1 - ka <= 2 * lanes).all(), 'row block larger than the tile'
+    p = numpy.arange(lanes)[None, :]
     e = 2 * p
-    pad = numpy.zeros(2 * LANES + 4, dtype=numpy.int64)
+    pad = numpy.zeros(2 * lanes + 4, dtype=numpy.int64)
     colsp = numpy.concatenate([cols, pad])          # (never used out of range
     cx = colsp[ka[:, None] + e]                     #  by a kernel: see `ok`)
     cy = colsp[ka[:, None] + e + 1]

@@ -107,7 +107,7 @@ def test_rowblocks():
     rb = csr_stream_rowblocks(rowptr)
     assert rb[0] == 0 and rb[-1] == 5000 and (numpy.diff(rb) > 0).all()
     assert (numpy.diff(rb) <= _hip.SPMV_ROWS_PER_BLOCK).all()
-    assert (numpy.diff(rowptr[rb]) <= _hip.SPMV_NNZ_PER_BLOCK).all()
+    assert (numpy.diff(rowptr[rb]) <= _hip.spmv_tile_nnz(0)).all()
     with pytest.raises(AssertionError):
         csr_stream_rowblocks(numpy.array([0, 5000]))
 

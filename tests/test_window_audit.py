@@ -108,10 +108,11 @@ def test_operator_kernels_stay_inside_the_window(host_structs, world):
             covered = 0
             for g in range(world):
                 v = parallel.View(lay, st, g)
-                blocks = _host(v.rowblocks)
-                assert blocks[0] == v.r0 and blocks[-1] == v.r1
                 covered += v.r1 - v.r0
                 for variant in ('stream', 'block2', 'pair'):
+                    blocks = _host(v.rowblocks if variant == 'stream'
+                                   else v.rowblocks2)
+                    assert blocks[0] == v.r0 and blocks[-1] == v.r1
                     lo, hi = am.window(rowptr, cols, blocks, variant)
                     assert v.e0 <= lo and hi < v.e1, \
                         (name, degree, world, g, variant, (lo, hi),
