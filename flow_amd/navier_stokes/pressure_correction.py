@@ -530,10 +530,7 @@ def _compute_tentative_velocity(
         linear_its.append(its)
         last_step_info['newton_preconditioner'] = kind
         if pre is not None:
-            if refactored:
-                pre.base_its = max(its, npar['check_every'])
-            elif its > 2 * pre.base_its:
-                pre.stale = True
+            _age(pre, kind, refactored, its, sol.iterations, npar)
         ops.axpby(-1.0, dx, 1.0, ui.data)
         it += 1
     del keep0, keep1
@@ -542,6 +539,24 @@ def _compute_tentative_velocity(
     # operator + preconditioner applications of the linear solves
     last_step_info['newton_linear_applications'] = applications
     return ui, alpha
+
+
+def _age(pre, kind, rebuilt, its, applications, npar):
+    """When is a lagged preconditioner rebuilt?  The ILU(0): when a solve needs
+    more than twice the (BiCGStab-equivalent) iterations the fresh factors
+    needed.  The p-multigrid cycle ages gently (13 -> 16 applications over 200
+    plateau steps of the 10 M-DoF run) and a rebuild costs half a time step
+    (Jacobian assembly, packing, 2 x 25 power-method products): it is rebuilt as
+    soon as a solve needs 2 applications (or 15 %) more than the fresh one."""
+    if rebuilt:
+        pre.base_its = max(its, npar['check_every'])
+        pre.base_applications = applications
+    elif kind == 'pmg':
+        fresh = getattr(pre, 'base_applications', applications)
+        if applications >= fresh + max(2, int(round(0.15 * fresh))):
+            pre.stale = True
+    elif its > 2 * pre.base_its:
+        pre.stale = True
 
 
 def _contraction(pre, operator, lay, bc_dofs_host):
@@ -813,10 +828,7 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
         applications.append(sol.iterations)
         linear_its.append(its)
         last_step_info['newton_preconditioner'] = kind + ' (block Jacobi)'
-        if refactored:
-            pre.base_its = max(its, npar['check_every'])
-        elif its > 2 * pre.base_its:
-            pre.stale = True
+        _age(pre, kind, refactored, its, sol.iterations, npar)
         # (dx is zero outside the owned rows)
         ops.axpby(-1.0, dx, 1.0, ui.data)
         parallel.halo(ui.data, lay, 2)
