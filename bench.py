@@ -495,7 +495,9 @@ def main():
         # the contract of the settle phase: plateau steps only
         dts = head['dt']
         assert min(head['newton_iterations']) >= 1, head['newton_iterations']
-        assert max(dts) / min(dts) < 1.2, dts
+        # (no step of the controller's start-up ramp, which doubles dt: the step
+        # size moves by a few per cent per step at most)
+        assert all(0.95 < b / a < 1.05 for a, b in zip(dts, dts[1:])), dts
 
     # --- pressure-Poisson SpMV against the HBM roofline (dominant kernel) ---
     P = prob.P
