@@ -6,8 +6,9 @@ tests/test_karman_vortex_street.py:29-33) and DOLFIN XML (`Mesh('test.xml')`,
 :52-53) -- and the XDMF time series they write (`XDMFFile(...).write(u0, t)`,
 :214-227; tests/test_boussinesq.py:164-166, 307-309).
 
-Plain-text implementations (MSH 2.2 ASCII, DOLFIN XML, XDMF with inline XML
-data items): no meshio / h5py offline.  Host-side I/O only.
+Own implementations (MSH 2.2 ASCII and binary, DOLFIN XML, XDMF with inline XML
+data items): no meshio / h5py offline, so no HDF5-backed XDMF.  Host-side I/O
+only.
 '''
 from __future__ import print_function
 
@@ -25,14 +26,75 @@ def mpi_comm_world():
 
 
 # -- meshes -------------------------------------------------------------------
+def _mesh_from_gmsh(ids, xyz, tris):
+    '''Compress node ids to the vertices the triangles use, keep file order.'''
+    tris = numpy.asarray(tris, dtype=numpy.int64).reshape(-1, 3)
+    used = numpy.unique(tris)
+    lookup = -numpy.ones(int(ids.max()) + 1, dtype=numpy.int64)
+    pos = {int(v): k for k, v in enumerate(ids)}
+    rows = numpy.array([pos[int(v)] for v in used])
+    lookup[used] = numpy.arange(len(used))
+    return Mesh(numpy.asarray(xyz)[rows][:, :2], lookup[tris])
+
+
+_GMSH_NODES = {1: 2, 2: 3, 3: 4, 4: 4, 5: 8, 6: 6, 7: 5, 8: 3, 9: 6, 10: 9,
+               11: 10, 15: 1}     # nodes per element type (the common ones)
+
+
+def _read_msh_binary(raw, start):
+    '''The sections of a binary MSH 2.2 file behind the format line: `raw` is
+    the file, `start` the offset of the byte behind that line.'''
+    one = numpy.frombuffer(raw, dtype='<i4', count=1, offset=start)[0]
+    order = '<' if one == 1 else '>'
+    if numpy.frombuffer(raw, dtype=order + 'i4', count=1, offset=start)[0] != 1:
+        raise ValueError('binary MSH: bad endianness marker')
+
+    def section(name):
+        tag = ('$%s\n' % name).encode()
+        at = raw.index(tag) + len(tag)
+        eol = raw.index(b'\n', at)
+        return int(raw[at:eol]), eol + 1
+
+    n, at = section('Nodes')
+    rec = numpy.dtype([('id', order + 'i4'), ('x', order + 'f8', (3,))])
+    nodes = numpy.frombuffer(raw, dtype=rec, count=n, offset=at)
+    m, at = section('Elements')
+    tris = []
+    seen = 0
+    while seen < m:
+        etype, count, ntags = numpy.frombuffer(raw, dtype=order + 'i4', count=3,
+                                               offset=at)
+        at += 12
+        if int(etype) not in _GMSH_NODES:
+            raise ValueError('binary MSH: element type %d' % etype)
+        width = 1 + int(ntags) + _GMSH_NODES[int(etype)]
+        block = numpy.frombuffer(raw, dtype=order + 'i4',
+                                 count=int(count) * width,
+                                 offset=at).reshape(int(count), width)
+        at += 4 * int(count) * width
+        if int(etype) == 2:
+            tris.append(block[:, 1 + int(ntags):])
+        seen += int(count)
+    if not tris:
+        raise ValueError('binary MSH: no triangles')
+    return _mesh_from_gmsh(nodes['id'].astype(numpy.int64), nodes['x'],
+                           numpy.concatenate(tris))
+
+
 def read_msh(path):
-    '''gmsh MSH 2.2 ASCII: triangles (element type 2) of a planar mesh.'''
-    with open(path) as fh:
-        lines = [ln.strip() for ln in fh]
-    i = lines.index('$MeshFormat')
-    version = lines[i + 1].split()
-    if not version[0].startswith('2') or version[1] != '0':
-        raise ValueError('only MSH 2.x ASCII is supported (got %r)' % version)
+    '''gmsh MSH 2.2, ASCII or binary (what `pygmsh` caches; gmsh writes the
+    binary flavour with `-bin`): triangles (element type 2) of a planar
+    mesh.'''
+    with open(path, 'rb') as fh:
+        raw = fh.read()
+    head = raw.index(b'$MeshFormat') + len(b'$MeshFormat')
+    eol = raw.index(b'\n', head + 1)
+    version = raw[head:eol].split()
+    if not version[0].startswith(b'2'):
+        raise ValueError('only MSH 2.x is supported (got %r)' % version)
+    if version[1] == b'1':
+        return _read_msh_binary(raw, eol + 1)
+    lines = [ln.strip() for ln in raw.decode().splitlines()]
     i = lines.index('$Nodes')
     n = int(lines[i + 1])
     nodes = numpy.array([ln.split() for ln in lines[i + 2:i + 2 + n]],
@@ -46,17 +108,12 @@ def read_msh(path):
         if int(t[1]) == 2:                   # 3-node triangle
             ntags = int(t[2])
             tris.append([int(v) for v in t[3 + ntags:3 + ntags + 3]])
-    tris = numpy.array(tris, dtype=numpy.int64)
-    # compress node ids to the vertices actually used, keep file order
-    used = numpy.unique(tris)
-    lookup = -numpy.ones(ids.max() + 1, dtype=numpy.int64)
-    pos = {int(v): k for k, v in enumerate(ids)}
-    rows = numpy.array([pos[int(v)] for v in used])
-    lookup[used] = numpy.arange(len(used))
-    return Mesh(nodes[rows][:, 1:3], lookup[tris])
+    return _mesh_from_gmsh(ids, nodes[:, 1:4], tris)
 
 
-def write_msh(path, mesh):
+def write_msh(path, mesh, binary=False):
+    if binary:
+        return _write_msh_binary(path, mesh)
     with open(path, 'w') as fh:
         fh.write('$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n%d\n'
                  % mesh.num_vertices())
@@ -67,6 +124,29 @@ def write_msh(path, mesh):
             fh.write('%d 2 2 0 1 %d %d %d\n' % (k + 1, c[0] + 1, c[1] + 1,
                                                  c[2] + 1))
         fh.write('$EndElements\n')
+
+
+def _write_msh_binary(path, mesh):
+    '''MSH 2.2 binary, little endian: one element block of triangles with two
+    tags each, boundary edges (type 1) in a block before it as gmsh writes
+    physical lines.'''
+    nv, nc = mesh.num_vertices(), mesh.num_cells()
+    rec = numpy.zeros(nv, dtype=[('id', '<i4'), ('x', '<f8', (3,))])
+    rec['id'] = numpy.arange(1, nv + 1)
+    rec['x'][:, :2] = mesh.points
+    tri = numpy.zeros((nc, 6), dtype='<i4')
+    tri[:, 0] = numpy.arange(1, nc + 1)
+    tri[:, 2] = 1
+    tri[:, 3:] = mesh.cell_vertices + 1
+    with open(path, 'wb') as fh:
+        fh.write(b'$MeshFormat\n2.2 1 8\n')
+        fh.write(numpy.array([1], dtype='<i4').tobytes())
+        fh.write(b'\n$EndMeshFormat\n$Nodes\n%d\n' % nv)
+        fh.write(rec.tobytes())
+        fh.write(b'\n$EndNodes\n$Elements\n%d\n' % nc)
+        fh.write(numpy.array([2, nc, 2], dtype='<i4').tobytes())
+        fh.write(tri.tobytes())
+        fh.write(b'\n$EndElements\n')
 
 
 def read_dolfin_xml(path):

@@ -1,6 +1,6 @@
 # -*- coding: utf-8 -*-
 '''
-Mesh readers/writers (gmsh MSH 2.2 ASCII, DOLFIN XML) and the XDMF time-series
+Mesh readers/writers (gmsh MSH 2.2 ASCII and binary, DOLFIN XML) and the XDMF time-series
 writer the reference's drivers use (tests/test_karman_vortex_street.py:29-53,
 214-227).  CPU only.
 '''
@@ -11,11 +11,14 @@ from flow_amd import fem
 from flow_amd.fem import io
 
 
-@pytest.mark.parametrize('ext', ['msh', 'xml'])
+@pytest.mark.parametrize('ext', ['msh', 'msh-binary', 'xml'])
 def test_mesh_round_trip(tmp_path, ext):
     mesh = fem.karman_channel(20, 6)
-    path = str(tmp_path / ('mesh.' + ext))
-    (io.write_msh if ext == 'msh' else io.write_dolfin_xml)(path, mesh)
+    path = str(tmp_path / ('mesh.' + ext.split('-')[0]))
+    if ext == 'xml':
+        io.write_dolfin_xml(path, mesh)
+    else:
+        io.write_msh(path, mesh, binary=ext.endswith('binary'))
     back = fem.Mesh(path)
     assert numpy.array_equal(back.points, mesh.points)
     assert numpy.array_equal(back.cell_vertices, mesh.cell_vertices)
@@ -49,6 +52,31 @@ $EndElements
     mesh = io.read_mesh(str(path))
     assert mesh.num_vertices() == 4 and mesh.num_cells() == 2
     assert mesh.cell_areas().sum() == pytest.approx(1.0)
+
+
+def test_binary_msh_with_other_element_types(tmp_path):
+    '''The binary flavour of the same file: element blocks of points, lines and
+    triangles (type, count, number of tags | id, tags, nodes), node records
+    (int32 id, 3 doubles), both byte orders.'''
+    nodes = [(1, 0, 0), (2, 1, 0), (3, 0, 1), (4, 1, 1), (5, 0.5, 0.5)]
+    blocks = [(15, 2, [[1, 0, 1, 1]]), (1, 2, [[2, 0, 1, 1, 2]]),
+              (2, 2, [[3, 0, 6, 1, 2, 3], [4, 0, 6, 2, 4, 3]])]
+    for order in ('<', '>'):
+        raw = b'$MeshFormat\n2.2 1 8\n' + numpy.array([1], order + 'i4').tobytes() \
+            + b'\n$EndMeshFormat\n$Nodes\n5\n'
+        for k, x, y in nodes:
+            raw += numpy.array([k], order + 'i4').tobytes() \
+                + numpy.array([x, y, 0.0], order + 'f8').tobytes()
+        raw += b'\n$EndNodes\n$Elements\n4\n'
+        for etype, ntags, rows in blocks:
+            raw += numpy.array([etype, len(rows), ntags], order + 'i4').tobytes()
+            raw += numpy.array(rows, order + 'i4').tobytes()
+        raw += b'\n$EndElements\n'
+        path = tmp_path / ('g%s.msh' % ('le' if order == '<' else 'be'))
+        path.write_bytes(raw)
+        mesh = io.read_mesh(str(path))
+        assert mesh.num_vertices() == 4 and mesh.num_cells() == 2
+        assert mesh.cell_areas().sum() == pytest.approx(1.0)
 
 
 def test_xdmf_time_series(tmp_path):
