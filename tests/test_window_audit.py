@@ -21,7 +21,7 @@ import numpy
 import pytest
 import torch
 
-from flow_amd import _hip, device, fem, parallel
+from flow_amd import _hip, fem, parallel
 from flow_amd.fem import ilu
 from flow_amd.fem.multigrid import Multigrid
 from flow_amd.fem.space import scalar_layout
