@@ -13,7 +13,8 @@ if len(sys.argv) > 2:      # e.g. newton.linear_atol_factor=0.1
         grp, name = key.split('.')
         navsto.solver_parameters[grp][name] = type(navsto.solver_parameters[grp][name])(float(val))
         print('set', grp, name, navsto.solver_parameters[grp][name])
-prob = karman.KarmanProblem(2182, 509, velocity_degree=2)
+NX = int(os.environ.get('NX', '2182'))
+prob = karman.KarmanProblem(NX, int(round(NX * 509.0 / 2182.0)), velocity_degree=2)
 if os.environ.get('START', 'stokes') == 'stokes':
     prob.set_initial_stokes()
 else:
@@ -35,8 +36,9 @@ for k in range(nsteps):
         tot_lin += its
     if k % 10 == 9 or k == nsteps - 1:
         device.synchronize()
-        print('step %4d  t %.4f  dt %.3e  |u|inf %.4f  newton %d  applications %2d  cg(p) %3d  cg(corr) %d  wall %.1f s'
+        print('step %4d  t %.4f  dt %.3e  |u|inf %.4f  newton %d  applications %2d (%s)  cg(p) %3d  cg(corr) %d  wall %.1f s'
               % (k + 1, prob.t, info['dt'], info['unorm'], len(info['newton_linear_iterations']), its,
+                 info.get('newton_preconditioner', '-'),
                  info['pressure'].iterations, info['correction'].iterations, time.time() - t0), flush=True)
 assert numpy.isfinite(info['unorm'])
 device.synchronize()
