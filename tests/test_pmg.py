@@ -56,6 +56,53 @@ def test_transfer_tables_embed_p1_in_p2(fitted):
     assert abs(got - R.dot(x)).max() < 1e-13
 
 
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_block_transfer_tables_are_the_diagonal_blocks(world):
+    '''The strips use the cycle rank-locally (block Jacobi): the tables of a
+    rank are the diagonal block P[r0:r1, v0:v1] of the global prolongation in
+    local numbering -- an end point outside the block names the dummy coarse
+    row, the restriction lists are the transpose of exactly that block -- and
+    the level's local CSR keeps the pattern of its rows with the couplings
+    that leave the block marked (keep = 0, column = own row).'''
+    from flow_amd import parallel
+    from flow_amd.fem.pmg import local_transfer_tables
+    mesh = fem.karman_channel(120, 30, fitted=True)
+    lay2 = scalar_layout(mesh, 2)
+    lay1 = scalar_layout(mesh, 1)
+    P = _prolongation(lay2)[0]
+    st = parallel.Strips(mesh, world)
+    b2, b1 = st.blocks(lay2), st.blocks(lay1)
+    rp = lay2.pattern('rowptr').astype(numpy.int64)
+    cols = lay2.pattern('cols').astype(numpy.int64)
+    for g in range(world):
+        (r0, r1), (v0, v1) = b2.rows(g), b1.rows(g)
+        n, n1 = r1 - r0, v1 - v0
+        ends, rptr, rsrc = local_transfer_tables(lay2, (r0, r1), (v0, v1))
+        assert ends.shape == (n, 2) and ends.min() >= 0 and ends.max() <= n1
+        rows = numpy.repeat(numpy.arange(n), 2)
+        Ploc = sp.csr_matrix((numpy.full(2 * n, 0.5), (rows, ends.ravel())),
+                             shape=(n, n1 + 1))[:, :n1]          # drop the dummy
+        want = P[r0:r1, v0:v1]
+        assert abs(Ploc - want).max() == 0.0
+        # restriction lists = transpose of the block, own dof first
+        R = sp.lil_matrix((n1, n))
+        for v in range(n1):
+            lst = rsrc[rptr[v]:rptr[v + 1]]
+            assert lst[0] == lay2.vertex_dofs[v0 + v] - r0
+            R[v, lst[0]] = 1.0
+            for i in lst[1:]:
+                R[v, i] = 0.5
+        assert abs(R.tocsr() - want.T).max() == 0.0
+    # the level's local pattern (host tables only: no device needed)
+    g = world - 1
+    r0, r1 = b2.rows(g)
+    seg = cols[rp[r0]:rp[r1]]
+    inside = (seg >= r0) & (seg < r1)
+    assert inside.sum() < len(seg)              # couplings across the strip edge
+    row_of = numpy.repeat(numpy.arange(r0, r1), numpy.diff(rp[r0:r1 + 1]))
+    assert (row_of[~inside] < r1).all()
+
+
 # -- numpy restatement of one application -------------------------------------------
 def _cheb(A, D, lo, hi, k, r, x=None):
     theta, delta = 0.5 * (hi + lo), 0.5 * (hi - lo)
