@@ -225,9 +225,27 @@ class Comm(object):
                 lib.flow_rccl_comm_destroy(comm)
             return
         self._rccl_comm = comm
-        self.direct = _hip.RcclBinding(
+        binding = _hip.RcclBinding(
             comm, ctypes.c_void_p(self.buf.data_ptr()),
             ctypes.c_void_p(device.stream_handle()))
+        # 4. a reduction whose result is known, through the binding itself:
+        #    every rank contributes (rank + 1, 1); used only if every rank got
+        #    (world (world + 1) / 2, world)
+        self.buf[:2] = torch.tensor([self.rank + 1.0, 1.0], dtype=torch.float64,
+                                    device=self.buf.device)
+        device.synchronize()
+        rc = lib.flow_rccl_allreduce(
+            ctypes.cast(ctypes.pointer(binding), ctypes.c_void_p), 2)
+        device.synchronize()
+        got = device.to_host(self.buf[:2]).numpy()
+        ok = int(rc == 0 and got[0] == 0.5 * self.world * (self.world + 1)
+                 and got[1] == float(self.world))
+        self.buf[:2] = 0.0
+        if not all_ok(ok):
+            lib.flow_rccl_comm_destroy(comm)
+            self._rccl_comm = None
+            return
+        self.direct = binding
         self._point_struct_at_rccl()
 
     def _point_struct_at_rccl(self):
