@@ -605,13 +605,15 @@ def main():
             if settled else None,
             'newton_iterations_min': min(head['newton_iterations']),
             'stokes_start': start.get('info'),
+            # (what the last timed step actually ran with: the p-multigrid
+            # cycle, or the ILU(0) where that is rejected / not applicable)
             'newton_linear_solver': navsto.solver_parameters['newton'].get(
-                'linear_solver', 'gmres') + '+' + (
-                    'ilu0' if 'jacobian_pmg' not in prob.W.layout._dev
-                    or 'pmg_rejected' in prob.W.layout._dev else
-                    'pmg (two-level p-multigrid, Chebyshev smoothing; '
-                    'contraction %.2f)'
-                    % prob.W.layout._dev['jacobian_pmg'].contraction),
+                'linear_solver', 'gmres') + '+' + str(
+                    infos[-1].get('newton_preconditioner', 'none')),
+            'pmg_contraction': next(
+                (pre.contraction for name, pre in prob.W.layout._dev.items()
+                 if name in ('jacobian_pmg', 'jacobian_pmg_strip')
+                 and hasattr(pre, 'contraction')), None),
             'newton_overrides': args.newton,
             # every Krylov vector, matrix, dot product and update is fp64; the
             # PRECONDITIONERS of the flexible GMRES keep their own copies of
