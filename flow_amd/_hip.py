@@ -128,6 +128,20 @@ class PmgS(ctypes.Structure):
         ]
 
 
+class MassS(ctypes.Structure):
+    _fields_ = [
+        ('A', ctypes.POINTER(Operator)),
+        ('dinv', ctypes.c_void_p),
+        ('nblocks16', ctypes.c_int),
+        ('rowblocks16', ctypes.c_void_p),
+        ('vals16', ctypes.c_void_p),
+        ('lam_min', ctypes.c_double), ('lam_max', ctypes.c_double),
+        ('steps', ctypes.c_int),
+        ('contraction', ctypes.c_double),
+        ('work16', ctypes.c_void_p),
+        ]
+
+
 class MeshS(ctypes.Structure):
     _fields_ = [('nc', ctypes.c_int), ('xy', ctypes.c_void_p),
                 ('c0', ctypes.c_int), ('c1', ctypes.c_int)]
@@ -247,6 +261,9 @@ SYMBOLS = {
     'flow_pmg_pack': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _P(_D), _VP],
     'flow_pmg_apply': [_P(PmgS), _VP, _VP, _VP],
+    'flow_mass_pack': [_I, _VP, _VP, _VP, _VP, _VP],
+    'flow_mass_solve': [_P(MassS), _VP, _VP, _D, _D, _I, _I, _VP,
+                        ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_gather_rows': [_I, _VP, _I, _VP, _I, _VP, _I, _VP],
     'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],
     'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],

@@ -26,6 +26,15 @@ int pmg_apply(const flow_pmg* M, const double* r, double* z, hipStream_t st,
 int pmg_check(const flow_pmg* M, int op_size);
 // la_kernels.hip
 int sum_partials_host(double* work, int nparts, double* host, hipStream_t st);
+int check_operator(const flow_operator* A);
+int fill(int n, double value, double* y, hipStream_t st);
+// Krylov scalar slots in HBM (a solver's S = work + 3*kRedBlocks); read_state:
+// all of them -> host with ONE synchronisation (through the mailbox)
+enum Slot {
+  kGamma = 0, kAlpha, kBeta, kRes2, kB2, kRho, kOmega, kRhoNew, kTmp,
+  kBreak, kTarget2, kDone, kConvIt, kIter, kNumSlots = 16
+};
+int read_state(const double* S, double* host, hipStream_t st);
 
 // assembly_kernels.hip: the matrix-free operator (flow_operator kind 3)
 int momentum_jvp_check(const flow_momentum_jvp* J);

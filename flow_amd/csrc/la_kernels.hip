@@ -17,6 +17,7 @@
 //  * Krylov scalars (alpha, beta, ...) live in HBM; the host only reads the
 //    residual norm every `check_every` iterations.
 #include "common.h"
+#include "csr_stream.h"
 
 namespace flow {
 
@@ -32,10 +33,7 @@ void set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 // Krylov: scalar slots in HBM
 // ---------------------------------------------------------------------------
-enum Slot {
-  kGamma = 0, kAlpha, kBeta, kRes2, kB2, kRho, kOmega, kRhoNew, kTmp,
-  kBreak, kTarget2, kDone, kConvIt, kIter, kNumSlots = 16
-};
+// (enum Slot: common.h)
 // (the scalars move with load_scalar / store_scalar: common.h)
 // work layout: [0, 3*kRedBlocks) partials, [3*kRedBlocks, +kNumSlots) scalars
 static_assert(3 * kRedBlocks + kNumSlots <= FLOW_REDUCE_WORK, "work size");
@@ -55,92 +53,10 @@ static_assert(3 * kRedBlocks + kNumSlots <= FLOW_REDUCE_WORK, "work size");
 // ---------------------------------------------------------------------------
 // SpMV
 // ---------------------------------------------------------------------------
-// Tiles of the kernels that park ONE product per nonzero in LDS (operator kinds
-// 0 and 1, the multigrid level kernels): kPairs index pairs per lane; tiles of
-// the kernels that park two (kinds 2 and 4): kPairs2.
-#ifndef FLOW_SPMV_PAIRS
-#define FLOW_SPMV_PAIRS 2
-#endif
-constexpr int kPairs = FLOW_SPMV_PAIRS;         // nonzero pairs per lane
-constexpr int kTile = 2 * kBlock * kPairs;      // LDS products per workgroup
-constexpr int kPairs2 = 2;
-constexpr int kTile2 = 2 * kBlock * kPairs2;
-static_assert(FLOW_SPMV_ROWS_PER_BLOCK == kBlock, "one lane per row");
-static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTile2 - 2, "tile minus alignment slack");
-
+// (tiles: csr_stream.h)
 // scalar plane(s): blockIdx.y selects the component of a block-diagonal operator.
 // DOT: the workgroup also leaves its share of x.y (= x.Ax) in
 // dpart[blockIdx.y * gridDim.x + blockIdx.x] (CG's z.w without another pass).
-// One tile of the CSR stream -- the rows [r0, r1) of workgroup blockIdx.x: the
-// products go through LDS (prod, kTile doubles), then lane i sums row r0 + i.
-// Returns that row's sum; r / r1 tell the caller whether the lane has a row.
-__device__ __forceinline__ double stream_tile_row_sum(
-    const int* __restrict__ rowptr, const int* __restrict__ cols,
-    const double* __restrict__ vals, const int* __restrict__ rowblocks,
-    const double* __restrict__ x, double* __restrict__ prod, int& r, int& r1) {
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int r0 = rowblocks[tile];
-  r1 = rowblocks[tile + 1];
-  const int k0 = rowptr[r0];
-  const int k1 = rowptr[r1];
-  // 16-byte value loads / 8-byte index loads: every lane owns PAIRS pairs of
-  // consecutive nonzeros; the tile base is aligned down to an even index (value
-  // planes start 16-B aligned and the host caps a block at kTile-2 nonzeros).
-  const int ka = k0 & ~1;
-  r = r0 + threadIdx.x;
-  int a = 0, b = 0;
-  if (r < r1) {
-    a = rowptr[r] - ka;
-    b = rowptr[r + 1] - ka;
-  }
-  const double2* __restrict__ v2p = reinterpret_cast<const double2*>(vals + ka);
-  const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
-  const int npair = (k1 - ka + 1) >> 1;   // a trailing odd element reads one
-                                          // entry of the next tile (unused)
-  double2 v[kPairs];
-  int2 c[kPairs];
-#pragma unroll
-  for (int j = 0; j < kPairs; ++j) {
-    const int p = threadIdx.x + j * kBlock;
-    const bool ok = p < npair;
-    v[j] = ok ? v2p[p] : make_double2(0.0, 0.0);
-    c[j] = ok ? c2p[p] : make_int2(0, 0);
-  }
-  // x is only gathered for the tile's OWN nonzeros [k0, k1): the alignment
-  // slack before k0, the odd element behind k1 (a column of another row, or
-  // the padding 0 behind the last nonzero) and the idle lanes must not be
-  // dereferenced -- x may be a window of a larger vector (row-sharded solves
-  // pass x shifted to global row numbering: x[0] is then far outside it)
-  // Those entries gather the tile's first column instead (an index select,
-  // the loads themselves stay unconditional and all in flight).
-  const int lo = k0 - ka, hi = k1 - ka;
-  const int safe = cols[k0 < k1 ? k0 : (k0 > 0 ? k0 - 1 : 0)];
-  double x0[kPairs], x1[kPairs];
-  if (k0 < k1) {                       // (block-uniform)
-#pragma unroll
-    for (int j = 0; j < kPairs; ++j) {   // all gathers in flight before any use
-      const int e = 2 * (threadIdx.x + j * kBlock);
-      x0[j] = x[(e >= lo && e < hi) ? c[j].x : safe];
-      x1[j] = x[(e + 1 < hi) ? c[j].y : safe];
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < kPairs; ++j) x0[j] = x1[j] = 0.0;
-  }
-#pragma unroll
-  for (int j = 0; j < kPairs; ++j) {
-    const int p = threadIdx.x + j * kBlock;
-    if (p < npair) {
-      prod[2 * p] = v[j].x * x0[j];
-      prod[2 * p + 1] = v[j].y * x1[j];
-    }
-  }
-  __syncthreads();
-  double s = 0.0;
-  for (int k = a; k < b; ++k) s += prod[k];
-  return s;
-}
-
 template <bool DOT>
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
     int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
@@ -283,67 +199,13 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
     const unsigned char* __restrict__ mask, const double* __restrict__ x,
     double* __restrict__ y, int xs, double* __restrict__ dpart,
     const double* __restrict__ stop) {
-  // the products of the two components side by side (double2): 16 KB of LDS
-  // per workgroup -- with the 1022-nonzero tile that still leaves the 8
-  // workgroups per CU the wave limit allows, and both row sums come out of ONE
-  // pass over the segment (the single array used twice cost two barriers
-  // more: 166 -> see DESIGN.md)
+  // (the tile: stream_tile_pair_row_sum, csr_stream.h)
   __shared__ double2 prod[kTile2];
   if (stopped(stop)) return;
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int r0 = rowblocks[tile];
-  const int r1 = rowblocks[tile + 1];
-  const int k0 = rowptr[r0];
-  const int k1 = rowptr[r1];
-  const int ka = k0 & ~1;
-  const int r = r0 + threadIdx.x;
-  int a = 0, b = 0;
-  if (r < r1) {
-    a = rowptr[r] - ka;
-    b = rowptr[r + 1] - ka;
-  }
-  const double2* __restrict__ v2p = reinterpret_cast<const double2*>(vals + ka);
-  const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
-  const int npair = (k1 - ka + 1) >> 1;
-  double2 v[kPairs2];
-  int2 c[kPairs2];
-#pragma unroll
-  for (int j = 0; j < kPairs2; ++j) {
-    const int p = threadIdx.x + j * kBlock;
-    const bool ok = p < npair;
-    v[j] = ok ? v2p[p] : make_double2(0.0, 0.0);
-    c[j] = ok ? c2p[p] : make_int2(0, 0);
-  }
-  // (only the tile's own columns are dereferenced: see stream_tile_row_sum;
-  // a block of this square operator is never empty)
-  const int lo = k0 - ka, hi = k1 - ka;
-  const int safe = cols[k0];
-  double xa[kPairs2], xb[kPairs2], ua[kPairs2], ub[kPairs2];
-#pragma unroll
-  for (int j = 0; j < kPairs2; ++j) {   // all gathers in flight before any use
-    const int e = 2 * (threadIdx.x + j * kBlock);
-    const int cx = (e >= lo && e < hi) ? c[j].x : safe;
-    const int cy = (e + 1 < hi) ? c[j].y : safe;
-    xa[j] = x[cx];
-    xb[j] = x[cy];
-    ua[j] = x[xs + cx];
-    ub[j] = x[xs + cy];
-  }
-#pragma unroll
-  for (int j = 0; j < kPairs2; ++j) {
-    const int p = threadIdx.x + j * kBlock;
-    if (p < npair) {
-      prod[2 * p] = make_double2(v[j].x * xa[j], v[j].x * ua[j]);
-      prod[2 * p + 1] = make_double2(v[j].y * xb[j], v[j].y * ub[j]);
-    }
-  }
-  __syncthreads();
-  double s0 = 0.0, s1 = 0.0;
-  for (int k = a; k < b; ++k) {
-    const double2 q = prod[k];
-    s0 += q.x;
-    s1 += q.y;
-  }
+  int r, r1;
+  const double2 s =
+      stream_tile_pair_row_sum(rowptr, cols, vals, rowblocks, x, xs, prod, r, r1);
+  double s0 = s.x, s1 = s.y;
   double t = 0.0;
   if (r < r1) {
     const double x0 = x[r], x1 = x[xs + r];
@@ -359,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
   }
 }
 
-static int check_operator(const flow_operator* A) {
+int check_operator(const flow_operator* A) {
   FLOW_REQUIRE(A != nullptr, "operator is NULL");
   FLOW_REQUIRE(A->kind >= 0 && A->kind <= 4, "operator kind");
   if (A->kind == 3) {   // matrix-free: no pattern, no value planes
@@ -540,7 +402,7 @@ __global__ void fill_kernel(int n, double value, double* __restrict__ y) {
     y[i] = value;
 }
 
-static int fill(int n, double value, double* y, hipStream_t st) {
+int fill(int n, double value, double* y, hipStream_t st) {
   hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
                      value, y);
   FLOW_CHECK_LAUNCH();
@@ -974,7 +836,7 @@ __global__ void mailbox_state_kernel(const double* __restrict__ S,
   __threadfence_system();
 }
 
-static int read_state(const double* S, double* host, hipStream_t st) {
+int read_state(const double* S, double* host, hipStream_t st) {
   double *mailbox = nullptr, *dev_view = nullptr;
   int rc = mailbox_of_thread(&mailbox, &dev_view);
   if (rc) return rc;
@@ -1331,7 +1193,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 21; }
+extern "C" int flow_abi_version(void) { return 22; }
 
 // nonzeros a CSR-stream row block of an operator of `kind` may hold (the host
 // builds the row blocks: flow_amd/fem/space.py)

@@ -1,0 +1,480 @@
+// K18: mass-matrix solves by mixed-precision defect correction on gfx950
+// (include/flow_hip.h, flow_mass).
+//
+// Replaces, for the velocity correction (flow/navier_stokes/
+// pressure_correction.py:436-465: CG + hypre_amg on the vector mass system) and
+// the callers' L2 projections (tests/test_karman_vortex_street.py:262-267), the
+// Jacobi-CG of la_kernels.hip: 11-14 iterations of [fp64 product 12 B/nnz +
+// 5-vector update + scalar kernel] become 3-4 defect corrections of [one fp64
+// product whose epilogue leaves the scaled residual in fp32 + k-1 products with
+// an fp16 copy of D^-1 M at 6 B/nnz, no dot products, one launch each].  The
+// spectrum of D^-1 M is known a priori (Wathen), so the Chebyshev polynomial
+// is fixed and its contraction is a bound, not an estimate.
+//
+// All kernels are HBM-bound CSR-stream products (csr_stream.h; the fp16 tile
+// is the one of pmg_kernels.hip with ONE half per nonzero instead of a half2:
+// the mass matrix is the same for both velocity components).
+#include "common.h"
+#include "csr_stream.h"
+
+#include <hip/hip_fp16.h>
+
+namespace flow {
+
+constexpr int kMassQuads = 2;                       // quads of nonzeros per lane
+constexpr int kMassTile = kBlock * 4 * kMassQuads;  // LDS products per workgroup
+static_assert(FLOW_PMG_NNZ_PER_BLOCK == kMassTile - 4,
+              "tile minus alignment slack (base aligned down to a multiple of 4)");
+
+struct Half4 {              // four nonzeros, 8 bytes
+  __half v[4];
+};
+static_assert(sizeof(Half4) == 8, "packed quad");
+
+// fp32 vectors: one float per dof (scalar systems) or the two components
+// interleaved (float2: one 8-byte gather per nonzero serves both)
+__device__ __forceinline__ float vscale(float w, float g) { return w * g; }
+__device__ __forceinline__ float2 vscale(float w, float2 g) {
+  return make_float2(w * g.x, w * g.y);
+}
+__device__ __forceinline__ void vadd(float& s, float p) { s += p; }
+__device__ __forceinline__ void vadd(float2& s, float2 p) {
+  s.x += p.x;
+  s.y += p.y;
+}
+__device__ __forceinline__ void vzero(float& s) { s = 0.f; }
+__device__ __forceinline__ void vzero(float2& s) { s = make_float2(0.f, 0.f); }
+
+// One tile of the fp16 stream -- rows [r0, r1) of workgroup blockIdx.x (at most
+// kBlock rows, kMassTile - 4 nonzeros): every lane loads kMassQuads quads of
+// values (8 B) and of column indices (16 B) from a base aligned down to a
+// multiple of four nonzeros, all of them and all gathers behind them in flight
+// before the first use; products through LDS, lane i sums row r0 + i.
+// Window-safe like stream_tile_row_sum: g is only dereferenced for the tile's
+// own nonzeros (slack and idle lanes gather the tile's first column).
+template <class V>
+__device__ __forceinline__ V mass_tile_row_sum(
+    const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const __half* __restrict__ vals, const int* __restrict__ rowblocks,
+    const V* __restrict__ g, V* __restrict__ prod, int& r, int& r1) {
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int r0 = rowblocks[tile];
+  r1 = rowblocks[tile + 1];
+  const int k0 = rowptr[r0];
+  const int k1 = rowptr[r1];
+  const int ka = k0 & ~3;
+  r = r0 + threadIdx.x;
+  int a = 0, b = 0;
+  if (r < r1) {
+    a = rowptr[r] - ka;
+    b = rowptr[r + 1] - ka;
+  }
+  const int lo = k0 - ka, hi = k1 - ka;          // hi <= kMassTile - 1
+  const Half4* __restrict__ vq = reinterpret_cast<const Half4*>(vals + ka);
+  const int4* __restrict__ cq = reinterpret_cast<const int4*>(cols + ka);
+  Half4 v[kMassQuads];
+  int4 c[kMassQuads];
+#pragma unroll
+  for (int q = 0; q < kMassQuads; ++q) {
+    const int p = threadIdx.x + q * kBlock;
+    c[q] = make_int4(0, 0, 0, 0);
+    if (4 * p < hi) {
+      v[q] = vq[p];
+      c[q] = cq[p];
+    }
+  }
+  if (k0 < k1) {                                   // (block-uniform)
+    const int safe = cols[k0];
+    V gg[kMassQuads][4];
+#pragma unroll
+    for (int q = 0; q < kMassQuads; ++q) {          // all gathers in flight
+      const int e0 = 4 * (threadIdx.x + q * kBlock);
+      const int cc[4] = {c[q].x, c[q].y, c[q].z, c[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j;
+        gg[q][j] = g[(e >= lo && e < hi) ? cc[j] : safe];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kMassQuads; ++q) {
+      const int e0 = 4 * (threadIdx.x + q * kBlock);
+      if (e0 < hi) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          prod[e0 + j] = vscale(__half2float(v[q].v[j]), gg[q][j]);
+      }
+    }
+  }
+  __syncthreads();
+  V s;
+  vzero(s);
+  for (int k = a; k < b; ++k) vadd(s, prod[k]);
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// fp64 residual with the fp32 epilogue: rho0 = D^-1 (b - A x)
+// ---------------------------------------------------------------------------
+// scalar operator (kind 0)
+__global__ __launch_bounds__(kBlock) void mass_residual_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vals, const int* __restrict__ rowblocks,
+    const double* __restrict__ x, const double* __restrict__ b,
+    const double* __restrict__ dinv, float* __restrict__ rho0,
+    const double* __restrict__ stop) {
+  __shared__ double prod[kTile];
+  if (stopped(stop)) return;
+  int r, r1;
+  const double s =
+      stream_tile_row_sum(rowptr, cols, vals, rowblocks, x, prod, r, r1);
+  if (r < r1) rho0[r] = static_cast<float>(dinv[r] * (b[r] - s));
+}
+
+// one plane, both components, identity rows by mask (kind 4); x: component
+// stride xs, b / dinv / mask: component stride n
+__global__ __launch_bounds__(kBlock) void mass_residual_pair_kernel(
+    int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vals, const int* __restrict__ rowblocks,
+    const unsigned char* __restrict__ mask, const double* __restrict__ x, int xs,
+    const double* __restrict__ b, const double* __restrict__ dinv,
+    float2* __restrict__ rho0, const double* __restrict__ stop) {
+  __shared__ double2 prod[kTile2];
+  if (stopped(stop)) return;
+  int r, r1;
+  const double2 s =
+      stream_tile_pair_row_sum(rowptr, cols, vals, rowblocks, x, xs, prod, r, r1);
+  if (r < r1) {
+    const double s0 = mask[r] ? s.x : x[r];
+    const double s1 = mask[n + r] ? s.y : x[xs + r];
+    rho0[r] = make_float2(
+        static_cast<float>(dinv[r] * (b[r] - s0)),
+        static_cast<float>(dinv[static_cast<size_t>(n) + r] *
+                           (b[static_cast<size_t>(n) + r] - s1)));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Chebyshev steps on the fp16 copy:  s = (D^-1 A) g  row by row, then
+//   MODE 0  first product (g = rho0 = rho_in, d_0 = c0 rho0 folded in):
+//             rho_1 = rho0 - c0 s ; d_1 = c1 c0 rho0 + c2 rho_1 ;
+//             rho_out = rho_1 ; d_out = d_1 ; acc = c0 rho0 + d_1
+//   MODE 1  step (g = d):  rho' = rho_in - s ; d' = c1 g_own + c2 rho' ;
+//             rho_out = rho' (may alias rho_in: row-local) ; d_out = d' (NOT g) ;
+//             acc += d'
+//   MODE 2  last step: z = acc + d' ;  x += z in fp64 (component stride xs) ;
+//             the workgroup's shares of z.z and x.x -> zz_part / xx_part
+// Identity rows (mask, 0 = identity; nullptr: none): s = the row's own g.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void apply_mask(const unsigned char* mask, int n, int r,
+                                           float own, float& s) {
+  if (mask && !mask[r]) s = own;
+}
+__device__ __forceinline__ void apply_mask(const unsigned char* mask, int n, int r,
+                                           float2 own, float2& s) {
+  if (mask) {
+    if (!mask[r]) s.x = own.x;
+    if (!mask[n + r]) s.y = own.y;
+  }
+}
+__device__ __forceinline__ float vaxpby(float a, float x, float b, float y) {
+  return a * x + b * y;
+}
+__device__ __forceinline__ float2 vaxpby(float a, float2 x, float b, float2 y) {
+  return make_float2(a * x.x + b * y.x, a * x.y + b * y.y);
+}
+// x += z, returns (z.z, x.x) of the row
+__device__ __forceinline__ double2 add_to_x(double* x, int xs, int r, float z) {
+  const double xn = x[r] + static_cast<double>(z);
+  x[r] = xn;
+  return make_double2(static_cast<double>(z) * z, xn * xn);
+}
+__device__ __forceinline__ double2 add_to_x(double* x, int xs, int r, float2 z) {
+  const double x0 = x[r] + static_cast<double>(z.x);
+  const double x1 = x[xs + r] + static_cast<double>(z.y);
+  x[r] = x0;
+  x[xs + r] = x1;
+  return make_double2(static_cast<double>(z.x) * z.x + static_cast<double>(z.y) * z.y,
+                      x0 * x0 + x1 * x1);
+}
+
+template <class V, int MODE>
+__global__ __launch_bounds__(kBlock) void mass_cheb_kernel(
+    int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const __half* __restrict__ vals, const int* __restrict__ rowblocks,
+    const unsigned char* __restrict__ mask, const V* __restrict__ g,
+    const V* rho_in, V* rho_out, float c0, float c1, float c2,
+    V* __restrict__ d_out, V* __restrict__ acc, double* __restrict__ x, int xs,
+    double* __restrict__ zz_part, double* __restrict__ xx_part,
+    const double* __restrict__ stop) {
+  __shared__ V prod[kMassTile];
+  if (stopped(stop)) return;
+  int r, r1;
+  V s = mass_tile_row_sum<V>(rowptr, cols, vals, rowblocks, g, prod, r, r1);
+  double2 dots = make_double2(0.0, 0.0);
+  if (r < r1) {
+    const V own = g[r];
+    apply_mask(mask, n, r, own, s);
+    if (MODE == 0) {
+      const V rho = vaxpby(1.f, own, -c0, s);
+      const V d = vaxpby(c1 * c0, own, c2, rho);
+      rho_out[r] = rho;
+      d_out[r] = d;
+      acc[r] = vaxpby(c0, own, 1.f, d);
+    } else {
+      const V rho = vaxpby(1.f, rho_in[r], -1.f, s);
+      const V d = vaxpby(c1, own, c2, rho);
+      if (MODE == 1) {
+        rho_out[r] = rho;
+        d_out[r] = d;
+        acc[r] = vaxpby(1.f, acc[r], 1.f, d);
+      } else {
+        dots = add_to_x(x, xs, r, vaxpby(1.f, acc[r], 1.f, d));
+      }
+    }
+  }
+  if (MODE == 2) {
+    const double zz = block_sum(dots.x);
+    const double xx = block_sum(dots.y);
+    if (threadIdx.x == 0) {
+      zz_part[blockIdx.x] = zz;
+      xx_part[blockIdx.x] = xx;
+    }
+  }
+}
+
+// One workgroup: z.z and x.x from the partials of the last product; the
+// stopping test  contraction |z_k| <= max(rtol |x_{k+1}|, atol)  (x already
+// holds x_{k+1} = x_k + z_k, the iterate the test accepts: |B r_{k+1}| <=
+// |I - B M| |z_k|); S[kConvIt] = corrections applied, S[kRes2] = z.z
+constexpr int kMassScalarBlock = 1024;
+__global__ __launch_bounds__(kMassScalarBlock) void mass_scalar_kernel(
+    int nparts, const double* __restrict__ zz_part,
+    const double* __restrict__ xx_part, double contraction2, double rtol2,
+    double atol2, double* __restrict__ S) {
+  __shared__ double wsum[2][kMassScalarBlock / 64];
+  if (stopped(S + kDone)) return;
+  double z0 = 0.0, z1 = 0.0, x0 = 0.0, x1 = 0.0;
+  int i = threadIdx.x;
+  for (; i + kMassScalarBlock < nparts; i += 2 * kMassScalarBlock) {
+    z0 += load_scalar(zz_part + i);
+    z1 += load_scalar(zz_part + i + kMassScalarBlock);
+    x0 += load_scalar(xx_part + i);
+    x1 += load_scalar(xx_part + i + kMassScalarBlock);
+  }
+  for (; i < nparts; i += kMassScalarBlock) {
+    z0 += load_scalar(zz_part + i);
+    x0 += load_scalar(xx_part + i);
+  }
+  double zz = z0 + z1, xx = x0 + x1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    zz += __shfl_down(zz, off, 64);
+    xx += __shfl_down(xx, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    wsum[0][threadIdx.x >> 6] = zz;
+    wsum[1][threadIdx.x >> 6] = xx;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  zz = xx = 0.0;
+  for (int w = 0; w < kMassScalarBlock / 64; ++w) {
+    zz += wsum[0][w];
+    xx += wsum[1][w];
+  }
+  const double k = load_scalar(S + kIter) + 1.0;
+  const bool nan = !(zz == zz) || !(xx == xx);
+  if (nan || contraction2 * zz <= fmax(rtol2 * xx, atol2)) {
+    store_scalar(S + kConvIt, k);
+    store_scalar(S + kDone, nan ? 2.0 : 1.0);
+  }
+  store_scalar(S + kIter, k);
+  store_scalar(S + kRes2, zz);
+  store_scalar(S + kB2, xx);
+}
+
+// setup: vals16[k] = half(vals[k] / diagonal of row(k)); a lane per row
+__global__ void mass_pack_kernel(int n, const int* __restrict__ rowptr,
+                                 const int* __restrict__ diag_idx,
+                                 const double* __restrict__ vals,
+                                 __half* __restrict__ vals16) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    const double inv = 1.0 / vals[diag_idx[i]];
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      vals16[k] = __float2half_rn(static_cast<float>(vals[k] * inv));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Cheb {
+  double theta, delta, sigma, rho;
+  Cheb(double lo, double hi)
+      : theta(0.5 * (hi + lo)), delta(0.5 * (hi - lo)), sigma(theta / delta),
+        rho(1.0 / sigma) {}
+  float first() const { return static_cast<float>(1.0 / theta); }
+  // coefficients of the next step: d' = c1 d + c2 rho'
+  void next(float* c1, float* c2) {
+    const double rn = 1.0 / (2.0 * sigma - rho);
+    *c1 = static_cast<float>(rn * rho);
+    *c2 = static_cast<float>(2.0 * rn / delta);
+    rho = rn;
+  }
+};
+
+template <class V>
+int correction(const flow_mass* M, const double* b, double* x, double* zz_part,
+               double* xx_part, const double* stop, hipStream_t st) {
+  const flow_operator* A = M->A;
+  const int n = A->n;
+  const __half* v16 = static_cast<const __half*>(M->vals16);
+  V* w = reinterpret_cast<V*>(M->work16);
+  V* rho0 = w;
+  V* rho = rho0 + n;
+  V* d[2] = {rho + n, rho + 2 * static_cast<size_t>(n)};
+  V* acc = rho + 3 * static_cast<size_t>(n);
+  const dim3 g16(M->nblocks16), blk(kBlock);
+  Cheb ch(M->lam_min, M->lam_max);
+  const float c0 = ch.first();
+  float c1, c2;
+  V* const none = nullptr;
+  double* const nod = nullptr;
+  ch.next(&c1, &c2);
+  hipLaunchKernelGGL((mass_cheb_kernel<V, 0>), g16, blk, 0, st, n, A->rowptr,
+                     A->cols, v16, M->rowblocks16, A->rowmask, rho0, rho0, rho, c0,
+                     c1, c2, d[0], acc, nod, n, nod, nod, stop);
+  const int products = M->steps - 1;
+  for (int j = 1; j + 1 < products; ++j) {
+    ch.next(&c1, &c2);
+    hipLaunchKernelGGL((mass_cheb_kernel<V, 1>), g16, blk, 0, st, n, A->rowptr,
+                       A->cols, v16, M->rowblocks16, A->rowmask, d[(j - 1) & 1], rho,
+                       rho, 0.f, c1, c2, d[j & 1], acc, nod, n, nod, nod, stop);
+  }
+  ch.next(&c1, &c2);
+  hipLaunchKernelGGL((mass_cheb_kernel<V, 2>), g16, blk, 0, st, n, A->rowptr,
+                     A->cols, v16, M->rowblocks16, A->rowmask, d[(products - 2) & 1],
+                     rho, none, 0.f, c1, c2, none, acc, x, n, zz_part, xx_part, stop);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+}  // namespace
+
+static int mass_check(const flow_mass* M) {
+  FLOW_REQUIRE(M != nullptr && M->A != nullptr, "flow_mass is NULL");
+  int rc = check_operator(M->A);
+  if (rc) return rc;
+  FLOW_REQUIRE(M->A->kind == 0 || M->A->kind == 4,
+               "flow_mass: operator kind 0 (scalar) or 4 (one plane, two "
+               "components)");
+  FLOW_REQUIRE(M->dinv && M->rowblocks16 && M->vals16 && M->work16 &&
+                   M->nblocks16 > 0,
+               "flow_mass pointers");
+  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(M->vals16) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(M->A->cols) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(M->work16) % 16 == 0,
+               "flow_mass: vals16, cols and work16 must be 16-byte aligned");
+  FLOW_REQUIRE(M->lam_max > M->lam_min && M->lam_min > 0.0,
+               "Chebyshev interval (0 < lam_min < lam_max)");
+  FLOW_REQUIRE(M->steps >= 3 && M->steps <= 16, "Chebyshev steps (3..16)");
+  FLOW_REQUIRE(M->contraction > 0.0 && M->contraction <= 1.0,
+               "contraction bound in (0, 1]");
+  return FLOW_OK;
+}
+
+static int mass_solve(const flow_mass* M, const double* b, double* x, double rtol,
+                      double atol, int maxit, int first_check, double* work,
+                      int* iters_host, double* resid_host, hipStream_t st) {
+  const flow_operator* A = M->A;
+  double* S = work + 3 * kRedBlocks;
+  double* zz_part = work + FLOW_REDUCE_WORK;
+  double* xx_part = zz_part + M->nblocks16;
+  const double* stop = S + kDone;
+  const double c2 = M->contraction * M->contraction;
+  int rc;
+  if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
+  auto one = [&]() -> int {
+    if (A->kind == 4) {
+      hipLaunchKernelGGL(mass_residual_pair_kernel, dim3(A->nblocks), dim3(kBlock),
+                         0, st, A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
+                         A->rowmask, x, A->n, b, M->dinv,
+                         reinterpret_cast<float2*>(M->work16), stop);
+      if ((rc = correction<float2>(M, b, x, zz_part, xx_part, stop, st))) return rc;
+    } else {
+      hipLaunchKernelGGL(mass_residual_kernel, dim3(A->nblocks), dim3(kBlock), 0, st,
+                         A->rowptr, A->cols, A->vals[0], A->rowblocks, x, b, M->dinv,
+                         M->work16, stop);
+      if ((rc = correction<float>(M, b, x, zz_part, xx_part, stop, st))) return rc;
+    }
+    hipLaunchKernelGGL(mass_scalar_kernel, dim3(1), dim3(kMassScalarBlock), 0, st,
+                       M->nblocks16, zz_part, xx_part, c2, rtol * rtol, atol * atol,
+                       S);
+    FLOW_CHECK_LAUNCH();
+    return FLOW_OK;
+  };
+  double state[kNumSlots];
+  int launched = 0;
+  while (true) {
+    const int batch = (launched == 0 && first_check > 0) ? first_check : 1;
+    const int todo = (maxit - launched < batch) ? maxit - launched : batch;
+    for (int k = 0; k < todo; ++k)
+      if ((rc = one())) return rc;
+    launched += todo;
+    if ((rc = read_state(S, state, st))) return rc;
+    const double zz = state[kRes2];
+    if (state[kDone] == 2.0 || !(zz == zz)) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = zz;
+      set_error("mass solve broke down (NaN) at correction %d", *iters_host);
+      return FLOW_NOT_CONVERGED;
+    }
+    if (state[kDone] == 1.0) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = sqrt(zz);
+      return FLOW_OK;
+    }
+    if (launched >= maxit) {
+      *iters_host = launched;
+      *resid_host = sqrt(zz);
+      set_error("mass solve did not converge in %d defect corrections: |z| = "
+                "%.3e, |x| = %.3e", launched, sqrt(zz), sqrt(state[kB2]));
+      return FLOW_NOT_CONVERGED;
+    }
+  }
+}
+
+}  // namespace flow
+
+using namespace flow;
+
+extern "C" int flow_mass_pack(int n, const int* rowptr, const int* diag_idx,
+                              const double* vals, void* vals16, void* stream) {
+  FLOW_REQUIRE(n > 0 && rowptr && diag_idx && vals && vals16,
+               "flow_mass_pack arguments");
+  hipLaunchKernelGGL(mass_pack_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
+                     as_stream(stream), n, rowptr, diag_idx, vals,
+                     static_cast<__half*>(vals16));
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_mass_solve(const flow_mass* M, const double* b, double* x,
+                               double rtol, double atol, int maxit,
+                               int first_check, double* work, size_t work_len,
+                               int* iters_host, double* resid_host,
+                               void* stream) {
+  int rc = mass_check(M);
+  if (rc) return rc;
+  FLOW_REQUIRE(b && x && work && iters_host && resid_host, "solver pointers");
+  FLOW_REQUIRE(rtol >= 0.0 && atol >= 0.0 && maxit >= 1 && first_check >= 0,
+               "solver tolerances");
+  FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK + 2 * static_cast<size_t>(M->nblocks16),
+               "mass solve workspace too small");
+  return mass_solve(M, b, x, rtol, atol, maxit, first_check, work, iters_host,
+                    resid_host, as_stream(stream));
+}

@@ -610,6 +610,11 @@ def project(f, V, tol=1.0e-14):
     return out
 
 
+# how the mass systems of the projections below are solved: 'chebyshev' (defect
+# correction with a fixed Chebyshev polynomial, flow_amd/fem/mass.py) or 'cg'
+MASS_SOLVER = {'method': 'chebyshev', 'steps': 6}
+
+
 def project_magnitude(u, mode=0, tol=1.0e-12, initial_guess=None):
     '''`project(sqrt(ux**2 + uy**2), FunctionSpace(mesh, 'Lagrange', k))`
     (mode 0; tests/test_karman_vortex_street.py:262-267) or
@@ -643,6 +648,11 @@ def project_magnitude(u, mode=0, tol=1.0e-12, initial_guess=None):
     if strips:
         out.solve_info = parallel.cg(M, lay._dev[key], b, out.data, tol,
                                      maxit=1000, check_every=2, tag=tag)
+    elif MASS_SOLVER['method'] == 'chebyshev':
+        from .mass import MassSolver
+        out.solve_info = MassSolver.cached(
+            M, lay._dev[key], steps=MASS_SOLVER['steps']).solve(
+                b, out.data, tol, maxit=100, tag=tag)
     else:
         out.solve_info = krylov_solve(
             'cg', M, b, out.data, tol, maxit=1000, dinv=lay._dev[key],

@@ -130,7 +130,12 @@ solver_parameters = {
                  # rows below which the multigrid hierarchy stops coarsening
                  # (dense inverse there)
                  'mg_coarsest': 4200},
-    'correction': {'maxit': 10000, 'check_every': 2, 'extrapolate': False},
+    # 'method': 'chebyshev' = mixed-precision defect correction with a fixed
+    # Chebyshev polynomial of D^-1 M (flow_amd/fem/mass.py: 3-4 corrections of
+    # one fp64 + `chebyshev_steps` - 1 fp16 products, no dot products) or 'cg'
+    # (Jacobi-CG, 11-14 iterations; what the strips run)
+    'correction': {'maxit': 10000, 'check_every': 2, 'extrapolate': False,
+                   'method': 'chebyshev', 'chebyshev_steps': 6},
     }
 
 _MODES = {
@@ -982,6 +987,11 @@ def _compute_velocity_correction(
     if parallel.active():
         sol = parallel.cg(Mbc, dinv, b, u1.data, tol, 0.0, par['maxit'],
                           check_every=par['check_every'], tag='correction')
+    elif par.get('method', 'chebyshev') == 'chebyshev':
+        from ..fem.mass import MassSolver
+        sol = MassSolver.cached(
+            Mbc, dinv, steps=par.get('chebyshev_steps', 6)).solve(
+                b, u1.data, tol, maxit=min(par['maxit'], 100), tag='correction')
     else:
         sol = ops.krylov_solve(
             'cg', Mbc, b, u1.data, rtol=tol, atol=0.0, maxit=par['maxit'],

@@ -349,6 +349,61 @@ int flow_pmg_lambda_max(const flow_pmg_level* level, int iterations, float* work
 /* z = M^-1 r (r, z: 2*fine.n doubles, component-blocked) */
 int flow_pmg_apply(const flow_pmg* pmg, const double* r, double* z, void* stream);
 
+/* ---- K18: mass-matrix solves by mixed-precision defect correction ---------
+ * The velocity correction (pressure_correction.py:436-465: `solve(a3 == L3,
+ * u1, bcs)`, CG + hypre_amg, relative tolerance tol) and the callers' L2
+ * projections (tests/test_karman_vortex_street.py:262-267) are solves with a
+ * finite-element MASS matrix.  Its Jacobi-scaled spectrum is known a priori on
+ * any mesh (Wathen 1987: the extreme eigenvalues of D^-1 M lie between those
+ * of the scaled element matrices -- P1 triangles [1/2, 2], P2 triangles
+ * [0.3924, 2.0598]), so a fixed Chebyshev polynomial of D^-1 M is an
+ * approximate inverse B with a KNOWN contraction |I - B M| <= eps_k =
+ * 2 s^k / (1 + s^2k), s = 0.39 for P2 (k = 6 steps: 7e-3).  The solve is the
+ * defect correction
+ *     r = b - M x  (fp64, the CSR-stream SpMV of the operator, with the
+ *                   residual scaled by D^-1 and rounded to fp32 in its epilogue)
+ *     z = B r      (k Chebyshev steps = k - 1 products with a copy of D^-1 M
+ *                   rounded to fp16 -- ONE value plane, 6 B per nonzero with
+ *                   the index, also when it serves both velocity components --,
+ *                   vectors fp32, components interleaved)
+ *     x += z       (fp64, in the last product's epilogue)
+ * No dot product steers the iteration; one launch per product.  Stopping test:
+ * z_k = B r_k IS the preconditioned residual of PETSc's KSPCG test with a
+ * preconditioner as strong as the reference's AMG (B ~ M^-1), and B b ~ x:
+ *     contraction * |z_k| <= max(rtol |x_k + z_k|, atol)
+ * -- since B r_{k+1} = (I - B M) z_k, the iterate x_{k+1} = x_k + z_k then
+ * satisfies |B r_{k+1}| <= rtol |B b| (contraction = the bound on |I - B M|
+ * the caller vouches for; 1: test |z_k| itself, one more iteration).  Decided
+ * on the device like the Krylov drivers below (sticky flag, exact count).
+ * A: kind 0 (scalar) or kind 4 (one plane for both components, identity rows
+ * by mask; x should carry b on those rows on entry, else it converges there
+ * like everywhere).  dinv: op-size doubles (1 on masked rows).
+ * vals16: nnz halfs (D^-1 M)_ij (flow_mass_pack), 16-byte aligned, readable
+ * three entries past nnz like A->cols (quads of nonzeros per lane);
+ * rowblocks16: CSR-stream row blocks of <= FLOW_PMG_NNZ_PER_BLOCK nonzeros.
+ * work16: 5 * ncomp * n floats, 16-byte aligned. */
+typedef struct {
+  const flow_operator* A;
+  const double* dinv;
+  int nblocks16;
+  const int* rowblocks16;
+  const void* vals16;
+  double lam_min, lam_max;     /* Chebyshev interval of D^-1 M */
+  int steps;                   /* Chebyshev steps per defect correction, 3..16 */
+  double contraction;          /* bound on |I - B M| in (0, 1] */
+  float* work16;
+} flow_mass;
+/* vals16[k] = half(vals[k] / vals[diag_idx[row(k)]]) */
+int flow_mass_pack(int n, const int* rowptr, const int* diag_idx,
+                   const double* vals, void* vals16, void* stream);
+/* x holds the initial guess.  maxit / *iters_host count defect corrections;
+ * first_check: as flow_cg_solve (then one at a time).  *resid_host = |z| of
+ * the last correction.  work: FLOW_REDUCE_WORK + 2 * nblocks16 doubles. */
+int flow_mass_solve(const flow_mass* M, const double* b, double* x, double rtol,
+                    double atol, int maxit, int first_check, double* work,
+                    size_t work_len, int* iters_host, double* resid_host,
+                    void* stream);
+
 /* ---- K12: Krylov drivers -------------------------------------------------
  * Device-resident loops.  Convergence is decided ON THE DEVICE: the kernel
  * that computes the solver scalars compares the residual norm with the target
