@@ -420,14 +420,24 @@ def main():
         else:
             prob.set_initial_profile()
 
+    def apply_overrides():
+        # --newton KEY=VALUE; KEY may be dotted (pmg.coarse_steps=3) and may
+        # start with another group of solver_parameters (correction.method=cg)
+        for kv in args.newton:
+            key, val = kv.split('=', 1)
+            path = key.split('.')
+            d = navsto.solver_parameters
+            if path[0] not in d:
+                d = d['newton']
+            for part in path[:-1]:
+                d = d[part]
+            old = d[path[-1]]
+            d[path[-1]] = val if isinstance(old, str) else type(old)(float(val))
+
     def window(mode):
         '''W warm-up + K timed steps from the initial state in `mode`.'''
         navsto.set_mode(mode)
-        for kv in args.newton:
-            key, val = kv.split('=', 1)
-            old = navsto.solver_parameters['newton'][key]
-            navsto.solver_parameters['newton'][key] = \
-                val if isinstance(old, str) else type(old)(float(val))
+        apply_overrides()
         if settled:
             prob.restore(settled['state'])
         else:
@@ -476,11 +486,7 @@ def main():
     # everything that is built once and cached (operators, hierarchy, ILU
     # plan, ...), then the start state: all of it setup, outside the windows
     # (development overrides first: some of them shape those structures)
-    for kv in args.newton:
-        key, val = kv.split('=', 1)
-        old = navsto.solver_parameters['newton'][key]
-        navsto.solver_parameters['newton'][key] = \
-            val if isinstance(old, str) else type(old)(float(val))
+    apply_overrides()
     prob.prepare()
     initial_state()
     if not args.no_settle:

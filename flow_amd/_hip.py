@@ -223,6 +223,7 @@ class MomentumJvp(ctypes.Structure):
         ('scratch', ctypes.c_void_p),
         ('nbc', ctypes.c_int),
         ('bc_dofs', ctypes.c_void_p),
+        ('bc_mask', ctypes.c_void_p),
         ]
 
 

@@ -29,7 +29,12 @@ template <int NP>
 __global__ __launch_bounds__(kBlock) void gather_kernel(
     int nout, const int* __restrict__ ptr, const int* __restrict__ src,
     const double* __restrict__ scratch, size_t plane_stride, size_t out_stride,
-    double* __restrict__ out, const double* __restrict__ stop) {
+    double* __restrict__ out, const double* __restrict__ stop,
+    const unsigned char* __restrict__ idrow = nullptr, size_t id_stride = 0,
+    const double* __restrict__ v = nullptr, size_t v_stride = 0) {
+  // idrow != nullptr: identity rows -- where idrow[p * id_stride + k] is set,
+  // out = v[p * v_stride + k] instead of the sum (the Dirichlet rows of the
+  // matrix-free Jacobian: one launch less than copying them afterwards)
   if (stopped(stop)) return;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nout;
        k += gridDim.x * blockDim.x) {
@@ -42,16 +47,21 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(
       int idx[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) idx[j] = t + j < b ? src[t + j] : -1;
-      double v[NP][4];
+      double w[NP][4];
 #pragma unroll
       for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          v[p][j] = idx[j] >= 0 ? scratch[p * plane_stride + idx[j]] : 0.0;
+          w[p][j] = idx[j] >= 0 ? scratch[p * plane_stride + idx[j]] : 0.0;
 #pragma unroll
       for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s[p] += v[p][j];
+        for (int j = 0; j < 4; ++j) s[p] += w[p][j];
+    }
+    if (idrow) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        if (idrow[p * id_stride + k]) s[p] = v[p * v_stride + k];
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) out[static_cast<size_t>(p) * out_stride + k] = s[p];
@@ -62,21 +72,28 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(
 static int gather(int nout, int nplanes, const int* ptr, const int* src,
                   const double* scratch, size_t plane_stride, double* out,
                   hipStream_t st, size_t out_stride = 0, int r0 = 0, int r1 = 0,
-                  const double* stop = nullptr) {
+                  const double* stop = nullptr,
+                  const unsigned char* idrow = nullptr, const double* v = nullptr,
+                  size_t v_stride = 0) {
   const size_t os = out_stride ? out_stride : static_cast<size_t>(nout);
+  const size_t ids = static_cast<size_t>(nout);     // mask: component stride n
   if (r1 > 0) {
     ptr += r0;
     out += r0;
+    if (idrow) idrow += r0;
+    if (v) v += r0;
     nout = r1 - r0;
   }
   const dim3 grid(grid_for(nout, kBlock, 1 << 20));
   FLOW_REQUIRE(nplanes == 1 || nplanes == 2, "gather: 1 or 2 planes");
   if (nplanes == 1)
     hipLaunchKernelGGL(gather_kernel<1>, grid, dim3(kBlock), 0, st, nout, ptr,
-                       src, scratch, plane_stride, os, out, stop);
+                       src, scratch, plane_stride, os, out, stop, idrow, ids, v,
+                       v_stride);
   else
     hipLaunchKernelGGL(gather_kernel<2>, grid, dim3(kBlock), 0, st, nout, ptr,
-                       src, scratch, plane_stride, os, out, stop);
+                       src, scratch, plane_stride, os, out, stop, idrow, ids, v,
+                       v_stride);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -1210,11 +1227,13 @@ int flow::momentum_jvp_apply(const flow_momentum_jvp* J, const double* v,
   FLOW_DISPATCH_DEG(W->deg, momentum_jvp_kernel, cell_grid(cr.count()), st,
                     mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n, vs,
                     J->bfmask, J->ui, v, J->prm, J->scratch, stop);
+  // (Dirichlet rows are identity rows: with the byte mask the gather writes
+  // them itself; without it a copy kernel follows)
   if ((rc = gather(W->n, 2, W->vptr, W->vsrc, J->scratch,
                    static_cast<size_t>(nl) * mesh->nc, out, st, os, W->r0,
-                   W->r1, stop)))
+                   W->r1, stop, J->nbc > 0 ? J->bc_mask : nullptr, v, vs)))
     return rc;
-  if (J->nbc > 0) {
+  if (J->nbc > 0 && !J->bc_mask) {
     const int r0 = W->r1 > 0 ? W->r0 : 0, r1 = W->r1 > 0 ? W->r1 : W->n;
     hipLaunchKernelGGL(bc_copy_kernel, dim3(grid_for(J->nbc)), dim3(kBlock), 0,
                        st, J->nbc, J->bc_dofs, W->n, r0, r1, v, vs, out, os, stop);

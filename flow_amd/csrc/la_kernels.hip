@@ -1665,6 +1665,13 @@ __global__ __launch_bounds__(kBlock) void gmres_step_kernel(
   __shared__ double nrm[kGmresMax + 1], eta[kGmresMax];
   __shared__ double g[kGmresMax + 1], cs[kGmresMax], sn[kGmresMax], y[kGmresMax];
   if (stopped(S + kDone)) return;
+  // beta < 0: the cycle's |r0| and the target are on the device (left by
+  // gmres_begin_kernel: the single-GPU solver reads nothing back before the
+  // cycle's steps are enqueued)
+  if (beta < 0.0) {
+    beta = load_scalar(S + kBeta);
+    target = load_scalar(S + kTarget2);
+  }
   const int nd = j + 1;
   const int nval = nd + 1 + (j > 0 ? 1 : 0);
   const int lane = threadIdx.x & 63;
@@ -1802,6 +1809,43 @@ __global__ __launch_bounds__(kBlock) void gmres_step_kernel(
     if (done) store_scalar(S + kDone, 1.0);
     if (lucky) store_scalar(S + kDone, 3.0);     // end of cycle, no verdict
   }
+}
+
+// Start of a GMRES cycle, one workgroup: |r0|^2 (list 0 of `partial`) and, the
+// first time, |b|^2 (list 1; have_b2 = 0: b IS r0) -> S[kBeta] = |r0|,
+// S[kTarget2] = the target max(rtol |b|, atol) (NOT squared here), and the
+// verdict on the start itself: S[kDone] = 4 when r0 already passes (accept10:
+// within a factor 10 -- the verification behind a cycle that stopped on the
+// least-squares estimate), 2 when it is not a number.  With it the host
+// enqueues the cycle's Arnoldi steps without having read anything back.
+__global__ __launch_bounds__(kBlock) void gmres_begin_kernel(
+    int nparts, int have_b2, int first, int accept10, double rtol, double atol,
+    const double* __restrict__ partial, double* __restrict__ S) {
+  double r = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) {
+    r += load_scalar(partial + i);
+    if (have_b2) b += load_scalar(partial + kRedBlocks + i);
+  }
+  r = block_sum(r);
+  b = block_sum(b);
+  if (threadIdx.x != 0) return;
+  double target;
+  if (first) {
+    const double b2 = have_b2 ? b : r;
+    target = fmax(rtol * sqrt(b2), atol);
+    store_scalar(S + kB2, b2);
+    store_scalar(S + kTarget2, target);
+  } else {
+    target = load_scalar(S + kTarget2);
+  }
+  const double beta = sqrt(r);
+  store_scalar(S + kBeta, beta);
+  store_scalar(S + kRes2, beta);
+  store_scalar(S + kConvIt, 0.0);
+  if (!(r == r))
+    store_scalar(S + kDone, 2.0);
+  else if (beta <= target || (accept10 && beta <= 10.0 * target))
+    store_scalar(S + kDone, 4.0);
 }
 
 #define FLOW_NV_SWITCH(nv, CALL) \
@@ -1967,16 +2011,18 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
   };
 
   if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
-  if ((rc = dots(N, 1, b, b, b, b, b, b, partial, &np, st))) return rc;
-  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 1, 0,
-                     partial, S + kB2);
-  double b2 = 0.0, target = 0.0, resid = 0.0;
+  double resid = 0.0;
   int it = 0;
-  bool have_target = false;
+  bool first = true;
   bool claimed = false;     // the last cycle stopped on the residual estimate
+  double state[kNumSlots];
   while (true) {
-    // r0 = b - A x -> V_0, beta = |r0|
-    if (x_is_zero && it == 0) {
+    // r0 = b - A x -> V_0; |r0|^2 (the first time also |b|^2) in block
+    // partials; beta = |r0|, the target and the verdict on the start itself
+    // are left ON THE DEVICE by gmres_begin_kernel: nothing is read back
+    // before the cycle's Arnoldi steps are enqueued
+    const bool b_is_r0 = x_is_zero && it == 0;
+    if (b_is_r0) {
       hipLaunchKernelGGL(axpby_kernel, dim3(gv), dim3(kBlock), 0, st, N, 1.0, b,
                          0.0, V);
     } else {
@@ -1986,24 +2032,9 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
                          static_cast<const double*>(nullptr), V,
                          static_cast<double*>(nullptr));
     }
-    if ((rc = dots(N, 1, V, V, V, V, V, V, partial, &np, st))) return rc;
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, np, 1, 0,
-                       partial, S + kRes2);
-    FLOW_CHECK_LAUNCH();
-    double res2 = 0.0;
-    if ((rc = read_slots(S, kB2, kRes2, &b2, &res2, st))) return rc;
-    if (!have_target) {
-      target = fmax(rtol * sqrt(b2), atol);
-      have_target = true;
-    }
-    const double beta = sqrt(res2);
-    resid = beta;
-    if (!(res2 == res2)) {
-      *iters_host = it;
-      *resid_host = res2;
-      set_error("GMRES broke down (NaN residual) at iteration %d", it);
-      return FLOW_NOT_CONVERGED;
-    }
+    const int have_b2 = first && !b_is_r0;
+    if ((rc = dots(N, have_b2 ? 2 : 1, V, V, b, b, V, V, partial, &np, st)))
+      return rc;
     // behind a cycle that stopped on the least-squares ESTIMATE this is the
     // verification with the true residual b - A x (one operator application):
     // the one-pass Gram-Schmidt and a reduced-precision preconditioner can
@@ -2011,21 +2042,31 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
     // (seen in principle at rtol 1e-13, flow/heat.py's solves); within a
     // factor 10 of the target the iterate is accepted and the TRUE norm
     // reported, beyond it the solve goes on from here
-    if (beta <= target || (claimed && beta <= 10.0 * target)) break;
+    hipLaunchKernelGGL(gmres_begin_kernel, dim3(1), dim3(kBlock), 0, st, np,
+                       have_b2, first ? 1 : 0, claimed ? 1 : 0, rtol, atol,
+                       partial, S);
+    FLOW_CHECK_LAUNCH();
+    first = false;
     claimed = false;
     if (it >= maxit) {
+      if ((rc = read_state(S, state, st))) return rc;
+      resid = state[kBeta];
+      if (state[kDone] == 4.0) break;
       *iters_host = it;
-      *resid_host = beta;
-      set_error("GMRES did not converge in %d iterations: |r| = %.3e > %.3e", it,
-                beta, target);
+      *resid_host = resid;
+      if (state[kDone] == 2.0) {
+        set_error("GMRES broke down (NaN residual) at iteration %d", it);
+      } else {
+        set_error("GMRES did not converge in %d iterations: |r| = %.3e > %.3e",
+                  it, resid, state[kTarget2]);
+      }
       return FLOW_NOT_CONVERGED;
     }
 
     // one cycle: up to m columns; `cols` of them are known to be final
     const int it0 = it;
     int enq = 0, cols = 0;
-    bool converged = false;
-    double state[kNumSlots];
+    bool converged = false, start_passes = false;
     while (true) {
       const int room = (m < maxit - it0 ? m : maxit - it0) - enq;
       if (room <= 0) break;
@@ -2034,23 +2075,30 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
       if (plan > room) plan = room;
       for (int k = 0; k < plan; ++k, ++enq) {
         const bool last = enq + 1 >= m || it0 + enq + 1 >= maxit;
-        if ((rc = arnoldi(enq, beta, target, last))) return rc;
+        if ((rc = arnoldi(enq, -1.0, 0.0, last))) return rc;
       }
       if ((rc = read_state(S, state, st))) return rc;
       cols = static_cast<int>(state[kConvIt]);
       if (state[kDone] == 2.0) {
         *iters_host = it0 + cols;
-        *resid_host = resid;
+        *resid_host = state[kRes2];
         set_error("GMRES broke down (NaN) at iteration %d", it0 + cols);
         return FLOW_NOT_CONVERGED;
       }
       resid = state[kRes2];
+      if (state[kDone] == 4.0) {      // r0 itself passed: nothing was done
+        start_passes = true;
+        break;
+      }
       if (state[kDone] != 0.0) {
         converged = state[kDone] == 1.0;   // 3: verify with the true residual
         break;
       }
     }
-    it = it0 + cols;
+    if (start_passes) break;
+    // (a cycle that ends without a final column counts as one iteration: the
+    // loop makes progress towards maxit whatever the device reports)
+    it = it0 + (cols > 0 ? cols : 1);
     // x += sum_k y_k Z_k / nrm_k (coefficients left by the last step kernel
     // that ran); the flag is taken down first: it has done its work
     if ((rc = fill(1, 0.0, S + kDone, st))) return rc;

@@ -238,6 +238,7 @@ class MomentumJacobian(object):
             _hip.i32(bfmask, nc, 'bfmask'), _hip.f64(ui, n2, 'ui'), prm,
             _hip.f64(self._keep[3]), int(bc_dofs.numel()),
             _hip.i32(bc_dofs) if bc_dofs.numel() else None,
+            self._bc_mask(bc_dofs),
             )
         op = _hip.Operator()
         op.kind = 3
@@ -247,6 +248,22 @@ class MomentumJacobian(object):
 
     def operator(self):
         return self._op
+
+    def _bc_mask(self, bc_dofs):
+        '''Byte mask of the Dirichlet dofs (2n, component-blocked): with it the
+        gather of an application writes the identity rows itself.  Built once
+        per dof set (the caller hands in the same tensor while the conditions
+        are unchanged).'''
+        if not bc_dofs.numel():
+            return None
+        held = getattr(self, '_mask', None)
+        if held is None or held[0] is not bc_dofs:
+            mask = torch.zeros(self.size, dtype=torch.uint8,
+                               device=bc_dofs.device)
+            mask[bc_dofs.long()] = 1
+            device.synchronize()
+            self._mask = held = (bc_dofs, mask)
+        return _hip.u8(held[1], self.size, 'bc_mask')
 
     def rebind(self, bfmask, ui, prm, bc_dofs):
         '''Point the operator at another linearisation state (a time loop
@@ -260,6 +277,7 @@ class MomentumJacobian(object):
         s.prm = prm
         s.nbc = int(bc_dofs.numel())
         s.bc_dofs = _hip.i32(bc_dofs) if bc_dofs.numel() else None
+        s.bc_mask = self._bc_mask(bc_dofs)
         return self
 
     @classmethod

@@ -716,6 +716,9 @@ typedef struct {
   double* scratch;
   int nbc;
   const int* bc_dofs;        /* nbc Dirichlet dofs (component-blocked numbering) */
+  const unsigned char* bc_mask;   /* 2n bytes, 1 on those dofs, or NULL: with it
+                                     the gather writes the identity rows itself
+                                     (one launch less per application) */
 } flow_momentum_jvp;
 int flow_momentum_jvp_apply(const flow_momentum_jvp* J, const double* v,
                             double* out, void* stream);
