@@ -72,6 +72,9 @@ class MgS(ctypes.Structure):
         ('nc', ctypes.c_int), ('lda', ctypes.c_int),
         ('Ainv', ctypes.c_void_p),
         ('omega', ctypes.c_double),
+        ('C', Operator * MG_MAX_LEVELS),
+        ('up_rowblocks', ctypes.c_void_p * MG_MAX_LEVELS),
+        ('up_nblocks', ctypes.c_int * MG_MAX_LEVELS),
         ]
 
 
@@ -210,6 +213,8 @@ class MgShardS(ctypes.Structure):
     _fields_ = [
         ('mg', ctypes.POINTER(MgS)),
         ('Ah0', Operator), ('Ps0', Operator), ('Rg', Operator),
+        ('Cg', Operator),
+        ('up_rowblocks0', ctypes.c_void_p), ('up_nblocks0', ctypes.c_int),
         ]
 
 

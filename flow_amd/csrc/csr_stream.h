@@ -22,23 +22,20 @@ constexpr int kTile2 = 2 * kBlock * kPairs2;
 static_assert(FLOW_SPMV_ROWS_PER_BLOCK == kBlock, "one lane per row");
 static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTile2 - 2, "tile minus alignment slack");
 
-// One tile of the CSR stream -- the rows [r0, r1) of workgroup blockIdx.x: the
+// The rows [r0, r1) of one workgroup (<= kBlock rows, <= kTile - 2 nonzeros): the
 // products go through LDS (prod, kTile doubles), then lane i sums row r0 + i.
-// Returns that row's sum; r / r1 tell the caller whether the lane has a row.
-__device__ __forceinline__ double stream_tile_row_sum(
-    const int* __restrict__ rowptr, const int* __restrict__ cols,
-    const double* __restrict__ vals, const int* __restrict__ rowblocks,
-    const double* __restrict__ x, double* __restrict__ prod, int& r, int& r1) {
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int r0 = rowblocks[tile];
-  r1 = rowblocks[tile + 1];
+// Returns that row's sum (0 for a lane without a row).
+__device__ __forceinline__ double stream_rows_sum(
+    int r0, int r1, const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vals, const double* __restrict__ x,
+    double* __restrict__ prod) {
   const int k0 = rowptr[r0];
   const int k1 = rowptr[r1];
   // 16-byte value loads / 8-byte index loads: every lane owns PAIRS pairs of
   // consecutive nonzeros; the tile base is aligned down to an even index (value
   // planes start 16-B aligned and the host caps a block at kTile-2 nonzeros).
   const int ka = k0 & ~1;
-  r = r0 + threadIdx.x;
+  const int r = r0 + threadIdx.x;
   int a = 0, b = 0;
   if (r < r1) {
     a = rowptr[r] - ka;
@@ -90,6 +87,20 @@ __device__ __forceinline__ double stream_tile_row_sum(
   double s = 0.0;
   for (int k = a; k < b; ++k) s += prod[k];
   return s;
+}
+
+// One tile of the CSR stream -- the rows [r0, r1) of workgroup blockIdx.x (XCD-
+// aware tile mapping, common.h).  Returns the lane's row sum; r / r1 tell the
+// caller whether the lane has a row.
+__device__ __forceinline__ double stream_tile_row_sum(
+    const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vals, const int* __restrict__ rowblocks,
+    const double* __restrict__ x, double* __restrict__ prod, int& r, int& r1) {
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int r0 = rowblocks[tile];
+  r1 = rowblocks[tile + 1];
+  r = r0 + threadIdx.x;
+  return stream_rows_sum(r0, r1, rowptr, cols, vals, x, prod);
 }
 
 // The same tile with ONE value plane applied to both components of a

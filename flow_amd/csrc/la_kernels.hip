@@ -124,6 +124,48 @@ __global__ __launch_bounds__(kBlock) void mg_level_kernel(
   }
 }
 
+// The up-sweep of a multigrid level in ONE launch (flow_mg's two-launch form):
+//   y = Ps x' + w dinv (2 c - Ah c)
+// -- both products of the workgroup's rows, over row blocks that hold at most a
+// tile of nonzeros of Ps AND of Ah; DOTS as in mg_level_kernel.  y must not be c.
+template <bool DOTS>
+__global__ __launch_bounds__(kBlock) void mg_up2_kernel(
+    const int* __restrict__ rowblocks, const int* __restrict__ p_rowptr,
+    const int* __restrict__ p_cols, const double* __restrict__ p_vals,
+    const int* __restrict__ a_rowptr, const int* __restrict__ a_cols,
+    const double* __restrict__ a_vals, const double* __restrict__ xc,
+    const double* __restrict__ c, const double* __restrict__ dinv, double omega,
+    double* __restrict__ y, double* __restrict__ gpart,
+    double* __restrict__ rpart, const double* __restrict__ stop) {
+  __shared__ double prod_p[kTile];
+  __shared__ double prod_a[kTile];
+  if (stopped(stop)) return;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int r0 = rowblocks[tile];
+  const int r1 = rowblocks[tile + 1];
+  const int r = r0 + threadIdx.x;
+  const double sp = stream_rows_sum(r0, r1, p_rowptr, p_cols, p_vals, xc, prod_p);
+  const double sa = stream_rows_sum(r0, r1, a_rowptr, a_cols, a_vals, c, prod_a);
+  double g = 0.0, rr = 0.0;
+  if (r < r1) {
+    const double ci = c[r];
+    const double yi = sp + omega * dinv[r] * (2.0 * ci - sa);
+    y[r] = yi;
+    if (DOTS) {
+      g = ci * yi;
+      rr = yi * yi;
+    }
+  }
+  if (DOTS) {
+    g = block_sum(g);
+    rr = block_sum(rr);
+    if (threadIdx.x == 0) {
+      gpart[blockIdx.x] = g;
+      rpart[blockIdx.x] = rr;
+    }
+  }
+}
+
 // full 2x2 blocks over one scalar pattern (Newton Jacobian)
 template <bool DOT>
 __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
@@ -708,6 +750,12 @@ static int check_mg(const flow_mg* M, int n) {
     FLOW_REQUIRE(M->Ah[l].n == rows && M->Ps[l].n == rows, "mg level sizes");
     FLOW_REQUIRE(M->dinv[l] && M->t[l], "mg level vectors");
     FLOW_REQUIRE(l == 0 || (M->r[l] && M->x[l]), "mg level vectors");
+    if (M->C[0].rowptr) {     // the two-launch form: every level carries it
+      if ((rc = check_operator(&M->C[l]))) return rc;
+      FLOW_REQUIRE(M->C[l].kind == 0 && M->C[l].n == M->R[l].n &&
+                       M->up_rowblocks[l] && M->up_nblocks[l] > 0,
+                   "mg two-launch form: C and the common row blocks");
+    }
     rows = M->R[l].n;
   }
   const int last = M->nlevels - 1;
@@ -732,8 +780,14 @@ static int vcycle(const flow_mg* M, const double* r0, double* z0, hipStream_t st
   const int L = M->nlevels;
   int rc;
   double* const none = nullptr;
+  const bool fused = M->C[0].rowptr != nullptr;
   for (int l = l0; l + 1 < L; ++l) {
     const double* r = l == l0 ? r0 : M->r[l];
+    if (fused) {
+      // r_{l+1} = C r,  C = R (I - Ah)
+      if ((rc = apply(&M->C[l], r, M->r[l + 1], st, nullptr, stop))) return rc;
+      continue;
+    }
     const flow_operator* A = &M->Ah[l];
     // t = r - Ah r ; r_{l+1} = R t
     hipLaunchKernelGGL((mg_level_kernel<0, false>), dim3(A->nblocks), dim3(kBlock),
@@ -752,8 +806,26 @@ static int vcycle(const flow_mg* M, const double* r0, double* z0, hipStream_t st
     const double* r = l == l0 ? r0 : M->r[l];
     double* x = l == l0 ? z0 : M->x[l];
     const flow_operator* P = &M->Ps[l];
+    const bool with_dots = l == 0 && gpart;
+    if (fused) {
+      // x = Ps x_{l+1} + w D^-1 (2 r - Ah r)
+      const flow_operator* A = &M->Ah[l];
+      const dim3 grid(M->up_nblocks[l]);
+      if (with_dots)
+        hipLaunchKernelGGL(mg_up2_kernel<true>, grid, dim3(kBlock), 0, st,
+                           M->up_rowblocks[l], P->rowptr, P->cols, P->vals[0],
+                           A->rowptr, A->cols, A->vals[0], M->x[l + 1], r,
+                           M->dinv[l], M->omega, x, gpart, rpart, stop);
+      else
+        hipLaunchKernelGGL(mg_up2_kernel<false>, grid, dim3(kBlock), 0, st,
+                           M->up_rowblocks[l], P->rowptr, P->cols, P->vals[0],
+                           A->rowptr, A->cols, A->vals[0], M->x[l + 1], r,
+                           M->dinv[l], M->omega, x, none, none, stop);
+      if (with_dots) *nparts = M->up_nblocks[l];
+      continue;
+    }
     // x = Ps x_{l+1} + w D^-1 (r + t)
-    if (l == 0 && gpart) {
+    if (with_dots) {
       hipLaunchKernelGGL((mg_level_kernel<1, true>), dim3(P->nblocks),
                          dim3(kBlock), 0, st, P->rowptr, P->cols, P->vals[0],
                          P->rowblocks, M->x[l + 1], r, M->t[l], M->dinv[l],
@@ -867,12 +939,18 @@ int sum_partials_host(double* work, int nparts, double* host, hipStream_t st) {
 
 // Work of cg(): [reductions | r z w p s | z.w partials of the SpMV | rc zc |
 // r.z, z.z partials of the V-cycle's last kernel]
+// partials the V-cycle's last kernel leaves (r.z and z.z each)
+static inline int mg_parts(const flow_mg* M) {
+  if (!M || M->nlevels < 2) return 0;
+  return M->C[0].rowptr ? M->up_nblocks[0] : M->Ps[0].nblocks;
+}
+
 static inline size_t cg_work_len(const flow_operator* A, const flow_coarse* C,
                                  const flow_mg* M) {
   const size_t N = op_size(A);
   return FLOW_REDUCE_WORK + 5 * N + dot_parts(A) + 2 +
          (C ? 2 * static_cast<size_t>(C->lda) : 0) +
-         (M && M->nlevels > 1 ? 2 * static_cast<size_t>(M->Ps[0].nblocks) : 0);
+         2 * static_cast<size_t>(mg_parts(M));
 }
 
 // Chronopoulos-Gear CG.  Per iteration: update (x, r, p, s) -> preconditioner
@@ -898,7 +976,7 @@ static int cg(const flow_operator* A, const double* dinv,
   double* crc = dpart + nd + ((N + nd) & 1);
   double* czc = crc + (C ? C->lda : 0);
   double* mpart = czc + (C ? C->lda : 0);     // V-cycle partials (multigrid only)
-  const int nm = (M && M->nlevels > 1) ? M->Ps[0].nblocks : 0;
+  const int nm = mg_parts(M);
   const double* gpart = M ? mpart : partial;
   const double* rpart = M ? mpart + nm : partial + 2 * kRedBlocks;
   const int gv = grid_for(N);
@@ -2494,12 +2572,19 @@ __global__ __launch_bounds__(kScalarBlock) void shard_finish_pack_kernel(
 // thread 0 of block 0: Chronopoulos-Gear scalars + the stopping test from the
 // summed buf[0..3] (first: the target from buf[3] = |B b|^2), exactly as
 // cg_scalar_kernel; everybody: ghost rows of w <- the neighbours' slots
+// ncopy > 0: also copy_dst[0, ncopy) <- buf[copy_off, +ncopy) (the summed
+// coarse image C w of the two-collective multigrid CG)
 __global__ void shard_scalar_unpack_kernel(flow_rows R, int ncomp, int first,
                                            double rtol2, double atol2,
                                            const double* __restrict__ buf,
                                            double* __restrict__ S,
-                                           double* __restrict__ w, int stride) {
+                                           double* __restrict__ w, int stride,
+                                           int ncopy = 0, int copy_off = 0,
+                                           double* __restrict__ copy_dst = nullptr) {
   if (stopped(S + kDone)) return;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncopy;
+       t += gridDim.x * blockDim.x)
+    copy_dst[t] = load_scalar(buf + copy_off + t);
   const int per = R.recv_len[0] + R.recv_len[1];
   const double* halo = buf + 4;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncomp * per;
@@ -2578,34 +2663,48 @@ struct ShardCg {
   T* sh(T* v) const { return v - R->e0; }   // index by global row
 };
 
-// z (owned rows) = V-cycle(r), r ext-compact with current ghosts; two
-// collectives are NOT included: the caller makes z's ghosts current.  One
-// collective here: the partial coarse residuals.  gpart/rpart as vcycle().
-static int shard_vcycle(const ShardCg& c, const double* r, double* z,
-                        double* gpart, double* rpart, int* nparts,
-                        const double* stop) {
+// the coarse image of CG's recurrences (two-collective form):
+//   rc_s = rc_w + beta rc_s ;  rc_r -= alpha rc_s
+__global__ void shard_rc_update_kernel(int n1, const double* __restrict__ S,
+                                       const double* __restrict__ rc_w,
+                                       double* __restrict__ rc_s,
+                                       double* __restrict__ rc_r) {
+  if (stopped(S + kDone)) return;
+  const double alpha = load_scalar(S + kAlpha);
+  const double beta = load_scalar(S + kBeta);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1;
+       i += gridDim.x * blockDim.x) {
+    const double si = rc_w[i] + beta * rc_s[i];
+    rc_s[i] = si;
+    rc_r[i] -= alpha * si;
+  }
+}
+
+static inline bool shard_two_launch(const flow_mg_shard* G) {
+  return G && G->Cg.rowptr != nullptr && G->mg->C[0].rowptr != nullptr;
+}
+
+// the up-sweep of level 0 on the owned rows from the coarse solution M->x[1]
+static int shard_up0(const ShardCg& c, const double* r, double* z, double* gpart,
+                     double* rpart, int* nparts, const double* stop) {
   const flow_mg* M = c.G->mg;
   const flow_operator* A0 = &c.G->Ah0;
   const flow_operator* P0 = &c.G->Ps0;
-  const flow_operator* Rg = &c.G->Rg;
-  const int n1 = Rg->n;
   double* const none = nullptr;
-  int rc;
-  // t = r - Ah r on the owned rows
-  hipLaunchKernelGGL((mg_level_kernel<0, false>), dim3(A0->nblocks), dim3(kBlock),
-                     0, c.st, A0->rowptr, A0->cols, A0->vals[0], A0->rowblocks,
-                     c.sh(r), c.sh(r), none, none, M->omega, c.sh(c.t), none,
-                     none, stop);
-  // the rank's share of the coarse residual -> buf, summed over the ranks
-  if ((rc = apply(Rg, c.t + (c.R->r0 - c.R->e0), c.C->buf, c.st, nullptr, stop)))
-    return rc;
-  if ((rc = exchange(c.C, n1))) return rc;
-  // levels >= 1: replicated
-  if ((rc = vcycle(M, c.C->buf, M->x[1], c.st, nullptr, nullptr, nullptr, stop,
-                   1)))
-    return rc;
-  // z = Ps x_1 + w D^-1 (r + t) on the owned rows
-  if (gpart) {
+  if (shard_two_launch(c.G)) {
+    const dim3 grid(c.G->up_nblocks0);
+    if (gpart)
+      hipLaunchKernelGGL(mg_up2_kernel<true>, grid, dim3(kBlock), 0, c.st,
+                         c.G->up_rowblocks0, P0->rowptr, P0->cols, P0->vals[0],
+                         A0->rowptr, A0->cols, A0->vals[0], M->x[1], c.sh(r),
+                         M->dinv[0], M->omega, c.sh(z), gpart, rpart, stop);
+    else
+      hipLaunchKernelGGL(mg_up2_kernel<false>, grid, dim3(kBlock), 0, c.st,
+                         c.G->up_rowblocks0, P0->rowptr, P0->cols, P0->vals[0],
+                         A0->rowptr, A0->cols, A0->vals[0], M->x[1], c.sh(r),
+                         M->dinv[0], M->omega, c.sh(z), none, none, stop);
+    if (gpart) *nparts = c.G->up_nblocks0;
+  } else if (gpart) {
     hipLaunchKernelGGL((mg_level_kernel<1, true>), dim3(P0->nblocks), dim3(kBlock),
                        0, c.st, P0->rowptr, P0->cols, P0->vals[0], P0->rowblocks,
                        M->x[1], c.sh(r), c.sh(c.t), M->dinv[0], M->omega, c.sh(z),
@@ -2621,12 +2720,57 @@ static int shard_vcycle(const ShardCg& c, const double* r, double* z,
   return FLOW_OK;
 }
 
+// z (owned rows) = V-cycle(r), r ext-compact with current ghosts; two
+// collectives are NOT included: the caller makes z's ghosts current.  One
+// collective here: the partial coarse residuals.  gpart/rpart as vcycle().
+// rc_keep != nullptr (two-launch form): the summed coarse residual C r is also
+// left there (the start of the recurrences of the two-collective loop).
+static int shard_vcycle(const ShardCg& c, const double* r, double* z,
+                        double* gpart, double* rpart, int* nparts,
+                        const double* stop, double* rc_keep = nullptr) {
+  const flow_mg* M = c.G->mg;
+  const flow_operator* A0 = &c.G->Ah0;
+  const flow_operator* Rg = &c.G->Rg;
+  const int n1 = Rg->n;
+  double* const none = nullptr;
+  int rc;
+  if (shard_two_launch(c.G)) {
+    // the rank's share of C r: its owned COLUMNS, no ghost rows involved
+    if ((rc = apply(&c.G->Cg, r + (c.R->r0 - c.R->e0), c.C->buf, c.st, nullptr,
+                    stop)))
+      return rc;
+  } else {
+    // t = r - Ah r on the owned rows
+    hipLaunchKernelGGL((mg_level_kernel<0, false>), dim3(A0->nblocks),
+                       dim3(kBlock), 0, c.st, A0->rowptr, A0->cols, A0->vals[0],
+                       A0->rowblocks, c.sh(r), c.sh(r), none, none, M->omega,
+                       c.sh(c.t), none, none, stop);
+    // the rank's share of the coarse residual -> buf, summed over the ranks
+    if ((rc = apply(Rg, c.t + (c.R->r0 - c.R->e0), c.C->buf, c.st, nullptr, stop)))
+      return rc;
+  }
+  if ((rc = exchange(c.C, n1))) return rc;
+  if (rc_keep) {
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n1)), dim3(kBlock), 0, c.st, n1,
+                       1.0, c.C->buf, 0.0, rc_keep);
+    FLOW_CHECK_LAUNCH();
+  }
+  // levels >= 1: replicated
+  if ((rc = vcycle(M, c.C->buf, M->x[1], c.st, nullptr, nullptr, nullptr, stop,
+                   1)))
+    return rc;
+  return shard_up0(c, r, z, gpart, rpart, nparts, stop);
+}
+
 static size_t shard_cg_work_len(const flow_rows* R, const flow_operator* A,
                                 const flow_mg_shard* G) {
   const size_t ncomp = A->kind == 4 ? 2 : 1;
   const size_t L = ncomp * (R->e1 - R->e0);
-  return FLOW_REDUCE_WORK + (G ? 11 : 10) * L + A->nblocks + 2 +
-         (G ? 2 * static_cast<size_t>(G->Ps0.nblocks) : 0);
+  size_t parts = G ? G->Ps0.nblocks : 0;
+  if (G && G->Cg.rowptr && static_cast<size_t>(G->up_nblocks0) > parts)
+    parts = G->up_nblocks0;
+  return FLOW_REDUCE_WORK + (G ? 11 : 10) * L + A->nblocks + 2 + 2 * parts +
+         (G && G->Cg.rowptr ? 3 * static_cast<size_t>(G->Cg.n) + 2 : 0);
 }
 
 static int shard_cg(const flow_comm* C, const flow_rows* R,
@@ -2663,7 +2807,15 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
   c.dpart = tail;
   c.mpart = c.dpart + A->nblocks + ((L + A->nblocks) & 1);
   const int nd = A->nblocks;
-  const int nm = G ? G->Ps0.nblocks : 0;
+  const bool two = shard_two_launch(G);
+  int nm = G ? G->Ps0.nblocks : 0;
+  if (two && G->up_nblocks0 > nm) nm = G->up_nblocks0;
+  // two-collective multigrid CG: the coarse images of r, s, w (replicated)
+  const int n1 = two ? G->Cg.n : 0;
+  double* rc_r = c.mpart + 2 * nm + (nm & 1 ? 0 : 0);
+  rc_r += (reinterpret_cast<uintptr_t>(rc_r) & 15) ? 1 : 0;    // 16-byte aligned
+  double* rc_s = rc_r + n1;
+  double* rc_w = rc_s + n1;
   const int gl = grid_for(L);
   const int gu = grid_for(L, kBlock, kRedBlocks);
   const double rtol2 = rtol * rtol, atol2 = atol * atol;
@@ -2708,8 +2860,11 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
   if ((rc = halo(C, R, ncomp, c.sh(c.r), me, st))) return rc;
   // z = B r
   if (G) {
-    if ((rc = shard_vcycle(c, c.r, c.z, none, none, nullptr, nullptr))) return rc;
+    if ((rc = shard_vcycle(c, c.r, c.z, none, none, nullptr, nullptr,
+                           two ? rc_r : nullptr)))
+      return rc;
     if ((rc = halo(C, R, 1, c.sh(c.z), me, st))) return rc;
+    if (two && (rc = fill(n1, 0.0, rc_s, st))) return rc;
   } else {
     hipLaunchKernelGGL(vmul_kernel, dim3(gl), dim3(kBlock), 0, st, L, 1.0, c.dc,
                        c.r, c.z);
@@ -2720,7 +2875,17 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
                      c.r, c.z, c.z, c.z, c.partial, c.partial + 2 * kRedBlocks);
   const int gp = 1 + grid_for(ncomp * R->nhalo > 0 ? ncomp * R->nhalo : 1,
                               kScalarBlock, 64);
-  const int count = 4 + ncomp * R->nhalo;
+  // [3 sums, |B b|^2 | halo of w | (two-collective form) this rank's share of
+  // the coarse image C w]
+  const int coff = 4 + ncomp * R->nhalo;
+  const int count = coff + n1;
+  // C w: the rank's owned columns
+  auto coarse_image_of_w = [&](const double* flag) -> int {
+    return two ? apply(&G->Cg, c.w + (R->r0 - R->e0), C->buf + coff, st, nullptr,
+                       flag)
+               : FLOW_OK;
+  };
+  if ((rc = coarse_image_of_w(nullptr))) return rc;
   hipLaunchKernelGGL(shard_finish_pack_kernel, dim3(gp), dim3(kScalarBlock), 0, st,
                      *R, ncomp, gu, nd, c.partial, c.partial + 2 * kRedBlocks,
                      c.dpart, c.S + kB2, c.sh(c.w), me, C->buf,
@@ -2729,10 +2894,12 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
   if ((rc = exchange(C, count))) return rc;
 
   const int per = R->recv_len[0] + R->recv_len[1];
-  const int gs = grid_for(ncomp * per > 0 ? ncomp * per : 1);
-  // alpha, beta and the verdict on the start; ghost rows of w
+  int gs = grid_for(ncomp * per > 0 ? ncomp * per : 1);
+  if (two && grid_for(n1) > gs) gs = grid_for(n1);
+  // alpha, beta and the verdict on the start; ghost rows of w; rc_w
   hipLaunchKernelGGL(shard_scalar_unpack_kernel, dim3(gs), dim3(kBlock), 0, st, *R,
-                     ncomp, 1, rtol2, atol2, C->buf, c.S, c.sh(c.w), me);
+                     ncomp, 1, rtol2, atol2, C->buf, c.S, c.sh(c.w), me, n1, coff,
+                     rc_w);
   FLOW_CHECK_LAUNCH();
   double state[kNumSlots];
   int launched = 0;
@@ -2746,8 +2913,20 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
         hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gl), dim3(kBlock), 0, st,
                            L, c.S, c.dc, c.w, c.z, c.p, c.s, c.xc, c.r, 0,
                            c.partial, static_cast<const double*>(nullptr));
-        if ((rc = shard_vcycle(c, c.r, c.z, c.mpart, c.mpart + nm, &np, stop)))
+        if (two) {
+          // the coarse residual by recurrence (no collective), the levels
+          // >= 1 replicated, the up-sweep of level 0 on the owned rows
+          hipLaunchKernelGGL(shard_rc_update_kernel, dim3(grid_for(n1)),
+                             dim3(kBlock), 0, st, n1, c.S, rc_w, rc_s, rc_r);
+          if ((rc = vcycle(G->mg, rc_r, G->mg->x[1], st, nullptr, nullptr,
+                           nullptr, stop, 1)))
+            return rc;
+          if ((rc = shard_up0(c, c.r, c.z, c.mpart, c.mpart + nm, &np, stop)))
+            return rc;
+        } else if ((rc = shard_vcycle(c, c.r, c.z, c.mpart, c.mpart + nm, &np,
+                                      stop))) {
           return rc;
+        }
         if ((rc = halo(C, R, 1, c.sh(c.z), me, st))) return rc;
         gpart = c.mpart;
         rpart = c.mpart + nm;
@@ -2760,6 +2939,7 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
         rpart = c.partial + 2 * kRedBlocks;
       }
       if ((rc = apply(A, c.sh(c.z), c.sh(c.w), st, c.dpart, stop, me))) return rc;
+      if ((rc = coarse_image_of_w(stop))) return rc;
       hipLaunchKernelGGL(shard_finish_pack_kernel, dim3(gp), dim3(kScalarBlock), 0,
                          st, *R, ncomp, np, nd, gpart, rpart, c.dpart,
                          static_cast<const double*>(nullptr), c.sh(c.w), me,
@@ -2768,7 +2948,7 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
       if ((rc = exchange(C, count))) return rc;
       hipLaunchKernelGGL(shard_scalar_unpack_kernel, dim3(gs), dim3(kBlock), 0,
                          st, *R, ncomp, 0, rtol2, atol2, C->buf, c.S, c.sh(c.w),
-                         me);
+                         me, n1, coff, rc_w);
     }
     FLOW_CHECK_LAUNCH();
     launched += todo;
@@ -3114,6 +3294,14 @@ extern "C" int flow_shard_mgcg_solve(
                    mgs->Rg.n == mgs->mg->R[0].n,
                "sharded hierarchy operators");
   long long need = 4 + rows->nhalo;
+  if (mgs->Cg.rowptr) {
+    if ((rc = check_operator(&mgs->Cg))) return rc;
+    FLOW_REQUIRE(mgs->mg->C[0].rowptr && mgs->Cg.kind == 0 &&
+                     mgs->Cg.n == mgs->Rg.n && mgs->up_rowblocks0 &&
+                     mgs->up_nblocks0 > 0,
+                 "sharded hierarchy: two-launch form");
+    need += mgs->Cg.n;
+  }
   if (mgs->Rg.n > need) need = mgs->Rg.n;
   if ((rc = check_comm(comm, need))) return rc;
   FLOW_REQUIRE(work_len >= shard_cg_work_len(rows, A, mgs),

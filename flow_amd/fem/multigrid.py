@@ -88,7 +88,10 @@ class Multigrid(object):
     the coarsest level.'''
 
     def __init__(self, A, isbc=None, singular=False, s=3.0, coarsest=4200,
-                 omega=0.8, keep_host=False):
+                 omega=0.8, keep_host=False, two_launch=True):
+        '''two_launch: also form C = R (I - Ah) and the row blocks common to
+        Ps and Ah per level, so that the device cycle runs its two-launch
+        form (include/flow_hip.h, flow_mg).'''
         import scipy.sparse as sp
         assert A.kind == 0
         lay = A.layout
@@ -103,6 +106,7 @@ class Multigrid(object):
         self.host_levels = []     # keep_host: scipy (A, D, P) for the tests
         self.sizes = [n]
         self.R0_host = None
+        self.C0_host = None
         rng = numpy.random.RandomState(1)
         self.fine = A
         while Ah.shape[0] > coarsest and len(self.levels) < _hip.MG_MAX_LEVELS - 1:
@@ -129,12 +133,26 @@ class Multigrid(object):
             Ac = (R.dot(AP)).tocsr()
             Ahat = Ah.copy()
             Ahat.data = Ahat.data * (omega / D)[Ahat.indices]
+            Ps = (P - _scale_rows(AP, omega / D)).tocsr()
             self.levels.append(dict(
                 Ah=CsrOperator(Ahat),
                 dinv=device.to_device(1.0 / D),
-                Ps=CsrOperator(P - _scale_rows(AP, omega / D)), R=CsrOperator(R),
+                Ps=CsrOperator(Ps), R=CsrOperator(R),
                 t=device.zeros(m),
                 ))
+            if two_launch:
+                # C = R (I - Ah): restriction of the residual behind the
+                # pre-smoothing step in one product; and row blocks that hold
+                # a tile of Ps AND of Ah (the up-sweep does both products)
+                Cm = (R - R.dot(Ahat)).tocsr()
+                Cm.eliminate_zeros()
+                L = self.levels[-1]
+                L['C'] = CsrOperator(Cm)
+                Ps.sort_indices()
+                L['up_rb'] = device.to_device(csr_stream_rowblocks(
+                    [Ps.indptr, Ahat.indptr]))
+                if not self.levels[1:]:
+                    self.C0_host = Cm
             if keep_host:
                 self.host_levels.append((Ah, D, P))
             if not self.levels[1:]:
@@ -178,6 +196,11 @@ class Multigrid(object):
                            ctypes.sizeof(_hip.Operator))
             M.dinv[l] = _hip.f64(L['dinv'], self.sizes[l]).value
             M.t[l] = _hip.f64(L['t'], self.sizes[l]).value
+            if 'C' in L:
+                ctypes.memmove(ctypes.byref(M.C[l]), ctypes.byref(L['C'].op),
+                               ctypes.sizeof(_hip.Operator))
+                M.up_rowblocks[l] = _hip.i32(L['up_rb']).value
+                M.up_nblocks[l] = L['up_rb'].numel() - 1
         for l in range(1, self.nlevels):
             M.r[l] = _hip.f64(self._r[l], self.sizes[l]).value
             M.x[l] = _hip.f64(self._x[l], self.sizes[l]).value

@@ -538,7 +538,8 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     wk = work(_hip.REDUCE_WORK + nvec * n
               + (nparts if method == 'cg' else 0)
               + (2 * coarse.struct.lda if coarse else 0)
-              + (2 * mg.struct.Ps[0].nblocks if mg is not None else 0)
+              + (2 * max(mg.struct.Ps[0].nblocks, mg.struct.up_nblocks[0])
+                 if mg is not None else 0)
               + (n if ilu is not None and method == 'bicgstab' else 0)
               + (_hip.GMRES_PARTIALS + _hip.GMRES_STATE
                  if method == 'gmres' else 0))

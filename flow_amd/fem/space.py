@@ -165,22 +165,29 @@ def csr_stream_rowblocks(rowptr, rows_per_block=SPMV_ROWS_PER_BLOCK,
     '''Row-block boundaries for the CSR-stream SpMV: consecutive rows are
     grouped so that a block has at most `rows_per_block` rows and at most
     `nnz_per_block` nonzeros (the LDS tile of products; default: what the
-    library's scalar kernels take, flow_spmv_tile_nnz(0)).'''
+    library's scalar kernels take, flow_spmv_tile_nnz(0)).  `rowptr` may be a
+    LIST of row pointers over the same rows (kernels that do the products of
+    several matrices for the rows of a workgroup: flow_mg's up-sweep): every
+    one of them then stays below the cap.'''
     if nnz_per_block is None:
         from .. import _hip
         nnz_per_block = _hip.spmv_tile_nnz(0)
-    n = len(rowptr) - 1
-    rowptr = numpy.asarray(rowptr, dtype=numpy.int64)
-    if n > 0:
-        assert (rowptr[1:] - rowptr[:-1]).max() <= nnz_per_block, \
-            'row longer than the CSR-stream LDS tile'
+    rowptrs = rowptr if isinstance(rowptr, (list, tuple)) else [rowptr]
+    rowptrs = [numpy.asarray(rp, dtype=numpy.int64) for rp in rowptrs]
+    n = len(rowptrs[0]) - 1
+    for rp in rowptrs:
+        assert len(rp) == n + 1
+        if n > 0:
+            assert (rp[1:] - rp[:-1]).max() <= nnz_per_block, \
+                'row longer than the CSR-stream LDS tile'
     blocks = [0]
     r = 0
     while r < n:
-        r_nnz = int(numpy.searchsorted(
-            rowptr, rowptr[r] + nnz_per_block, side='right'
-            )) - 1
-        r_next = min(r + rows_per_block, r_nnz, n)
+        r_next = min(r + rows_per_block, n)
+        for rp in rowptrs:
+            r_nnz = int(numpy.searchsorted(
+                rp, rp[r] + nnz_per_block, side='right')) - 1
+            r_next = min(r_next, r_nnz)
         assert r_next > r
         blocks.append(r_next)
         r = r_next

@@ -99,18 +99,29 @@ def comm():
 
 
 def describe(world, nrows=None):
-    '''One line for bench.py's `config.parallelism`.'''
+    '''One line for bench.py's `config.parallelism`: names the solvers the
+    strips are actually bound to (the Newton preconditioner is whatever the
+    last step ran with: navier_stokes.last_step_info).'''
     if active():
-        return ('x-strips x%d: every sub-step sharded (block-Jacobi ILU(0) '
-                'GMRES, row-sharded V-cycle CG, Jacobi-CG mass solves); '
-                'collectives: %s' % (
-                    world, 'ncclAllReduce issued by the library on its stream'
+        from .navier_stokes import pressure_correction as pc
+        pre = pc.last_step_info.get('newton_preconditioner')
+        if pre is None:
+            pre = '%s (block Jacobi)' % pc.solver_parameters['newton'].get(
+                'preconditioner', 'ilu0')
+        return ('x-strips x%d: every sub-step sharded (GMRES + %s, row-sharded '
+                'V-cycle CG, %s mass solves); collectives: %s' % (
+                    world, pre, MASS_SOLVER_ON_STRIPS,
+                    'ncclAllReduce issued by the library on its stream'
                     if comm().direct is not None else
                     'torch.distributed.all_reduce (%s)' % (
                         'gloo, host-staged' if comm().staged else 'RCCL')))
     if world == 1:
         return 'single GPU'
     return 'replicated x%d' % world
+
+
+# what parallel.cg-based mass solves are (bench.py's parallelism line)
+MASS_SOLVER_ON_STRIPS = 'Jacobi-CG'
 
 
 # -- communicator ---------------------------------------------------------------
@@ -605,6 +616,23 @@ class MgShard(object):
         s.Ah0 = owned_operator(lvl['Ah'].op, self._blocks(lvl['Ah'], v))
         s.Ps0 = owned_operator(lvl['Ps'].op, self._blocks(lvl['Ps'], v))
         s.Rg = self.Rg.op
+        self.Cg = None
+        if mg.C0_host is not None:
+            # the two-collective form: C = R (I - Ah) cut to the owned COLUMNS
+            # (no ghost rows needed for the rank's share of C r), and row
+            # blocks of the owned rows that hold a tile of Ps AND of Ah
+            Cg = mg.C0_host[:, v.r0:v.r1].tocsr()
+            assert Cg.nnz > 0
+            self.Cg = CsrOperator(Cg)
+            s.Cg = self.Cg.op
+            rps = [device.to_host(lvl[k]._rowptr).numpy().astype(numpy.int64)
+                   for k in ('Ps', 'Ah')]
+            rb = csr_stream_rowblocks(
+                [rp[v.r0:v.r1 + 1] - rp[v.r0] for rp in rps]) + v.r0
+            t = device.to_device(rb.astype(numpy.int32))
+            self._keep.append(t)
+            s.up_rowblocks0 = _hip.i32(t).value
+            s.up_nblocks0 = t.numel() - 1
         self.struct = s
 
     def _blocks(self, op, v):
@@ -626,11 +654,14 @@ def mgcg(A, dinv, mg, b, x, rtol, atol=0.0, maxit=1000, check_every=2,
     if key not in mg.__dict__:
         mg.__dict__[key] = MgShard(mg, v)
     ms = mg.__dict__[key]
-    c.ensure(max(4 + v.rows.nhalo, ms.struct.Rg.n))
+    n1 = ms.struct.Rg.n
+    two = ms.Cg is not None
+    c.ensure(max(4 + v.rows.nhalo + (n1 if two else 0), n1))
     op = v.operator(A)
     n = A.size
     wlen = _hip.REDUCE_WORK + 11 * (v.e1 - v.e0) + op.nblocks \
-        + 2 * ms.struct.Ps0.nblocks + 2
+        + 2 * max(ms.struct.Ps0.nblocks, ms.struct.up_nblocks0) + 2 \
+        + (3 * n1 + 2 if two else 0)
     wk = ops.work(wlen)
     history = A.__dict__.setdefault('_solve_history', {}) if tag else None
     first = history[tag] + 1 if history is not None and tag in history else 0

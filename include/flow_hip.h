@@ -178,8 +178,14 @@ typedef struct {
  * regrouped so that a level costs three launches and ONE product with A:
  *   t = r - Ah r ; r' = R t ; [coarse] ; x = Ps x' + w D^-1 (r + t)
  * with Ah = A w D^-1 (columns scaled; shares A's pattern arrays) and
- * Ps = (I - w D^-1 A) P, both formed at setup.
- * All operators are kind-0 flow_operators (Ps and R rectangular: `n` = rows).
+ * Ps = (I - w D^-1 A) P, both formed at setup -- or, when the hierarchy also
+ * carries C = R (I - Ah) (formed at setup like the Galerkin products) and row
+ * blocks common to Ps and Ah, TWO launches:
+ *   r' = C r ; [coarse] ; x = Ps x' + w D^-1 (2 r - Ah r)
+ * (the second kernel does both products of its rows): no intermediate vector,
+ * one launch less per level -- what the small levels' cost consists of --, and
+ * on the strips of K15 the restriction needs no ghost rows of r at all.
+ * All operators are kind-0 flow_operators (Ps, R, C rectangular: `n` = rows).
  * Levels 0 .. nlevels-1; the last one is solved with the dense inverse. */
 #define FLOW_MG_MAX_LEVELS 8
 typedef struct {
@@ -194,6 +200,12 @@ typedef struct {
   int nc, lda;                            /* coarsest level: size, row stride */
   const float* Ainv;                      /* nc rows of lda floats, as flow_coarse */
   double omega;                           /* Jacobi damping w (0.8) */
+  /* the two-launch form: used for ALL levels when C[0].rowptr != NULL */
+  flow_operator C[FLOW_MG_MAX_LEVELS];    /* n_{l+1} x n_l: R[l] (I - Ah[l]) */
+  const int* up_rowblocks[FLOW_MG_MAX_LEVELS];  /* row blocks of level l that hold
+                                             <= flow_spmv_tile_nnz(0) nonzeros of
+                                             Ps[l] AND of Ah[l] */
+  int up_nblocks[FLOW_MG_MAX_LEVELS];
 } flow_mg;
 /* z = D^-1 r + P Ac^-1 P^T r: one application of the two-level preconditioner
  * (for callers that drive their own Krylov loop: the preconditioned MINRES of
@@ -580,11 +592,23 @@ int flow_shard_cg_solve(const flow_comm* comm, const flow_rows* rows,
  * of the fine residual, the partial coarse residuals are summed by the
  * collective, and the levels below (a tenth of the rows, latency-bound on one
  * GPU already) run replicated on every rank.  Three collectives per iteration:
- * [dots + halo of w], [coarse residual], [halo of z].
- * work: FLOW_REDUCE_WORK + 11 * (e1 - e0) + A->nblocks + 2 * Ps0.nblocks + 2. */
+ * [dots + halo of w], [coarse residual], [halo of z] -- or, when the hierarchy
+ * carries the two-launch form (mg->C) and Cg / up_rowblocks0 are given, TWO:
+ * the coarse residual rc = C r is then carried by the recurrences of CG itself,
+ *     rc_s = rc_w + beta rc_s ;  rc_r -= alpha rc_s ,   rc_w = C w = sum over
+ *     the ranks of Cg w_owned,
+ * whose only collective part, rc_w, rides with the dots and the halo of w (C is
+ * restricted by COLUMNS: a rank needs no ghost rows for its share).
+ * work: FLOW_REDUCE_WORK + 11 * (e1 - e0) + A->nblocks +
+ * 2 * max(Ps0.nblocks, up_nblocks0) + 2 [+ 3 * Cg.n]. */
 typedef struct {
   const flow_mg* mg;
   flow_operator Ah0, Ps0, Rg;
+  flow_operator Cg;             /* mg->C[0] restricted to the owned columns
+                                   (column index minus r0); rowptr NULL: the
+                                   three-collective form */
+  const int* up_rowblocks0;     /* mg->up_rowblocks[0] for the owned rows */
+  int up_nblocks0;
 } flow_mg_shard;
 int flow_shard_mgcg_solve(const flow_comm* comm, const flow_rows* rows,
                           const flow_operator* A, const double* dinv,

@@ -144,7 +144,9 @@ def _worker(rank, world, port, out):
                           device.to_host(x2).numpy()))
 
         yp = device.zeros(play.N)
+        calls0 = parallel.comm().calls
         sp = parallel.mgcg(Kbc, kdinv, mg, bp, yp, 1e-11, maxit=500)
+        res['mgcg_calls'] = (parallel.comm().calls - calls0, sp.iterations)
         res['mgcg'] = (sp.iterations, refp.iterations,
                        _rel(device.to_host(parallel.gather_field(
                            yp.clone(), play)).numpy(),
@@ -213,6 +215,14 @@ def test_strip_sharded_solvers_and_step(hip, world):
             assert abs(its - its_ref) <= slack, (key, its, its_ref)
             assert err < 1e-9, (key, err)
         assert res['cg1_ghosts']
+        # collectives of the sharded V-cycle CG: TWO per iteration -- [dots +
+        # halo of w + the coarse image C w] and [halo of z]; the coarse
+        # residual itself is carried by CG's recurrences -- plus the start
+        # (|B b|: halo + coarse residual; r0: 2 halos; z0: coarse residual +
+        # halo; the first [dots + ...]); iterations enqueued behind the
+        # accepted iterate (check_every = 2) still issue theirs
+        calls, its = res['mgcg_calls']
+        assert calls <= 2 * (its + 2) + 7, (calls, its)
         st = res['step']
         assert 'x-strips x%d' % world in st['method']
         assert st['ghosts_u'] and st['ghosts_p']
