@@ -290,8 +290,8 @@ SYMBOLS = {
                               _P(MgShardS), _VP, _VP, _D, _D, _I, _I, _I, _VP,
                               ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_shard_gmres_solve': [_P(CommS), _P(RowsS), _P(Operator), _P(IluS),
-                               _P(PmgS), _VP, _VP, _D, _D, _I, _I, _I, _I, _VP,
-                               ctypes.c_size_t, _P(_I), _P(_D), _VP],
+                               _P(PmgS), _VP, _VP, _D, _D, _I, _I, _I, _I, _I,
+                               _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_assemble_scalar_matrix': [_I, _P(MeshS), _P(SpaceS), _VP, _VP, _VP],
     'flow_assemble_pressure_rhs': [_P(MeshS), _P(SpaceS), _P(SpaceS), _VP, _VP,
                                    _D, _D, _I, _VP, _VP, _VP],

@@ -166,11 +166,9 @@ class CoupledStep(object):
             fem.Constant(self.dt), {0: self.u0}, self.p0, pb.no_slip, [],
             pb.rho_room, fem.Constant(pb.mu), f={0: buoyancy, 1: buoyancy},
             verbose=False, tol=self.flow_tol)
-        if parallel.active():
-            # the step ran on the ranks' strips; the heat operator is assembled
-            # replicated and needs whole fields
-            parallel.gather_field(u.data, pb.W.layout, 2)
-            parallel.gather_field(p.data, pb.P.layout)
+        # (on the strips of flow_amd.parallel the fields stay valid on the
+        # rank's owned + ghost rows: the heat operator is assembled and solved
+        # on the strips too)
         return u, p
 
     def sweep(self):
@@ -181,10 +179,18 @@ class CoupledStep(object):
         u, p = self.flow()
         du = self._copy(u)
         fem.ops.axpby(-1.0, self.u.data, 1.0, du.data)
-        u_dist = fem.project_magnitude(du, mode=1).vector().norm('linf')
+        umag = fem.project_magnitude(du, mode=1)
         dth = self._copy(theta)
         fem.ops.axpby(-1.0, self.theta.data, 1.0, dth.data)
-        theta_dist = dth.vector().norm('linf')
+        if parallel.active():
+            # (maxima over the owned rows of all ranks: the same numbers, and
+            # with them the same decisions, everywhere)
+            u_dist = parallel.norm_linf(umag.data,
+                                        umag.function_space().layout)
+            theta_dist = parallel.norm_linf(dth.data, self.pb.Q.layout)
+        else:
+            u_dist = umag.vector().norm('linf')
+            theta_dist = dth.vector().norm('linf')
         self.u, self.p, self.theta = u, p, theta
         return u_dist, theta_dist
 

@@ -798,7 +798,8 @@ __device__ __forceinline__ double supg_tau(const double px[3], const double py[3
 
 template <int DEGQ, int DEGW, bool SUPG>
 __global__ __launch_bounds__(kBlock) void heat_kernel(
-    int nc, const double* __restrict__ xy, const int* __restrict__ cdw, int nw,
+    int nc, int cb, int ce, const double* __restrict__ xy,
+    const int* __restrict__ cdw, int nw,
     const double* __restrict__ conv, double kappa, double rho_cp,
     double* __restrict__ scratch, double* __restrict__ tau_out,
     int* __restrict__ status) {
@@ -807,8 +808,8 @@ __global__ __launch_bounds__(kBlock) void heat_kernel(
   // plain operator: conv(2) grad u(1) v(2) = degree 5 -> 7-point rule;
   // SUPG terms reach degree 7 -> 16-point rule (FFC picks the exact degree)
   constexpr int NQ = SUPG ? 16 : 7;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nc) return;
+  const int c = cb + blockIdx.x * blockDim.x + threadIdx.x;   // [cb, ce): the
+  if (c >= ce) return;                                        // rank's cells
   const Geom g = load_geom(xy, nc, c);
   double Cv[2][NW];
   load_local<NW>(conv, nw, cdw, nc, c, 2, Cv);
@@ -900,13 +901,14 @@ __global__ __launch_bounds__(kBlock) void heat_kernel(
 // the local dof order); degree k + 1 + 2 + 1 <= 6: the 16-point rule is exact.
 template <int DEGQ, int DEGW>
 __global__ __launch_bounds__(kBlock) void heat_supg_source_kernel(
-    int nc, const double* __restrict__ xy, const int* __restrict__ cdw, int nw,
+    int nc, int cb, int ce, const double* __restrict__ xy,
+    const int* __restrict__ cdw, int nw,
     const double* __restrict__ conv, double kappa, double rho_cp, flow_coef f,
     double* __restrict__ scratch, int* __restrict__ status) {
   constexpr int NL = Elem<DEGQ>::NL;
   constexpr int NW = Elem<DEGW>::NL;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nc) return;
+  const int c = cb + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ce) return;
   const Geom g = load_geom(xy, nc, c);
   double Cv[2][NW];
   load_local<NW>(conv, nw, cdw, nc, c, 2, Cv);
@@ -1356,17 +1358,21 @@ extern "C" int flow_assemble_heat(const flow_mesh* mesh, const flow_space* Q,
   FLOW_REQUIRE(!supg || Msupg_vals, "Msupg_vals required with supg");
   FLOW_REQUIRE(kappa > 0.0 && rho_cp > 0.0, "coefficients");
   hipStream_t st = as_stream(stream);
-  const dim3 grid = cell_grid(mesh->nc);
+  // K15: the rank's cells (mesh->c0 / c1) and the nonzeros of its rows
+  // (Q->nnz0 / nnz1), everything by default
+  const CellRange cr(mesh);
+  const dim3 grid = cell_grid(cr.count());
 #define FLOW_HEAT(DQ, DW)                                                      \
   do {                                                                         \
     if (supg)                                                                  \
       hipLaunchKernelGGL((heat_kernel<DQ, DW, true>), grid, dim3(kBlock), 0, st, \
-                         mesh->nc, mesh->xy, W->cell_dofs, W->n, conv, kappa,  \
-                         rho_cp, scratch, tau_out, status_dev);                \
+                         mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n, \
+                         conv, kappa, rho_cp, scratch, tau_out, status_dev);   \
     else                                                                       \
       hipLaunchKernelGGL((heat_kernel<DQ, DW, false>), grid, dim3(kBlock), 0,  \
-                         st, mesh->nc, mesh->xy, W->cell_dofs, W->n, conv,     \
-                         kappa, rho_cp, scratch, tau_out, status_dev);         \
+                         st, mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs,   \
+                         W->n, conv, kappa, rho_cp, scratch, tau_out,          \
+                         status_dev);                                          \
   } while (0)
   if (Q->deg == 1 && W->deg == 1) FLOW_HEAT(1, 1);
   else if (Q->deg == 1 && W->deg == 2) FLOW_HEAT(1, 2);
@@ -1376,9 +1382,18 @@ extern "C" int flow_assemble_heat(const flow_mesh* mesh, const flow_space* Q,
   FLOW_CHECK_LAUNCH();
   const int nl = Q->deg == 1 ? 3 : 6;
   const size_t plane = static_cast<size_t>(nl) * nl * mesh->nc;
-  if ((rc = gather(Q->nnz, 1, Q->cptr, Q->csrc, scratch, 0, Avals, st))) return rc;
+  int k0 = 0, k1 = 0;          // (0, 0): every nonzero
+  if (Q->r1 > 0) {
+    FLOW_REQUIRE(Q->nnz0 >= 0 && Q->nnz0 < Q->nnz1 && Q->nnz1 <= Q->nnz,
+                 "space nonzero range");
+    k0 = Q->nnz0;
+    k1 = Q->nnz1;
+  }
+  if ((rc = gather(Q->nnz, 1, Q->cptr, Q->csrc, scratch, 0, Avals, st, 0, k0, k1)))
+    return rc;
   if (supg)
-    return gather(Q->nnz, 1, Q->cptr, Q->csrc, scratch + plane, 0, Msupg_vals, st);
+    return gather(Q->nnz, 1, Q->cptr, Q->csrc, scratch + plane, 0, Msupg_vals, st,
+                  0, k0, k1);
   return FLOW_OK;
 }
 
@@ -1398,16 +1413,17 @@ extern "C" int flow_assemble_heat_supg_source(
                "pointers");
   FLOW_REQUIRE(kappa > 0.0 && rho_cp > 0.0, "coefficients");
   hipStream_t st = as_stream(stream);
-  const dim3 grid = cell_grid(mesh->nc);
+  const CellRange cr(mesh);
+  const dim3 grid = cell_grid(cr.count());
 #define FLOW_HEAT(DQ, DW)                                                        \
   hipLaunchKernelGGL((heat_supg_source_kernel<DQ, DW>), grid, dim3(kBlock), 0,   \
-                     st, mesh->nc, mesh->xy, W->cell_dofs, W->n, conv, kappa,    \
-                     rho_cp, *source, scratch, status_dev)
+                     st, mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n,   \
+                     conv, kappa, rho_cp, *source, scratch, status_dev)
   if (Q->deg == 1 && W->deg == 1) FLOW_HEAT(1, 1);
   else if (Q->deg == 1 && W->deg == 2) FLOW_HEAT(1, 2);
   else if (Q->deg == 2 && W->deg == 1) FLOW_HEAT(2, 1);
   else FLOW_HEAT(2, 2);
 #undef FLOW_HEAT
   FLOW_CHECK_LAUNCH();
-  return gather(Q->n, 1, Q->vptr, Q->vsrc, scratch, 0, b, st);
+  return gather(Q->n, 1, Q->vptr, Q->vsrc, scratch, 0, b, st, 0, Q->r0, Q->r1);
 }

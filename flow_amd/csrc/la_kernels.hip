@@ -2991,18 +2991,21 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
                        const flow_pmg* pmg,
                        const double* b, double* x, double rtol, double atol,
                        int maxit, int m, int x_is_zero, int expected,
-                       double* work, int* iters_host, double* resid_host,
-                       hipStream_t st) {
+                       int verify, double* work, int* iters_host,
+                       double* resid_host, hipStream_t st) {
   const int mo = R->r1 - R->r0;         // owned rows
   const int me = R->e1 - R->e0;
   const int n = R->n;
-  const int N = 2 * mo;
+  // two components (the Newton systems: kind 3) or one (a scalar operator of
+  // kind 0 on the rank's rows: the heat system)
+  const int ncomp = A->kind == 0 ? 1 : 2;
+  const int N = ncomp * mo;
   double* V = work + FLOW_REDUCE_WORK;
   double* Z = V + static_cast<size_t>(m + 1) * N;
   double* iwork = Z + static_cast<size_t>(m) * N;
   double* xc = iwork + N;
   double* bc = xc + N;
-  double* stage = bc + N;                    // 2 * me, ext-compact
+  double* stage = bc + N;                    // ncomp * me, ext-compact
   double* P = stage + 2 * static_cast<size_t>(me);
   double* Pww = P + kGmresMax * kRedBlocks;
   double* Pnn = Pww + kRedBlocks;
@@ -3018,8 +3021,8 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
   // same sequence)
   auto apply_owned = [&](const double* v, double* w, const double* flag) -> int {
     int r;
-    if ((r = copy2d(2, mo, v, mo, stage + (R->r0 - R->e0), me, st))) return r;
-    if ((r = halo(C, R, 2, stage - R->e0, me, st))) return r;
+    if ((r = copy2d(ncomp, mo, v, mo, stage + (R->r0 - R->e0), me, st))) return r;
+    if ((r = halo(C, R, ncomp, stage - R->e0, me, st))) return r;
     return apply(A, stage - R->e0, w - R->r0, st, nullptr, flag, me, mo);
   };
   // sums of nv partial lists (list k at base + k*kRedBlocks) -> all ranks'
@@ -3034,10 +3037,10 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
     return read_values(C->buf, nv, host, st);
   };
 
-  if ((rc = copy2d(2, mo, b + R->r0, n, bc, mo, st))) return rc;
+  if ((rc = copy2d(ncomp, mo, b + R->r0, n, bc, mo, st))) return rc;
   if (x_is_zero) {
     if ((rc = fill(N, 0.0, xc, st))) return rc;
-  } else if ((rc = copy2d(2, mo, x + R->r0, n, xc, mo, st))) {
+  } else if ((rc = copy2d(ncomp, mo, x + R->r0, n, xc, mo, st))) {
     return rc;
   }
   if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
@@ -3083,6 +3086,7 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
   double target = 0.0, resid = 0.0;
   int it = 0;
   bool have_target = false;
+  bool claimed = false;     // the last cycle stopped on the residual estimate
   while (true) {
     // r0 = b - A x -> V_0
     if (x_is_zero && it == 0) {
@@ -3116,7 +3120,10 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
       set_error("sharded GMRES broke down (NaN residual) at iteration %d", it);
       return FLOW_NOT_CONVERGED;
     }
-    if (beta <= target) break;
+    // (behind a cycle that stopped on the estimate: the verification with the
+    // true residual, as gmres() -- every rank sees the same sums)
+    if (beta <= target || (claimed && beta <= 10.0 * target)) break;
+    claimed = false;
     if (it >= maxit) {
       *iters_host = it;
       *resid_host = beta;
@@ -3161,10 +3168,11 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
                                 nullptr, true, nullptr, st)))
       return rc;
     x_is_zero = 0;
-    if (converged) break;
+    if (converged && !verify) break;
+    claimed = converged;
   }
   // the owned rows of x
-  if ((rc = copy2d(2, mo, xc, mo, x + R->r0, n, st))) return rc;
+  if ((rc = copy2d(ncomp, mo, xc, mo, x + R->r0, n, st))) return rc;
   *iters_host = it;
   *resid_host = resid;
   return FLOW_OK;
@@ -3314,32 +3322,40 @@ extern "C" int flow_shard_gmres_solve(
     const flow_comm* comm, const flow_rows* rows, const flow_operator* A,
     const flow_ilu* ilu, const flow_pmg* pmg, const double* b, double* x,
     double rtol, double atol, int maxit, int restart, int x_is_zero,
-    int expected_its, double* work, size_t work_len, int* iters_host,
-    double* resid_host, void* stream) {
+    int expected_its, int verify, double* work, size_t work_len,
+    int* iters_host, double* resid_host, void* stream) {
   int rc = check_shard_solver(comm, rows, A, b, x, rtol, atol, maxit, work,
                               iters_host, resid_host);
   if (rc) return rc;
-  FLOW_REQUIRE(A->kind == 3, "sharded GMRES: the matrix-free Jacobian action");
+  FLOW_REQUIRE(A->kind == 3 || A->kind == 0,
+               "sharded GMRES: the matrix-free Jacobian action (kind 3) or a "
+               "scalar operator on the rank's rows (kind 0)");
   FLOW_REQUIRE(expected_its >= 0, "expected iterations");
   FLOW_REQUIRE(restart >= 1 && restart <= FLOW_GMRES_MAX_RESTART,
                "GMRES restart length");
-  const flow_momentum_jvp* J = static_cast<const flow_momentum_jvp*>(A->matfree);
-  FLOW_REQUIRE(J->W->r0 == rows->r0 && J->W->r1 == rows->r1,
-               "the operator's row range must be the rank's owned rows");
+  const int ncomp = A->kind == 0 ? 1 : 2;
+  if (A->kind == 3) {
+    const flow_momentum_jvp* J =
+        static_cast<const flow_momentum_jvp*>(A->matfree);
+    FLOW_REQUIRE(J->W->r0 == rows->r0 && J->W->r1 == rows->r1,
+                 "the operator's row range must be the rank's owned rows");
+  }
   const int mo = rows->r1 - rows->r0, me = rows->e1 - rows->e0;
   FLOW_REQUIRE((ilu != nullptr) != (pmg != nullptr),
                "sharded GMRES needs ONE block-Jacobi preconditioner: ilu or pmg");
-  if (ilu && (rc = ilu_check(ilu, 2 * mo))) return rc;
+  FLOW_REQUIRE(pmg == nullptr || ncomp == 2,
+               "the p-multigrid cycle is a two-component preconditioner");
+  if (ilu && (rc = ilu_check(ilu, ncomp * mo))) return rc;
   if (pmg && (rc = pmg_check(pmg, 2 * mo))) return rc;
-  long long need = 2LL * rows->nhalo;
+  long long need = static_cast<long long>(ncomp) * rows->nhalo;
   if (need < FLOW_GMRES_MAX_RESTART + 2) need = FLOW_GMRES_MAX_RESTART + 2;
   if ((rc = check_comm(comm, need))) return rc;
   FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK +
-                               (2 * static_cast<size_t>(restart) + 4) * 2 * mo +
+                               (2 * static_cast<size_t>(restart) + 4) * ncomp * mo +
                                2 * static_cast<size_t>(me) + FLOW_GMRES_PARTIALS +
                                FLOW_GMRES_STATE,
                "sharded GMRES workspace too small");
   return shard_gmres(comm, rows, A, ilu, pmg, b, x, rtol, atol, maxit, restart,
-                     x_is_zero, expected_its, work, iters_host, resid_host,
-                     as_stream(stream));
+                     x_is_zero, expected_its, verify, work, iters_host,
+                     resid_host, as_stream(stream));
 }

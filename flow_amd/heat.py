@@ -18,6 +18,11 @@ All operators are assembled by the HIP kernels of libflow_hip.so (K13/K14):
   b  rhs(f) = -int source v (UFL's rhs() negates; reference :88).
 The reference solves with sparse LU (:117-121); here BiCGStab + ILU(0) on the
 row-equilibrated system (GMRES(30) first, BiCGStab as the second try).
+
+On the strips of flow_amd.parallel (several GPUs) every rank assembles A over
+ITS cells for ITS rows, evaluates on its rows, and the solve is the sharded
+GMRES with the rank's own ILU(0) of its diagonal block (flow_shard_gmres_solve
+with a scalar operator); fields come in and go out valid on owned + ghost rows.
 '''
 import ctypes
 
@@ -30,6 +35,7 @@ from .fem.function import (
     )
 from . import _hip
 from . import device
+from . import parallel
 from . import stabilization
 
 solver_parameters = {'rtol': 1.0e-13, 'maxit': 2000, 'check_every': 10,
@@ -78,10 +84,14 @@ class Heat(object):
         W = conv.function_space()
         assert W.dim == 2 and W.mesh() is mesh
         buf = ops.scratch(mesh, 2 * lay.nloc**2 * nc)
+        # (on the strips: the rank's cells, the nonzeros of its rows)
+        strips = parallel.active()
+        mesh_s = parallel.mesh_view(mesh) if strips else ops.mesh_struct(mesh)
+        q_s = parallel.view(lay).space if strips else ops.space_struct(lay)
+        w_s = parallel.view(W.layout).space if strips \
+            else ops.space_struct(W.layout)
         _hip.check(lib.flow_assemble_heat(
-            ctypes.byref(ops.mesh_struct(mesh)),
-            ctypes.byref(ops.space_struct(lay)),
-            ctypes.byref(ops.space_struct(W.layout)),
+            ctypes.byref(mesh_s), ctypes.byref(q_s), ctypes.byref(w_s),
             _hip.f64(conv.data, W.size()), kappa, rho_cp,
             int(bool(supg_stabilization)), _hip.f64(buf),
             _hip.f64(self.A.vals), _hip.f64(msupg), None, _hip.i32(status),
@@ -111,11 +121,9 @@ class Heat(object):
                 assert coef.nl in (1, 3, 6), \
                     'SUPG source: Constant or Expression of degree <= 2'
                 cs, keep = ops.coef_struct(coef, mesh, lay.degree)
-                bs = device.empty(V.N)
+                bs = device.zeros(V.N)
                 _hip.check(lib.flow_assemble_heat_supg_source(
-                    ctypes.byref(ops.mesh_struct(mesh)),
-                    ctypes.byref(ops.space_struct(lay)),
-                    ctypes.byref(ops.space_struct(W.layout)),
+                    ctypes.byref(mesh_s), ctypes.byref(q_s), ctypes.byref(w_s),
                     _hip.f64(conv.data, W.size()), kappa, rho_cp,
                     ctypes.byref(cs), _hip.f64(buf), _hip.f64(bs),
                     _hip.i32(status), _hip.stream()
@@ -131,6 +139,18 @@ class Heat(object):
         alpha = float(alpha)
         beta = float(beta)
         n = self.V.N
+        if parallel.active():
+            # the rank's rows (u valid on owned + ghost rows; zeros elsewhere)
+            out = device.zeros(n)
+            tmp = device.zeros(n)
+            v = parallel.view(self.V.layout)
+            for mat, dst in ((self.M, out), (self.A, tmp)):
+                _hip.check(_hip.lib().flow_operator_apply(
+                    ctypes.byref(v.operator(mat)), _hip.f64(uvec, n, 'u'),
+                    _hip.f64(dst, n), _hip.stream()))
+            ops.axpby(1.0, self.b.data, 1.0, tmp)
+            ops.axpby(beta, tmp, alpha, out)
+            return Vector(out)
         out = device.empty(n)
         tmp = device.empty(n)
         self.M.apply(uvec, out)                 # M u
@@ -174,6 +194,9 @@ class Heat(object):
         # residual is a relative error to within the conditioning of a
         # diagonally scaled M-matrix-like operator.
         dinv = A.diag_inv()
+        if parallel.active():
+            # (rows the rank does not own are empty here: keep them finite)
+            dinv[~torch.isfinite(dinv)] = 1.0
         _hip.check(lib.flow_scale_rows(
             lay.N, _hip.i32(lay.dev('rowptr')), _hip.f64(dinv, lay.N),
             _hip.f64(A.vals, lay.nnz), st
@@ -182,6 +205,16 @@ class Heat(object):
         u = Function(self.V)
         # warm start is not used: x0 = 0 like a direct solve has no history
         par = solver_parameters
+        if parallel.active():
+            # block-Jacobi ILU(0) GMRES on the strips; the ghost rows of the
+            # solution from their owners
+            pre = parallel.local_ilu(A)
+            info = parallel.gmres(A, pre, bvec, u.data, rtol=par['rtol'],
+                                  atol=0.0, maxit=par['maxit'], restart=30,
+                                  x_is_zero=True, verify=True)
+            parallel.halo(u.data, lay, 1)
+            last_solve_info['heat'] = info
+            return u
         pre = None
         if par.get('preconditioner', 'ilu0') == 'ilu0':
             # The zero-mass edge rows and the skew convection make the diagonal

@@ -679,32 +679,36 @@ def mgcg(A, dinv, mg, b, x, rtol, atol=0.0, maxit=1000, check_every=2,
 
 
 def gmres(Jop, pre, b, x, rtol, atol=0.0, maxit=1000, restart=20,
-          x_is_zero=True, expected=0):
+          x_is_zero=True, expected=0, verify=False):
     '''GMRES + a block-Jacobi preconditioner on the strips -- `pre`: the rank's
     own ILU(0) (local_ilu) or two-level cycle (local_pmg) of its diagonal
-    block; Jop: a MomentumJacobian built on the rank's views (kind 3).  b, x:
-    global-length velocity fields (owned rows).'''
+    block.  Jop: a MomentumJacobian built on the rank's views (kind 3; b, x:
+    global-length velocity fields), or a scalar ops.Matrix (kind 0: applied on
+    the rank's rows; b, x: global-length scalar fields).  b valid on the owned
+    rows; x (start: owned rows) -> the owned rows of the solution.'''
     from .fem.pmg import Pmg
     is_pmg = isinstance(pre, Pmg)
     from .fem import ops
     c = comm()
     lay = Jop.layout
     v = view(lay)
-    c.ensure(max(2 * v.rows.nhalo, _hip.GMRES_MAX_RESTART + 2))
+    ncomp = 1 if Jop.kind == 0 else 2
+    op = v.operator(Jop) if Jop.kind == 0 else Jop.operator()
+    c.ensure(max(ncomp * v.rows.nhalo, _hip.GMRES_MAX_RESTART + 2))
     mo, me = v.r1 - v.r0, v.e1 - v.e0
-    wlen = _hip.REDUCE_WORK + (2 * restart + 4) * 2 * mo + 2 * me \
+    wlen = _hip.REDUCE_WORK + (2 * restart + 4) * ncomp * mo + 2 * me \
         + _hip.GMRES_PARTIALS + _hip.GMRES_STATE
     wk = ops.work(wlen)
     its = ctypes.c_int(0)
     res = ctypes.c_double(0.0)
-    n2 = 2 * lay.N
+    nn = ncomp * lay.N
     _hip.check(_hip.lib().flow_shard_gmres_solve(
-        ctypes.byref(c.struct), ctypes.byref(v.rows),
-        ctypes.byref(Jop.operator()),
+        ctypes.byref(c.struct), ctypes.byref(v.rows), ctypes.byref(op),
         None if is_pmg else ctypes.byref(pre.struct),
         ctypes.byref(pre.struct) if is_pmg else None,
-        _hip.f64(b, n2, 'b'), _hip.f64(x, n2, 'x'), float(rtol), float(atol),
+        _hip.f64(b, nn, 'b'), _hip.f64(x, nn, 'x'), float(rtol), float(atol),
         int(maxit), int(restart), int(bool(x_is_zero)), int(expected),
+        int(bool(verify)),
         _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
         _hip.stream()))
     return _solve_info(its.value, res.value,

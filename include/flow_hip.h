@@ -617,9 +617,12 @@ int flow_shard_mgcg_solve(const flow_comm* comm, const flow_rows* rows,
                           int first_check, double* work, size_t work_len,
                           int* iters_host, double* resid_host, void* stream);
 
-/* GMRES(restart) for the Newton systems on the strips.  The operator is the
+/* GMRES(restart) on the strips: for the Newton systems -- the operator is the
  * matrix-free Jacobian action (kind 3) whose flow_mesh / flow_space carry the
- * rank's cell and row ranges (below); the preconditioner is block Jacobi, no
+ * rank's cell and row ranges (below) -- and for scalar systems (kind 0 with the
+ * row blocks of the owned rows, one component: the heat system,
+ * flow/heat.py:103-122; verify as flow_gmres_solve).  The preconditioner is
+ * block Jacobi, no
  * communication: EITHER ilu, the factors of the rank's own diagonal block (plan
  * over the owned rows in local numbering), OR pmg, the two-level cycle of K17
  * on that block (levels in local numbering, flow_pmg_pack).  The Krylov vectors hold the owned rows only
@@ -635,8 +638,9 @@ int flow_shard_gmres_solve(const flow_comm* comm, const flow_rows* rows,
                            const flow_pmg* pmg, const double* b, double* x,
                            double rtol, double atol,
                            int maxit, int restart, int x_is_zero,
-                           int expected_its, double* work, size_t work_len,
-                           int* iters_host, double* resid_host, void* stream);
+                           int expected_its, int verify, double* work,
+                           size_t work_len, int* iters_host, double* resid_host,
+                           void* stream);
 
 /* ---- assembly ------------------------------------------------------------
  * Two-phase, atomic-free: a cell kernel writes local tensors to `scratch`

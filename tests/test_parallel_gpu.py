@@ -429,3 +429,93 @@ def test_block_pmg_on_strips(hip, world):
     print('world %d: GMRES applications %r (single GPU %r), contraction %.2f'
           % (world, [sum(a) for a in out[0]['applications']], ref_apps,
              out[0]['contraction'][0]))
+
+
+# -- the coupled Boussinesq sweeps on the strips ------------------------------------
+BOX_NX = 40
+
+
+def _boussinesq_steps(supg):
+    '''Two accepted steps of the reference driver's loop
+    (tests/test_boussinesq.py:213-253: per sweep one heat assemble + solve and
+    one Rotational.step) from a perturbed state, so that both fields move.'''
+    import torch
+    from flow_amd import boussinesq, fem, device
+    import flow_amd.navier_stokes as navsto
+    navsto.solver_parameters['pressure']['mg_coarsest'] = 200
+    mesh = fem.heater_box(BOX_NX, fitted=True)
+    stepper = boussinesq.FixedPointStepper(
+        boussinesq.HeaterBox(mesh, supg=supg), 1.0e-2)
+    # a warm plume and a weak swirl: the buoyancy acts from the first sweep
+    Q, W = stepper.pb.Q, stepper.pb.W
+    x = Q.layout.dof_coords
+    bump = 2.0 * numpy.exp(-((x[:, 0] - 0.05)**2 + (x[:, 1] - 0.11)**2) / 4e-4)
+    stepper.theta.data += device.to_device(bump)
+    n = W.layout.N
+    swirl = numpy.concatenate([-(x[:, 1] - 0.1), (x[:, 0] - 0.05)]) * 1e-3
+    inner = (x[:, 0] > 1e-9) & (x[:, 0] < 0.1 - 1e-9) & (x[:, 1] > 1e-9) \
+        & (x[:, 1] < 0.2 - 1e-9) \
+        & ((x[:, 0] - 0.05)**2 + (x[:, 1] - 0.05)**2 > 0.0201**2)
+    swirl *= numpy.tile(inner, 2)
+    stepper.u.data += device.to_device(swirl)
+    log = [stepper.advance().sweeps for _ in range(2)]
+    torch.cuda.synchronize()
+    return stepper, log
+
+
+def _boussinesq_worker(rank, world, port, supg, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LOCAL_RANK'] = '0'
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from flow_amd import parallel, device, heat
+        parallel.enable(dist.group.WORLD, force=True)
+        stepper, log = _boussinesq_steps(supg)
+        pb = stepper.pb
+
+        def whole(f, lay, ncomp=1):
+            return device.to_host(parallel.gather_field(
+                f.data.clone(), lay, ncomp)).numpy()
+        v = parallel.view(pb.Q.layout)
+        th_loc = device.to_host(stepper.theta.data).numpy().copy()
+        th = whole(stepper.theta, pb.Q.layout)
+        out[rank] = dict(
+            u=whole(stepper.u, pb.W.layout, 2), p=whole(stepper.p, pb.P.layout),
+            theta=th, sweeps=log, dt=stepper.dt, t=stepper.t,
+            ghosts=bool(numpy.array_equal(th_loc[v.e0:v.e1], th[v.e0:v.e1])),
+            heat=heat.last_solve_info['heat'].method)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('supg', [False, True])
+def test_boussinesq_sweeps_on_strips(hip, supg):
+    '''BASELINE config 4's loop body with NOTHING replicated: the heat operator
+    is assembled over the rank's cells, evaluated on its rows and solved by
+    the sharded GMRES with the rank's block ILU(0) (flow/heat.py:20-122), the
+    flow step runs on the strips as before -- against the single-process run:
+    theta, u, p <= 1e-7, the same sweeps and step sizes on every rank.'''
+    stepper, log = _boussinesq_steps(supg)
+    ref = dict(u=stepper.u.vector().get_local(), p=stepper.p.vector().get_local(),
+               theta=stepper.theta.vector().get_local())
+    world = 2
+    manager = mp.get_context('spawn').Manager()
+    out = manager.dict()
+    mp.spawn(_boussinesq_worker, args=(world, _free_port(), supg, out),
+             nprocs=world, join=True)
+    for r in range(world):
+        res = out[r]
+        assert res['sweeps'] == log, (res['sweeps'], log)
+        assert abs(res['dt'] - stepper.dt) <= 1e-12 * stepper.dt
+        assert 'x-strips x2' in res['heat'], res['heat']
+        assert res['ghosts']
+        # theta: relative to its excess over room temperature
+        eth = float(numpy.linalg.norm(res['theta'] - ref['theta'])
+                    / numpy.linalg.norm(ref['theta'] - 293.0))
+        eu, ep = _rel(res['u'], ref['u']), _rel(res['p'], ref['p'])
+        assert eth < 1e-7 and eu < 1e-7 and ep < 1e-7, (eth, eu, ep)
+        assert numpy.array_equal(res['theta'], out[0]['theta'])
+    print('Boussinesq on 2 strips (supg %r): dtheta %.2e du %.2e dp %.2e, '
+          'sweeps %r' % (supg, eth, eu, ep, log))
