@@ -224,6 +224,53 @@ def pmc(fetch_dir, write_dir, out, kernel='flow::spmv_stream_kernel<false>',
     print(json.dumps(res))
 
 
+def counters(out, *dirs):
+    '''Per (kernel, dispatch size): the median over its dispatches of every
+    counter found in the given rocprofv3 --pmc output directories (one pass
+    each), as a markdown table; rows ordered by dispatch count.  Byte columns:
+    FETCH_SIZE / WRITE_SIZE are KiB; `HBM MB` = (2 FETCH + WRITE) * 1024 / 1e6
+    (gfx950 correction of MI355X_MICROARCH.md).'''
+    vals = defaultdict(lambda: defaultdict(list))
+    names = []
+    for d in dirs:
+        for path in _find(d, 'counter_collection.csv'):
+            with open(path) as fh:
+                for r in csv.DictReader(fh):
+                    k = r['Kernel_Name'].split('(')[0].replace('void ', '') \
+                        .replace('flow::', '')
+                    g = int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0)
+                    c = r['Counter_Name']
+                    if c not in names:
+                        names.append(c)
+                    vals[(k, g)][c].append(float(r['Counter_Value']))
+
+    def med(v):
+        v = sorted(v)
+        return v[len(v) // 2]
+    rows = []
+    for (k, g), cs in vals.items():
+        n = max(len(v) for v in cs.values())
+        if n < 5:
+            continue
+        row = {c: med(v) for c, v in cs.items()}
+        if 'FETCH_SIZE' in row and 'WRITE_SIZE' in row:
+            row['HBM MB'] = (2.0 * row['FETCH_SIZE'] + row['WRITE_SIZE']) \
+                * 1024.0 / 1e6
+        rows.append((n, k, g, row))
+    rows.sort(key=lambda r: -r[0])
+    cols = names + (['HBM MB'] if 'FETCH_SIZE' in names and 'WRITE_SIZE' in names
+                    else [])
+    lines = ['| kernel | grid | dispatches | ' + ' | '.join(cols) + ' |',
+             '|---|---|---|' + '---|' * len(cols)]
+    for n, k, g, row in rows:
+        lines.append('| %s | %d | %d | %s |' % (
+            k[:70], g, n, ' | '.join(
+                ('%.4g' % row[c]) if c in row else '' for c in cols)))
+    with open(out, 'w') as fh:
+        fh.write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[:40]))
+
+
 def sequence(directory, out, window, min_gap_us=15.0):
     '''The kernels of a window "a:b" (ms before the end of the trace) in launch
     order, runs of equal names folded, every idle interval >= min_gap_us shown:
@@ -263,6 +310,9 @@ def sequence(directory, out, window, min_gap_us=15.0):
 
 
 if __name__ == '__main__':
+    if sys.argv[1] == 'counters':
+        counters(sys.argv[2], *sys.argv[3:])
+        sys.exit(0)
     if sys.argv[1] == 'gaps':
         gaps(sys.argv[2], sys.argv[3],
              window=sys.argv[4] if len(sys.argv) > 4 else None)
