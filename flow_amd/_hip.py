@@ -142,6 +142,8 @@ class MassS(ctypes.Structure):
         ('steps', ctypes.c_int),
         ('contraction', ctypes.c_double),
         ('work16', ctypes.c_void_p),
+        ('packed16', ctypes.c_void_p),
+        ('cbase16', ctypes.c_void_p),
         ]
 
 
@@ -268,6 +270,7 @@ SYMBOLS = {
     'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _P(_D), _VP],
     'flow_pmg_apply': [_P(PmgS), _VP, _VP, _VP],
     'flow_mass_pack': [_I, _VP, _VP, _VP, _VP, _VP],
+    'flow_mass_pack16': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_mass_solve': [_P(MassS), _VP, _VP, _D, _D, _I, _I, _VP,
                         ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_gather_rows': [_I, _VP, _I, _VP, _I, _VP, _I, _VP],

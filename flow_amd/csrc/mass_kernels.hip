@@ -113,6 +113,74 @@ __device__ __forceinline__ V mass_tile_row_sum(
   return s;
 }
 
+// The same tile from the PACKED stream: one 32-bit word per nonzero -- the fp16
+// value in the low half, the column as a 16-bit offset from the tile's lowest
+// column (cbase[tile]) in the high half -- so a quad of nonzeros is ONE 16-byte
+// load (4 B per nonzero instead of 6, half the stream-load instructions).
+// Possible whenever a tile's columns span < 65536 (any banded numbering; the
+// host checks and falls back to the plain stream otherwise).
+template <class V>
+__device__ __forceinline__ V mass_tile_row_sum_packed(
+    const int* __restrict__ rowptr, const unsigned* __restrict__ packed,
+    const int* __restrict__ cbase, const int* __restrict__ rowblocks,
+    const V* __restrict__ g, V* __restrict__ prod, int& r, int& r1) {
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int r0 = rowblocks[tile];
+  r1 = rowblocks[tile + 1];
+  const int base = cbase[tile];
+  const int k0 = rowptr[r0];
+  const int k1 = rowptr[r1];
+  const int ka = k0 & ~3;
+  r = r0 + threadIdx.x;
+  int a = 0, b = 0;
+  if (r < r1) {
+    a = rowptr[r] - ka;
+    b = rowptr[r + 1] - ka;
+  }
+  const int lo = k0 - ka, hi = k1 - ka;
+  const uint4* __restrict__ pq = reinterpret_cast<const uint4*>(packed + ka);
+  uint4 w[kMassQuads];
+#pragma unroll
+  for (int q = 0; q < kMassQuads; ++q) {
+    const int p = threadIdx.x + q * kBlock;
+    w[q] = make_uint4(0u, 0u, 0u, 0u);
+    if (4 * p < hi) w[q] = pq[p];
+  }
+  if (k0 < k1) {                                   // (block-uniform)
+    const int safe = base + static_cast<int>(packed[k0] >> 16);
+    V gg[kMassQuads][4];
+#pragma unroll
+    for (int q = 0; q < kMassQuads; ++q) {          // all gathers in flight
+      const int e0 = 4 * (threadIdx.x + q * kBlock);
+      const unsigned ww[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j;
+        gg[q][j] = g[(e >= lo && e < hi) ? base + static_cast<int>(ww[j] >> 16)
+                                         : safe];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kMassQuads; ++q) {
+      const int e0 = 4 * (threadIdx.x + q * kBlock);
+      if (e0 < hi) {
+        const unsigned ww[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          prod[e0 + j] = vscale(
+              __half2float(__ushort_as_half(static_cast<unsigned short>(
+                  ww[j] & 0xffffu))),
+              gg[q][j]);
+      }
+    }
+  }
+  __syncthreads();
+  V s;
+  vzero(s);
+  for (int k = a; k < b; ++k) vadd(s, prod[k]);
+  return s;
+}
+
 // ---------------------------------------------------------------------------
 // fp64 residual with the fp32 epilogue: rho0 = D^-1 (b - A x)
 // ---------------------------------------------------------------------------
@@ -198,10 +266,10 @@ __device__ __forceinline__ double2 add_to_x(double* x, int xs, int r, float2 z) 
                       x0 * x0 + x1 * x1);
 }
 
-template <class V, int MODE>
+template <class V, int MODE, bool PACKED>
 __global__ __launch_bounds__(kBlock) void mass_cheb_kernel(
     int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
-    const __half* __restrict__ vals, const int* __restrict__ rowblocks,
+    const void* __restrict__ vals, const int* __restrict__ rowblocks,
     const unsigned char* __restrict__ mask, const V* __restrict__ g,
     const V* rho_in, V* rho_out, float c0, float c1, float c2,
     V* __restrict__ d_out, V* __restrict__ acc, double* __restrict__ x, int xs,
@@ -209,8 +277,15 @@ __global__ __launch_bounds__(kBlock) void mass_cheb_kernel(
     const double* __restrict__ stop) {
   __shared__ V prod[kMassTile];
   if (stopped(stop)) return;
+  // (PACKED: `vals` is the packed stream, `cols` the tiles' base columns)
   int r, r1;
-  V s = mass_tile_row_sum<V>(rowptr, cols, vals, rowblocks, g, prod, r, r1);
+  V s = PACKED
+            ? mass_tile_row_sum_packed<V>(rowptr,
+                                          static_cast<const unsigned*>(vals), cols,
+                                          rowblocks, g, prod, r, r1)
+            : mass_tile_row_sum<V>(rowptr, cols,
+                                   static_cast<const __half*>(vals), rowblocks, g,
+                                   prod, r, r1);
   double2 dots = make_double2(0.0, 0.0);
   if (r < r1) {
     const V own = g[r];
@@ -307,6 +382,43 @@ __global__ void mass_pack_kernel(int n, const int* __restrict__ rowptr,
   }
 }
 
+// setup of the packed stream: a workgroup per tile finds the tile's lowest
+// column (cbase) and writes (offset << 16 | fp16 bits) per nonzero; *overflow
+// is set when an offset does not fit in 16 bits (the caller then keeps the
+// plain stream)
+__global__ __launch_bounds__(kBlock) void mass_pack16_kernel(
+    const int* __restrict__ rowblocks, const int* __restrict__ rowptr,
+    const int* __restrict__ cols, const int* __restrict__ diag_idx,
+    const double* __restrict__ vals, int* __restrict__ cbase,
+    unsigned* __restrict__ packed, int* __restrict__ overflow) {
+  __shared__ int wmin[kBlock / 64];
+  const int tile = blockIdx.x;
+  const int r0 = rowblocks[tile], r1 = rowblocks[tile + 1];
+  const int k0 = rowptr[r0], k1 = rowptr[r1];
+  int m = 0x7fffffff;
+  for (int k = k0 + threadIdx.x; k < k1; k += kBlock) m = min(m, cols[k]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = m;
+  __syncthreads();
+  int base = wmin[0];
+#pragma unroll
+  for (int w = 1; w < kBlock / 64; ++w) base = min(base, wmin[w]);
+  if (k0 >= k1) base = 0;
+  if (threadIdx.x == 0) cbase[tile] = base;
+  const int r = r0 + threadIdx.x;
+  if (r < r1) {
+    const double inv = 1.0 / vals[diag_idx[r]];
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      const int off = cols[k] - base;
+      if (off > 0xffff) atomicOr(overflow, 1);
+      const unsigned short h =
+          __half_as_ushort(__float2half_rn(static_cast<float>(vals[k] * inv)));
+      packed[k] = (static_cast<unsigned>(off & 0xffff) << 16) | h;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -327,12 +439,15 @@ struct Cheb {
   }
 };
 
-template <class V>
-int correction(const flow_mass* M, const double* b, double* x, double* zz_part,
-               double* xx_part, const double* stop, hipStream_t st) {
+template <class V, bool PACKED>
+int correction(const flow_mass* M, double* x, double* zz_part, double* xx_part,
+               const double* stop, hipStream_t st) {
   const flow_operator* A = M->A;
   const int n = A->n;
-  const __half* v16 = static_cast<const __half*>(M->vals16);
+  // (PACKED: the packed stream and the tiles' base columns take the places of
+  // the fp16 values and the column indices)
+  const void* v16 = PACKED ? M->packed16 : M->vals16;
+  const int* cols = PACKED ? M->cbase16 : A->cols;
   V* w = reinterpret_cast<V*>(M->work16);
   V* rho0 = w;
   V* rho = rho0 + n;
@@ -345,20 +460,22 @@ int correction(const flow_mass* M, const double* b, double* x, double* zz_part,
   V* const none = nullptr;
   double* const nod = nullptr;
   ch.next(&c1, &c2);
-  hipLaunchKernelGGL((mass_cheb_kernel<V, 0>), g16, blk, 0, st, n, A->rowptr,
-                     A->cols, v16, M->rowblocks16, A->rowmask, rho0, rho0, rho, c0,
-                     c1, c2, d[0], acc, nod, n, nod, nod, stop);
+  hipLaunchKernelGGL((mass_cheb_kernel<V, 0, PACKED>), g16, blk, 0, st, n,
+                     A->rowptr, cols, v16, M->rowblocks16, A->rowmask, rho0, rho0,
+                     rho, c0, c1, c2, d[0], acc, nod, n, nod, nod, stop);
   const int products = M->steps - 1;
   for (int j = 1; j + 1 < products; ++j) {
     ch.next(&c1, &c2);
-    hipLaunchKernelGGL((mass_cheb_kernel<V, 1>), g16, blk, 0, st, n, A->rowptr,
-                       A->cols, v16, M->rowblocks16, A->rowmask, d[(j - 1) & 1], rho,
-                       rho, 0.f, c1, c2, d[j & 1], acc, nod, n, nod, nod, stop);
+    hipLaunchKernelGGL((mass_cheb_kernel<V, 1, PACKED>), g16, blk, 0, st, n,
+                       A->rowptr, cols, v16, M->rowblocks16, A->rowmask,
+                       d[(j - 1) & 1], rho, rho, 0.f, c1, c2, d[j & 1], acc, nod, n,
+                       nod, nod, stop);
   }
   ch.next(&c1, &c2);
-  hipLaunchKernelGGL((mass_cheb_kernel<V, 2>), g16, blk, 0, st, n, A->rowptr,
-                     A->cols, v16, M->rowblocks16, A->rowmask, d[(products - 2) & 1],
-                     rho, none, 0.f, c1, c2, none, acc, x, n, zz_part, xx_part, stop);
+  hipLaunchKernelGGL((mass_cheb_kernel<V, 2, PACKED>), g16, blk, 0, st, n,
+                     A->rowptr, cols, v16, M->rowblocks16, A->rowmask,
+                     d[(products - 2) & 1], rho, none, 0.f, c1, c2, none, acc, x, n,
+                     zz_part, xx_part, stop);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -372,13 +489,17 @@ static int mass_check(const flow_mass* M) {
   FLOW_REQUIRE(M->A->kind == 0 || M->A->kind == 4,
                "flow_mass: operator kind 0 (scalar) or 4 (one plane, two "
                "components)");
-  FLOW_REQUIRE(M->dinv && M->rowblocks16 && M->vals16 && M->work16 &&
-                   M->nblocks16 > 0,
+  FLOW_REQUIRE(M->dinv && M->rowblocks16 && (M->vals16 || M->packed16) &&
+                   M->work16 && M->nblocks16 > 0,
                "flow_mass pointers");
   FLOW_REQUIRE(reinterpret_cast<uintptr_t>(M->vals16) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(M->packed16) % 16 == 0 &&
                    reinterpret_cast<uintptr_t>(M->A->cols) % 16 == 0 &&
                    reinterpret_cast<uintptr_t>(M->work16) % 16 == 0,
-               "flow_mass: vals16, cols and work16 must be 16-byte aligned");
+               "flow_mass: vals16 / packed16, cols and work16 must be 16-byte "
+               "aligned");
+  FLOW_REQUIRE(M->packed16 == nullptr || M->cbase16 != nullptr,
+               "flow_mass: the packed stream needs the tiles' base columns");
   FLOW_REQUIRE(M->lam_max > M->lam_min && M->lam_min > 0.0,
                "Chebyshev interval (0 < lam_min < lam_max)");
   FLOW_REQUIRE(M->steps >= 3 && M->steps <= 16, "Chebyshev steps (3..16)");
@@ -404,12 +525,18 @@ static int mass_solve(const flow_mass* M, const double* b, double* x, double rto
                          0, st, A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
                          A->rowmask, x, A->n, b, M->dinv,
                          reinterpret_cast<float2*>(M->work16), stop);
-      if ((rc = correction<float2>(M, b, x, zz_part, xx_part, stop, st))) return rc;
+      rc = M->packed16
+               ? correction<float2, true>(M, x, zz_part, xx_part, stop, st)
+               : correction<float2, false>(M, x, zz_part, xx_part, stop, st);
+      if (rc) return rc;
     } else {
       hipLaunchKernelGGL(mass_residual_kernel, dim3(A->nblocks), dim3(kBlock), 0, st,
                          A->rowptr, A->cols, A->vals[0], A->rowblocks, x, b, M->dinv,
                          M->work16, stop);
-      if ((rc = correction<float>(M, b, x, zz_part, xx_part, stop, st))) return rc;
+      rc = M->packed16
+               ? correction<float, true>(M, x, zz_part, xx_part, stop, st)
+               : correction<float, false>(M, x, zz_part, xx_part, stop, st);
+      if (rc) return rc;
     }
     hipLaunchKernelGGL(mass_scalar_kernel, dim3(1), dim3(kMassScalarBlock), 0, st,
                        M->nblocks16, zz_part, xx_part, c2, rtol * rtol, atol * atol,
@@ -459,6 +586,21 @@ extern "C" int flow_mass_pack(int n, const int* rowptr, const int* diag_idx,
   hipLaunchKernelGGL(mass_pack_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
                      as_stream(stream), n, rowptr, diag_idx, vals,
                      static_cast<__half*>(vals16));
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_mass_pack16(int n, int nblocks16, const int* rowblocks16,
+                                const int* rowptr, const int* cols,
+                                const int* diag_idx, const double* vals,
+                                int* cbase16, void* packed16, int* overflow_dev,
+                                void* stream) {
+  FLOW_REQUIRE(n > 0 && nblocks16 > 0 && rowblocks16 && rowptr && cols &&
+                   diag_idx && vals && cbase16 && packed16 && overflow_dev,
+               "flow_mass_pack16 arguments");
+  hipLaunchKernelGGL(mass_pack16_kernel, dim3(nblocks16), dim3(kBlock), 0,
+                     as_stream(stream), rowblocks16, rowptr, cols, diag_idx, vals,
+                     cbase16, static_cast<unsigned*>(packed16), overflow_dev);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }

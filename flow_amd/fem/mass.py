@@ -45,7 +45,7 @@ class MassSolver(object):
     kind 4: one plane for both components with identity rows by mask).
     `dinv`: 1 / diagonal (1 on masked rows), A.size doubles.'''
 
-    def __init__(self, A, dinv, steps=6, safety=1.5):
+    def __init__(self, A, dinv, steps=6, safety=1.5, packed=True):
         assert A.kind in (0, 4)
         lay = A.layout
         self.A = A
@@ -83,6 +83,25 @@ class MassSolver(object):
         s.work16 = _hip.f32(self.work16, 5 * self.ncomp * n).value
         # (cols is read in quads too)
         assert lay.dev('cols').numel() >= nnz + 4
+        # the packed stream (4 B per nonzero): wherever every tile's columns
+        # span < 65536 -- any mesh numbered along one axis
+        self.packed16 = None
+        if packed:
+            nb = s.nblocks16
+            pk = torch.zeros(nnz + 8, dtype=torch.int32, device=device.get())
+            cb = torch.zeros(nb, dtype=torch.int32, device=device.get())
+            flag = torch.zeros(1, dtype=torch.int32, device=device.get())
+            assert pk.data_ptr() % 16 == 0
+            _hip.check(_hip.lib().flow_mass_pack16(
+                n, nb, _hip.i32(self.rowblocks16),
+                _hip.i32(lay.dev('rowptr'), n + 1),
+                _hip.i32(lay.dev('cols'), nnz), _hip.i32(lay.dev('diag_idx'), n),
+                _hip.f64(A.vals, nnz), _hip.i32(cb, nb), _hip.i32(pk, nnz),
+                _hip.i32(flag, 1), _hip.stream()))
+            if int(device.to_host(flag).item()) == 0:
+                self.packed16 = (pk, cb)
+                s.packed16 = _hip.i32(pk, nnz).value
+                s.cbase16 = _hip.i32(cb, nb).value
         self.struct = s
         self.history = {}
 

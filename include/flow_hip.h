@@ -404,10 +404,24 @@ typedef struct {
   int steps;                   /* Chebyshev steps per defect correction, 3..16 */
   double contraction;          /* bound on |I - B M| in (0, 1] */
   float* work16;
+  /* the PACKED stream (used instead of vals16 + A->cols when not NULL): one
+   * 32-bit word per nonzero, fp16 value | (column - cbase16[tile]) << 16 --
+   * 4 B per nonzero and one 16-byte load per quad of nonzeros; nnz words,
+   * 16-byte aligned, readable three past nnz.  Needs every tile's columns to
+   * span < 65536 (flow_mass_pack16 reports otherwise). */
+  const void* packed16;
+  const int* cbase16;          /* nblocks16: lowest column of each tile */
 } flow_mass;
 /* vals16[k] = half(vals[k] / vals[diag_idx[row(k)]]) */
 int flow_mass_pack(int n, const int* rowptr, const int* diag_idx,
                    const double* vals, void* vals16, void* stream);
+/* the packed stream of the same matrix over the row blocks rowblocks16;
+ * *overflow_dev (an int the caller zeroes) is set to 1 when a column offset
+ * does not fit in 16 bits: keep the plain stream then */
+int flow_mass_pack16(int n, int nblocks16, const int* rowblocks16,
+                     const int* rowptr, const int* cols, const int* diag_idx,
+                     const double* vals, int* cbase16, void* packed16,
+                     int* overflow_dev, void* stream);
 /* x holds the initial guess.  maxit / *iters_host count defect corrections;
  * first_check: as flow_cg_solve (then one at a time).  *resid_host = |z| of
  * the last correction.  work: FLOW_REDUCE_WORK + 2 * nblocks16 doubles. */

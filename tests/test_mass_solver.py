@@ -136,15 +136,18 @@ def _dev(a):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('packed', [False, True])
 @pytest.mark.parametrize('deg', [1, 2])
-def test_scalar_mass_solve_matches_direct_solve(hip, deg):
+def test_scalar_mass_solve_matches_direct_solve(hip, deg, packed):
     from flow_amd.fem import ops
     rng = numpy.random.RandomState(7)
     for name, mesh in [('karman-48', fem.karman_channel(48, 12)),
                        ('karman-60-fitted', fem.karman_channel(60, 14, fitted=True))]:
         V = fem.FunctionSpace(mesh, 'CG', deg)
         M = ops.assemble_mass(V)
-        solver = fmass.MassSolver(M, M.diag_inv())
+        # (packed: fp16 value + 16-bit column offset in one word per nonzero)
+        solver = fmass.MassSolver(M, M.diag_inv(), packed=packed)
+        assert (solver.packed16 is not None) == packed
         Ms = M.to_scipy().tocsc()
         b = rng.standard_normal(V.N)
         ref = spla.splu(Ms).solve(b)
@@ -163,7 +166,8 @@ def test_scalar_mass_solve_matches_direct_solve(hip, deg):
 
 
 @pytest.mark.gpu
-def test_pair_mass_solve_with_identity_rows(hip):
+@pytest.mark.parametrize('packed', [False, True])
+def test_pair_mass_solve_with_identity_rows(hip, packed):
     '''flow_operator kind 4 (the velocity correction's system, reference
     :451-464) against the symmetrically eliminated direct solve; the count the
     device reports is exact whatever the host enqueues ahead.'''
@@ -177,7 +181,7 @@ def test_pair_mass_solve_with_identity_rows(hip):
     M = ops.assemble_mass(V)
     free = (rng.uniform(size=2 * n) > 0.07).astype(numpy.uint8)
     A = ops.Matrix(lay, 4, M.vals, rowmask=_dev(free))
-    solver = fmass.MassSolver(A, A.diag_inv())
+    solver = fmass.MassSolver(A, A.diag_inv(), packed=packed)
     Ms = M.to_scipy()
     g = rng.standard_normal(2 * n)
     b = rng.standard_normal(2 * n)
