@@ -60,13 +60,21 @@ static_assert(sizeof(Half2x4) == 16, "packed quad");
 // vector g go through LDS, then lane i sums row r0 + i.  Window-safe like
 // stream_tile_row_sum (la_kernels.hip): g is only dereferenced for the tile's
 // own nonzeros (slack and idle lanes gather the tile's first column).
+// C16: the column indices are 16-bit offsets from the tile's lowest column
+// (cols16 / cbase of flow_pmg_level: 6 B per nonzero instead of 8).
+template <bool C16>
 __device__ __forceinline__ float2 pmg_tile_row_sum(
-    const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const int* __restrict__ rowptr, const void* __restrict__ cols_any,
+    const int* __restrict__ cbase,
     const __half2* __restrict__ vals, const int* __restrict__ rowblocks,
     const float2* __restrict__ g, float2* __restrict__ prod, int& r, int& r1) {
+  const int* __restrict__ cols = static_cast<const int*>(cols_any);
+  const unsigned short* __restrict__ cols16 =
+      static_cast<const unsigned short*>(cols_any);
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int r0 = rowblocks[tile];
   r1 = rowblocks[tile + 1];
+  const int base = C16 ? cbase[tile] : 0;
   const int k0 = rowptr[r0];
   const int k1 = rowptr[r1];
   const int ka = k0 & ~3;
@@ -79,6 +87,8 @@ __device__ __forceinline__ float2 pmg_tile_row_sum(
   const int lo = k0 - ka, hi = k1 - ka;          // hi <= kPmgTile - 1
   const Half2x4* __restrict__ vq = reinterpret_cast<const Half2x4*>(vals + ka);
   const int4* __restrict__ cq = reinterpret_cast<const int4*>(cols + ka);
+  const ushort4* __restrict__ cq16 =
+      reinterpret_cast<const ushort4*>(cols16 + ka);
   Half2x4 v[kPmgQuads];
   int4 c[kPmgQuads];
 #pragma unroll
@@ -87,11 +97,16 @@ __device__ __forceinline__ float2 pmg_tile_row_sum(
     c[q] = make_int4(0, 0, 0, 0);
     if (4 * p < hi) {
       v[q] = vq[p];
-      c[q] = cq[p];
+      if (C16) {
+        const ushort4 u = cq16[p];
+        c[q] = make_int4(base + u.x, base + u.y, base + u.z, base + u.w);
+      } else {
+        c[q] = cq[p];
+      }
     }
   }
   if (k0 < k1) {                                   // (block-uniform)
-    const int safe = cols[k0];
+    const int safe = C16 ? base + cols16[k0] : cols[k0];
     float2 gg[kPmgQuads][4];
 #pragma unroll
     for (int q = 0; q < kPmgQuads; ++q) {          // all gathers in flight
@@ -135,9 +150,10 @@ __device__ __forceinline__ float2 pmg_tile_row_sum(
 //                           blocked (z[a*n + row]); Dirichlet rows (bc != 0)
 //                           return the input r there: identity rows of J
 // rho_out may alias rho_in (row-local); g must not be written.
-template <int MODE>
+template <int MODE, bool C16>
 __global__ __launch_bounds__(kBlock) void pmg_cheb_kernel(
-    int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
+    int n, const int* __restrict__ rowptr, const void* __restrict__ cols,
+    const int* __restrict__ cbase,
     const __half2* __restrict__ vals, const int* __restrict__ rowblocks,
     const float2* __restrict__ g, const float2* rho_in, float2* rho_out,
     const float2* __restrict__ d_own, float c1, float c2,
@@ -148,7 +164,8 @@ __global__ __launch_bounds__(kBlock) void pmg_cheb_kernel(
   __shared__ float2 prod[kPmgTile];
   if (stopped(stop)) return;
   int r, r1;
-  const float2 s = pmg_tile_row_sum(rowptr, cols, vals, rowblocks, g, prod, r, r1);
+  const float2 s =
+      pmg_tile_row_sum<C16>(rowptr, cols, cbase, vals, rowblocks, g, prod, r, r1);
   if (r >= r1) return;
   float2 rho = rho_in[r];
   rho.x -= s.x;
@@ -321,6 +338,33 @@ __global__ void pmg_pack_kernel(int n, const int* __restrict__ rowptr,
   }
 }
 
+// setup: 16-bit column offsets from each tile's lowest column (a workgroup per
+// tile); *overflow set when one does not fit
+__global__ __launch_bounds__(kBlock) void pmg_cols16_kernel(
+    const int* __restrict__ rowblocks, const int* __restrict__ rowptr,
+    const int* __restrict__ cols, int* __restrict__ cbase,
+    unsigned short* __restrict__ cols16, int* __restrict__ overflow) {
+  __shared__ int wmin[kBlock / 64];
+  const int tile = blockIdx.x;
+  const int k0 = rowptr[rowblocks[tile]], k1 = rowptr[rowblocks[tile + 1]];
+  int m = 0x7fffffff;
+  for (int k = k0 + threadIdx.x; k < k1; k += kBlock) m = min(m, cols[k]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = m;
+  __syncthreads();
+  int base = wmin[0];
+#pragma unroll
+  for (int w = 1; w < kBlock / 64; ++w) base = min(base, wmin[w]);
+  if (k0 >= k1) base = 0;
+  if (threadIdx.x == 0) cbase[tile] = base;
+  for (int k = k0 + threadIdx.x; k < k1; k += kBlock) {
+    const int off = cols[k] - base;
+    if (off > 0xffff) atomicOr(overflow, 1);
+    cols16[k] = static_cast<unsigned short>(off & 0xffff);
+  }
+}
+
 // power iteration for the spectral radius of D^-1 A: |w|^2 in block partials
 // (w = -(D^-1 A) v comes out of the product kernel with rho_in = 0)
 __global__ __launch_bounds__(kBlock) void pmg_norm_kernel(
@@ -371,8 +415,11 @@ static int check_level(const flow_pmg_level* L, const char* which) {
                    L->dinv,
                which);
   FLOW_REQUIRE(reinterpret_cast<uintptr_t>(L->vals) % 16 == 0 &&
-                   reinterpret_cast<uintptr_t>(L->cols) % 16 == 0,
+                   reinterpret_cast<uintptr_t>(L->cols) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(L->cols16) % 16 == 0,
                "packed values and column indices must be 16-byte aligned");
+  FLOW_REQUIRE(L->cols16 == nullptr || L->cbase != nullptr,
+               "16-bit column offsets need the tiles' base columns");
   FLOW_REQUIRE(L->lam_max > L->lam_min && L->lam_min > 0.0,
                "Chebyshev interval (0 < lam_min < lam_max)");
   return FLOW_OK;
@@ -416,11 +463,20 @@ void launch_cheb(const flow_pmg_level* L, const float2* g, const float2* rho_in,
                  float2* d_out, float2* x, const float2* d_extra, double* z,
                  const unsigned char* bc, const double* rin, const double* stop,
                  hipStream_t st) {
-  hipLaunchKernelGGL((pmg_cheb_kernel<MODE>), dim3(L->nblocks), dim3(kBlock), 0,
-                     st, L->n, L->rowptr, L->cols,
-                     reinterpret_cast<const __half2*>(L->vals), L->rowblocks, g,
-                     rho_in, rho_out, d_own, c1, c2, d_out, x, d_extra, z, bc, rin,
-                     stop);
+  if (L->cols16)
+    hipLaunchKernelGGL((pmg_cheb_kernel<MODE, true>), dim3(L->nblocks),
+                       dim3(kBlock), 0, st, L->n, L->rowptr,
+                       static_cast<const void*>(L->cols16), L->cbase,
+                       reinterpret_cast<const __half2*>(L->vals), L->rowblocks, g,
+                       rho_in, rho_out, d_own, c1, c2, d_out, x, d_extra, z, bc,
+                       rin, stop);
+  else
+    hipLaunchKernelGGL((pmg_cheb_kernel<MODE, false>), dim3(L->nblocks),
+                       dim3(kBlock), 0, st, L->n, L->rowptr,
+                       static_cast<const void*>(L->cols), L->cbase,
+                       reinterpret_cast<const __half2*>(L->vals), L->rowblocks, g,
+                       rho_in, rho_out, d_own, c1, c2, d_out, x, d_extra, z, bc,
+                       rin, stop);
 }
 
 }  // namespace
@@ -519,6 +575,19 @@ extern "C" int flow_pmg_pack(int n, int nnz, const int* rowptr,
                      reinterpret_cast<__half2*>(vals),
                      reinterpret_cast<float2*>(diag),
                      reinterpret_cast<float2*>(dinv));
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+extern "C" int flow_pmg_cols16(int nblocks, const int* rowblocks,
+                               const int* rowptr, const int* cols, int* cbase,
+                               void* cols16, int* overflow_dev, void* stream) {
+  FLOW_REQUIRE(nblocks > 0 && rowblocks && rowptr && cols && cbase && cols16 &&
+                   overflow_dev,
+               "flow_pmg_cols16 arguments");
+  hipLaunchKernelGGL(pmg_cols16_kernel, dim3(nblocks), dim3(kBlock), 0,
+                     as_stream(stream), rowblocks, rowptr, cols, cbase,
+                     static_cast<unsigned short*>(cols16), overflow_dev);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }

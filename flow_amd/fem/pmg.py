@@ -33,6 +33,11 @@ from .. import _hip
 from .. import device
 
 
+# 16-bit column offsets in the packed levels (include/flow_hip.h,
+# flow_pmg_level.cols16); False: plain int32 columns
+COLS16 = True
+
+
 def transfer_tables(lay2):
     '''(ends, rptr, rsrc) between the P2 layout and the P1 layout of its mesh:
     ends[i] = the two P1 rows (= vertices) P2 dof i interpolates from (a vertex
@@ -137,6 +142,23 @@ class _Level(object):
         s.diag = _hip.f32(self.diag, 2 * n, 'diag')
         s.dinv = _hip.f32(self.dinv, 2 * n, 'dinv')
         s.lam_min, s.lam_max = 0.25, 2.0
+        # 16-bit column offsets from each row block's lowest column (6 B per
+        # nonzero with the values instead of 8): any banded numbering allows it
+        self._cols16 = None
+        if COLS16:
+            nb = rb.numel() - 1
+            c16 = torch.zeros(nnz + 8, dtype=torch.int16, device=device.get())
+            cb = torch.zeros(nb, dtype=torch.int32, device=device.get())
+            flag = torch.zeros(1, dtype=torch.int32, device=device.get())
+            assert c16.data_ptr() % 16 == 0
+            _hip.check(_hip.lib().flow_pmg_cols16(
+                nb, _hip.i32(rb), _hip.i32(rowptr, n + 1), _hip.i32(cols, nnz),
+                _hip.i32(cb, nb), ctypes.c_void_p(c16.data_ptr()),
+                _hip.i32(flag, 1), _hip.stream()))
+            if int(device.to_host(flag).item()) == 0:
+                self._cols16 = (c16, cb)
+                s.cols16 = c16.data_ptr()
+                s.cbase = _hip.i32(cb, nb).value
         self.struct = s
 
     def _init_block(self, lay, rows):

@@ -326,6 +326,12 @@ typedef struct {
   const float* dinv;       /* n float2: 1 / diagonal */
   double lam_min, lam_max; /* Chebyshev interval for D^-1 A (flow_pmg_lambda_max
                               gives the upper end) */
+  /* optional: the column indices as 16-bit offsets from the lowest column of
+   * each row block (6 B per nonzero instead of 8; nnz ushorts, 16-byte aligned,
+   * readable three past nnz); used instead of cols when not NULL.  Needs every
+   * block's columns to span < 65536 (flow_pmg_cols16 reports otherwise). */
+  const void* cols16;
+  const int* cbase;        /* nblocks */
 } flow_pmg_level;
 typedef struct {
   flow_pmg_level fine, coarse;
@@ -354,6 +360,11 @@ int flow_pmg_pack(int n, int nnz, const int* rowptr, const int* diag_idx,
                   const double* a00, const double* a11,
                   const unsigned char* keep, void* vals, float* diag,
                   float* dinv, void* stream);
+/* cols16 / cbase of a level's pattern; *overflow_dev (zeroed by the caller) is
+ * set when an offset does not fit in 16 bits */
+int flow_pmg_cols16(int nblocks, const int* rowblocks, const int* rowptr,
+                    const int* cols, int* cbase, void* cols16,
+                    int* overflow_dev, void* stream);
 /* spectral radius of D^-1 A of a level by `iterations` (>= 2) steps of the
  * power method.  work: 6*n floats, dwork: FLOW_REDUCE_WORK doubles. */
 int flow_pmg_lambda_max(const flow_pmg_level* level, int iterations, float* work,
