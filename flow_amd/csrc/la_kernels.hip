@@ -1913,6 +1913,12 @@ __global__ __launch_bounds__(kBlock) void gmres_begin_kernel(
     target = fmax(rtol * sqrt(b2), atol);
     store_scalar(S + kB2, b2);
     store_scalar(S + kTarget2, target);
+    // a start vector that leaves a LARGER residual than zero would is dropped:
+    // S[kTmp] = 1 tells gmres_drop_start_kernel to put V_0 = b, x = 0
+    if (have_b2 && r > b2) {
+      store_scalar(S + kTmp, 1.0);
+      r = b2;
+    }
   } else {
     target = load_scalar(S + kTarget2);
   }
@@ -1924,6 +1930,20 @@ __global__ __launch_bounds__(kBlock) void gmres_begin_kernel(
     store_scalar(S + kDone, 2.0);
   else if (beta <= target || (accept10 && beta <= 10.0 * target))
     store_scalar(S + kDone, 4.0);
+}
+
+// behind gmres_begin_kernel of a solve that was handed a start vector: when that
+// vector was worse than zero (S[kTmp] set), V_0 = b and x = 0
+__global__ void gmres_drop_start_kernel(int n, const double* __restrict__ S,
+                                        const double* __restrict__ b,
+                                        double* __restrict__ v0,
+                                        double* __restrict__ x) {
+  if (load_scalar(S + kTmp) == 0.0) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    v0[i] = b[i];
+    x[i] = 0.0;
+  }
 }
 
 #define FLOW_NV_SWITCH(nv, CALL) \
@@ -2123,6 +2143,9 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
     hipLaunchKernelGGL(gmres_begin_kernel, dim3(1), dim3(kBlock), 0, st, np,
                        have_b2, first ? 1 : 0, claimed ? 1 : 0, rtol, atol,
                        partial, S);
+    if (have_b2)     // (a start vector was handed in: keep it only if it helps)
+      hipLaunchKernelGGL(gmres_drop_start_kernel, dim3(gv), dim3(kBlock), 0, st,
+                         N, S, b, V, x);
     FLOW_CHECK_LAUNCH();
     first = false;
     claimed = false;
@@ -3110,6 +3133,14 @@ static int shard_gmres(const flow_comm* C, const flow_rows* R,
     if (!have_target) {
       target = fmax(rtol * sqrt(host[0]), atol);
       have_target = true;
+      // a start vector that leaves a larger residual than zero would is
+      // dropped (every rank sees the same sums): V_0 = b, x = 0
+      if (!x_is_zero && host[1] > host[0]) {
+        hipLaunchKernelGGL(axpby_kernel, dim3(gv), dim3(kBlock), 0, st, N, 1.0, bc,
+                           0.0, V);
+        if ((rc = fill(N, 0.0, xc, st))) return rc;
+        host[1] = host[0];
+      }
     }
     const double res2 = host[1];
     const double beta = sqrt(res2);

@@ -112,6 +112,7 @@ class KarmanProblem(object):
         self._umag_start = fem.ops.StartChooser()
         self.W.layout._dev.pop('step_history', None)
         self.W.layout._dev.pop('newton_quad_C', None)
+        self.W.layout._dev.pop('newton_increments', None)
         return
 
     def prepare(self):

@@ -117,6 +117,13 @@ solver_parameters = {
                # preconditioner was applied
                'ilu_vector': 'fp32',
                'adaptive_forcing': False, 'matrix_free': True,
+               # start vector of the FIRST Newton iteration's linear solve:
+               # 'extrapolated' = the Newton increments of the previous calls,
+               # extrapolated linearly in time (a time loop's steps differ
+               # little: fewer Krylov iterations to the same tolerance -- the
+               # Newton path is untouched: still from u0, still a step solved
+               # to linear_atol_factor * tol); 'zero' = nothing carried
+               'linear_start': 'extrapolated', 'linear_start_points': 3,
                # 'previous' = always u0, the reference's choice (:204-220);
                # 'best' (mode 'fast'): see _compute_tentative_velocity
                'initial_guess': 'previous', 'guess_retry': 4},
@@ -141,13 +148,15 @@ solver_parameters = {
 _MODES = {
     'parity': {
         'newton': {'initial_guess': 'previous', 'linear_atol_factor': 1.0e-6,
-                   'forcing': 0.0, 'adaptive_forcing': False},
+                   'forcing': 0.0, 'adaptive_forcing': False,
+                   'linear_start': 'extrapolated'},
         'pressure': {'extrapolate': False},
         'correction': {'extrapolate': False},
         },
     'fast': {
         'newton': {'initial_guess': 'best', 'linear_atol_factor': 0.02,
-                   'forcing': 1.0e-4, 'adaptive_forcing': True},
+                   'forcing': 1.0e-4, 'adaptive_forcing': True,
+                   'linear_start': 'zero'},
         'pressure': {'extrapolate': True},
         'correction': {'extrapolate': True},
         },
@@ -239,6 +248,45 @@ def _bc_mask(dofs, n, comp=None):
         sel = dofs[(dofs >= comp * n) & (dofs < (comp + 1) * n)] - comp * n
         mask[sel] = 1
     return mask
+
+
+def _extrapolated_increment(lay, dt, dx, points=2):
+    '''dx <- the first Newton increment this call is likely to find: the
+    increments per unit time of the last calls (rates at the mid points of
+    their steps), extrapolated in time through `points` of them (Lagrange) to
+    the middle of this step and scaled with its size.  Only ever the START
+    VECTOR of a linear solve that is then converged to the same tolerance as
+    from zero.  Returns False (dx untouched) without a history.'''
+    hist = [h for h in lay._dev.get('newton_increments', [])
+            if h[0].numel() == dx.numel()][:points]
+    if not hist:
+        return False
+    # mid points of the past steps, time 0 = the end of the latest one
+    mids, t = [], 0.0
+    for _d, dtk in hist:
+        mids.append(t - 0.5 * dtk)
+        t -= dtk
+    m = 0.5 * dt
+    first = True
+    for i, (d, dtk) in enumerate(hist):
+        w = 1.0
+        for j in range(len(hist)):
+            if j != i:
+                w *= (m - mids[j]) / (mids[i] - mids[j])
+        ops.axpby(w * dt / dtk, d, 0.0 if first else 1.0, dx)
+        first = False
+    return True
+
+
+def _remember_increment(lay, dt, dx, keep_points=3):
+    hist = lay._dev.setdefault('newton_increments', [])
+    hist[:] = [h for h in hist if h[0].numel() == dx.numel()]
+    if len(hist) >= keep_points:
+        keep = hist.pop()[0]          # (re-use the oldest buffer)
+        ops.copy(keep, dx)
+    else:
+        keep = _hip.clone(dx)
+    hist.insert(0, (keep, dt))
 
 
 def _compute_tentative_velocity(
@@ -400,6 +448,10 @@ def _compute_tentative_velocity(
                 ))
 
         ops.fill(dx, 0.0)
+        dx_is_zero = True
+        if it == 0 and npar.get('linear_start') == 'extrapolated':
+            dx_is_zero = not _extrapolated_increment(
+                lay, dt, dx, int(npar.get('linear_start_points', 3)))
         pre = None
         kind = npar.get('preconditioner', 'jacobi')
         use_gmres = npar.get('linear_solver', 'gmres') == 'gmres'
@@ -508,7 +560,7 @@ def _compute_tentative_velocity(
                     'gmres', operator, F, dx, rtol=lin_rtol, atol=0.0,
                     maxit=maxit, ilu=pre if kind == 'ilu0' else None,
                     pmg=pre if kind == 'pmg' else None,
-                    restart=npar['gmres_restart'], x_is_zero=True,
+                    restart=npar['gmres_restart'], x_is_zero=dx_is_zero,
                     dinv='jacobi' if pre is None else None,
                     first_check=expected.get(it, 0),
                     # (the next Newton residual is the check of this solve)
@@ -524,6 +576,7 @@ def _compute_tentative_velocity(
                     lay._dev['pmg_rejected'] = (key, dt)
                     info('p-multigrid: GMRES stalled, redone with ILU(0)')
                     ops.fill(dx, 0.0)
+                    dx_is_zero = True
                     kind, pre, refactored = build('ilu0')
                     sol = gmres(npar['linear_maxit'])
             else:
@@ -541,6 +594,8 @@ def _compute_tentative_velocity(
         last_step_info['newton_preconditioner'] = kind
         if pre is not None:
             _age(pre, kind, refactored, its, sol.iterations, npar)
+        if it == 0 and npar.get('linear_start') == 'extrapolated':
+            _remember_increment(lay, dt, dx)
         ops.axpby(-1.0, dx, 1.0, ui.data)
         it += 1
     del keep0, keep1
@@ -694,13 +749,20 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
         lin_atol = max(npar['linear_atol_factor'] * tol, npar['forcing'] * nrm)
         lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
         ops.fill(dx, 0.0)
+        dx_is_zero = True
+        if it == 0 and npar.get('linear_start') == 'extrapolated':
+            # (every rank keeps the increments of its own rows: the same
+            # history length and step sizes everywhere)
+            dx_is_zero = not _extrapolated_increment(
+                lay, dt, dx, int(npar.get('linear_start_points', 3)))
         # (the count of the previous call's Newton iteration `it`: the same
         # number on every rank -- they all ran the same solve)
         expected = lay._dev.setdefault('gmres_expected_strip', {})
         def solve(maxit):
             return parallel.gmres(Jop, pre, F, dx, rtol=lin_rtol, atol=0.0,
                                   maxit=maxit, restart=npar['gmres_restart'],
-                                  x_is_zero=True, expected=expected.get(it, 0))
+                                  x_is_zero=dx_is_zero,
+                                  expected=expected.get(it, 0))
         if kind == 'pmg':
             # (no contraction test on the strips: a GMRES that has not
             # converged after `pmg_maxit` applications -- the count is the same
@@ -710,6 +772,7 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
             except _hip.NotConverged:
                 lay._dev['pmg_rejected_strip'] = (key, dt)
                 ops.fill(dx, 0.0)
+                dx_is_zero = True
                 kind, pre, refactored = build('ilu0')
                 sol = solve(npar['linear_maxit'])
         else:
@@ -720,6 +783,8 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
         linear_its.append(its)
         last_step_info['newton_preconditioner'] = kind + ' (block Jacobi)'
         _age(pre, kind, refactored, its, sol.iterations, npar)
+        if it == 0 and npar.get('linear_start') == 'extrapolated':
+            _remember_increment(lay, dt, dx)
         # (dx is zero outside the owned rows)
         ops.axpby(-1.0, dx, 1.0, ui.data)
         parallel.halo(ui.data, lay, 2)
