@@ -275,6 +275,8 @@ SYMBOLS = {
     'flow_mass_pack16': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_mass_solve': [_P(MassS), _VP, _VP, _D, _D, _I, _I, _VP,
                         ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_mass_solve_increment': [_P(MassS), _VP, _VP, _VP, _VP, _D, _D, _I, _I, _VP,
+                                  ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_gather_rows': [_I, _VP, _I, _VP, _I, _VP, _I, _VP],
     'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],
     'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],

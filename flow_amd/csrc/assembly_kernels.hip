@@ -212,7 +212,9 @@ __global__ __launch_bounds__(kBlock) void correction_rhs_kernel(
   double U[2][NL];
   load_local<NL>(u, nu, cdu, nc, c, 2, U);
   double d[3] = {0.0, 0.0, 0.0};
-  if (rotational) div_at_vertices<DEG>(g, U, d);
+  if (rotational & 1) div_at_vertices<DEG>(g, U, d);
+  // (bit 1: the increment's right-hand side, no (u, v) term)
+  const double mass = (rotational & 2) ? 0.0 : 1.0;
   double gphi_f[2] = {0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void correction_rhs_kernel(
       double uq = 0.0;
 #pragma unroll
       for (int j = 0; j < NL; ++j) uq += U[a][j] * phi[j];
-      const double val = w * (uq - dt_rho * gphi_f[a]);
+      const double val = w * (mass * uq - dt_rho * gphi_f[a]);
 #pragma unroll
       for (int i = 0; i < NL; ++i) acc[a][i] += val * phi[i];
     }

@@ -222,6 +222,20 @@ __global__ __launch_bounds__(kBlock) void mass_residual_pair_kernel(
   }
 }
 
+// the first defect of an INCREMENT solve (delta = 0): rho0 = D^-1 g, no product
+__global__ void mass_rho0_kernel(int n, int ncomp, const double* __restrict__ g,
+                                 const double* __restrict__ dinv,
+                                 float* __restrict__ rho0,
+                                 const double* __restrict__ stop) {
+  if (stopped(stop)) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x)
+    for (int a = 0; a < ncomp; ++a) {
+      const size_t k = static_cast<size_t>(a) * n + i;
+      rho0[static_cast<size_t>(i) * ncomp + a] = static_cast<float>(dinv[k] * g[k]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Chebyshev steps on the fp16 copy:  s = (D^-1 A) g  row by row, then
 //   MODE 0  first product (g = rho0 = rho_in, d_0 = c0 rho0 folded in):
@@ -251,19 +265,26 @@ __device__ __forceinline__ float vaxpby(float a, float x, float b, float y) {
 __device__ __forceinline__ float2 vaxpby(float a, float2 x, float b, float2 y) {
   return make_float2(a * x.x + b * y.x, a * x.y + b * y.y);
 }
-// x += z, returns (z.z, x.x) of the row
-__device__ __forceinline__ double2 add_to_x(double* x, int xs, int r, float z) {
+// x += z, returns (z.z, y.y) of the row, y = x [+ base: x is then the increment
+// of a solve around `base`, and the norm in the stopping test is the whole
+// solution's]
+__device__ __forceinline__ double2 add_to_x(double* x, const double* base, int xs,
+                                           int r, float z) {
   const double xn = x[r] + static_cast<double>(z);
   x[r] = xn;
-  return make_double2(static_cast<double>(z) * z, xn * xn);
+  const double y = base ? base[r] + xn : xn;
+  return make_double2(static_cast<double>(z) * z, y * y);
 }
-__device__ __forceinline__ double2 add_to_x(double* x, int xs, int r, float2 z) {
+__device__ __forceinline__ double2 add_to_x(double* x, const double* base, int xs,
+                                           int r, float2 z) {
   const double x0 = x[r] + static_cast<double>(z.x);
   const double x1 = x[xs + r] + static_cast<double>(z.y);
   x[r] = x0;
   x[xs + r] = x1;
+  const double y0 = base ? base[r] + x0 : x0;
+  const double y1 = base ? base[xs + r] + x1 : x1;
   return make_double2(static_cast<double>(z.x) * z.x + static_cast<double>(z.y) * z.y,
-                      x0 * x0 + x1 * x1);
+                      y0 * y0 + y1 * y1);
 }
 
 template <class V, int MODE, bool PACKED>
@@ -272,7 +293,8 @@ __global__ __launch_bounds__(kBlock) void mass_cheb_kernel(
     const void* __restrict__ vals, const int* __restrict__ rowblocks,
     const unsigned char* __restrict__ mask, const V* __restrict__ g,
     const V* rho_in, V* rho_out, float c0, float c1, float c2,
-    V* __restrict__ d_out, V* __restrict__ acc, double* __restrict__ x, int xs,
+    V* __restrict__ d_out, V* __restrict__ acc, double* __restrict__ x,
+    const double* __restrict__ xbase, int xs,
     double* __restrict__ zz_part, double* __restrict__ xx_part,
     const double* __restrict__ stop) {
   __shared__ V prod[kMassTile];
@@ -304,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void mass_cheb_kernel(
         d_out[r] = d;
         acc[r] = vaxpby(1.f, acc[r], 1.f, d);
       } else {
-        dots = add_to_x(x, xs, r, vaxpby(1.f, acc[r], 1.f, d));
+        dots = add_to_x(x, xbase, xs, r, vaxpby(1.f, acc[r], 1.f, d));
       }
     }
   }
@@ -440,8 +462,8 @@ struct Cheb {
 };
 
 template <class V, bool PACKED>
-int correction(const flow_mass* M, double* x, double* zz_part, double* xx_part,
-               const double* stop, hipStream_t st) {
+int correction(const flow_mass* M, double* x, const double* xbase, double* zz_part,
+               double* xx_part, const double* stop, hipStream_t st) {
   const flow_operator* A = M->A;
   const int n = A->n;
   // (PACKED: the packed stream and the tiles' base columns take the places of
@@ -462,20 +484,20 @@ int correction(const flow_mass* M, double* x, double* zz_part, double* xx_part,
   ch.next(&c1, &c2);
   hipLaunchKernelGGL((mass_cheb_kernel<V, 0, PACKED>), g16, blk, 0, st, n,
                      A->rowptr, cols, v16, M->rowblocks16, A->rowmask, rho0, rho0,
-                     rho, c0, c1, c2, d[0], acc, nod, n, nod, nod, stop);
+                     rho, c0, c1, c2, d[0], acc, nod, nod, n, nod, nod, stop);
   const int products = M->steps - 1;
   for (int j = 1; j + 1 < products; ++j) {
     ch.next(&c1, &c2);
     hipLaunchKernelGGL((mass_cheb_kernel<V, 1, PACKED>), g16, blk, 0, st, n,
                        A->rowptr, cols, v16, M->rowblocks16, A->rowmask,
-                       d[(j - 1) & 1], rho, rho, 0.f, c1, c2, d[j & 1], acc, nod, n,
-                       nod, nod, stop);
+                       d[(j - 1) & 1], rho, rho, 0.f, c1, c2, d[j & 1], acc, nod,
+                       nod, n, nod, nod, stop);
   }
   ch.next(&c1, &c2);
   hipLaunchKernelGGL((mass_cheb_kernel<V, 2, PACKED>), g16, blk, 0, st, n,
                      A->rowptr, cols, v16, M->rowblocks16, A->rowmask,
-                     d[(products - 2) & 1], rho, none, 0.f, c1, c2, none, acc, x, n,
-                     zz_part, xx_part, stop);
+                     d[(products - 2) & 1], rho, none, 0.f, c1, c2, none, acc, x,
+                     xbase, n, zz_part, xx_part, stop);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -508,7 +530,11 @@ static int mass_check(const flow_mass* M) {
   return FLOW_OK;
 }
 
-static int mass_solve(const flow_mass* M, const double* b, double* x, double rtol,
+// xbase != nullptr: the INCREMENT form -- b is the defect g = b' - M xbase of
+// the start xbase, x the increment; x_is_zero: it is zero on entry, the first
+// correction then needs no product with M
+static int mass_solve(const flow_mass* M, const double* b, double* x,
+                      const double* xbase, bool x_is_zero, double rtol,
                       double atol, int maxit, int first_check, double* work,
                       int* iters_host, double* resid_host, hipStream_t st) {
   const flow_operator* A = M->A;
@@ -520,24 +546,31 @@ static int mass_solve(const flow_mass* M, const double* b, double* x, double rto
   int rc;
   if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
   auto one = [&]() -> int {
-    if (A->kind == 4) {
+    if (x_is_zero) {
+      hipLaunchKernelGGL(mass_rho0_kernel, dim3(grid_for(A->n)), dim3(kBlock), 0,
+                         st, A->n, A->kind == 4 ? 2 : 1, b, M->dinv, M->work16,
+                         stop);
+      x_is_zero = false;
+    } else if (A->kind == 4) {
       hipLaunchKernelGGL(mass_residual_pair_kernel, dim3(A->nblocks), dim3(kBlock),
                          0, st, A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
                          A->rowmask, x, A->n, b, M->dinv,
                          reinterpret_cast<float2*>(M->work16), stop);
-      rc = M->packed16
-               ? correction<float2, true>(M, x, zz_part, xx_part, stop, st)
-               : correction<float2, false>(M, x, zz_part, xx_part, stop, st);
-      if (rc) return rc;
     } else {
       hipLaunchKernelGGL(mass_residual_kernel, dim3(A->nblocks), dim3(kBlock), 0, st,
                          A->rowptr, A->cols, A->vals[0], A->rowblocks, x, b, M->dinv,
                          M->work16, stop);
-      rc = M->packed16
-               ? correction<float, true>(M, x, zz_part, xx_part, stop, st)
-               : correction<float, false>(M, x, zz_part, xx_part, stop, st);
-      if (rc) return rc;
     }
+    if (A->kind == 4) {
+      rc = M->packed16
+               ? correction<float2, true>(M, x, xbase, zz_part, xx_part, stop, st)
+               : correction<float2, false>(M, x, xbase, zz_part, xx_part, stop, st);
+    } else {
+      rc = M->packed16
+               ? correction<float, true>(M, x, xbase, zz_part, xx_part, stop, st)
+               : correction<float, false>(M, x, xbase, zz_part, xx_part, stop, st);
+    }
+    if (rc) return rc;
     hipLaunchKernelGGL(mass_scalar_kernel, dim3(1), dim3(kMassScalarBlock), 0, st,
                        M->nblocks16, zz_part, xx_part, c2, rtol * rtol, atol * atol,
                        S);
@@ -617,6 +650,51 @@ extern "C" int flow_mass_solve(const flow_mass* M, const double* b, double* x,
                "solver tolerances");
   FLOW_REQUIRE(work_len >= FLOW_REDUCE_WORK + 2 * static_cast<size_t>(M->nblocks16),
                "mass solve workspace too small");
-  return mass_solve(M, b, x, rtol, atol, maxit, first_check, work, iters_host,
-                    resid_host, as_stream(stream));
+  return mass_solve(M, b, x, nullptr, false, rtol, atol, maxit, first_check, work,
+                    iters_host, resid_host, as_stream(stream));
+}
+
+// y = a + b  (the solution of an increment solve; b == nullptr: y = a)
+__global__ void mass_sum_kernel(int n, const double* __restrict__ a,
+                                const double* __restrict__ b,
+                                double* __restrict__ y) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x)
+    y[i] = b ? a[i] + b[i] : a[i];
+}
+
+extern "C" int flow_mass_solve_increment(const flow_mass* M, const double* g,
+                                         const double* xbase,
+                                         const double* delta0, double* x,
+                                         double rtol, double atol, int maxit,
+                                         int first_check, double* work,
+                                         size_t work_len, int* iters_host,
+                                         double* resid_host, void* stream) {
+  int rc = mass_check(M);
+  if (rc) return rc;
+  FLOW_REQUIRE(g && xbase && x && work && iters_host && resid_host,
+               "solver pointers");
+  FLOW_REQUIRE(rtol >= 0.0 && atol >= 0.0 && maxit >= 1 && first_check >= 0,
+               "solver tolerances");
+  const size_t N = M->A->kind == 4 ? 2 * static_cast<size_t>(M->A->n) : M->A->n;
+  const size_t head = FLOW_REDUCE_WORK + 2 * static_cast<size_t>(M->nblocks16);
+  FLOW_REQUIRE(work_len >= head + (head & 1) + N, "mass solve workspace too small");
+  hipStream_t st = as_stream(stream);
+  double* delta = work + head + (head & 1);
+  if (delta0) {
+    hipLaunchKernelGGL(mass_sum_kernel, dim3(grid_for(N)), dim3(kBlock), 0, st,
+                       static_cast<int>(N), delta0, static_cast<const double*>(nullptr),
+                       delta);
+    FLOW_CHECK_LAUNCH();
+  } else if ((rc = fill(static_cast<int>(N), 0.0, delta, st))) {
+    return rc;
+  }
+  rc = mass_solve(M, g, delta, xbase, delta0 == nullptr, rtol, atol, maxit,
+                  first_check, work, iters_host, resid_host, st);
+  // (the increment found so far is added also when the solve did not converge,
+  // like the in-place solve leaves its last iterate)
+  hipLaunchKernelGGL(mass_sum_kernel, dim3(grid_for(N)), dim3(kBlock), 0, st,
+                     static_cast<int>(N), xbase, delta, x);
+  FLOW_CHECK_LAUNCH();
+  return rc;
 }

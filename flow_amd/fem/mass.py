@@ -113,6 +113,32 @@ class MassSolver(object):
             held[key] = cls(A, dinv, **kw)
         return held[key]
 
+    def solve_increment(self, g, xbase, x, rtol, atol=0.0, maxit=50, tag=None,
+                        first_check=0, delta0=None):
+        '''x = xbase + increment, M increment = g (g = b - M xbase handed in by
+        the caller: no product with M to form it, and fp64 only has to resolve
+        the increment); x may be xbase.'''
+        n = self.A.size
+        head = _hip.REDUCE_WORK + 2 * self.struct.nblocks16
+        wk = ops.work(head + 2 + n)
+        if first_check == 0 and tag is not None and tag in self.history:
+            first_check = self.history[tag]
+        its = ctypes.c_int(0)
+        res = ctypes.c_double(0.0)
+        _hip.check(_hip.lib().flow_mass_solve_increment(
+            ctypes.byref(self.struct), _hip.f64(g, n, 'g'),
+            _hip.f64(xbase, n, 'xbase'),
+            _hip.f64(delta0, n, 'delta0') if delta0 is not None else None,
+            _hip.f64(x, n, 'x'),
+            float(rtol), float(atol), int(maxit), int(first_check),
+            _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
+            _hip.stream()))
+        if tag is not None:
+            self.history[tag] = its.value
+        return ops.SolveInfo(its.value, res.value,
+                             'defect correction (increment) + chebyshev%d/fp16'
+                             % self.struct.steps)
+
     def solve(self, b, x, rtol, atol=0.0, maxit=50, tag=None, first_check=0):
         '''x holds the initial guess; raises _hip.NotConverged like the Krylov
         solvers.  tag: the solve recurs in a time loop under that name -- as

@@ -142,7 +142,10 @@ solver_parameters = {
     # one fp64 + `chebyshev_steps` - 1 fp16 products, no dot products) or 'cg'
     # (Jacobi-CG, 11-14 iterations; what the strips run)
     'correction': {'maxit': 10000, 'check_every': 2, 'extrapolate': False,
-                   'method': 'chebyshev', 'chebyshev_steps': 6},
+                   'method': 'chebyshev', 'chebyshev_steps': 6,
+                   # solve for u1 - ui (flow_mass_solve_increment), started from
+                   # the previous increments extrapolated in time ('zero': not)
+                   'increment': True, 'increment_start': 'extrapolated'},
     }
 
 _MODES = {
@@ -250,14 +253,15 @@ def _bc_mask(dofs, n, comp=None):
     return mask
 
 
-def _extrapolated_increment(lay, dt, dx, points=2):
+def _extrapolated_increment(lay, dt, dx, points=2, key='newton_increments',
+                            power=1):
     '''dx <- the first Newton increment this call is likely to find: the
     increments per unit time of the last calls (rates at the mid points of
     their steps), extrapolated in time through `points` of them (Lagrange) to
     the middle of this step and scaled with its size.  Only ever the START
     VECTOR of a linear solve that is then converged to the same tolerance as
     from zero.  Returns False (dx untouched) without a history.'''
-    hist = [h for h in lay._dev.get('newton_increments', [])
+    hist = [h for h in lay._dev.get(key, [])
             if h[0].numel() == dx.numel()][:points]
     if not hist:
         return False
@@ -273,13 +277,14 @@ def _extrapolated_increment(lay, dt, dx, points=2):
         for j in range(len(hist)):
             if j != i:
                 w *= (m - mids[j]) / (mids[i] - mids[j])
-        ops.axpby(w * dt / dtk, d, 0.0 if first else 1.0, dx)
+        # (what is smooth in time is increment / dt^power)
+        ops.axpby(w * (dt / dtk)**power, d, 0.0 if first else 1.0, dx)
         first = False
     return True
 
 
-def _remember_increment(lay, dt, dx, keep_points=3):
-    hist = lay._dev.setdefault('newton_increments', [])
+def _remember_increment(lay, dt, dx, keep_points=3, key='newton_increments'):
+    hist = lay._dev.setdefault(key, [])
     hist[:] = [h for h in hist if h[0].numel() == dx.numel()]
     if len(hist) >= keep_points:
         keep = hist.pop()[0]          # (re-use the oldest buffer)
@@ -998,13 +1003,25 @@ def _compute_velocity_correction(
     n2 = W.size()
     st = _hip.stream()
 
+    par = solver_parameters['correction']
+    # With the defect-correction solver the system is solved for the INCREMENT
+    # u1 - ui: its right-hand side -dt/rho (grad phi, v) is the defect of the
+    # start ui itself, assembled without the (ui, v) term -- one fp64 product
+    # and (the increment being ~1e-5 of the field) one correction less
+    # (not with an extrapolated start vector -- mode 'fast' --: the right-hand
+    # side below is the defect of the start ui and of nothing else)
+    increment = (not parallel.active()
+                 and par.get('method', 'chebyshev') == 'chebyshev'
+                 and par.get('increment', True)
+                 and not par.get('extrapolate', False))
     b = _zeros(n2) if parallel.active() else device.empty(n2)
     buf = ops.scratch(mesh, 2 * lay.nloc * nc)
     _hip.check(lib.flow_assemble_correction_rhs(
         ctypes.byref(_mesh_s(mesh)), ctypes.byref(_space_s(lay)),
         ctypes.byref(_space_s(P.layout)), _hip.f64(ui.data, n2),
         _hip.f64(p1.data, P.N), _hip.f64(p0.data, P.N), dt / rho, mu,
-        int(rotational_form), _hip.f64(buf), _hip.f64(b, n2), st
+        int(rotational_form) | (2 if increment else 0), _hip.f64(buf),
+        _hip.f64(b, n2), st
         ))
     # `solve(a == L, u1, bcs, 'symmetric': True)` eliminates the Dirichlet dofs
     # symmetrically (assemble_system).  Both velocity components share ONE mass
@@ -1044,19 +1061,54 @@ def _compute_velocity_correction(
         ops.axpby(r, hist['u_out'], 1.0, u1.data)
         ops.axpby(-r, hist['ui'], 1.0, u1.data)
     if nbc > 0:
-        for vec in (b, u1.data):
+        _hip.check(lib.flow_bc_set_values(
+            nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(u1.data), st
+            ))
+        if increment:
+            # (the increment vanishes on the Dirichlet rows: the start carries
+            # the boundary values)
+            zeros = lay._dev.get(('bc_zeros', nbc))
+            if zeros is None:
+                zeros = lay._dev[('bc_zeros', nbc)] = _zeros(nbc)
             _hip.check(lib.flow_bc_set_values(
-                nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(vec), st
-                ))
-    par = solver_parameters['correction']
+                nbc, _hip.i32(bc_dofs), _hip.f64(zeros), _hip.f64(b), st))
+        else:
+            _hip.check(lib.flow_bc_set_values(
+                nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(b), st))
     if parallel.active():
         sol = parallel.cg(Mbc, dinv, b, u1.data, tol, 0.0, par['maxit'],
                           check_every=par['check_every'], tag='correction')
     elif par.get('method', 'chebyshev') == 'chebyshev':
         from ..fem.mass import MassSolver
-        sol = MassSolver.cached(
-            Mbc, dinv, steps=par.get('chebyshev_steps', 6)).solve(
-                b, u1.data, tol, maxit=min(par['maxit'], 100), tag='correction')
+        solver = MassSolver.cached(Mbc, dinv,
+                                   steps=par.get('chebyshev_steps', 6))
+        if increment:
+            # start of the increment: the previous calls' increments,
+            # extrapolated in time (u1 - ui = -dt/rho M^-1 grad(phi) ~ dt^2
+            # p_t: smooth from step to step) -- a start vector only
+            d0 = None
+            if par.get('increment_start') == 'extrapolated':
+                d0 = device.empty(n2)
+                if not _extrapolated_increment(
+                        lay, dt, d0, 3, key='correction_increments', power=2):
+                    d0 = None
+                elif nbc > 0:
+                    _hip.check(lib.flow_bc_set_values(
+                        nbc, _hip.i32(bc_dofs),
+                        _hip.f64(lay._dev[('bc_zeros', nbc)]), _hip.f64(d0),
+                        st))
+            ui_keep = ui.data
+            sol = solver.solve_increment(
+                b, u1.data, u1.data, tol, maxit=min(par['maxit'], 100),
+                tag='correction', delta0=d0)
+            if par.get('increment_start') == 'extrapolated':
+                d0 = d0 if d0 is not None else device.empty(n2)
+                ops.copy(d0, u1.data)
+                ops.axpby(-1.0, ui_keep, 1.0, d0)
+                _remember_increment(lay, dt, d0, key='correction_increments')
+        else:
+            sol = solver.solve(b, u1.data, tol, maxit=min(par['maxit'], 100),
+                               tag='correction')
     else:
         sol = ops.krylov_solve(
             'cg', Mbc, b, u1.data, rtol=tol, atol=0.0, maxit=par['maxit'],

@@ -441,6 +441,24 @@ int flow_mass_solve(const flow_mass* M, const double* b, double* x, double rtol,
                     size_t work_len, int* iters_host, double* resid_host,
                     void* stream);
 
+/* The same for a solve whose start xbase is close, in INCREMENT form:
+ * M (x - xbase) = g with the defect g = b - M xbase GIVEN by the caller -- the
+ * velocity correction's is -dt/rho (grad phi, v), assembled without the
+ * (ui, v) term (flow_assemble_correction_rhs, flag bit 1) -- and the increment
+ * iterated from zero in a vector of its own: the first correction needs no
+ * product with M, and fp64 only has to resolve the increment.  delta0 (or
+ * NULL): a start vector for the increment (a time loop's previous increments,
+ * extrapolated; the first defect is then g - M delta0).  The stopping
+ * test is the one above with |x| = |xbase + increment|.  x = xbase + increment
+ * on return (x may be xbase; the rows A masks as identity rows need g = 0).
+ * work: FLOW_REDUCE_WORK + 2 * nblocks16 + 1 + op-size doubles. */
+int flow_mass_solve_increment(const flow_mass* M, const double* g,
+                              const double* xbase, const double* delta0,
+                              double* x, double rtol,
+                              double atol, int maxit, int first_check,
+                              double* work, size_t work_len, int* iters_host,
+                              double* resid_host, void* stream);
+
 /* ---- K12: Krylov drivers -------------------------------------------------
  * Device-resident loops.  Convergence is decided ON THE DEVICE: the kernel
  * that computes the solver scalars compares the residual norm with the target
@@ -725,7 +743,10 @@ int flow_assemble_pressure_rhs(const flow_mesh* mesh, const flow_space* W,
 
 /* K4: L3 (pressure_correction.py:444-449):
  *   b_(a,i) = (u_a, v_i) - dt/rho (d_a phi, v_i),
- *   phi = p1 - p0 [+ mu div u  if rotational].   scratch: 2*nloc*nc. */
+ *   phi = p1 - p0 [+ mu div u  if rotational & 1].   scratch: 2*nloc*nc.
+ * rotational & 2: WITHOUT the (u_a, v_i) term -- the defect b - M u of the
+ * start u = ui, the right-hand side of the correction's increment
+ * (flow_mass_solve_increment). */
 int flow_assemble_correction_rhs(const flow_mesh* mesh, const flow_space* W,
                                  const flow_space* P, const double* u,
                                  const double* p1, const double* p0,
