@@ -114,6 +114,7 @@ class KarmanProblem(object):
         self.W.layout._dev.pop('newton_quad_C', None)
         self.W.layout._dev.pop('newton_increments', None)
         self.W.layout._dev.pop('correction_increments', None)
+        self.P.layout._dev.pop('pressure_increments', None)
         return
 
     def prepare(self):

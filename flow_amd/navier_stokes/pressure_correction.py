@@ -136,7 +136,10 @@ solver_parameters = {
                  'multigrid': True, 'coarse_size': 4096, 'extrapolate': False,
                  # rows below which the multigrid hierarchy stops coarsening
                  # (dense inverse there)
-                 'mg_coarsest': 4200},
+                 'mg_coarsest': 4200,
+                 # start vector: p0 ('zero') or p0 + the previous increments
+                 # extrapolated in time ('extrapolated'; Dirichlet branch)
+                 'start': 'extrapolated'},
     # 'method': 'chebyshev' = mixed-precision defect correction with a fixed
     # Chebyshev polynomial of D^-1 M (flow_amd/fem/mass.py: 3-4 corrections of
     # one fp64 + `chebyshev_steps` - 1 fp16 products, no dot products) or 'cg'
@@ -153,14 +156,14 @@ _MODES = {
         'newton': {'initial_guess': 'previous', 'linear_atol_factor': 1.0e-6,
                    'forcing': 0.0, 'adaptive_forcing': False,
                    'linear_start': 'extrapolated'},
-        'pressure': {'extrapolate': False},
+        'pressure': {'extrapolate': False, 'start': 'extrapolated'},
         'correction': {'extrapolate': False},
         },
     'fast': {
         'newton': {'initial_guess': 'best', 'linear_atol_factor': 0.02,
                    'forcing': 1.0e-4, 'adaptive_forcing': True,
                    'linear_start': 'zero'},
-        'pressure': {'extrapolate': True},
+        'pressure': {'extrapolate': True, 'start': 'zero'},
         'correction': {'extrapolate': True},
         },
     }
@@ -900,6 +903,15 @@ def _compute_pressure(
     # zero like the reference's zero start, so that no constant accumulates
     # from step to step, and still exact on a state of rest.
     ops.copy(p1.data, p0.data)
+    phi_start = None
+    if hist is None and par.get('start') == 'extrapolated':
+        # ... plus the previous calls' pressure increments p1 - p0 extrapolated
+        # in time (3-point, as the Newton increments: a start vector only; on
+        # the strips every rank extrapolates its own + ghost rows)
+        phi_start = device.empty(P.N)
+        if _extrapolated_increment(lay, dt, phi_start, 3,
+                                   key='pressure_increments', power=1):
+            ops.axpby(1.0, phi_start, 1.0, p1.data)
     if not p_bcs:
         one = lay._dev.get('ones')
         if one is None:
@@ -980,6 +992,10 @@ def _compute_pressure(
             lay._dev[key] = K.diag_inv()
         coarse = _preconditioner(lay, key, K, None, True, par)
         sol = _pressure_cg(K, lay._dev[key], coarse, b, p1.data, tol, par)
+    if phi_start is not None:
+        ops.copy(phi_start, p1.data)
+        ops.axpby(-1.0, p0.data, 1.0, phi_start)
+        _remember_increment(lay, dt, phi_start, key='pressure_increments')
     if verbose:
         info('pressure: %r' % sol)
     last_step_info['pressure'] = sol

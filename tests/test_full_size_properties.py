@@ -221,6 +221,10 @@ def test_steps_are_reproducible(problem):
     prob, infos = problem
 
     def rerun(p):
+        # (reset: fields, clock, step size and everything a time loop carries
+        # from step to step -- the controller's memory, the start-vector
+        # histories of the linear solves)
+        p.reset(1.0e-5)
         p.set_initial_profile()
         _hip.fill(p.p0.data, 0.0)
         p.dt, p.t = 1.0e-5, 0.0

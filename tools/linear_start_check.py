@@ -33,11 +33,13 @@ def main():
         navsto.solver_parameters['newton']['linear_start_points'] = \
             int(os.environ.get('POINTS', '3'))
         navsto.solver_parameters['correction']['increment_start'] = mode
+        navsto.solver_parameters['pressure']['start'] = mode
         prob.restore(snap)
         fields, apps = [], []
         for _ in range(steps):
             info = prob.step()
             apps.append((sum(info['newton_linear_applications']),
+                         info['pressure'].iterations,
                          info['correction'].iterations))
             fields.append((device.to_host(prob.u0.data).numpy().copy(),
                            device.to_host(prob.p0.data).numpy().copy(),
@@ -47,7 +49,7 @@ def main():
     for k in range(steps):
         du = numpy.linalg.norm(fa[k][0] - fb[k][0]) / numpy.linalg.norm(fa[k][0])
         dp = numpy.linalg.norm(fa[k][1] - fb[k][1]) / numpy.linalg.norm(fa[k][1])
-        print('step %2d: du %.2e dp %.2e ddt %.1e  applications, corrections '
+        print('step %2d: du %.2e dp %.2e ddt %.1e  GMRES applications, pressure its, corrections '
               '%r -> %r' % (k, du, dp, abs(fa[k][2] - fb[k][2]) / fa[k][2],
                             aa[k], ab[k]))
 
