@@ -1092,8 +1092,28 @@ def _compute_velocity_correction(
             _hip.check(lib.flow_bc_set_values(
                 nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(b), st))
     if parallel.active():
+        # Jacobi-CG on the strips, started from ui + the previous increments
+        # u1 - ui extrapolated in time (as the single-GPU solver's increment)
+        extrap = par.get('increment_start') == 'extrapolated' \
+            and not par.get('extrapolate', False)
+        if extrap:
+            d0 = _zeros(n2)
+            if _extrapolated_increment(lay, dt, d0, 3,
+                                       key='correction_increments', power=2):
+                if nbc > 0:
+                    zeros = lay._dev.get(('bc_zeros', nbc))
+                    if zeros is None:
+                        zeros = lay._dev[('bc_zeros', nbc)] = _zeros(nbc)
+                    _hip.check(lib.flow_bc_set_values(
+                        nbc, _hip.i32(bc_dofs), _hip.f64(zeros), _hip.f64(d0),
+                        st))
+                ops.axpby(1.0, d0, 1.0, u1.data)
         sol = parallel.cg(Mbc, dinv, b, u1.data, tol, 0.0, par['maxit'],
                           check_every=par['check_every'], tag='correction')
+        if extrap:
+            ops.copy(d0, u1.data)
+            ops.axpby(-1.0, ui.data, 1.0, d0)
+            _remember_increment(lay, dt, d0, key='correction_increments')
     elif par.get('method', 'chebyshev') == 'chebyshev':
         from ..fem.mass import MassSolver
         solver = MassSolver.cached(Mbc, dinv,

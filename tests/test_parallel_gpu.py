@@ -519,3 +519,71 @@ def test_boussinesq_sweeps_on_strips(hip, supg):
         assert numpy.array_equal(res['theta'], out[0]['theta'])
     print('Boussinesq on 2 strips (supg %r): dtheta %.2e du %.2e dp %.2e, '
           'sweeps %r' % (supg, eth, eu, ep, log))
+
+
+# -- collectives per time step --------------------------------------------------------
+def _count_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LOCAL_RANK'] = '0'
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from flow_amd import parallel, karman
+        import flow_amd.navier_stokes as navsto
+        navsto.solver_parameters['pressure']['mg_coarsest'] = 200
+        parallel.enable(dist.group.WORLD, force=True)
+        # the bench's protocol at a sixteenth of its size: the non-dimensional
+        # regime of the headline workload (viscosity scaled with the mesh
+        # width: cell Peclet number ~2), Stokes start, settled to the plateau
+        # of the step-size controller -- what a run spends its time in
+        prob = karman.KarmanProblem(386, 90, mu=0.0113)
+        prob.prepare()
+        prob.reset(1.0e-5)
+        prob.set_initial_stokes()
+        prob.settle()
+        for _ in range(4):          # (the start-vector histories fill up)
+            prob.step()
+        comm = parallel.comm()
+        rows = []
+        for _ in range(6):
+            c0 = comm.calls
+            info = prob.step()
+            rows.append(dict(
+                calls=comm.calls - c0,
+                newton=len(info['newton_residuals']) - 1,
+                gmres=sum(info['newton_linear_applications']),
+                pressure=info['pressure'].iterations,
+                correction=info['correction'].iterations,
+                projection=info.get('projection_iterations', 0)))
+        out[rank] = rows
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collectives_per_time_step(hip):
+    '''What one settled time step costs in collectives on the strips (counted at
+    the all-reduce callback, every halo and every reduction is one): two per
+    GMRES application (halo of the operator's input, Gram-Schmidt sums), two
+    per V-cycle CG iteration (the coarse residual travels by recurrence), one
+    per mass-CG iteration, plus the starts of the solves and the norms of the
+    Newton iteration and the step-size controller -- and, with the start
+    vectors extrapolated in time, few iterations of each.  Round 3 counted ~110
+    per step at the headline size; the same accounting gives ~60 there now and
+    78-86 on this small problem (two narrow strips cost the block-Jacobi cycle
+    more GMRES applications than eight strips of the headline mesh do).'''
+    world = 2
+    manager = mp.get_context('spawn').Manager()
+    out = manager.dict()
+    mp.spawn(_count_worker, args=(world, _free_port(), out), nprocs=world,
+             join=True)
+    assert out[0] == out[1]           # the same path on every rank
+    for row in out[0]:
+        # the budget of a step, from its own iteration counts
+        budget = (2 * row['gmres'] + 6 * max(row['newton'], 1) + 2
+                  + 2 * (row['pressure'] + 2) + 7
+                  + (row['correction'] + 2) + 3
+                  + (row['projection'] + 2) + 3 + 2)
+        assert row['calls'] <= budget, (row, budget)
+    print('collectives per settled step on 2 strips: %r' % (out[0],))
+    assert max(r['calls'] for r in out[0][2:]) <= 90, out[0]
