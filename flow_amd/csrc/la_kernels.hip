@@ -1570,6 +1570,31 @@ extern "C" int flow_profile_marker(int id, void* stream) {
   return FLOW_OK;
 }
 
+// y = a0 x0 + a1 x1 + a2 x2 in one pass (terms with a NULL vector are skipped)
+__global__ void lincomb3_kernel(int n, double a0, const double* __restrict__ x0,
+                                double a1, const double* __restrict__ x1,
+                                double a2, const double* __restrict__ x2,
+                                double* __restrict__ y) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    double v = a0 * x0[i];
+    if (x1) v += a1 * x1[i];
+    if (x2) v += a2 * x2[i];
+    y[i] = v;
+  }
+}
+
+extern "C" int flow_lincomb3(int n, double a0, const double* x0, double a1,
+                             const double* x1, double a2, const double* x2,
+                             double* y, void* stream) {
+  FLOW_REQUIRE(n >= 0 && x0 && y, "lincomb3 arguments");
+  if (n == 0) return FLOW_OK;
+  hipLaunchKernelGGL(lincomb3_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
+                     as_stream(stream), n, a0, x0, a1, x1, a2, x2, y);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
 extern "C" int flow_fill(int n, double value, double* y, void* stream) {
   FLOW_REQUIRE(n > 0 && y, "fill arguments");
   return fill(n, value, y, as_stream(stream));

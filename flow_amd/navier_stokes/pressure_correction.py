@@ -265,7 +265,7 @@ def _extrapolated_increment(lay, dt, dx, points=2, key='newton_increments',
     VECTOR of a linear solve that is then converged to the same tolerance as
     from zero.  Returns False (dx untouched) without a history.'''
     hist = [h for h in lay._dev.get(key, [])
-            if h[0].numel() == dx.numel()][:points]
+            if h[0].numel() == dx.numel()][:min(points, 3)]
     if not hist:
         return False
     # mid points of the past steps, time 0 = the end of the latest one
@@ -274,15 +274,22 @@ def _extrapolated_increment(lay, dt, dx, points=2, key='newton_increments',
         mids.append(t - 0.5 * dtk)
         t -= dtk
     m = 0.5 * dt
-    first = True
+    terms = []
     for i, (d, dtk) in enumerate(hist):
         w = 1.0
         for j in range(len(hist)):
             if j != i:
                 w *= (m - mids[j]) / (mids[i] - mids[j])
         # (what is smooth in time is increment / dt^power)
-        ops.axpby(w * (dt / dtk)**power, d, 0.0 if first else 1.0, dx)
-        first = False
+        terms.append((w * (dt / dtk)**power, d))
+    while len(terms) < 3:
+        terms.append((0.0, None))
+    n = dx.numel()
+    _hip.check(_hip.lib().flow_lincomb3(
+        n, terms[0][0], _hip.f64(terms[0][1], n),
+        terms[1][0], _hip.f64(terms[1][1], n) if terms[1][1] is not None else None,
+        terms[2][0], _hip.f64(terms[2][1], n) if terms[2][1] is not None else None,
+        _hip.f64(dx, n), _hip.stream()))
     return True
 
 

@@ -140,6 +140,12 @@ int flow_axpby(int n, double a, const double* x, double b, double* y,
 int flow_vmul(int n, double a, const double* x, const double* y, double* out,
               void* stream);                        /* out = a x .* y */
 int flow_fill(int n, double value, double* y, void* stream);   /* y = value */
+/* y = a0 x0 + a1 x1 + a2 x2 in one pass (x1 / x2 may be NULL: term skipped; y
+ * must not be one of the x): the start vectors a time loop extrapolates from
+ * its previous increments */
+int flow_lincomb3(int n, double a0, const double* x0, double a1,
+                  const double* x1, double a2, const double* x2, double* y,
+                  void* stream);
 /* dst[a*dst_stride + k] = src[a*src_stride + idx[k]], k < m, a < ncomp: the
  * vertex values of a P2 field (the linearisation point of the P1 level of
  * flow_pmg) */
