@@ -49,16 +49,23 @@ def _read_msh_binary(raw, start):
     if numpy.frombuffer(raw, dtype=order + 'i4', count=1, offset=start)[0] != 1:
         raise ValueError('binary MSH: bad endianness marker')
 
-    def section(name):
-        tag = ('$%s\n' % name).encode()
-        at = raw.index(tag) + len(tag)
+    def section(name, frm):
+        # sections are found SEQUENTIALLY, from the end of the one before: a
+        # search over the whole file could hit the tag's bytes inside a binary
+        # payload
+        tag = ('$%s' % name).encode()
+        at = raw.index(tag, frm) + len(tag)
+        eol = raw.index(b'\n', at)            # (LF or CRLF line ends)
+        at = eol + 1
         eol = raw.index(b'\n', at)
-        return int(raw[at:eol]), eol + 1
+        return int(raw[at:eol].strip()), eol + 1
 
-    n, at = section('Nodes')
+    # behind the format line: the 4-byte endianness marker, its line end, then
+    # $EndMeshFormat
+    n, at = section('Nodes', start + 4)
     rec = numpy.dtype([('id', order + 'i4'), ('x', order + 'f8', (3,))])
     nodes = numpy.frombuffer(raw, dtype=rec, count=n, offset=at)
-    m, at = section('Elements')
+    m, at = section('Elements', at + n * rec.itemsize)
     tris = []
     seen = 0
     while seen < m:
@@ -127,15 +134,22 @@ def write_msh(path, mesh, binary=False):
 
 
 def _write_msh_binary(path, mesh):
-    '''MSH 2.2 binary, little endian: one element block of triangles with two
-    tags each, boundary edges (type 1) in a block before it as gmsh writes
-    physical lines.'''
+    '''MSH 2.2 binary, little endian: the boundary edges (element type 1, two
+    tags) in a block of their own BEFORE the block of triangles, as gmsh
+    writes physical lines -- readers have to walk mixed blocks.'''
     nv, nc = mesh.num_vertices(), mesh.num_cells()
     rec = numpy.zeros(nv, dtype=[('id', '<i4'), ('x', '<f8', (3,))])
     rec['id'] = numpy.arange(1, nv + 1)
     rec['x'][:, :2] = mesh.points
+    bedges = mesh.edges[mesh.bfacets]
+    nb = len(bedges)
+    lines = numpy.zeros((nb, 5), dtype='<i4')
+    lines[:, 0] = numpy.arange(1, nb + 1)
+    lines[:, 1] = 1
+    lines[:, 2] = 1
+    lines[:, 3:] = bedges + 1
     tri = numpy.zeros((nc, 6), dtype='<i4')
-    tri[:, 0] = numpy.arange(1, nc + 1)
+    tri[:, 0] = numpy.arange(nb + 1, nb + nc + 1)
     tri[:, 2] = 1
     tri[:, 3:] = mesh.cell_vertices + 1
     with open(path, 'wb') as fh:
@@ -143,7 +157,9 @@ def _write_msh_binary(path, mesh):
         fh.write(numpy.array([1], dtype='<i4').tobytes())
         fh.write(b'\n$EndMeshFormat\n$Nodes\n%d\n' % nv)
         fh.write(rec.tobytes())
-        fh.write(b'\n$EndNodes\n$Elements\n%d\n' % nc)
+        fh.write(b'\n$EndNodes\n$Elements\n%d\n' % (nb + nc))
+        fh.write(numpy.array([1, nb, 2], dtype='<i4').tobytes())
+        fh.write(lines.tobytes())
         fh.write(numpy.array([2, nc, 2], dtype='<i4').tobytes())
         fh.write(tri.tobytes())
         fh.write(b'\n$EndElements\n')

@@ -171,7 +171,12 @@ def csr_stream_rowblocks(rowptr, rows_per_block=SPMV_ROWS_PER_BLOCK,
     one of them then stays below the cap.'''
     if nnz_per_block is None:
         from .. import _hip
-        nnz_per_block = _hip.spmv_tile_nnz(0)
+        try:
+            nnz_per_block = _hip.spmv_tile_nnz(0)
+        except (OSError, _hip.HipError):
+            # host-only use (mesh IO, transfer tables, oracle comparisons)
+            # without a built library: the header's constant
+            nnz_per_block = _hip.SPMV_NNZ_PER_BLOCK
     rowptrs = rowptr if isinstance(rowptr, (list, tuple)) else [rowptr]
     rowptrs = [numpy.asarray(rp, dtype=numpy.int64) for rp in rowptrs]
     n = len(rowptrs[0]) - 1

@@ -529,6 +529,9 @@ def _compute_tentative_velocity(
                 last_step_info['pmg_contraction'] = pre.contraction
                 if not pre.contraction < npar.get('pmg_accept', 0.8):
                     lay._dev['pmg_rejected'] = (key, dt)
+                    # (once the rejection lapses the cycle is refactored and
+                    # tested again, not taken from the slot as it is)
+                    pre.stale = True
                     info('p-multigrid rejected (contraction %.2f): ILU(0)'
                          % pre.contraction)
                     return build('ilu0')
@@ -589,6 +592,7 @@ def _compute_tentative_velocity(
                                     npar.get('pmg_maxit', 150)))
                 except _hip.NotConverged:
                     lay._dev['pmg_rejected'] = (key, dt)
+                    pre.stale = True
                     info('p-multigrid: GMRES stalled, redone with ILU(0)')
                     ops.fill(dx, 0.0)
                     dx_is_zero = True
@@ -747,6 +751,7 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
                 last_step_info['pmg_contraction'] = pre.contraction
                 if not pre.contraction < npar.get('pmg_accept', 0.8):
                     lay._dev['pmg_rejected_strip'] = (key, dt)
+                    pre.stale = True
                     return build('ilu0')
                 return 'pmg', pre, True
             elif pre is None:
@@ -786,6 +791,7 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
                 sol = solve(min(npar['linear_maxit'], npar.get('pmg_maxit', 150)))
             except _hip.NotConverged:
                 lay._dev['pmg_rejected_strip'] = (key, dt)
+                pre.stale = True
                 ops.fill(dx, 0.0)
                 dx_is_zero = True
                 kind, pre, refactored = build('ilu0')

@@ -15,6 +15,10 @@ Variants (the kernel each one restates):
   'stream'       stream_tile_row_sum: spmv_stream_kernel, mg_level_kernel
   'block2'       spmv_stream_block2_kernel
   'pair'         spmv_stream_pair_kernel (both components use the same indices)
+  'quad'         pmg_tile_row_sum (pmg_kernels.hip) / mass_tile_row_sum
+                 (mass_kernels.hip): QUADS of nonzeros per lane from a base
+                 aligned down to a multiple of four, FLOW_PMG_NNZ_PER_BLOCK
+                 nonzeros per tile; arrays readable three entries past nnz
   'stream_r2a'   stream_tile_row_sum as it was when the world-3 fault of round 2
                  happened (every lane gathers x[col] of whatever index pair it
                  loaded; idle lanes hold column 0) -- kept to show that the
@@ -86,6 +90,41 @@ def tile_accesses(rowptr, cols, rowblocks, variant='stream'):
                        numpy.where(used, iy, -1).max(axis=1))
     assert len(lo) == nt
     return lo, hi
+
+
+def quad_tile_accesses(rowptr, cols, rowblocks):
+    '''tile_accesses for the quad-based tiles of the fp16 kernels: per tile
+    the smallest / largest index of the gathered vector, and the largest index
+    of `cols` (= of the value array) a lane loads.'''
+    rowptr = numpy.asarray(rowptr, dtype=numpy.int64)
+    cols = numpy.asarray(cols, dtype=numpy.int64)
+    rb = numpy.asarray(rowblocks, dtype=numpy.int64)
+    quads = (_hip.PMG_NNZ_PER_BLOCK + 4) // (4 * BLOCK)      # kPmgQuads
+    k0 = rowptr[rb[:-1]]
+    k1 = rowptr[rb[1:]]
+    ka = k0 & ~3
+    lo_e = (k0 - ka)[:, None]
+    hi_e = (k1 - ka)[:, None]
+    assert (k1 - ka <= 4 * BLOCK * quads - 1).all(), 'row block larger than tile'
+    p = numpy.arange(BLOCK * quads)[None, :]
+    loaded = 4 * p < hi_e                       # the quad is loaded at all
+    big = numpy.iinfo(numpy.int64).max
+    lo = numpy.full(len(k0), big)
+    hi = numpy.full(len(k0), -1)
+    last_loaded = numpy.where(loaded, ka[:, None] + 4 * p + 3, -1).max(axis=1)
+    assert last_loaded.max() < len(cols), \
+        'cols / vals must be readable three entries past nnz'
+    safe = cols[numpy.minimum(k0, len(cols) - 1)][:, None]
+    nonempty = (k0 < k1)[:, None]
+    for j in range(4):
+        e = 4 * p + j
+        idx = numpy.minimum(ka[:, None] + e, len(cols) - 1)
+        c = numpy.where(loaded, cols[idx], 0)
+        ix = numpy.where((e >= lo_e) & (e < hi_e), c, safe)
+        used = numpy.broadcast_to(nonempty, ix.shape)
+        lo = numpy.minimum(lo, numpy.where(used, ix, big).min(axis=1))
+        hi = numpy.maximum(hi, numpy.where(used, ix, -1).max(axis=1))
+    return lo, hi, last_loaded
 
 
 def window(rowptr, cols, rowblocks, variant='stream'):

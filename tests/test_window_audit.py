@@ -213,3 +213,66 @@ def test_block_ilu_plans_are_local(host_structs, world):
         rowptr = lay.pattern('rowptr')
         src = plan.host['src_pos']
         assert src.min() >= rowptr[s.r0] and src.max() < rowptr[s.r1]
+
+
+@pytest.mark.parametrize('world', WORLDS)
+def test_block_pmg_levels_are_local(host_structs, world, monkeypatch):
+    '''The rank-local two-level cycle of the strips (parallel.local_pmg, the
+    quad-based tiles of pmg_kernels.hip): both packed levels in LOCAL
+    numbering -- every column the tiles gather lies inside the block, couplings
+    that leave it point at their own row with keep = 0 --, cols / vals
+    readable three entries past nnz (the `+4` padding contract of quads loaded
+    from a base aligned down to a multiple of four), and the transfer tables
+    name rows of the block or the dummy coarse row n1 (a zero in the work
+    buffer).'''
+    from flow_amd.fem import pmg
+    from flow_amd.fem.space import csr_stream_rowblocks
+    monkeypatch.setattr(pmg, 'COLS16', False)      # (a kernel call: GPU only)
+    mesh = fem.karman_channel(120, 30, fitted=True)
+    lay2, lay1 = scalar_layout(mesh, 2), scalar_layout(mesh, 1)
+    st = parallel.Strips(mesh, world)
+    for g in range(world):
+        s2, s1 = st.blocks(lay2).struct(g), st.blocks(lay1).struct(g)
+        for lay, s in ((lay2, s2), (lay1, s1)):
+            lvl = pmg._Level(lay, (s.r0, s.r1))
+            h = lvl._host
+            n, nnz = s.r1 - s.r0, lvl.nnz
+            assert len(h['cols']) >= nnz + 4
+            assert lvl.vals.numel() >= 2 * (nnz + 4)
+            rb = csr_stream_rowblocks(h['rowptr'],
+                                      nnz_per_block=_hip.PMG_NNZ_PER_BLOCK)
+            lo, hi, last = am.quad_tile_accesses(h['rowptr'], h['cols'], rb)
+            sel = lo <= hi
+            assert sel.all()                       # no empty tiles in a block
+            assert lo.min() >= 0 and hi.max() < n, (world, g, lay.degree)
+            assert last.max() < nnz + 4
+            # dropped couplings: value 0 (keep), column = the own row
+            row_of = numpy.repeat(numpy.arange(n), numpy.diff(h['rowptr']))
+            dropped = h['keep'] == 0
+            assert (h['cols'][:nnz][dropped] == row_of[dropped]).all()
+            assert dropped.any() == (world > 1)
+        ends, rptr, rsrc = pmg.local_transfer_tables(
+            lay2, (s2.r0, s2.r1), (s1.r0, s1.r1))
+        n2, n1 = s2.r1 - s2.r0, s1.r1 - s1.r0
+        assert ends.min() >= 0 and ends.max() <= n1       # n1: the dummy row
+        # (an edge dof belongs to the rank of its LOWER vertex: only a partner
+        # vertex further right can lie outside the block)
+        assert (ends == n1).any() == (g < world - 1)
+        assert rsrc.min() >= 0 and rsrc.max() < n2
+        assert len(rptr) == n1 + 1 and rptr[-1] == len(rsrc)
+
+
+def test_mass_solver_tiles_stay_inside_the_vector(host_structs):
+    '''The fp16 stream of the mass solver (mass_kernels.hip) over the whole
+    pattern: gathers inside [0, n), quads readable past nnz.'''
+    from flow_amd.fem.space import csr_stream_rowblocks
+    for name, mesh in _meshes()[1:]:
+        for degree in (1, 2):
+            lay = scalar_layout(mesh, degree)
+            cols = numpy.concatenate([lay.pattern('cols'),
+                                      numpy.zeros(4, dtype=numpy.int64)])
+            rb = csr_stream_rowblocks(lay.pattern('rowptr'),
+                                      nnz_per_block=_hip.PMG_NNZ_PER_BLOCK)
+            lo, hi, last = am.quad_tile_accesses(lay.pattern('rowptr'), cols, rb)
+            assert lo.min() >= 0 and hi.max() < lay.N
+            assert last.max() < lay.nnz + 4
