@@ -1570,27 +1570,46 @@ extern "C" int flow_profile_marker(int id, void* stream) {
   return FLOW_OK;
 }
 
-// y = a0 x0 + a1 x1 + a2 x2 in one pass (terms with a NULL vector are skipped)
-__global__ void lincomb3_kernel(int n, double a0, const double* __restrict__ x0,
-                                double a1, const double* __restrict__ x1,
-                                double a2, const double* __restrict__ x2,
-                                double* __restrict__ y) {
+// y = sum_k a_k x_k, k < nterms <= 6, in one pass
+constexpr int kLincombMax = 6;
+struct LincombArgs {
+  double a[kLincombMax];
+  const double* x[kLincombMax];
+};
+template <int NT>
+__global__ void lincomb_kernel(int n, LincombArgs t, double* __restrict__ y) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x) {
-    double v = a0 * x0[i];
-    if (x1) v += a1 * x1[i];
-    if (x2) v += a2 * x2[i];
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) v += t.a[k] * t.x[k][i];
     y[i] = v;
   }
 }
 
-extern "C" int flow_lincomb3(int n, double a0, const double* x0, double a1,
-                             const double* x1, double a2, const double* x2,
-                             double* y, void* stream) {
-  FLOW_REQUIRE(n >= 0 && x0 && y, "lincomb3 arguments");
+extern "C" int flow_lincomb(int n, int nterms, const double* coef_host,
+                            const double* const* x_host, double* y,
+                            void* stream) {
+  FLOW_REQUIRE(n >= 0 && nterms >= 1 && nterms <= kLincombMax && coef_host &&
+                   x_host && y,
+               "lincomb arguments (1..6 terms)");
   if (n == 0) return FLOW_OK;
-  hipLaunchKernelGGL(lincomb3_kernel, dim3(grid_for(n)), dim3(kBlock), 0,
-                     as_stream(stream), n, a0, x0, a1, x1, a2, x2, y);
+  LincombArgs t = {};
+  for (int k = 0; k < nterms; ++k) {
+    FLOW_REQUIRE(x_host[k] != nullptr && x_host[k] != y, "lincomb term");
+    t.a[k] = coef_host[k];
+    t.x[k] = x_host[k];
+  }
+  const dim3 grid(grid_for(n)), blk(kBlock);
+  hipStream_t st = as_stream(stream);
+  switch (nterms) {
+    case 1: hipLaunchKernelGGL(lincomb_kernel<1>, grid, blk, 0, st, n, t, y); break;
+    case 2: hipLaunchKernelGGL(lincomb_kernel<2>, grid, blk, 0, st, n, t, y); break;
+    case 3: hipLaunchKernelGGL(lincomb_kernel<3>, grid, blk, 0, st, n, t, y); break;
+    case 4: hipLaunchKernelGGL(lincomb_kernel<4>, grid, blk, 0, st, n, t, y); break;
+    case 5: hipLaunchKernelGGL(lincomb_kernel<5>, grid, blk, 0, st, n, t, y); break;
+    default: hipLaunchKernelGGL(lincomb_kernel<6>, grid, blk, 0, st, n, t, y); break;
+  }
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -2728,6 +2747,20 @@ __global__ void shard_rc_update_kernel(int n1, const double* __restrict__ S,
   }
 }
 
+// iterations between two recomputations of the coarse images (see shard_cg)
+constexpr int kRcRefresh = 8;
+__global__ void shard_rc_refresh_kernel(int n1, const double* __restrict__ buf,
+                                        double* __restrict__ rc_r,
+                                        double* __restrict__ rc_s,
+                                        const double* __restrict__ stop) {
+  if (stopped(stop)) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1;
+       i += gridDim.x * blockDim.x) {
+    rc_r[i] = load_scalar(buf + i);
+    rc_s[i] = load_scalar(buf + n1 + i);
+  }
+}
+
 static inline bool shard_two_launch(const flow_mg_shard* G) {
   return G && G->Cg.rowptr != nullptr && G->mg->C[0].rowptr != nullptr;
 }
@@ -2966,6 +2999,22 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
           // >= 1 replicated, the up-sweep of level 0 on the owned rows
           hipLaunchKernelGGL(shard_rc_update_kernel, dim3(grid_for(n1)),
                              dim3(kBlock), 0, st, n1, c.S, rc_w, rc_s, rc_r);
+          // Every kRcRefresh-th iteration the coarse images are recomputed
+          // from the vectors they belong to, C r and C s (one more collective
+          // then): carried by recurrence alone they drift away from the
+          // rank-local r and s, and the preconditioner with them -- seen on a
+          // 2.5 M-DoF start-up step that needs 38 iterations, where CG then
+          // stagnated a factor 2.5 above its target
+          if ((launched + k) % kRcRefresh == kRcRefresh - 1) {
+            const int own0 = R->r0 - R->e0;
+            if ((rc = apply(&G->Cg, c.r + own0, C->buf, st, nullptr, stop)))
+              return rc;
+            if ((rc = apply(&G->Cg, c.s + own0, C->buf + n1, st, nullptr, stop)))
+              return rc;
+            if ((rc = exchange(C, 2 * n1))) return rc;
+            hipLaunchKernelGGL(shard_rc_refresh_kernel, dim3(grid_for(n1)),
+                               dim3(kBlock), 0, st, n1, C->buf, rc_r, rc_s, stop);
+          }
           if ((rc = vcycle(G->mg, rc_r, G->mg->x[1], st, nullptr, nullptr,
                            nullptr, stop, 1)))
             return rc;
@@ -3365,6 +3414,7 @@ extern "C" int flow_shard_mgcg_solve(
                      mgs->up_nblocks0 > 0,
                  "sharded hierarchy: two-launch form");
     need += mgs->Cg.n;
+    if (2LL * mgs->Cg.n > need) need = 2LL * mgs->Cg.n;
   }
   if (mgs->Rg.n > need) need = mgs->Rg.n;
   if ((rc = check_comm(comm, need))) return rc;

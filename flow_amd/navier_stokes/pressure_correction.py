@@ -123,7 +123,11 @@ solver_parameters = {
                # little: fewer Krylov iterations to the same tolerance -- the
                # Newton path is untouched: still from u0, still a step solved
                # to linear_atol_factor * tol); 'zero' = nothing carried
-               'linear_start': 'extrapolated', 'linear_start_points': 3,
+               'linear_start': 'extrapolated', 'linear_start_points': 5,
+               # (cubic least-squares fit through 5 points: one point more than
+               # interpolation needs averages the solver noise of the stored
+               # increments instead of amplifying it; 0: interpolation)
+               'linear_start_degree': 3,
                # 'previous' = always u0, the reference's choice (:204-220);
                # 'best' (mode 'fast'): see _compute_tentative_velocity
                'initial_guess': 'previous', 'guess_retry': 4},
@@ -139,7 +143,7 @@ solver_parameters = {
                  'mg_coarsest': 4200,
                  # start vector: p0 ('zero') or p0 + the previous increments
                  # extrapolated in time ('extrapolated'; Dirichlet branch)
-                 'start': 'extrapolated'},
+                 'start': 'extrapolated', 'start_points': 5, 'start_degree': 3},
     # 'method': 'chebyshev' = mixed-precision defect correction with a fixed
     # Chebyshev polynomial of D^-1 M (flow_amd/fem/mass.py: 3-4 corrections of
     # one fp64 + `chebyshev_steps` - 1 fp16 products, no dot products) or 'cg'
@@ -148,7 +152,8 @@ solver_parameters = {
                    'method': 'chebyshev', 'chebyshev_steps': 6,
                    # solve for u1 - ui (flow_mass_solve_increment), started from
                    # the previous increments extrapolated in time ('zero': not)
-                   'increment': True, 'increment_start': 'extrapolated'},
+                   'increment': True, 'increment_start': 'extrapolated',
+                   'start_points': 5, 'start_degree': 3},
     }
 
 _MODES = {
@@ -256,44 +261,60 @@ def _bc_mask(dofs, n, comp=None):
     return mask
 
 
-def _extrapolated_increment(lay, dt, dx, points=2, key='newton_increments',
-                            power=1):
-    '''dx <- the first Newton increment this call is likely to find: the
-    increments per unit time of the last calls (rates at the mid points of
-    their steps), extrapolated in time through `points` of them (Lagrange) to
-    the middle of this step and scaled with its size.  Only ever the START
-    VECTOR of a linear solve that is then converged to the same tolerance as
-    from zero.  Returns False (dx untouched) without a history.'''
-    hist = [h for h in lay._dev.get(key, [])
-            if h[0].numel() == dx.numel()][:min(points, 3)]
-    if not hist:
-        return False
-    # mid points of the past steps, time 0 = the end of the latest one
+def extrapolation_weights(dts, dt, power=1, degree=None):
+    '''Weights w_i with  increment(dt) ~ sum_i w_i increment_i  for past
+    increments over steps of sizes dts (newest first): what is smooth in time
+    is the RATE increment / dt^power, taken at the mid points of the steps; a
+    polynomial of `degree` is fitted through the rates by least squares
+    (degree None or len(dts) - 1: interpolation, Lagrange) and evaluated at
+    the middle of the new step.  More points than degree + 1 average the
+    solver noise of the stored increments instead of amplifying it.'''
+    m = len(dts)
+    q = m - 1 if degree is None or int(degree) <= 0 else min(int(degree), m - 1)
     mids, t = [], 0.0
-    for _d, dtk in hist:
+    for dtk in dts:             # time 0 = the end of the latest step
         mids.append(t - 0.5 * dtk)
         t -= dtk
-    m = 0.5 * dt
-    terms = []
-    for i, (d, dtk) in enumerate(hist):
-        w = 1.0
-        for j in range(len(hist)):
-            if j != i:
-                w *= (m - mids[j]) / (mids[i] - mids[j])
-        # (what is smooth in time is increment / dt^power)
-        terms.append((w * (dt / dtk)**power, d))
-    while len(terms) < 3:
-        terms.append((0.0, None))
+    scale = abs(t) if t != 0.0 else 1.0
+    x = numpy.array(mids) / scale
+    xs = 0.5 * dt / scale
+    V = numpy.vander(x, q + 1, increasing=True)          # (m, q+1)
+    e = xs**numpy.arange(q + 1)
+    w = numpy.linalg.lstsq(V.T.dot(V), e, rcond=None)[0].dot(V.T)
+    return [float(wi) * (dt / dtk)**power for wi, dtk in zip(w, dts)]
+
+
+def _extrapolated_increment(lay, dt, dx, points=2, key='newton_increments',
+                            power=1, degree=None):
+    '''dx <- the increment this call is likely to find, extrapolated in time
+    from the increments of the previous calls (extrapolation_weights).  Only
+    ever the START VECTOR of a linear solve that is then converged to the same
+    tolerance as from zero.  Returns False (dx untouched) without a
+    history.'''
+    hist = []
+    for h in lay._dev.get(key, []):
+        # only while the step size is settled: through the start-up ramp of a
+        # controller that doubles dt the rates are not smooth in time, and a
+        # start vector FAR from the solution costs a Krylov solve iterations
+        # and attainable accuracy (CG's recurrence residual drifts from the
+        # true one in proportion to the largest residual it has seen)
+        if h[0].numel() != dx.numel() or not (1.0 / 1.5 <= dt / h[1] <= 1.5) \
+                or len(hist) >= min(points, 6):
+            break
+        hist.append(h)
+    if not hist:
+        return False
+    w = extrapolation_weights([h[1] for h in hist], dt, power, degree)
     n = dx.numel()
-    _hip.check(_hip.lib().flow_lincomb3(
-        n, terms[0][0], _hip.f64(terms[0][1], n),
-        terms[1][0], _hip.f64(terms[1][1], n) if terms[1][1] is not None else None,
-        terms[2][0], _hip.f64(terms[2][1], n) if terms[2][1] is not None else None,
-        _hip.f64(dx, n), _hip.stream()))
+    k = len(hist)
+    coef = (ctypes.c_double * k)(*w)
+    ptrs = (ctypes.c_void_p * k)(*[_hip.f64(h[0], n).value for h in hist])
+    _hip.check(_hip.lib().flow_lincomb(n, k, coef, ptrs, _hip.f64(dx, n),
+                                       _hip.stream()))
     return True
 
 
-def _remember_increment(lay, dt, dx, keep_points=3, key='newton_increments'):
+def _remember_increment(lay, dt, dx, keep_points=6, key='newton_increments'):
     hist = lay._dev.setdefault(key, [])
     hist[:] = [h for h in hist if h[0].numel() == dx.numel()]
     if len(hist) >= keep_points:
@@ -466,7 +487,8 @@ def _compute_tentative_velocity(
         dx_is_zero = True
         if it == 0 and npar.get('linear_start') == 'extrapolated':
             dx_is_zero = not _extrapolated_increment(
-                lay, dt, dx, int(npar.get('linear_start_points', 3)))
+                lay, dt, dx, int(npar.get('linear_start_points', 5)),
+                degree=npar.get('linear_start_degree'))
         pre = None
         kind = npar.get('preconditioner', 'jacobi')
         use_gmres = npar.get('linear_solver', 'gmres') == 'gmres'
@@ -774,7 +796,8 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
             # (every rank keeps the increments of its own rows: the same
             # history length and step sizes everywhere)
             dx_is_zero = not _extrapolated_increment(
-                lay, dt, dx, int(npar.get('linear_start_points', 3)))
+                lay, dt, dx, int(npar.get('linear_start_points', 5)),
+                degree=npar.get('linear_start_degree'))
         # (the count of the previous call's Newton iteration `it`: the same
         # number on every rank -- they all ran the same solve)
         expected = lay._dev.setdefault('gmres_expected_strip', {})
@@ -922,8 +945,10 @@ def _compute_pressure(
         # in time (3-point, as the Newton increments: a start vector only; on
         # the strips every rank extrapolates its own + ghost rows)
         phi_start = device.empty(P.N)
-        if _extrapolated_increment(lay, dt, phi_start, 3,
-                                   key='pressure_increments', power=1):
+        if _extrapolated_increment(lay, dt, phi_start,
+                                   int(par.get('start_points', 5)),
+                                   key='pressure_increments', power=1,
+                                   degree=par.get('start_degree')):
             ops.axpby(1.0, phi_start, 1.0, p1.data)
     if not p_bcs:
         one = lay._dev.get('ones')
@@ -1111,8 +1136,10 @@ def _compute_velocity_correction(
             and not par.get('extrapolate', False)
         if extrap:
             d0 = _zeros(n2)
-            if _extrapolated_increment(lay, dt, d0, 3,
-                                       key='correction_increments', power=2):
+            if _extrapolated_increment(lay, dt, d0,
+                                       int(par.get('start_points', 5)),
+                                       key='correction_increments', power=2,
+                                       degree=par.get('start_degree')):
                 if nbc > 0:
                     zeros = lay._dev.get(('bc_zeros', nbc))
                     if zeros is None:
@@ -1139,7 +1166,9 @@ def _compute_velocity_correction(
             if par.get('increment_start') == 'extrapolated':
                 d0 = device.empty(n2)
                 if not _extrapolated_increment(
-                        lay, dt, d0, 3, key='correction_increments', power=2):
+                        lay, dt, d0, int(par.get('start_points', 5)),
+                        key='correction_increments', power=2,
+                        degree=par.get('start_degree')):
                     d0 = None
                 elif nbc > 0:
                     _hip.check(lib.flow_bc_set_values(

@@ -617,7 +617,8 @@ class MgShard(object):
         s.Ps0 = owned_operator(lvl['Ps'].op, self._blocks(lvl['Ps'], v))
         s.Rg = self.Rg.op
         self.Cg = None
-        if mg.C0_host is not None:
+        if mg.C0_host is not None and \
+                os.environ.get('FLOW_AMD_MGCG_COLLECTIVES', '2') != '3':
             # the two-collective form: C = R (I - Ah) cut to the owned COLUMNS
             # (no ghost rows needed for the rank's share of C r), and row
             # blocks of the owned rows that hold a tile of Ps AND of Ah
@@ -656,7 +657,7 @@ def mgcg(A, dinv, mg, b, x, rtol, atol=0.0, maxit=1000, check_every=2,
     ms = mg.__dict__[key]
     n1 = ms.struct.Rg.n
     two = ms.Cg is not None
-    c.ensure(max(4 + v.rows.nhalo + (n1 if two else 0), n1))
+    c.ensure(max(4 + v.rows.nhalo + (n1 if two else 0), 2 * n1 if two else n1))
     op = v.operator(A)
     n = A.size
     wlen = _hip.REDUCE_WORK + 11 * (v.e1 - v.e0) + op.nblocks \

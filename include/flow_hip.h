@@ -140,12 +140,11 @@ int flow_axpby(int n, double a, const double* x, double b, double* y,
 int flow_vmul(int n, double a, const double* x, const double* y, double* out,
               void* stream);                        /* out = a x .* y */
 int flow_fill(int n, double value, double* y, void* stream);   /* y = value */
-/* y = a0 x0 + a1 x1 + a2 x2 in one pass (x1 / x2 may be NULL: term skipped; y
- * must not be one of the x): the start vectors a time loop extrapolates from
- * its previous increments */
-int flow_lincomb3(int n, double a0, const double* x0, double a1,
-                  const double* x1, double a2, const double* x2, double* y,
-                  void* stream);
+/* y = sum_k coef_host[k] * x_host[k], k < nterms <= 6, in one pass (coef_host
+ * and the pointer list x_host are HOST arrays; y must not be one of the x): the
+ * start vectors a time loop extrapolates from its previous increments */
+int flow_lincomb(int n, int nterms, const double* coef_host,
+                 const double* const* x_host, double* y, void* stream);
 /* dst[a*dst_stride + k] = src[a*src_stride + idx[k]], k < m, a < ncomp: the
  * vertex values of a P2 field (the linearisation point of the P1 level of
  * flow_pmg) */
@@ -647,7 +646,10 @@ int flow_shard_cg_solve(const flow_comm* comm, const flow_rows* rows,
  *     rc_s = rc_w + beta rc_s ;  rc_r -= alpha rc_s ,   rc_w = C w = sum over
  *     the ranks of Cg w_owned,
  * whose only collective part, rc_w, rides with the dots and the halo of w (C is
- * restricted by COLUMNS: a rank needs no ghost rows for its share).
+ * restricted by COLUMNS: a rank needs no ghost rows for its share).  Every
+ * eighth iteration rc_r and rc_s are recomputed from r and s themselves (one
+ * more collective then): carried by recurrence alone they drift away from the
+ * rank-local vectors and CG stagnates short of a tight target.
  * work: FLOW_REDUCE_WORK + 11 * (e1 - e0) + A->nblocks +
  * 2 * max(Ps0.nblocks, up_nblocks0) + 2 [+ 3 * Cg.n]. */
 typedef struct {

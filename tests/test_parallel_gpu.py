@@ -222,7 +222,9 @@ def test_strip_sharded_solvers_and_step(hip, world):
         # halo; the first [dots + ...]); iterations enqueued behind the
         # accepted iterate (check_every = 2) still issue theirs
         calls, its = res['mgcg_calls']
-        assert calls <= 2 * (its + 2) + 7, (calls, its)
+        # (+ one every eighth iteration: the coarse images are recomputed from
+        # the vectors they belong to, against the drift of the recurrences)
+        assert calls <= 2 * (its + 2) + 7 + (its + 2) // 8 + 1, (calls, its)
         st = res['step']
         assert 'x-strips x%d' % world in st['method']
         assert st['ghosts_u'] and st['ghosts_p']
@@ -581,7 +583,7 @@ def test_collectives_per_time_step(hip):
     for row in out[0]:
         # the budget of a step, from its own iteration counts
         budget = (2 * row['gmres'] + 6 * max(row['newton'], 1) + 2
-                  + 2 * (row['pressure'] + 2) + 7
+                  + 2 * (row['pressure'] + 2) + 7 + (row['pressure'] + 2) // 8 + 1
                   + (row['correction'] + 2) + 3
                   + (row['projection'] + 2) + 3 + 2)
         assert row['calls'] <= budget, (row, budget)

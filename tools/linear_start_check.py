@@ -31,8 +31,15 @@ def main():
     for mode in ('zero', 'extrapolated'):
         navsto.solver_parameters['newton']['linear_start'] = mode
         navsto.solver_parameters['newton']['linear_start_points'] = \
-            int(os.environ.get('POINTS', '3'))
+            int(os.environ.get('POINTS', '5'))
+        navsto.solver_parameters['newton']['linear_start_degree'] = \
+            int(os.environ.get('DEGREE', '3'))
         navsto.solver_parameters['correction']['increment_start'] = mode
+        for grp in ('pressure', 'correction'):
+            navsto.solver_parameters[grp]['start_points'] = \
+                int(os.environ.get('POINTS', '5'))
+            navsto.solver_parameters[grp]['start_degree'] = \
+                int(os.environ.get('DEGREE', '3'))
         navsto.solver_parameters['pressure']['start'] = mode
         prob.restore(snap)
         fields, apps = [], []
