@@ -258,6 +258,7 @@ SYMBOLS = {
     'flow_vmul': [_I, _D, _VP, _VP, _VP, _VP],
     'flow_fill': [_I, _D, _VP, _VP],
     'flow_lincomb': [_I, _I, _P(_D), _P(_VP), _VP, _VP],
+    'flow_extrapolation_weights': [_I, _P(_D), _D, _I, _I, _P(_D)],
     'flow_scale_rows': [_I, _VP, _VP, _VP, _VP],
     'flow_cg_solve': [_P(Operator), _VP, _P(CoarseS), _P(MgS), _VP, _VP, _D, _D,
                       _I, _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],

@@ -1587,6 +1587,65 @@ __global__ void lincomb_kernel(int n, LincombArgs t, double* __restrict__ y) {
   }
 }
 
+// Host arithmetic only (no GPU): the weights of flow_lincomb for an
+// extrapolation in time -- see include/flow_hip.h.
+extern "C" int flow_extrapolation_weights(int m, const double* dts_host, double dt,
+                                          int power, int degree,
+                                          double* w_host) {
+  FLOW_REQUIRE(m >= 1 && m <= kLincombMax && dts_host && w_host && dt > 0.0,
+               "extrapolation weights: 1..6 past steps");
+  const int q = (degree <= 0 || degree > m - 1) ? m - 1 : degree;
+  const int n = q + 1;
+  double x[kLincombMax], t = 0.0;
+  for (int i = 0; i < m; ++i) {      // mid points; time 0 = end of the newest
+    FLOW_REQUIRE(dts_host[i] > 0.0, "extrapolation weights: step sizes");
+    x[i] = t - 0.5 * dts_host[i];
+    t -= dts_host[i];
+  }
+  const double scale = -t;
+  for (int i = 0; i < m; ++i) x[i] /= scale;
+  const double xs = 0.5 * dt / scale;
+  // w = V (V^T V)^-1 e,  V_ik = x_i^k,  e_k = xs^k
+  double V[kLincombMax][kLincombMax], N[kLincombMax][kLincombMax + 1];
+  for (int i = 0; i < m; ++i) {
+    double p = 1.0;
+    for (int k = 0; k < n; ++k, p *= x[i]) V[i][k] = p;
+  }
+  double e = 1.0;
+  for (int a = 0; a < n; ++a, e *= xs) {
+    for (int b = 0; b < n; ++b) {
+      double sum = 0.0;
+      for (int i = 0; i < m; ++i) sum += V[i][a] * V[i][b];
+      N[a][b] = sum;
+    }
+    N[a][n] = e;
+  }
+  for (int c = 0; c < n; ++c) {      // Gauss-Jordan with partial pivoting
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (fabs(N[r][c]) > fabs(N[piv][c])) piv = r;
+    FLOW_REQUIRE(N[piv][c] != 0.0, "extrapolation weights: singular fit");
+    for (int k = 0; k <= n; ++k) {
+      const double tmp = N[c][k];
+      N[c][k] = N[piv][k];
+      N[piv][k] = tmp;
+    }
+    const double d = N[c][c];
+    for (int k = 0; k <= n; ++k) N[c][k] /= d;
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = N[r][c];
+      for (int k = 0; k <= n; ++k) N[r][k] -= f * N[c][k];
+    }
+  }
+  for (int i = 0; i < m; ++i) {
+    double w = 0.0;
+    for (int a = 0; a < n; ++a) w += V[i][a] * N[a][n];
+    w_host[i] = w * pow(dt / dts_host[i], power);
+  }
+  return FLOW_OK;
+}
+
 extern "C" int flow_lincomb(int n, int nterms, const double* coef_host,
                             const double* const* x_host, double* y,
                             void* stream) {

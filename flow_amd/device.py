@@ -93,11 +93,26 @@ def empty(n, dtype=torch.float64):
     return torch.empty(int(n), dtype=dtype, device=get())
 
 
+_HANDLE = None
+_FOLLOW_TORCH = bool(os.environ.get('FLOW_AMD_FOLLOW_TORCH_STREAM'))
+
+
 def stream_handle():
-    '''Raw hipStream_t of torch's current stream (0 on the CPU).'''
-    if on_gpu():
+    '''Raw hipStream_t everything is enqueued on (0 on the CPU): the package's
+    own stream, which get() also made torch's current one.  The handle is
+    cached -- asking torch for its current stream costs ~10 us, and a time step
+    asks ~40 times between launches that take ~5 us each.  A caller that
+    switches torch's current stream afterwards and wants the library to follow
+    sets FLOW_AMD_FOLLOW_TORCH_STREAM=1 (the handle is then looked up every
+    time).'''
+    global _HANDLE
+    if not on_gpu():
+        return 0
+    if _FOLLOW_TORCH:
         return torch.cuda.current_stream().cuda_stream
-    return 0
+    if _HANDLE is None:
+        _HANDLE = _STREAM.cuda_stream
+    return _HANDLE
 
 
 def synchronize():

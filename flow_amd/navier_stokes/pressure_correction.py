@@ -266,22 +266,18 @@ def extrapolation_weights(dts, dt, power=1, degree=None):
     increments over steps of sizes dts (newest first): what is smooth in time
     is the RATE increment / dt^power, taken at the mid points of the steps; a
     polynomial of `degree` is fitted through the rates by least squares
-    (degree None or len(dts) - 1: interpolation, Lagrange) and evaluated at
-    the middle of the new step.  More points than degree + 1 average the
-    solver noise of the stored increments instead of amplifying it.'''
+    (degree None / <= 0 / >= len(dts) - 1: interpolation) and evaluated at the
+    middle of the new step.  More points than degree + 1 average the solver
+    noise of the stored increments instead of amplifying it.  (Host arithmetic
+    of the library, flow_extrapolation_weights: this runs between kernel
+    launches three times per time step.)'''
     m = len(dts)
-    q = m - 1 if degree is None or int(degree) <= 0 else min(int(degree), m - 1)
-    mids, t = [], 0.0
-    for dtk in dts:             # time 0 = the end of the latest step
-        mids.append(t - 0.5 * dtk)
-        t -= dtk
-    scale = abs(t) if t != 0.0 else 1.0
-    x = numpy.array(mids) / scale
-    xs = 0.5 * dt / scale
-    V = numpy.vander(x, q + 1, increasing=True)          # (m, q+1)
-    e = xs**numpy.arange(q + 1)
-    w = numpy.linalg.lstsq(V.T.dot(V), e, rcond=None)[0].dot(V.T)
-    return [float(wi) * (dt / dtk)**power for wi, dtk in zip(w, dts)]
+    arr = (ctypes.c_double * m)(*dts)
+    out = (ctypes.c_double * m)()
+    _hip.check(_hip.load_library().flow_extrapolation_weights(
+        m, arr, float(dt), int(power),
+        0 if degree is None else int(degree), out))
+    return list(out)
 
 
 def _extrapolated_increment(lay, dt, dx, points=2, key='newton_increments',

@@ -145,6 +145,14 @@ int flow_fill(int n, double value, double* y, void* stream);   /* y = value */
  * start vectors a time loop extrapolates from its previous increments */
 int flow_lincomb(int n, int nterms, const double* coef_host,
                  const double* const* x_host, double* y, void* stream);
+/* Its weights for an extrapolation in time (HOST arithmetic, no GPU): for past
+ * increments over steps of sizes dts_host[0 .. m) (newest first, m <= 6), what
+ * is smooth in time is the rate increment / dt^power at the mid point of its
+ * step; a polynomial of `degree` (<= 0 or >= m: m - 1, interpolation) is fitted
+ * through the rates by least squares and evaluated at the middle of the new
+ * step of size dt:  increment(dt) ~ sum_i w_host[i] * increment_i. */
+int flow_extrapolation_weights(int m, const double* dts_host, double dt,
+                               int power, int degree, double* w_host);
 /* dst[a*dst_stride + k] = src[a*src_stride + idx[k]], k < m, a < ncomp: the
  * vertex values of a P2 field (the linearisation point of the P1 level of
  * flow_pmg) */
