@@ -461,10 +461,14 @@ def main():
         # profiles/summarize.py cuts there; outside the clock)
         _hip.check(_hip.lib().flow_profile_marker(1, _hip.stream()))
         barrier()
+        calls0 = parallel.comm().calls if parallel.active() else 0
         t0 = time.perf_counter()
         infos = [prob.step(tol=args.tol) for _ in range(args.steps)]
         barrier()
         elapsed = time.perf_counter() - t0
+        if parallel.active():
+            # (every halo and every reduction of the strips is one all-reduce)
+            infos[0]['collectives_in_window'] = parallel.comm().calls - calls0
         _hip.check(_hip.lib().flow_profile_marker(2, _hip.stream()))
         if world > 1:
             tt = torch.tensor([elapsed], dtype=torch.float64,
@@ -494,6 +498,9 @@ def main():
             'cfl_projection_cg_iterations': [
                 i.get('projection_iterations', 0) for i in infos],
             'substep_s': tim,
+            'collectives_per_step': (
+                infos[0]['collectives_in_window'] / float(len(infos))
+                if 'collectives_in_window' in infos[0] else None),
             }
 
     # everything that is built once and cached (operators, hierarchy, ILU

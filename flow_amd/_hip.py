@@ -145,6 +145,16 @@ class MassS(ctypes.Structure):
         ('work16', ctypes.c_void_p),
         ('packed16', ctypes.c_void_p),
         ('cbase16', ctypes.c_void_p),
+        ('work16_rows', ctypes.c_int),
+        ]
+
+
+class MassStripsS(ctypes.Structure):
+    _fields_ = [
+        ('nlevels', ctypes.c_int),
+        ('rowblocks16', ctypes.c_void_p * 16),
+        ('nblocks16', ctypes.c_int * 16),
+        ('row_lo_last', ctypes.c_int), ('row_hi_last', ctypes.c_int),
         ]
 
 
@@ -297,6 +307,9 @@ SYMBOLS = {
                             _P(_D), _VP],
     'flow_shard_mgcg_solve': [_P(CommS), _P(RowsS), _P(Operator), _VP,
                               _P(MgShardS), _VP, _VP, _D, _D, _I, _I, _I, _VP,
+                              ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_shard_mass_solve': [_P(CommS), _P(RowsS), _P(MassS), _P(MassStripsS),
+                              _VP, _VP, _VP, _VP, _D, _D, _I, _I, _VP,
                               ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_shard_gmres_solve': [_P(CommS), _P(RowsS), _P(Operator), _P(IluS),
                                _P(PmgS), _VP, _VP, _D, _D, _I, _I, _I, _I, _I,

@@ -35,6 +35,10 @@ enum Slot {
   kBreak, kTarget2, kDone, kConvIt, kIter, kNumSlots = 16
 };
 int read_state(const double* S, double* host, hipStream_t st);
+// K15 (la_kernels.hip): argument checks and the one collective
+int check_comm(const flow_comm* c, long long need);
+int check_rows(const flow_rows* R);
+int exchange(const flow_comm* c, int count);
 
 // assembly_kernels.hip: the matrix-free operator (flow_operator kind 3)
 int momentum_jvp_check(const flow_momentum_jvp* J);

@@ -2450,7 +2450,7 @@ extern "C" int flow_gmres_solve(const flow_operator* A, const double* dinv,
 // ===========================================================================
 namespace flow {
 
-static int check_comm(const flow_comm* c, long long need) {
+int check_comm(const flow_comm* c, long long need) {
   FLOW_REQUIRE(c != nullptr && c->allreduce != nullptr && c->buf != nullptr,
                "communicator");
   FLOW_REQUIRE(c->world >= 1 && c->world <= kNumSlots && c->rank >= 0 &&
@@ -2462,7 +2462,7 @@ static int check_comm(const flow_comm* c, long long need) {
   return FLOW_OK;
 }
 
-static int check_rows(const flow_rows* R) {
+int check_rows(const flow_rows* R) {
   FLOW_REQUIRE(R != nullptr, "row ranges are NULL");
   FLOW_REQUIRE(0 <= R->e0 && R->e0 <= R->r0 && R->r0 < R->r1 && R->r1 <= R->e1 &&
                    R->e1 <= R->n,
@@ -2488,7 +2488,7 @@ static int check_rows(const flow_rows* R) {
   return FLOW_OK;
 }
 
-static int exchange(const flow_comm* c, int count) {
+int exchange(const flow_comm* c, int count) {
   const int rc = c->allreduce(c->user, count);
   if (rc != 0) {
     set_error("the all-reduce callback failed (code %d, %d doubles)", rc, count);

@@ -223,12 +223,15 @@ __global__ __launch_bounds__(kBlock) void mass_residual_pair_kernel(
 }
 
 // the first defect of an INCREMENT solve (delta = 0): rho0 = D^-1 g, no product
+// (rows [r0, r1) of n; rho0 is indexed by global row)
 __global__ void mass_rho0_kernel(int n, int ncomp, const double* __restrict__ g,
                                  const double* __restrict__ dinv,
                                  float* __restrict__ rho0,
-                                 const double* __restrict__ stop) {
+                                 const double* __restrict__ stop, int r0 = 0,
+                                 int r1 = 0x7fffffff) {
   if (stopped(stop)) return;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+  if (r1 > n) r1 = n;
+  for (int i = r0 + blockIdx.x * blockDim.x + threadIdx.x; i < r1;
        i += gridDim.x * blockDim.x)
     for (int a = 0; a < ncomp; ++a) {
       const size_t k = static_cast<size_t>(a) * n + i;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void mass_cheb_kernel(
     V* __restrict__ d_out, V* __restrict__ acc, double* __restrict__ x,
     const double* __restrict__ xbase, int xs,
     double* __restrict__ zz_part, double* __restrict__ xx_part,
-    const double* __restrict__ stop) {
+    const double* __restrict__ stop, int own_lo = 0, int own_hi = 0x7fffffff) {
   __shared__ V prod[kMassTile];
   if (stopped(stop)) return;
   // (PACKED: `vals` is the packed stream, `cols` the tiles' base columns)
@@ -327,6 +330,9 @@ __global__ __launch_bounds__(kBlock) void mass_cheb_kernel(
         acc[r] = vaxpby(1.f, acc[r], 1.f, d);
       } else {
         dots = add_to_x(x, xbase, xs, r, vaxpby(1.f, acc[r], 1.f, d));
+        // (K15: the sums only count the rank's OWN rows; the ghost rows it
+        // also advances are counted by their owners)
+        if (r < own_lo || r >= own_hi) dots = make_double2(0.0, 0.0);
       }
     }
   }
@@ -461,45 +467,71 @@ struct Cheb {
   }
 };
 
+// tiles of the products of one correction: by default every product runs over
+// M->rowblocks16; K15: product j over its own, shrinking row range
+struct MassTiles {
+  const int* rowblocks[16];
+  int nblocks[16];
+  int shift;            // the fp32 vectors are windows starting at this row
+  int own_lo, own_hi;   // rows whose sums count
+};
+
 template <class V, bool PACKED>
-int correction(const flow_mass* M, double* x, const double* xbase, double* zz_part,
-               double* xx_part, const double* stop, hipStream_t st) {
+int correction(const flow_mass* M, const MassTiles& T, double* x,
+               const double* xbase, double* zz_part, double* xx_part,
+               const double* stop, hipStream_t st) {
   const flow_operator* A = M->A;
   const int n = A->n;
   // (PACKED: the packed stream and the tiles' base columns take the places of
   // the fp16 values and the column indices)
   const void* v16 = PACKED ? M->packed16 : M->vals16;
   const int* cols = PACKED ? M->cbase16 : A->cols;
-  V* w = reinterpret_cast<V*>(M->work16);
+  // (the vectors are indexed by global row: windows are shifted)
+  V* w = reinterpret_cast<V*>(M->work16) - T.shift;
+  const size_t len = static_cast<size_t>(M->work16_rows > 0 ? M->work16_rows : n);
   V* rho0 = w;
-  V* rho = rho0 + n;
-  V* d[2] = {rho + n, rho + 2 * static_cast<size_t>(n)};
-  V* acc = rho + 3 * static_cast<size_t>(n);
-  const dim3 g16(M->nblocks16), blk(kBlock);
+  V* rho = rho0 + len;
+  V* d[2] = {rho + len, rho + 2 * len};
+  V* acc = rho + 3 * len;
+  const dim3 blk(kBlock);
   Cheb ch(M->lam_min, M->lam_max);
   const float c0 = ch.first();
   float c1, c2;
   V* const none = nullptr;
   double* const nod = nullptr;
   ch.next(&c1, &c2);
-  hipLaunchKernelGGL((mass_cheb_kernel<V, 0, PACKED>), g16, blk, 0, st, n,
-                     A->rowptr, cols, v16, M->rowblocks16, A->rowmask, rho0, rho0,
-                     rho, c0, c1, c2, d[0], acc, nod, nod, n, nod, nod, stop);
+  hipLaunchKernelGGL((mass_cheb_kernel<V, 0, PACKED>), dim3(T.nblocks[0]), blk, 0,
+                     st, n, A->rowptr, cols, v16, T.rowblocks[0], A->rowmask, rho0,
+                     rho0, rho, c0, c1, c2, d[0], acc, nod, nod, n, nod, nod, stop,
+                     0, 0x7fffffff);
   const int products = M->steps - 1;
   for (int j = 1; j + 1 < products; ++j) {
     ch.next(&c1, &c2);
-    hipLaunchKernelGGL((mass_cheb_kernel<V, 1, PACKED>), g16, blk, 0, st, n,
-                       A->rowptr, cols, v16, M->rowblocks16, A->rowmask,
+    hipLaunchKernelGGL((mass_cheb_kernel<V, 1, PACKED>), dim3(T.nblocks[j]), blk,
+                       0, st, n, A->rowptr, cols, v16, T.rowblocks[j], A->rowmask,
                        d[(j - 1) & 1], rho, rho, 0.f, c1, c2, d[j & 1], acc, nod,
-                       nod, n, nod, nod, stop);
+                       nod, n, nod, nod, stop, 0, 0x7fffffff);
   }
   ch.next(&c1, &c2);
-  hipLaunchKernelGGL((mass_cheb_kernel<V, 2, PACKED>), g16, blk, 0, st, n,
-                     A->rowptr, cols, v16, M->rowblocks16, A->rowmask,
+  hipLaunchKernelGGL((mass_cheb_kernel<V, 2, PACKED>),
+                     dim3(T.nblocks[products - 1]), blk, 0, st, n, A->rowptr, cols,
+                     v16, T.rowblocks[products - 1], A->rowmask,
                      d[(products - 2) & 1], rho, none, 0.f, c1, c2, none, acc, x,
-                     xbase, n, zz_part, xx_part, stop);
+                     xbase, n, zz_part, xx_part, stop, T.own_lo, T.own_hi);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
+}
+
+static MassTiles default_tiles(const flow_mass* M) {
+  MassTiles T;
+  for (int j = 0; j < 16; ++j) {
+    T.rowblocks[j] = M->rowblocks16;
+    T.nblocks[j] = M->nblocks16;
+  }
+  T.shift = 0;
+  T.own_lo = 0;
+  T.own_hi = 0x7fffffff;
+  return T;
 }
 
 }  // namespace
@@ -561,14 +593,17 @@ static int mass_solve(const flow_mass* M, const double* b, double* x,
                          A->rowptr, A->cols, A->vals[0], A->rowblocks, x, b, M->dinv,
                          M->work16, stop);
     }
+    const MassTiles T = default_tiles(M);
     if (A->kind == 4) {
-      rc = M->packed16
-               ? correction<float2, true>(M, x, xbase, zz_part, xx_part, stop, st)
-               : correction<float2, false>(M, x, xbase, zz_part, xx_part, stop, st);
+      rc = M->packed16 ? correction<float2, true>(M, T, x, xbase, zz_part, xx_part,
+                                                  stop, st)
+                       : correction<float2, false>(M, T, x, xbase, zz_part,
+                                                   xx_part, stop, st);
     } else {
-      rc = M->packed16
-               ? correction<float, true>(M, x, xbase, zz_part, xx_part, stop, st)
-               : correction<float, false>(M, x, xbase, zz_part, xx_part, stop, st);
+      rc = M->packed16 ? correction<float, true>(M, T, x, xbase, zz_part, xx_part,
+                                                 stop, st)
+                       : correction<float, false>(M, T, x, xbase, zz_part, xx_part,
+                                                  stop, st);
     }
     if (rc) return rc;
     hipLaunchKernelGGL(mass_scalar_kernel, dim3(1), dim3(kMassScalarBlock), 0, st,
@@ -603,6 +638,208 @@ static int mass_solve(const flow_mass* M, const double* b, double* x,
       *resid_host = sqrt(zz);
       set_error("mass solve did not converge in %d defect corrections: |z| = "
                 "%.3e, |x| = %.3e", launched, sqrt(zz), sqrt(state[kB2]));
+      return FLOW_NOT_CONVERGED;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// K15: the same solver on the strips of a node (flow_shard_mass_solve).
+// The polynomial of one correction reaches steps - 1 matrix hops: with the
+// scaled defect rho0 known on a ghost zone `steps` vertex columns deep, the
+// rank computes its products on shrinking row ranges -- product j on the rows
+// within steps - 1 - j hops of its own -- and ends with x advanced on its own
+// rows AND its first ghost layer, without communication inside the correction.
+// ONE collective per correction carries the deep halo of rho0 and, riding
+// along, the norms that decide about the correction before.  Rows computed
+// redundantly by two ranks come out bitwise equal: the same inputs, the same
+// order of summation per row.
+// ---------------------------------------------------------------------------
+constexpr int kMassPackBlock = 1024;
+
+// block 0: sums of the partial lists of the last product (z.z, x.x over the
+// rank's own rows) -> buf[0], buf[1] (first: zeros); blocks >= 1: the halo
+// slots of rho0 at buf + 4 (own boundary rows as doubles, zeros elsewhere)
+__global__ __launch_bounds__(kMassPackBlock) void shard_mass_pack_kernel(
+    flow_rows R, int ncomp, int first, int nparts,
+    const double* __restrict__ zz_part, const double* __restrict__ xx_part,
+    const float* __restrict__ rho0, double* __restrict__ buf,
+    const double* __restrict__ stop) {
+  if (stopped(stop)) return;
+  if (blockIdx.x > 0) {
+    const int total = ncomp * R.nhalo;
+    for (int t = (blockIdx.x - 1) * blockDim.x + threadIdx.x; t < total;
+         t += (gridDim.x - 1) * blockDim.x) {
+      const int a = t / R.nhalo, k = t - a * R.nhalo;
+      double v = 0.0;
+#pragma unroll
+      for (int sd = 0; sd < 2; ++sd)
+        if (k >= R.send_slot[sd] && k < R.send_slot[sd] + R.send_len[sd])
+          v = static_cast<double>(
+              rho0[static_cast<size_t>(R.send_row[sd] + (k - R.send_slot[sd])) *
+                       ncomp + a]);
+      buf[4 + t] = v;
+    }
+    return;
+  }
+  __shared__ double wsum[2][kMassPackBlock / 64];
+  double zz = 0.0, xx = 0.0;
+  if (!first)
+    for (int i = threadIdx.x; i < nparts; i += kMassPackBlock) {
+      zz += load_scalar(zz_part + i);
+      xx += load_scalar(xx_part + i);
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    zz += __shfl_down(zz, off, 64);
+    xx += __shfl_down(xx, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    wsum[0][threadIdx.x >> 6] = zz;
+    wsum[1][threadIdx.x >> 6] = xx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    zz = xx = 0.0;
+    for (int w = 0; w < kMassPackBlock / 64; ++w) {
+      zz += wsum[0][w];
+      xx += wsum[1][w];
+    }
+    buf[0] = zz;
+    buf[1] = xx;
+    buf[2] = 0.0;
+    buf[3] = 0.0;
+  }
+}
+
+// ghost rows of rho0 <- the neighbours' slots; thread 0 of block 0: the verdict
+// on the correction BEFORE (its norms have just been summed over the ranks):
+// `applied` corrections are in x when it passes
+__global__ void shard_mass_unpack_kernel(flow_rows R, int ncomp, int first,
+                                         int applied, double contraction2,
+                                         double rtol2, double atol2,
+                                         const double* __restrict__ buf,
+                                         float* __restrict__ rho0,
+                                         double* __restrict__ S) {
+  if (stopped(S + kDone)) return;
+  const int per = R.recv_len[0] + R.recv_len[1];
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncomp * per;
+       t += gridDim.x * blockDim.x) {
+    const int a = t / per, k = t - a * per;
+    const int sd = k < R.recv_len[0] ? 0 : 1;
+    const int j = sd == 0 ? k : k - R.recv_len[0];
+    rho0[static_cast<size_t>(R.recv_row[sd] + j) * ncomp + a] = static_cast<float>(
+        load_scalar(buf + 4 + static_cast<size_t>(a) * R.nhalo + R.recv_slot[sd] + j));
+  }
+  if (blockIdx.x != 0 || threadIdx.x != 0 || first) return;
+  const double zz = load_scalar(buf), xx = load_scalar(buf + 1);
+  const bool nan = !(zz == zz) || !(xx == xx);
+  if (nan || contraction2 * zz <= fmax(rtol2 * xx, atol2)) {
+    store_scalar(S + kConvIt, static_cast<double>(applied));
+    store_scalar(S + kDone, nan ? 2.0 : 1.0);
+  }
+  store_scalar(S + kIter, static_cast<double>(applied));
+  store_scalar(S + kRes2, zz);
+  store_scalar(S + kB2, xx);
+}
+
+static int shard_mass_solve(const flow_comm* C, const flow_rows* R,
+                            const flow_mass* M, const flow_mass_strips* L,
+                            const double* b, double* x, const double* xbase,
+                            bool x_is_zero, double rtol, double atol, int maxit,
+                            int first_check, double* work, int* iters_host,
+                            double* resid_host, hipStream_t st) {
+  const flow_operator* A = M->A;
+  const int ncomp = A->kind == 4 ? 2 : 1;
+  const int products = M->steps - 1;
+  double* S = work + 3 * kRedBlocks;
+  double* zz_part = work + FLOW_REDUCE_WORK;
+  const int nlast = L->nblocks16[products - 1];
+  double* xx_part = zz_part + nlast;
+  const double* stop = S + kDone;
+  const double c2 = M->contraction * M->contraction;
+  MassTiles T;
+  for (int j = 0; j < products; ++j) {
+    T.rowblocks[j] = L->rowblocks16[j];
+    T.nblocks[j] = L->nblocks16[j];
+  }
+  T.shift = R->e0;
+  T.own_lo = R->r0;
+  T.own_hi = R->r1;
+  float* rho0 = M->work16 - static_cast<ptrdiff_t>(R->e0) * ncomp;
+  const int count = 4 + ncomp * R->nhalo;
+  const int gp = 1 + grid_for(ncomp * R->nhalo > 0 ? ncomp * R->nhalo : 1,
+                              kMassPackBlock, 64);
+  const int per = R->recv_len[0] + R->recv_len[1];
+  const int gs = grid_for(ncomp * per > 0 ? ncomp * per : 1);
+  int rc;
+  if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
+  int k = 0;                       // corrections enqueued so far
+  // one pass: the defect on the own rows, the collective (deep halo of rho0 +
+  // the norms of correction k - 1), the verdict on k - 1, correction k
+  auto one = [&]() -> int {
+    if (x_is_zero && k == 0) {
+      hipLaunchKernelGGL(mass_rho0_kernel, dim3(grid_for(R->r1 - R->r0)),
+                         dim3(kBlock), 0, st, A->n, ncomp, b, M->dinv, rho0, stop,
+                         R->r0, R->r1);
+    } else if (A->kind == 4) {
+      hipLaunchKernelGGL(mass_residual_pair_kernel, dim3(A->nblocks), dim3(kBlock),
+                         0, st, A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
+                         A->rowmask, x, A->n, b, M->dinv,
+                         reinterpret_cast<float2*>(rho0), stop);
+    } else {
+      hipLaunchKernelGGL(mass_residual_kernel, dim3(A->nblocks), dim3(kBlock), 0, st,
+                         A->rowptr, A->cols, A->vals[0], A->rowblocks, x, b, M->dinv,
+                         rho0, stop);
+    }
+    hipLaunchKernelGGL(shard_mass_pack_kernel, dim3(gp), dim3(kMassPackBlock), 0,
+                       st, *R, ncomp, k == 0 ? 1 : 0, nlast, zz_part, xx_part, rho0,
+                       C->buf, stop);
+    FLOW_CHECK_LAUNCH();
+    // (every rank issues the same sequence of collectives, whatever the flag)
+    if ((rc = exchange(C, count))) return rc;
+    hipLaunchKernelGGL(shard_mass_unpack_kernel, dim3(gs), dim3(kBlock), 0, st, *R,
+                       ncomp, k == 0 ? 1 : 0, k, c2, rtol * rtol, atol * atol,
+                       C->buf, rho0, S);
+    FLOW_CHECK_LAUNCH();
+    if (A->kind == 4)
+      rc = correction<float2, false>(M, T, x, xbase, zz_part, xx_part, stop, st);
+    else
+      rc = correction<float, false>(M, T, x, xbase, zz_part, xx_part, stop, st);
+    ++k;
+    return rc;
+  };
+  double state[kNumSlots];
+  bool started = false;
+  while (true) {
+    // the verdict on correction j comes with pass j + 1: `first_check`
+    // corrections (what the previous call needed) need one pass more
+    int todo = (!started && first_check > 0) ? first_check + 1 : 1;
+    if (!started && first_check == 0) todo = 2;
+    started = true;
+    if (k + todo > maxit + 1) todo = maxit + 1 - k;
+    for (int i = 0; i < todo; ++i)
+      if ((rc = one())) return rc;
+    if ((rc = read_state(S, state, st))) return rc;
+    const double zz = state[kRes2];
+    if (state[kDone] == 2.0 || !(zz == zz)) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = zz;
+      set_error("sharded mass solve broke down (NaN) at correction %d",
+                *iters_host);
+      return FLOW_NOT_CONVERGED;
+    }
+    if (state[kDone] == 1.0) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = sqrt(zz);
+      return FLOW_OK;
+    }
+    if (k > maxit) {
+      *iters_host = maxit;
+      *resid_host = sqrt(zz);
+      set_error("sharded mass solve did not converge in %d defect corrections: "
+                "|z| = %.3e, |x| = %.3e", maxit, sqrt(zz), sqrt(state[kB2]));
       return FLOW_NOT_CONVERGED;
     }
   }
@@ -695,6 +932,82 @@ extern "C" int flow_mass_solve_increment(const flow_mass* M, const double* g,
   // like the in-place solve leaves its last iterate)
   hipLaunchKernelGGL(mass_sum_kernel, dim3(grid_for(N)), dim3(kBlock), 0, st,
                      static_cast<int>(N), xbase, delta, x);
+  FLOW_CHECK_LAUNCH();
+  return rc;
+}
+
+// y[i] = a[i] + b[i] on the rows [lo, hi) of ncomp components (stride n)
+__global__ void mass_sum_rows_kernel(int n, int ncomp, int lo, int hi,
+                                     const double* __restrict__ a,
+                                     const double* __restrict__ b,
+                                     double* __restrict__ y) {
+  const int m = hi - lo;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncomp * m;
+       t += gridDim.x * blockDim.x) {
+    const int c = t / m, i = lo + (t - c * m);
+    const size_t k = static_cast<size_t>(c) * n + i;
+    y[k] = a[k] + b[k];
+  }
+}
+
+extern "C" int flow_shard_mass_solve(
+    const flow_comm* comm, const flow_rows* rows, const flow_mass* M,
+    const flow_mass_strips* levels, const double* b, const double* xbase,
+    const double* delta0, double* x, double rtol, double atol, int maxit,
+    int first_check, double* work, size_t work_len, int* iters_host,
+    double* resid_host, void* stream) {
+  int rc = mass_check(M);
+  if (rc) return rc;
+  if ((rc = check_rows(rows))) return rc;
+  FLOW_REQUIRE(M->vals16 != nullptr,
+               "sharded mass solve: the plain fp16 stream (vals16)");
+  FLOW_REQUIRE(levels && b && x && work && iters_host && resid_host,
+               "solver pointers");
+  FLOW_REQUIRE(rtol >= 0.0 && atol >= 0.0 && maxit >= 1 && first_check >= 0,
+               "solver tolerances");
+  const flow_operator* A = M->A;
+  FLOW_REQUIRE(A->n == rows->n, "operator / row ranges");
+  const int ncomp = A->kind == 4 ? 2 : 1;
+  const int products = M->steps - 1;
+  FLOW_REQUIRE(levels->nlevels == products,
+               "one set of row blocks per product of a correction");
+  for (int j = 0; j < products; ++j)
+    FLOW_REQUIRE(levels->rowblocks16[j] && levels->nblocks16[j] > 0,
+                 "row blocks of a product");
+  FLOW_REQUIRE(M->work16_rows == rows->e1 - rows->e0,
+               "work16 must cover the rank's window [e0, e1)");
+  if ((rc = check_comm(comm, 4 + static_cast<long long>(ncomp) * rows->nhalo)))
+    return rc;
+  const size_t N = static_cast<size_t>(ncomp) * A->n;
+  const size_t head = FLOW_REDUCE_WORK +
+                      2 * static_cast<size_t>(levels->nblocks16[products - 1]);
+  FLOW_REQUIRE(work_len >= head + (head & 1) + (xbase ? N : 0),
+               "sharded mass solve workspace too small");
+  hipStream_t st = as_stream(stream);
+  if (!xbase) {
+    FLOW_REQUIRE(delta0 == nullptr, "delta0 belongs to the increment form");
+    return shard_mass_solve(comm, rows, M, levels, b, x, nullptr, false, rtol,
+                            atol, maxit, first_check, work, iters_host,
+                            resid_host, st);
+  }
+  // increment form: delta in a vector of its own (global length: the kernels
+  // index by global row; valid on the own + first ghost rows)
+  double* delta = work + head + (head & 1);
+  if (delta0) {
+    hipLaunchKernelGGL(mass_sum_kernel, dim3(grid_for(N)), dim3(kBlock), 0, st,
+                       static_cast<int>(N), delta0,
+                       static_cast<const double*>(nullptr), delta);
+    FLOW_CHECK_LAUNCH();
+  } else if ((rc = fill(static_cast<int>(N), 0.0, delta, st))) {
+    return rc;
+  }
+  rc = shard_mass_solve(comm, rows, M, levels, b, delta, xbase,
+                        delta0 == nullptr, rtol, atol, maxit, first_check, work,
+                        iters_host, resid_host, st);
+  // x = xbase + delta where the last product ran (own + first ghost rows)
+  const int lo = levels->row_lo_last, hi = levels->row_hi_last;
+  hipLaunchKernelGGL(mass_sum_rows_kernel, dim3(grid_for(ncomp * (hi - lo))),
+                     dim3(kBlock), 0, st, A->n, ncomp, lo, hi, xbase, delta, x);
   FLOW_CHECK_LAUNCH();
   return rc;
 }

@@ -664,7 +664,12 @@ def project_magnitude(u, mode=0, tol=1.0e-12, initial_guess=None):
     if initial_guess is not None:
         out.assign(initial_guess)
     tag = 'project_magnitude' if initial_guess is not None else None
-    if strips:
+    if strips and MASS_SOLVER['method'] == 'chebyshev':
+        from .mass import MassSolver
+        out.solve_info = parallel.mass_solve(
+            MassSolver.cached(M, lay._dev[key], steps=MASS_SOLVER['steps']),
+            b, out.data, tol, maxit=100, tag=tag)
+    elif strips:
         out.solve_info = parallel.cg(M, lay._dev[key], b, out.data, tol,
                                      maxit=1000, check_every=2, tag=tag)
     elif MASS_SOLVER['method'] == 'chebyshev':

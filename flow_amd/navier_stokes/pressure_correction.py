@@ -1060,8 +1060,7 @@ def _compute_velocity_correction(
     # and (the increment being ~1e-5 of the field) one correction less
     # (not with an extrapolated start vector -- mode 'fast' --: the right-hand
     # side below is the defect of the start ui and of nothing else)
-    increment = (not parallel.active()
-                 and par.get('method', 'chebyshev') == 'chebyshev'
+    increment = (par.get('method', 'chebyshev') == 'chebyshev'
                  and par.get('increment', True)
                  and not par.get('extrapolate', False))
     b = _zeros(n2) if parallel.active() else device.empty(n2)
@@ -1125,31 +1124,9 @@ def _compute_velocity_correction(
         else:
             _hip.check(lib.flow_bc_set_values(
                 nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(b), st))
-    if parallel.active():
-        # Jacobi-CG on the strips, started from ui + the previous increments
-        # u1 - ui extrapolated in time (as the single-GPU solver's increment)
-        extrap = par.get('increment_start') == 'extrapolated' \
-            and not par.get('extrapolate', False)
-        if extrap:
-            d0 = _zeros(n2)
-            if _extrapolated_increment(lay, dt, d0,
-                                       int(par.get('start_points', 5)),
-                                       key='correction_increments', power=2,
-                                       degree=par.get('start_degree')):
-                if nbc > 0:
-                    zeros = lay._dev.get(('bc_zeros', nbc))
-                    if zeros is None:
-                        zeros = lay._dev[('bc_zeros', nbc)] = _zeros(nbc)
-                    _hip.check(lib.flow_bc_set_values(
-                        nbc, _hip.i32(bc_dofs), _hip.f64(zeros), _hip.f64(d0),
-                        st))
-                ops.axpby(1.0, d0, 1.0, u1.data)
+    if parallel.active() and par.get('method', 'chebyshev') != 'chebyshev':
         sol = parallel.cg(Mbc, dinv, b, u1.data, tol, 0.0, par['maxit'],
                           check_every=par['check_every'], tag='correction')
-        if extrap:
-            ops.copy(d0, u1.data)
-            ops.axpby(-1.0, ui.data, 1.0, d0)
-            _remember_increment(lay, dt, d0, key='correction_increments')
     elif par.get('method', 'chebyshev') == 'chebyshev':
         from ..fem.mass import MassSolver
         solver = MassSolver.cached(Mbc, dinv,
@@ -1172,14 +1149,25 @@ def _compute_velocity_correction(
                         _hip.f64(lay._dev[('bc_zeros', nbc)]), _hip.f64(d0),
                         st))
             ui_keep = ui.data
-            sol = solver.solve_increment(
-                b, u1.data, u1.data, tol, maxit=min(par['maxit'], 100),
-                tag='correction', delta0=d0)
+            if parallel.active():
+                # (on the strips: one collective per correction, the deep halo
+                # of the defect; u1 comes back valid on own + ghost rows)
+                sol = parallel.mass_solve(
+                    solver, b, u1.data, tol, maxit=min(par['maxit'], 100),
+                    tag='correction', xbase=u1.data, delta0=d0)
+            else:
+                sol = solver.solve_increment(
+                    b, u1.data, u1.data, tol, maxit=min(par['maxit'], 100),
+                    tag='correction', delta0=d0)
             if par.get('increment_start') == 'extrapolated':
                 d0 = d0 if d0 is not None else device.empty(n2)
                 ops.copy(d0, u1.data)
                 ops.axpby(-1.0, ui_keep, 1.0, d0)
                 _remember_increment(lay, dt, d0, key='correction_increments')
+        elif parallel.active():
+            sol = parallel.mass_solve(solver, b, u1.data, tol,
+                                      maxit=min(par['maxit'], 100),
+                                      tag='correction')
         else:
             sol = solver.solve(b, u1.data, tol, maxit=min(par['maxit'], 100),
                                tag='correction')

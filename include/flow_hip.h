@@ -435,6 +435,8 @@ typedef struct {
    * span < 65536 (flow_mass_pack16 reports otherwise). */
   const void* packed16;
   const int* cbase16;          /* nblocks16: lowest column of each tile */
+  int work16_rows;             /* rows the fp32 work vectors cover (0: A->n); K15:
+                                  the rank's window, flow_shard_mass_solve */
 } flow_mass;
 /* vals16[k] = half(vals[k] / vals[diag_idx[row(k)]]) */
 int flow_mass_pack(int n, const int* rowptr, const int* diag_idx,
@@ -675,6 +677,37 @@ int flow_shard_mgcg_solve(const flow_comm* comm, const flow_rows* rows,
                           double rtol, double atol, int maxit, int check_every,
                           int first_check, double* work, size_t work_len,
                           int* iters_host, double* resid_host, void* stream);
+
+/* The mass solver of K18 on the strips.  A correction's polynomial reaches
+ * steps - 1 matrix hops: with the scaled defect known on a ghost zone `steps`
+ * vertex columns deep the rank computes product j on the rows within
+ * steps - 1 - j hops of its own (rowblocks16[j]: CSR-stream row blocks of that
+ * row range, <= FLOW_PMG_NNZ_PER_BLOCK nonzeros each, global row numbers) and
+ * ends with x advanced on its own rows and its first ghost layer (the rows
+ * [row_lo_last, row_hi_last) of the last product) -- no communication inside a
+ * correction, ONE collective per correction: the deep halo of the defect with
+ * the norms of the correction before riding along (so a solve that needs m
+ * corrections issues m + 1).  `rows`: the owned rows with the DEEP ghost range
+ * [e0, e1) and its halo slots; M->A: the operator with the row blocks of the
+ * owned rows; M->work16: 5 * ncomp * (e1 - e0) floats (work16_rows = e1 - e0);
+ * the plain fp16 stream M->vals16 is used (the packed one is tiled once).
+ * xbase != NULL: the increment form (b = the defect of xbase; delta0 or NULL
+ * as flow_mass_solve_increment; x = xbase + increment on the rows of the last
+ * product); xbase == NULL: x holds the start, valid on own + first ghost rows.
+ * work: FLOW_REDUCE_WORK + 2 * nblocks16[last] + 1 [+ op size] doubles. */
+typedef struct {
+  int nlevels;                    /* = steps - 1 */
+  const int* rowblocks16[16];
+  int nblocks16[16];
+  int row_lo_last, row_hi_last;
+} flow_mass_strips;
+int flow_shard_mass_solve(const flow_comm* comm, const flow_rows* rows,
+                          const flow_mass* M, const flow_mass_strips* levels,
+                          const double* b, const double* xbase,
+                          const double* delta0, double* x, double rtol,
+                          double atol, int maxit, int first_check, double* work,
+                          size_t work_len, int* iters_host, double* resid_host,
+                          void* stream);
 
 /* GMRES(restart) on the strips: for the Newton systems -- the operator is the
  * matrix-free Jacobian action (kind 3) whose flow_mesh / flow_space carry the
