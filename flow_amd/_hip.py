@@ -117,6 +117,7 @@ class PmgLevelS(ctypes.Structure):
         ('dinv', ctypes.c_void_p),
         ('lam_min', ctypes.c_double), ('lam_max', ctypes.c_double),
         ('cols16', ctypes.c_void_p), ('cbase', ctypes.c_void_p),
+        ('packed', ctypes.c_void_p), ('idrows', ctypes.c_void_p),
         ]
 
 
@@ -280,6 +281,8 @@ SYMBOLS = {
                          _D, _I, _I, _I, _I, _I, _VP, ctypes.c_size_t, _P(_I),
                          _P(_D), _VP],
     'flow_pmg_pack': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
+    'flow_pmg_pack1': [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                       _VP, _VP, _VP, _VP],
     'flow_pmg_cols16': [_I, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _P(_D), _VP],
     'flow_pmg_apply': [_P(PmgS), _VP, _VP, _VP],

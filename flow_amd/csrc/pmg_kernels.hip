@@ -32,6 +32,7 @@
 // so that no kernel but the first reads the diagonal.  Every kernel is
 // HBM-bound: 8 B per nonzero + a few float2 vectors.
 #include "common.h"
+#include "csr_stream16.h"
 
 #include <hip/hip_fp16.h>
 
@@ -41,6 +42,7 @@ constexpr int kPmgQuads = 2;                      // quads of nonzeros per lane
 constexpr int kPmgTile = kBlock * 4 * kPmgQuads;  // LDS products per workgroup
 static_assert(FLOW_PMG_NNZ_PER_BLOCK == kPmgTile - 4,
               "tile minus alignment slack (base aligned down to a multiple of 4)");
+static_assert(kPmgTile == kMassTile, "one tile shape for both fp16 streams");
 
 __device__ __forceinline__ float2 f2(float a, float b) { return make_float2(a, b); }
 
@@ -150,11 +152,17 @@ __device__ __forceinline__ float2 pmg_tile_row_sum(
 //                           blocked (z[a*n + row]); Dirichlet rows (bc != 0)
 //                           return the input r there: identity rows of J
 // rho_out may alias rho_in (row-local); g must not be written.
-template <int MODE, bool C16>
+// FMT 0: half2 values + int32 columns; 1: half2 values + 16-bit column offsets;
+// 2: ONE plane for both components as the packed stream of csr_stream16.h
+// (`vals`: a 32-bit word per nonzero, fp16 value | 16-bit column offset) --
+// rows flagged in idrows (component-blocked, stride n) are identity rows of
+// their component.
+template <int MODE, int FMT>
 __global__ __launch_bounds__(kBlock) void pmg_cheb_kernel(
     int n, const int* __restrict__ rowptr, const void* __restrict__ cols,
     const int* __restrict__ cbase,
-    const __half2* __restrict__ vals, const int* __restrict__ rowblocks,
+    const void* __restrict__ vals, const unsigned char* __restrict__ idrows,
+    const int* __restrict__ rowblocks,
     const float2* __restrict__ g, const float2* rho_in, float2* rho_out,
     const float2* __restrict__ d_own, float c1, float c2,
     float2* __restrict__ d_out, float2* __restrict__ x,
@@ -164,8 +172,20 @@ __global__ __launch_bounds__(kBlock) void pmg_cheb_kernel(
   __shared__ float2 prod[kPmgTile];
   if (stopped(stop)) return;
   int r, r1;
-  const float2 s =
-      pmg_tile_row_sum<C16>(rowptr, cols, cbase, vals, rowblocks, g, prod, r, r1);
+  float2 s;
+  if (FMT == 2) {
+    s = mass_tile_row_sum_packed<float2>(rowptr,
+                                         static_cast<const unsigned*>(vals),
+                                         cbase, rowblocks, g, prod, r, r1);
+    if (r < r1 && idrows) {
+      if (idrows[r]) s.x = g[r].x;
+      if (idrows[static_cast<size_t>(n) + r]) s.y = g[r].y;
+    }
+  } else {
+    s = pmg_tile_row_sum<FMT == 1>(rowptr, cols, cbase,
+                                   static_cast<const __half2*>(vals), rowblocks,
+                                   g, prod, r, r1);
+  }
   if (r >= r1) return;
   float2 rho = rho_in[r];
   rho.x -= s.x;
@@ -338,6 +358,78 @@ __global__ void pmg_pack_kernel(int n, const int* __restrict__ rowptr,
   }
 }
 
+// setup of the ONE-plane level, step 1: idrows[a n + i] = 1 where row i of block
+// a is an identity row (no off-diagonal entry inside the block: a Dirichlet
+// dof of component a)
+__global__ void pmg_idrows_kernel(int n, const int* __restrict__ rowptr,
+                                  const int* __restrict__ diag_idx,
+                                  const double* __restrict__ a00,
+                                  const double* __restrict__ a11,
+                                  const unsigned char* __restrict__ keep,
+                                  unsigned char* __restrict__ idrows) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    const int kd = diag_idx[i];
+    bool id0 = true, id1 = true;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      if (k == kd || (keep != nullptr && keep[k] == 0)) continue;
+      if (a00[k] != 0.0) id0 = false;
+      if (a11[k] != 0.0) id1 = false;
+    }
+    idrows[i] = id0 ? 1 : 0;
+    idrows[static_cast<size_t>(n) + i] = id1 ? 1 : 0;
+  }
+}
+
+// step 2: the packed stream (fp16 value | 16-bit column offset from cbase[tile],
+// csr_stream16.h).  The two diagonal blocks of the Jacobian differ by the
+// reaction term of the Newton linearisation, +-(du_a/dx_a) M -- of the size of
+// the off-diagonal blocks the cycle drops anyway, and their mean is the Oseen
+// operator (div u ~ 0): ONE plane serves both components (tools/ab_bench.sh:
+// the same GMRES counts).  Entry (i, j) = mean over the components in which
+// neither row i nor column j is a Dirichlet dof, over the mean diagonal of the
+// free components of row i; identity rows are applied by flag (idrows), their
+// diag / dinv entries are the blocks' own.  A workgroup per tile.
+__global__ __launch_bounds__(kBlock) void pmg_pack1_kernel(
+    int n, const int* __restrict__ rowblocks, const int* __restrict__ rowptr,
+    const int* __restrict__ cols, const int* __restrict__ diag_idx,
+    const double* __restrict__ a00, const double* __restrict__ a11,
+    const unsigned char* __restrict__ keep,
+    const unsigned char* __restrict__ idrows, const int* __restrict__ cbase,
+    unsigned* __restrict__ packed, float2* __restrict__ diag,
+    float2* __restrict__ dinv) {
+  const int tile = blockIdx.x;
+  const int r0 = rowblocks[tile], r1 = rowblocks[tile + 1];
+  const int base = cbase[tile];
+  const int i = r0 + threadIdx.x;
+  if (i >= r1) return;
+  const int kd = diag_idx[i];
+  const bool f0 = idrows[i] == 0, f1 = idrows[static_cast<size_t>(n) + i] == 0;
+  const double e0 = a00[kd], e1 = a11[kd];
+  const double d = f0 && f1 ? 0.5 * (e0 + e1) : (f0 ? e0 : (f1 ? e1 : 1.0));
+  const double inv = 1.0 / d;
+  const double d0 = f0 ? d : e0, d1 = f1 ? d : e1;
+  diag[i] = f2(static_cast<float>(d0), static_cast<float>(d1));
+  dinv[i] = f2(static_cast<float>(1.0 / d0), static_cast<float>(1.0 / d1));
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+    const int j = cols[k];
+    double v = 0.0;
+    if (keep == nullptr || keep[k] != 0) {
+      const bool u0 = f0 && idrows[j] == 0;
+      const bool u1 = f1 && idrows[static_cast<size_t>(n) + j] == 0;
+      if (u0 && u1)
+        v = 0.5 * (a00[k] + a11[k]);
+      else if (u0)
+        v = a00[k];
+      else if (u1)
+        v = a11[k];
+    }
+    const unsigned short h =
+        __half_as_ushort(__float2half_rn(static_cast<float>(v * inv)));
+    packed[k] = (static_cast<unsigned>((j - base) & 0xffff) << 16) | h;
+  }
+}
+
 // setup: 16-bit column offsets from each tile's lowest column (a workgroup per
 // tile); *overflow set when one does not fit
 __global__ __launch_bounds__(kBlock) void pmg_cols16_kernel(
@@ -411,15 +503,19 @@ __global__ void pmg_zero_kernel(int n, float2* __restrict__ v) {
 // ---------------------------------------------------------------------------
 static int check_level(const flow_pmg_level* L, const char* which) {
   FLOW_REQUIRE(L->n > 0 && L->nnz > 0 && L->nblocks > 0, which);
-  FLOW_REQUIRE(L->rowptr && L->cols && L->rowblocks && L->vals && L->diag &&
-                   L->dinv,
+  FLOW_REQUIRE(L->rowptr && L->cols && L->rowblocks && (L->vals || L->packed) &&
+                   L->diag && L->dinv,
                which);
   FLOW_REQUIRE(reinterpret_cast<uintptr_t>(L->vals) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(L->packed) % 16 == 0 &&
                    reinterpret_cast<uintptr_t>(L->cols) % 16 == 0 &&
                    reinterpret_cast<uintptr_t>(L->cols16) % 16 == 0,
                "packed values and column indices must be 16-byte aligned");
-  FLOW_REQUIRE(L->cols16 == nullptr || L->cbase != nullptr,
+  FLOW_REQUIRE((L->cols16 == nullptr && L->packed == nullptr) ||
+                   L->cbase != nullptr,
                "16-bit column offsets need the tiles' base columns");
+  FLOW_REQUIRE(L->packed == nullptr || L->idrows != nullptr,
+               "the one-plane stream needs the identity-row flags");
   FLOW_REQUIRE(L->lam_max > L->lam_min && L->lam_min > 0.0,
                "Chebyshev interval (0 < lam_min < lam_max)");
   return FLOW_OK;
@@ -463,20 +559,26 @@ void launch_cheb(const flow_pmg_level* L, const float2* g, const float2* rho_in,
                  float2* d_out, float2* x, const float2* d_extra, double* z,
                  const unsigned char* bc, const double* rin, const double* stop,
                  hipStream_t st) {
-  if (L->cols16)
-    hipLaunchKernelGGL((pmg_cheb_kernel<MODE, true>), dim3(L->nblocks),
-                       dim3(kBlock), 0, st, L->n, L->rowptr,
-                       static_cast<const void*>(L->cols16), L->cbase,
-                       reinterpret_cast<const __half2*>(L->vals), L->rowblocks, g,
-                       rho_in, rho_out, d_own, c1, c2, d_out, x, d_extra, z, bc,
-                       rin, stop);
+  if (L->packed)
+    hipLaunchKernelGGL((pmg_cheb_kernel<MODE, 2>), dim3(L->nblocks), dim3(kBlock),
+                       0, st, L->n, L->rowptr, static_cast<const void*>(nullptr),
+                       L->cbase, L->packed, L->idrows, L->rowblocks, g, rho_in,
+                       rho_out, d_own, c1, c2, d_out, x, d_extra, z, bc, rin,
+                       stop);
+  else if (L->cols16)
+    hipLaunchKernelGGL((pmg_cheb_kernel<MODE, 1>), dim3(L->nblocks), dim3(kBlock),
+                       0, st, L->n, L->rowptr,
+                       static_cast<const void*>(L->cols16), L->cbase, L->vals,
+                       static_cast<const unsigned char*>(nullptr), L->rowblocks,
+                       g, rho_in, rho_out, d_own, c1, c2, d_out, x, d_extra, z,
+                       bc, rin, stop);
   else
-    hipLaunchKernelGGL((pmg_cheb_kernel<MODE, false>), dim3(L->nblocks),
-                       dim3(kBlock), 0, st, L->n, L->rowptr,
-                       static_cast<const void*>(L->cols), L->cbase,
-                       reinterpret_cast<const __half2*>(L->vals), L->rowblocks, g,
-                       rho_in, rho_out, d_own, c1, c2, d_out, x, d_extra, z, bc,
-                       rin, stop);
+    hipLaunchKernelGGL((pmg_cheb_kernel<MODE, 0>), dim3(L->nblocks), dim3(kBlock),
+                       0, st, L->n, L->rowptr, static_cast<const void*>(L->cols),
+                       L->cbase, L->vals,
+                       static_cast<const unsigned char*>(nullptr), L->rowblocks,
+                       g, rho_in, rho_out, d_own, c1, c2, d_out, x, d_extra, z,
+                       bc, rin, stop);
 }
 
 }  // namespace
@@ -579,6 +681,31 @@ extern "C" int flow_pmg_pack(int n, int nnz, const int* rowptr,
   return FLOW_OK;
 }
 
+extern "C" int flow_pmg_pack1(int n, int nnz, int nblocks, const int* rowblocks,
+                              const int* rowptr, const int* cols,
+                              const int* diag_idx, const double* a00,
+                              const double* a11, const unsigned char* keep,
+                              const int* cbase, unsigned char* idrows,
+                              void* packed, float* diag, float* dinv,
+                              void* stream) {
+  FLOW_REQUIRE(n > 0 && nnz > 0 && nblocks > 0 && rowblocks && rowptr && cols &&
+                   diag_idx && a00 && a11 && cbase && idrows && packed && diag &&
+                   dinv,
+               "flow_pmg_pack1 arguments");
+  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0,
+               "the packed stream must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(pmg_idrows_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n,
+                     rowptr, diag_idx, a00, a11, keep, idrows);
+  hipLaunchKernelGGL(pmg_pack1_kernel, dim3(nblocks), dim3(kBlock), 0, st, n,
+                     rowblocks, rowptr, cols, diag_idx, a00, a11, keep, idrows,
+                     cbase, static_cast<unsigned*>(packed),
+                     reinterpret_cast<float2*>(diag),
+                     reinterpret_cast<float2*>(dinv));
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
 extern "C" int flow_pmg_cols16(int nblocks, const int* rowblocks,
                                const int* rowptr, const int* cols, int* cbase,
                                void* cols16, int* overflow_dev, void* stream) {
@@ -595,8 +722,9 @@ extern "C" int flow_pmg_cols16(int nblocks, const int* rowblocks,
 extern "C" int flow_pmg_lambda_max(const flow_pmg_level* L, int iterations,
                                    float* work, double* dwork,
                                    double* result_host, void* stream) {
-  FLOW_REQUIRE(L && L->n > 0 && L->rowptr && L->cols && L->rowblocks && L->vals &&
-                   work && dwork && result_host && iterations >= 2,
+  FLOW_REQUIRE(L && L->n > 0 && L->rowptr && L->cols && L->rowblocks &&
+                   (L->vals || L->packed) && work && dwork && result_host &&
+                   iterations >= 2,
                "flow_pmg_lambda_max arguments");
   hipStream_t st = as_stream(stream);
   const int n = L->n;

@@ -23,6 +23,7 @@ Setup here is index tables only (numpy, once per mesh); `refactor` packs the
 matrices and estimates the spectral radii with kernels of the library.
 '''
 import ctypes
+import os
 
 import numpy
 import torch
@@ -36,6 +37,15 @@ from .. import device
 # 16-bit column offsets in the packed levels (include/flow_hip.h,
 # flow_pmg_level.cols16); False: plain int32 columns
 COLS16 = True
+# ONE plane for both velocity components (flow_pmg_level.packed: the mean of
+# the two diagonal blocks = the Oseen operator, 4 B per nonzero with the 16-bit
+# column offset; needs COLS16's tile bases) instead of the two blocks as half2.
+# Measured on the 10 M-DoF workload (tools/ab_env_long.sh, 60 steps): the
+# products are 10 % shorter (the kernel is bound by its chain of dependent
+# loads more than by bytes), an application 45 us of 590 -- and the GMRES needs
+# 5.4 applications per step instead of 4.9: 9.66 against 9.45 ms per step.
+# Off by default.
+ONE_PLANE = os.environ.get('FLOW_AMD_PMG_ONE_PLANE', '0') == '1'
 
 
 def transfer_tables(lay2):
@@ -159,6 +169,15 @@ class _Level(object):
                 self._cols16 = (c16, cb)
                 s.cols16 = c16.data_ptr()
                 s.cbase = _hip.i32(cb, nb).value
+        self._packed = None
+        self._cols, self._rb_used = cols, rb
+        if ONE_PLANE and self._cols16 is not None:
+            pk = torch.zeros(nnz + 8, dtype=torch.int32, device=device.get())
+            idr = torch.zeros(2 * n, dtype=torch.uint8, device=device.get())
+            assert pk.data_ptr() % 16 == 0
+            self._packed = (pk, idr)
+            s.packed = _hip.i32(pk, nnz).value
+            s.idrows = _hip.u8(idr, 2 * n).value
         self.struct = s
 
     def _init_block(self, lay, rows):
@@ -195,6 +214,21 @@ class _Level(object):
         lay = self.lay
         assert J.layout is lay and J.kind == 2
         n, nnz, k0 = self.n, self.nnz, self.offset
+        if self._packed is not None:
+            pk, idr = self._packed
+            rb, cb = self._rb_used, self._cols16[1]
+            _hip.check(_hip.lib().flow_pmg_pack1(
+                n, nnz, rb.numel() - 1, _hip.i32(rb),
+                _hip.i32(self.rowptr, n + 1, 'rowptr'),
+                _hip.i32(self._cols, nnz, 'cols'),
+                _hip.i32(self.diag_idx, n, 'diag_idx'),
+                _hip.f64(J.plane(0)[k0:k0 + nnz], nnz),
+                _hip.f64(J.plane(3)[k0:k0 + nnz], nnz),
+                _hip.u8(self.keep, nnz) if self.keep is not None else None,
+                _hip.i32(cb), _hip.u8(idr, 2 * n), _hip.i32(pk, nnz),
+                _hip.f32(self.diag, 2 * n), _hip.f32(self.dinv, 2 * n),
+                _hip.stream()))
+            return
         _hip.check(_hip.lib().flow_pmg_pack(
             n, nnz, _hip.i32(self.rowptr, n + 1, 'rowptr'),
             _hip.i32(self.diag_idx, n, 'diag_idx'),
@@ -204,7 +238,7 @@ class _Level(object):
             _hip.f16(self.vals, 2 * nnz), _hip.f32(self.diag, 2 * n),
             _hip.f32(self.dinv, 2 * n), _hip.stream()))
 
-    def lambda_max(self, work, iterations=25):
+    def lambda_max(self, work, iterations=32):
         res = ctypes.c_double(0.0)
         _hip.check(_hip.lib().flow_pmg_lambda_max(
             ctypes.byref(self.struct), int(iterations),

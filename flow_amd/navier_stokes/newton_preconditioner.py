@@ -23,7 +23,7 @@ def age(pre, kind, rebuilt, its, applications, npar):
     more than twice the (BiCGStab-equivalent) iterations the fresh factors
     needed.  The p-multigrid cycle ages gently (13 -> 16 applications over 200
     plateau steps of the 10 M-DoF run) and a rebuild costs half a time step
-    (Jacobian assembly, packing, 2 x 25 power-method products): it is rebuilt as
+    (Jacobian assembly, packing, 2 x 32 power-method products): it is rebuilt as
     soon as a solve needs 2 applications (or 15 %) more than the fresh one."""
     if rebuilt:
         pre.base_its = max(its, npar['check_every'])

@@ -345,6 +345,16 @@ typedef struct {
    * block's columns to span < 65536 (flow_pmg_cols16 reports otherwise). */
   const void* cols16;
   const int* cbase;        /* nblocks */
+  /* optional: ONE plane for both components -- the mean of the two blocks
+   * (they differ by the reaction term of the Newton linearisation, of the size
+   * of the off-diagonal blocks the cycle drops; the mean is the Oseen operator)
+   * -- as a 32-bit word per nonzero: fp16 value | 16-bit column offset from
+   * cbase (4 B per nonzero; nnz words, 16-byte aligned, readable three past
+   * nnz; filled by flow_pmg_pack1).  Used instead of vals / cols16 when not
+   * NULL; idrows (2 n, component-blocked) flags the identity rows of each
+   * component, which the plane cannot carry. */
+  const void* packed;
+  const unsigned char* idrows;
 } flow_pmg_level;
 typedef struct {
   flow_pmg_level fine, coarse;
@@ -373,6 +383,21 @@ int flow_pmg_pack(int n, int nnz, const int* rowptr, const int* diag_idx,
                   const double* a00, const double* a11,
                   const unsigned char* keep, void* vals, float* diag,
                   float* dinv, void* stream);
+/* The one-plane stream of a level (flow_pmg_level.packed) from the same two
+ * blocks: idrows[a n + i] = 1 where row i of block a has no off-diagonal entry
+ * (a Dirichlet dof of component a: found here, the caller passes no mask);
+ * entry (i, j) = mean of a00 / a11 over the components in which neither row i
+ * nor column j is such a dof, divided by the mean diagonal over the free
+ * components of row i, rounded to fp16 and packed with the column offset from
+ * cbase[tile] (flow_pmg_cols16 of the same row blocks, no overflow); diag /
+ * dinv as flow_pmg_pack's with the free components' entries replaced by the
+ * mean.  keep as in flow_pmg_pack. */
+int flow_pmg_pack1(int n, int nnz, int nblocks, const int* rowblocks,
+                   const int* rowptr, const int* cols, const int* diag_idx,
+                   const double* a00, const double* a11,
+                   const unsigned char* keep, const int* cbase,
+                   unsigned char* idrows, void* packed, float* diag,
+                   float* dinv, void* stream);
 /* cols16 / cbase of a level's pattern; *overflow_dev (zeroed by the caller) is
  * set when an offset does not fit in 16 bits */
 int flow_pmg_cols16(int nblocks, const int* rowblocks, const int* rowptr,
