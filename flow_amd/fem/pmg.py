@@ -258,8 +258,8 @@ class Pmg(object):
     power method (tools/precond_lab.py: 2 / 2 / 4 steps and ratios 8 / 8 are a
     flat optimum).'''
 
-    def __init__(self, W, pre=2, post=2, coarse_steps=4, ratio_fine=8.0,
-                 ratio_coarse=8.0, safety=1.1, rows=None, vrows=None):
+    def __init__(self, W, pre=1, post=2, coarse_steps=6, ratio_fine=5.0,
+                 ratio_coarse=12.0, safety=1.1, rows=None, vrows=None):
         '''rows / vrows = (r0, r1) / (v0, v1): block Jacobi on a strip -- the
         cycle on the diagonal block of those P2 / P1 rows in local numbering,
         couplings that leave the block dropped (flow_amd/parallel.py).'''

@@ -102,8 +102,15 @@ solver_parameters = {
                # products only (flow_amd/fem/pmg.py) -- 14-15 applications per
                # solve where the multicolour ILU(0) needs 33
                'preconditioner': 'pmg', 'ilu_lag': 8.0,
-               'pmg': {'pre': 2, 'post': 2, 'coarse_steps': 4,
-                       'ratio_fine': 8.0, 'ratio_coarse': 8.0},
+               # (Chebyshev steps before / after the coarse correction and
+               # on the P1 level; intervals [lam_max / ratio, 1.1 lam_max].
+               # r4, with the start vectors extrapolated in time -- the
+               # solves are short, what counts is the price of an
+               # application --: one fine product less and two cheap coarse
+               # ones more, tools/pmg_param_sweep.sh: 9.15 against 10.15
+               # ms/step with 2 / 2 / 4 and ratios 8 / 8)
+               'pmg': {'pre': 1, 'post': 2, 'coarse_steps': 6,
+                       'ratio_fine': 5.0, 'ratio_coarse': 12.0},
                # ... used where one cycle contracts a full-spectrum vector by
                # at least this factor (else: ILU(0)), and a GMRES that has not
                # converged after `pmg_maxit` applications is redone with ILU(0)

@@ -202,12 +202,14 @@ def test_the_cycle_as_an_algorithm_on_the_oracles_jacobian():
     of a body-fitted channel in the non-dimensional regime of the 10 M-DoF
     workload (viscosity scaled with the mesh width: cell Peclet ~2, CFL ~1.8,
     diffusion number ~0.85), the P1 discretisation of the same operator as
-    coarse level through the product's transfer tables, 2 + 2 Chebyshev steps
-    on P2 and 4 on P1 (the numpy restatement above, in fp64): one application
+    coarse level through the product's transfer tables, the default cycle
+    (1 + 2 Chebyshev steps on P2 and 6 on P1; the numpy restatement above, in
+    fp64): one application
     contracts a random vector, and flexible GMRES needs about a third of the
     applications Jacobi needs (tools/precond_lab.py: 132 / 34 / 14 for Jacobi /
     multicolour ILU(0) / this cycle at 300 x 70).'''
     from types import SimpleNamespace
+    import flow_amd.navier_stokes as navsto
     from flow_amd import karman
     from flow_amd.fem.bcs import collect
     from flow_amd.fem import reference
@@ -264,12 +266,15 @@ def test_the_cycle_as_an_algorithm_on_the_oracles_jacobian():
         A = J[a * n:(a + 1) * n, a * n:(a + 1) * n].tocsr()
         A1 = J1[a * n1:(a + 1) * n1, a * n1:(a + 1) * n1].tocsr()
         l0, l1 = lam_max(A), lam_max(A1)
+        # (the cycle the solver runs by default)
+        par = navsto.solver_parameters['newton']['pmg']
         pre = SimpleNamespace(
             fine=SimpleNamespace(struct=SimpleNamespace(
-                lam_min=l0 / 8.0, lam_max=1.1 * l0)),
+                lam_min=l0 / par['ratio_fine'], lam_max=1.1 * l0)),
             coarse=SimpleNamespace(struct=SimpleNamespace(
-                lam_min=l1 / 8.0, lam_max=1.1 * l1)),
-            struct=SimpleNamespace(pre=2, post=2, coarse_steps=4))
+                lam_min=l1 / par['ratio_coarse'], lam_max=1.1 * l1)),
+            struct=SimpleNamespace(pre=par['pre'], post=par['post'],
+                                   coarse_steps=par['coarse_steps']))
         return lambda r: _cycle(pre, A, A1, P, isbc0[a * n:(a + 1) * n],
                                 isbc1[a * n1:(a + 1) * n1], r)
     cyc = [block(0), block(1)]
