@@ -41,8 +41,6 @@ class Operator(ctypes.Structure):
         ('vals', ctypes.c_void_p * 4),
         ('matfree', ctypes.c_void_p),
         ('rowmask', ctypes.c_void_p),
-        ('cols16', ctypes.c_void_p),
-        ('cbase', ctypes.c_void_p),
         ]
 
 

@@ -25,16 +25,10 @@ static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTile2 - 2, "tile minus alignment slack
 // The rows [r0, r1) of one workgroup (<= kBlock rows, <= kTile - 2 nonzeros): the
 // products go through LDS (prod, kTile doubles), then lane i sums row r0 + i.
 // Returns that row's sum (0 for a lane without a row).
-// C16: the column indices are 16-bit offsets from `base`, the lowest column of
-// the row block (flow_operator.cols16 / cbase: 10 B per nonzero instead of 12).
-template <bool C16>
-__device__ __forceinline__ double stream_rows_sum_t(
-    int r0, int r1, const int* __restrict__ rowptr, const void* __restrict__ cols_any,
-    int base, const double* __restrict__ vals, const double* __restrict__ x,
+__device__ __forceinline__ double stream_rows_sum(
+    int r0, int r1, const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vals, const double* __restrict__ x,
     double* __restrict__ prod) {
-  const int* __restrict__ cols = static_cast<const int*>(cols_any);
-  const unsigned short* __restrict__ cols16 =
-      static_cast<const unsigned short*>(cols_any);
   const int k0 = rowptr[r0];
   const int k1 = rowptr[r1];
   // 16-byte value loads / 8-byte index loads: every lane owns PAIRS pairs of
@@ -49,7 +43,6 @@ __device__ __forceinline__ double stream_rows_sum_t(
   }
   const double2* __restrict__ v2p = reinterpret_cast<const double2*>(vals + ka);
   const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
-  const ushort2* __restrict__ h2p = reinterpret_cast<const ushort2*>(cols16 + ka);
   const int npair = (k1 - ka + 1) >> 1;   // a trailing odd element reads one
                                           // entry of the next tile (unused)
   double2 v[kPairs];
@@ -59,12 +52,7 @@ __device__ __forceinline__ double stream_rows_sum_t(
     const int p = threadIdx.x + j * kBlock;
     const bool ok = p < npair;
     v[j] = ok ? v2p[p] : make_double2(0.0, 0.0);
-    if (C16) {
-      const ushort2 h = ok ? h2p[p] : make_ushort2(0, 0);
-      c[j] = make_int2(base + h.x, base + h.y);
-    } else {
-      c[j] = ok ? c2p[p] : make_int2(0, 0);
-    }
+    c[j] = ok ? c2p[p] : make_int2(0, 0);
   }
   // x is only gathered for the tile's OWN nonzeros [k0, k1): the alignment
   // slack before k0, the odd element behind k1 (a column of another row, or
@@ -74,8 +62,7 @@ __device__ __forceinline__ double stream_rows_sum_t(
   // Those entries gather the tile's first column instead (an index select,
   // the loads themselves stay unconditional and all in flight).
   const int lo = k0 - ka, hi = k1 - ka;
-  const int ks = k0 < k1 ? k0 : (k0 > 0 ? k0 - 1 : 0);
-  const int safe = C16 ? base + cols16[ks] : cols[ks];
+  const int safe = cols[k0 < k1 ? k0 : (k0 > 0 ? k0 - 1 : 0)];
   double x0[kPairs], x1[kPairs];
   if (k0 < k1) {                       // (block-uniform)
 #pragma unroll
@@ -102,35 +89,18 @@ __device__ __forceinline__ double stream_rows_sum_t(
   return s;
 }
 
-__device__ __forceinline__ double stream_rows_sum(
-    int r0, int r1, const int* __restrict__ rowptr, const int* __restrict__ cols,
-    const double* __restrict__ vals, const double* __restrict__ x,
-    double* __restrict__ prod) {
-  return stream_rows_sum_t<false>(r0, r1, rowptr, cols, 0, vals, x, prod);
-}
-
 // One tile of the CSR stream -- the rows [r0, r1) of workgroup blockIdx.x (XCD-
 // aware tile mapping, common.h).  Returns the lane's row sum; r / r1 tell the
 // caller whether the lane has a row.
-template <bool C16>
-__device__ __forceinline__ double stream_tile_row_sum_t(
-    const int* __restrict__ rowptr, const void* __restrict__ cols_any,
-    const int* __restrict__ cbase, const double* __restrict__ vals,
-    const int* __restrict__ rowblocks, const double* __restrict__ x,
-    double* __restrict__ prod, int& r, int& r1) {
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int r0 = rowblocks[tile];
-  r1 = rowblocks[tile + 1];
-  r = r0 + threadIdx.x;
-  return stream_rows_sum_t<C16>(r0, r1, rowptr, cols_any, C16 ? cbase[tile] : 0,
-                                vals, x, prod);
-}
 __device__ __forceinline__ double stream_tile_row_sum(
     const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals, const int* __restrict__ rowblocks,
     const double* __restrict__ x, double* __restrict__ prod, int& r, int& r1) {
-  return stream_tile_row_sum_t<false>(rowptr, cols, nullptr, vals, rowblocks, x,
-                                      prod, r, r1);
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int r0 = rowblocks[tile];
+  r1 = rowblocks[tile + 1];
+  r = r0 + threadIdx.x;
+  return stream_rows_sum(r0, r1, rowptr, cols, vals, x, prod);
 }
 
 // The same tile with ONE value plane applied to both components of a
@@ -139,17 +109,12 @@ __device__ __forceinline__ double stream_tile_row_sum(
 // 1022-nonzero tile that still leaves the 8 workgroups per CU the wave limit
 // allows), both row sums out of ONE pass over the segment.  A block of a square
 // operator is never empty.  Returns (sum of component 0, sum of component 1).
-template <bool C16>
-__device__ __forceinline__ double2 stream_tile_pair_row_sum_t(
-    const int* __restrict__ rowptr, const void* __restrict__ cols_any,
-    const int* __restrict__ cbase, const double* __restrict__ vals,
-    const int* __restrict__ rowblocks, const double* __restrict__ x, int xs,
-    double2* __restrict__ prod, int& r, int& r1) {
-  const int* __restrict__ cols = static_cast<const int*>(cols_any);
-  const unsigned short* __restrict__ cols16 =
-      static_cast<const unsigned short*>(cols_any);
+__device__ __forceinline__ double2 stream_tile_pair_row_sum(
+    const int* __restrict__ rowptr, const int* __restrict__ cols,
+    const double* __restrict__ vals, const int* __restrict__ rowblocks,
+    const double* __restrict__ x, int xs, double2* __restrict__ prod, int& r,
+    int& r1) {
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int base = C16 ? cbase[tile] : 0;
   const int r0 = rowblocks[tile];
   r1 = rowblocks[tile + 1];
   const int k0 = rowptr[r0];
@@ -163,7 +128,6 @@ __device__ __forceinline__ double2 stream_tile_pair_row_sum_t(
   }
   const double2* __restrict__ v2p = reinterpret_cast<const double2*>(vals + ka);
   const int2* __restrict__ c2p = reinterpret_cast<const int2*>(cols + ka);
-  const ushort2* __restrict__ h2p = reinterpret_cast<const ushort2*>(cols16 + ka);
   const int npair = (k1 - ka + 1) >> 1;
   double2 v[kPairs2];
   int2 c[kPairs2];
@@ -172,16 +136,11 @@ __device__ __forceinline__ double2 stream_tile_pair_row_sum_t(
     const int p = threadIdx.x + j * kBlock;
     const bool ok = p < npair;
     v[j] = ok ? v2p[p] : make_double2(0.0, 0.0);
-    if (C16) {
-      const ushort2 h = ok ? h2p[p] : make_ushort2(0, 0);
-      c[j] = make_int2(base + h.x, base + h.y);
-    } else {
-      c[j] = ok ? c2p[p] : make_int2(0, 0);
-    }
+    c[j] = ok ? c2p[p] : make_int2(0, 0);
   }
   // (only the tile's own columns are dereferenced: see stream_tile_row_sum)
   const int lo = k0 - ka, hi = k1 - ka;
-  const int safe = C16 ? base + cols16[k0] : cols[k0];
+  const int safe = cols[k0];
   double xa[kPairs2], xb[kPairs2], ua[kPairs2], ub[kPairs2];
 #pragma unroll
   for (int j = 0; j < kPairs2; ++j) {   // all gathers in flight before any use
@@ -209,14 +168,6 @@ __device__ __forceinline__ double2 stream_tile_pair_row_sum_t(
     s1 += q.y;
   }
   return make_double2(s0, s1);
-}
-__device__ __forceinline__ double2 stream_tile_pair_row_sum(
-    const int* __restrict__ rowptr, const int* __restrict__ cols,
-    const double* __restrict__ vals, const int* __restrict__ rowblocks,
-    const double* __restrict__ x, int xs, double2* __restrict__ prod, int& r,
-    int& r1) {
-  return stream_tile_pair_row_sum_t<false>(rowptr, cols, nullptr, vals, rowblocks,
-                                           x, xs, prod, r, r1);
 }
 
 }  // namespace flow

@@ -57,11 +57,9 @@ static_assert(3 * kRedBlocks + kNumSlots <= FLOW_REDUCE_WORK, "work size");
 // scalar plane(s): blockIdx.y selects the component of a block-diagonal operator.
 // DOT: the workgroup also leaves its share of x.y (= x.Ax) in
 // dpart[blockIdx.y * gridDim.x + blockIdx.x] (CG's z.w without another pass).
-// C16: 16-bit column offsets (flow_operator.cols16 / cbase) instead of `cols`.
-template <bool DOT, bool C16 = false>
+template <bool DOT>
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
-    int n, const int* __restrict__ rowptr, const void* __restrict__ cols,
-    const int* __restrict__ cbase,
+    int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals0, const double* __restrict__ vals1,
     const int* __restrict__ rowblocks, const double* __restrict__ x,
     double* __restrict__ y, double* __restrict__ dpart,
@@ -72,8 +70,8 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
   x += static_cast<size_t>(blockIdx.y) * n;
   y += static_cast<size_t>(blockIdx.y) * n;
   int r, r1;
-  const double s = stream_tile_row_sum_t<C16>(rowptr, cols, cbase, vals, rowblocks,
-                                              x, prod, r, r1);
+  const double s =
+      stream_tile_row_sum(rowptr, cols, vals, rowblocks, x, prod, r, r1);
   double t = 0.0;
   if (r < r1) {
     y[r] = s;
@@ -236,10 +234,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_block2_kernel(
 // one value plane applied to both components of a component-blocked vector,
 // identity on the rows with mask 0 (flow_operator kind 4): the matrix is read
 // once for the two products
-template <bool DOT, bool C16 = false>
+template <bool DOT>
 __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
-    int n, const int* __restrict__ rowptr, const void* __restrict__ cols,
-    const int* __restrict__ cbase,
+    int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals, const int* __restrict__ rowblocks,
     const unsigned char* __restrict__ mask, const double* __restrict__ x,
     double* __restrict__ y, int xs, double* __restrict__ dpart,
@@ -248,8 +245,8 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_pair_kernel(
   __shared__ double2 prod[kTile2];
   if (stopped(stop)) return;
   int r, r1;
-  const double2 s = stream_tile_pair_row_sum_t<C16>(rowptr, cols, cbase, vals,
-                                                    rowblocks, x, xs, prod, r, r1);
+  const double2 s =
+      stream_tile_pair_row_sum(rowptr, cols, vals, rowblocks, x, xs, prod, r, r1);
   double s0 = s.x, s1 = s.y;
   double t = 0.0;
   if (r < r1) {
@@ -288,10 +285,6 @@ int check_operator(const flow_operator* A) {
   }
   FLOW_REQUIRE((reinterpret_cast<size_t>(A->cols) & 7) == 0,
                "cols must be 8-byte aligned");
-  FLOW_REQUIRE(A->cols16 == nullptr ||
-                   (A->cbase != nullptr &&
-                    (reinterpret_cast<size_t>(A->cols16) & 3) == 0),
-               "cols16 needs the row blocks' base columns and 4-byte alignment");
   return FLOW_OK;
 }
 
@@ -330,28 +323,15 @@ static int apply(const flow_operator* A, const double* x, double* y,
   const int xs = vec_stride ? vec_stride : A->n;
   const dim3 grid(A->nblocks, A->kind == 1 ? 2 : 1);
   const double* v1 = A->kind == 1 ? A->vals[1] : A->vals[0];
-  const void* const ci = A->cols;
-  const void* const c16 = A->cols16;
   if (A->kind == 4) {
-    if (dpart && c16)
-      hipLaunchKernelGGL((spmv_stream_pair_kernel<true, true>), grid, dim3(kBlock),
-                         0, st, A->n, A->rowptr, c16, A->cbase, A->vals[0],
-                         A->rowblocks, A->rowmask, x, y, xs, dpart, stop);
-    else if (dpart)
-      hipLaunchKernelGGL((spmv_stream_pair_kernel<true, false>), grid,
-                         dim3(kBlock), 0, st, A->n, A->rowptr, ci, A->cbase,
-                         A->vals[0], A->rowblocks, A->rowmask, x, y, xs, dpart,
-                         stop);
-    else if (c16)
-      hipLaunchKernelGGL((spmv_stream_pair_kernel<false, true>), grid,
-                         dim3(kBlock), 0, st, A->n, A->rowptr, c16, A->cbase,
-                         A->vals[0], A->rowblocks, A->rowmask, x, y, xs, dpart,
-                         stop);
+    if (dpart)
+      hipLaunchKernelGGL(spmv_stream_pair_kernel<true>, grid, dim3(kBlock), 0, st,
+                         A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
+                         A->rowmask, x, y, xs, dpart, stop);
     else
-      hipLaunchKernelGGL((spmv_stream_pair_kernel<false, false>), grid,
-                         dim3(kBlock), 0, st, A->n, A->rowptr, ci, A->cbase,
-                         A->vals[0], A->rowblocks, A->rowmask, x, y, xs, dpart,
-                         stop);
+      hipLaunchKernelGGL(spmv_stream_pair_kernel<false>, grid, dim3(kBlock), 0,
+                         st, A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
+                         A->rowmask, x, y, xs, dpart, stop);
   } else if (A->kind == 2) {
     if (dpart)
       hipLaunchKernelGGL(spmv_stream_block2_kernel<true>, grid, dim3(kBlock), 0,
@@ -367,23 +347,14 @@ static int apply(const flow_operator* A, const double* x, double* y,
     SpmvProfile& pf = g_spmv_profile;
     const bool timed = pf.used < pf.cap && A->kind == 0 && A->n == pf.rows;
     if (timed) FLOW_CHECK_HIP(hipEventRecord(pf.ev[2 * pf.used], st));
-    if (c16)
-      hipLaunchKernelGGL((spmv_stream_kernel<true, true>), grid, dim3(kBlock), 0,
-                         st, A->n, A->rowptr, c16, A->cbase, A->vals[0], v1,
-                         A->rowblocks, x, y, dpart, stop);
-    else
-      hipLaunchKernelGGL((spmv_stream_kernel<true, false>), grid, dim3(kBlock), 0,
-                         st, A->n, A->rowptr, ci, A->cbase, A->vals[0], v1,
-                         A->rowblocks, x, y, dpart, stop);
+    hipLaunchKernelGGL(spmv_stream_kernel<true>, grid, dim3(kBlock), 0, st, A->n,
+                       A->rowptr, A->cols, A->vals[0], v1, A->rowblocks, x, y,
+                       dpart, stop);
     if (timed) FLOW_CHECK_HIP(hipEventRecord(pf.ev[2 * pf.used++ + 1], st));
-  } else if (c16) {
-    hipLaunchKernelGGL((spmv_stream_kernel<false, true>), grid, dim3(kBlock), 0, st,
-                       A->n, A->rowptr, c16, A->cbase, A->vals[0], v1,
-                       A->rowblocks, x, y, dpart, stop);
   } else {
-    hipLaunchKernelGGL((spmv_stream_kernel<false, false>), grid, dim3(kBlock), 0,
-                       st, A->n, A->rowptr, ci, A->cbase, A->vals[0], v1,
-                       A->rowblocks, x, y, dpart, stop);
+    hipLaunchKernelGGL(spmv_stream_kernel<false>, grid, dim3(kBlock), 0, st,
+                       A->n, A->rowptr, A->cols, A->vals[0], v1, A->rowblocks, x,
+                       y, dpart, stop);
   }
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
@@ -1300,7 +1271,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 24; }
+extern "C" int flow_abi_version(void) { return 23; }
 
 // nonzeros a CSR-stream row block of an operator of `kind` may hold (the host
 // builds the row blocks: flow_amd/fem/space.py)

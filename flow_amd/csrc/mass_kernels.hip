@@ -26,10 +26,8 @@ namespace flow {
 // fp64 residual with the fp32 epilogue: rho0 = D^-1 (b - A x)
 // ---------------------------------------------------------------------------
 // scalar operator (kind 0)
-template <bool C16>
 __global__ __launch_bounds__(kBlock) void mass_residual_kernel(
-    const int* __restrict__ rowptr, const void* __restrict__ cols,
-    const int* __restrict__ cbase,
+    const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals, const int* __restrict__ rowblocks,
     const double* __restrict__ x, const double* __restrict__ b,
     const double* __restrict__ dinv, float* __restrict__ rho0,
@@ -37,17 +35,15 @@ __global__ __launch_bounds__(kBlock) void mass_residual_kernel(
   __shared__ double prod[kTile];
   if (stopped(stop)) return;
   int r, r1;
-  const double s = stream_tile_row_sum_t<C16>(rowptr, cols, cbase, vals, rowblocks,
-                                              x, prod, r, r1);
+  const double s =
+      stream_tile_row_sum(rowptr, cols, vals, rowblocks, x, prod, r, r1);
   if (r < r1) rho0[r] = static_cast<float>(dinv[r] * (b[r] - s));
 }
 
 // one plane, both components, identity rows by mask (kind 4); x: component
 // stride xs, b / dinv / mask: component stride n
-template <bool C16>
 __global__ __launch_bounds__(kBlock) void mass_residual_pair_kernel(
-    int n, const int* __restrict__ rowptr, const void* __restrict__ cols,
-    const int* __restrict__ cbase,
+    int n, const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals, const int* __restrict__ rowblocks,
     const unsigned char* __restrict__ mask, const double* __restrict__ x, int xs,
     const double* __restrict__ b, const double* __restrict__ dinv,
@@ -55,8 +51,8 @@ __global__ __launch_bounds__(kBlock) void mass_residual_pair_kernel(
   __shared__ double2 prod[kTile2];
   if (stopped(stop)) return;
   int r, r1;
-  const double2 s = stream_tile_pair_row_sum_t<C16>(rowptr, cols, cbase, vals,
-                                                    rowblocks, x, xs, prod, r, r1);
+  const double2 s =
+      stream_tile_pair_row_sum(rowptr, cols, vals, rowblocks, x, xs, prod, r, r1);
   if (r < r1) {
     const double s0 = mask[r] ? s.x : x[r];
     const double s1 = mask[n + r] ? s.y : x[xs + r];
@@ -381,34 +377,6 @@ static MassTiles default_tiles(const flow_mass* M) {
 
 }  // namespace
 
-// the fp64 residual launches (16-bit column offsets where the operator has them)
-static void launch_residual(const flow_mass* M, const double* x, const double* b,
-                            float* rho0, const double* stop, hipStream_t st) {
-  const flow_operator* A = M->A;
-  const dim3 grid(A->nblocks), blk(kBlock);
-  if (A->kind == 4) {
-    if (A->cols16)
-      hipLaunchKernelGGL(mass_residual_pair_kernel<true>, grid, blk, 0, st, A->n,
-                         A->rowptr, A->cols16, A->cbase, A->vals[0], A->rowblocks,
-                         A->rowmask, x, A->n, b, M->dinv,
-                         reinterpret_cast<float2*>(rho0), stop);
-    else
-      hipLaunchKernelGGL(mass_residual_pair_kernel<false>, grid, blk, 0, st, A->n,
-                         A->rowptr, static_cast<const void*>(A->cols), A->cbase,
-                         A->vals[0], A->rowblocks, A->rowmask, x, A->n, b, M->dinv,
-                         reinterpret_cast<float2*>(rho0), stop);
-  } else {
-    if (A->cols16)
-      hipLaunchKernelGGL(mass_residual_kernel<true>, grid, blk, 0, st, A->rowptr,
-                         A->cols16, A->cbase, A->vals[0], A->rowblocks, x, b,
-                         M->dinv, rho0, stop);
-    else
-      hipLaunchKernelGGL(mass_residual_kernel<false>, grid, blk, 0, st, A->rowptr,
-                         static_cast<const void*>(A->cols), A->cbase, A->vals[0],
-                         A->rowblocks, x, b, M->dinv, rho0, stop);
-  }
-}
-
 static int mass_check(const flow_mass* M) {
   FLOW_REQUIRE(M != nullptr && M->A != nullptr, "flow_mass is NULL");
   int rc = check_operator(M->A);
@@ -456,8 +424,15 @@ static int mass_solve(const flow_mass* M, const double* b, double* x,
                          st, A->n, A->kind == 4 ? 2 : 1, b, M->dinv, M->work16,
                          stop);
       x_is_zero = false;
+    } else if (A->kind == 4) {
+      hipLaunchKernelGGL(mass_residual_pair_kernel, dim3(A->nblocks), dim3(kBlock),
+                         0, st, A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
+                         A->rowmask, x, A->n, b, M->dinv,
+                         reinterpret_cast<float2*>(M->work16), stop);
     } else {
-      launch_residual(M, x, b, M->work16, stop, st);
+      hipLaunchKernelGGL(mass_residual_kernel, dim3(A->nblocks), dim3(kBlock), 0, st,
+                         A->rowptr, A->cols, A->vals[0], A->rowblocks, x, b, M->dinv,
+                         M->work16, stop);
     }
     const MassTiles T = default_tiles(M);
     if (A->kind == 4) {
@@ -649,8 +624,15 @@ static int shard_mass_solve(const flow_comm* C, const flow_rows* R,
       hipLaunchKernelGGL(mass_rho0_kernel, dim3(grid_for(R->r1 - R->r0)),
                          dim3(kBlock), 0, st, A->n, ncomp, b, M->dinv, rho0, stop,
                          R->r0, R->r1);
+    } else if (A->kind == 4) {
+      hipLaunchKernelGGL(mass_residual_pair_kernel, dim3(A->nblocks), dim3(kBlock),
+                         0, st, A->n, A->rowptr, A->cols, A->vals[0], A->rowblocks,
+                         A->rowmask, x, A->n, b, M->dinv,
+                         reinterpret_cast<float2*>(rho0), stop);
     } else {
-      launch_residual(M, x, b, rho0, stop, st);
+      hipLaunchKernelGGL(mass_residual_kernel, dim3(A->nblocks), dim3(kBlock), 0, st,
+                         A->rowptr, A->cols, A->vals[0], A->rowblocks, x, b, M->dinv,
+                         rho0, stop);
     }
     hipLaunchKernelGGL(shard_mass_pack_kernel, dim3(gp), dim3(kMassPackBlock), 0,
                        st, *R, ncomp, k == 0 ? 1 : 0, nlast, zz_part, xx_part, rho0,

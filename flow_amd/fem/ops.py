@@ -9,7 +9,6 @@ Everything numerical is a call into libflow_hip.so (flow_amd/_hip.py); torch
 only owns the HBM buffers.
 '''
 import ctypes
-import os
 
 import numpy
 import torch
@@ -106,32 +105,6 @@ def value_plane(layout):
     return device.zeros(plane_stride(layout))
 
 
-# 16-bit column offsets for the fp64 CSR-stream kernels (flow_operator.cols16:
-# 10 B per nonzero instead of 12); FLOW_AMD_COLS16=0: plain int32 columns
-COLS16 = os.environ.get('FLOW_AMD_COLS16', '1') != '0'
-
-
-def cols16_of(lay, rb, key):
-    """(cols16, cbase) device tensors of layout `lay` for the row blocks `rb`
-    (cached on the layout under `key`), or None where a block's columns span
-    more than 65535 -- or COLS16 is off."""
-    if not COLS16:
-        return None
-    key = ('cols16', key)
-    if key not in lay._dev:
-        n, nnz, nb = lay.N, lay.nnz, rb.numel() - 1
-        c16 = torch.zeros(nnz + 8, dtype=torch.int16, device=device.get())
-        cb = torch.zeros(nb, dtype=torch.int32, device=device.get())
-        flag = torch.zeros(1, dtype=torch.int32, device=device.get())
-        _hip.check(_hip.lib().flow_pmg_cols16(
-            nb, _hip.i32(rb), _hip.i32(lay.dev('rowptr'), n + 1),
-            _hip.i32(lay.dev('cols'), nnz), _hip.i32(cb, nb),
-            ctypes.c_void_p(c16.data_ptr()), _hip.i32(flag, 1), _hip.stream()))
-        ok = int(device.to_host(flag).item()) == 0
-        lay._dev[key] = (c16, cb) if ok else None
-    return lay._dev[key]
-
-
 class Matrix(object):
     '''Value planes over the CSR pattern of a scalar layout.
     kind 0: scalar (1 plane), 1: block-diagonal (2 planes), 2: 2x2 (4 planes),
@@ -190,12 +163,6 @@ class Matrix(object):
                 op.vals[p] = base + 8 * p * self.stride
             if self.rowmask is not None:
                 op.rowmask = _hip.u8(self.rowmask, 2 * lay.N, 'rowmask').value
-            if self.kind in (0, 1, 4):
-                rbname = 'rowblocks2' if self.kind == 4 else 'rowblocks'
-                c16 = cols16_of(lay, rb, rbname)
-                if c16 is not None:
-                    op.cols16 = c16[0].data_ptr()
-                    op.cbase = _hip.i32(c16[1], op.nblocks).value
             self._op = op
         return self._op
 

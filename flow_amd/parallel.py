@@ -506,19 +506,9 @@ class View(object):
 
     def operator(self, A):
         '''A copy of A's flow_operator that covers the owned rows only.'''
-        from .fem import ops
-        two = A.kind in (2, 4)
-        rb = self.rowblocks2 if two else self.rowblocks
-        op = owned_operator(A.operator(), rb)
-        # (16-bit column offsets belong to the row blocks: the rank's own)
-        op.cols16, op.cbase = None, None
-        if A.kind in (0, 1, 4):
-            c16 = ops.cols16_of(
-                self.layout, rb, ('strip', self.blocks.world, self.rows.r0, two))
-            if c16 is not None:
-                op.cols16 = c16[0].data_ptr()
-                op.cbase = _hip.i32(c16[1], rb.numel() - 1).value
-        return op
+        return owned_operator(
+            A.operator(),
+            self.rowblocks2 if A.kind in (2, 4) else self.rowblocks)
 
 
 def owned_operator(base, rowblocks):
@@ -527,8 +517,6 @@ def owned_operator(base, rowblocks):
                    ctypes.sizeof(_hip.Operator))
     op.rowblocks = _hip.i32(rowblocks)
     op.nblocks = rowblocks.numel() - 1
-    # (column offsets are per row block: not the base's)
-    op.cols16, op.cbase = None, None
     return op
 
 

@@ -85,14 +85,6 @@ typedef struct {
                               value PAIRS); cols likewise readable at nnz */
   const void* matfree;     /* kind 3 only: const flow_momentum_jvp* */
   const unsigned char* rowmask;   /* kind 4 only: 2n bytes, 0 = Dirichlet row */
-  /* optional (kinds 0, 1, 4): the column indices as 16-bit offsets from the
-   * lowest column of each row block -- cols16: nnz ushorts, 4-byte aligned,
-   * readable at nnz like cols; cbase: nblocks ints (flow_pmg_cols16 builds
-   * both for THESE rowblocks and reports a block whose columns span more
-   * than 65535).  The kernels then stream 10 B per nonzero instead of 12;
-   * cols stays required (setup kernels, kind 2). */
-  const void* cols16;
-  const int* cbase;
 } flow_operator;
 
 /* ---- K8: SpMV (PETSc MatMult inside every Krylov solve; heat.py:101) ---- */

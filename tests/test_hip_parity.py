@@ -144,46 +144,6 @@ def test_identity_row_operator(hip):
     assert torch.isfinite(xd).all()
 
 
-def test_16_bit_column_offsets_change_no_bit(hip, monkeypatch):
-    """flow_operator.cols16 / cbase (10 B per nonzero instead of 12): the same
-    products bit for bit as with the int32 columns, kinds 0, 1 and 4, on a
-    body-fitted mesh; the operators of a fresh Matrix carry them by default."""
-    import torch
-    rng = numpy.random.RandomState(3)
-    mesh = fem.karman_channel(60, 14, fitted=True)
-
-    def two_planes(lay, v0, v1):
-        A = ops.Matrix(lay, 1)
-        A.plane(0).copy_(v0[:lay.nnz])
-        A.plane(1).copy_(v1[:lay.nnz])
-        torch.cuda.synchronize()
-        return A.vals
-
-    for deg in (1, 2):
-        V = fem.FunctionSpace(mesh, 'CG', deg)
-        lay = V.layout
-        n = lay.N
-        M = ops.assemble_mass(V)
-        K = ops.assemble_scalar_matrix(lay, ops.STIFFNESS)
-        free = (rng.uniform(size=2 * n) > 0.07).astype(numpy.uint8)
-        mats = [lambda: ops.Matrix(lay, 0, K.vals),
-                lambda: ops.Matrix(lay, 1, two_planes(lay, M.vals, K.vals)),
-                lambda: ops.Matrix(lay, 4, M.vals, rowmask=_dev(free))]
-        for make in mats:
-            A = make()
-            assert A.operator().cols16 and A.operator().cbase
-            x = _dev(rng.standard_normal(A.size))
-            y16 = A.apply(x, _dev(numpy.zeros(A.size))).cpu().numpy()
-            monkeypatch.setattr(ops, 'COLS16', False)
-            B = make()
-            assert not B.operator().cols16
-            y32 = B.apply(x, _dev(numpy.zeros(A.size))).cpu().numpy()
-            monkeypatch.setattr(ops, 'COLS16', True)
-            assert numpy.array_equal(y16, y32), (deg, A.kind)
-            assert abs(y16 - A.to_scipy().dot(x.cpu().numpy())).max() \
-                <= 1e-13 * abs(y16).max()
-
-
 def test_cg_matches_direct_solve(hip):
     rng = numpy.random.RandomState(3)
     mesh = fem.karman_channel(48, 12)

@@ -34,9 +34,6 @@ def main():
     st = pstats.Stats(pr)
     st.sort_stats('tottime').print_stats(28)
     st.sort_stats('cumulative').print_stats(22)
-    # who launches the small vector kernels
-    for name in ('axpby', 'copy', 'fill', 'clone', 'vmul'):
-        st.print_callers(r'\(%s\)' % name)
 
 
 if __name__ == '__main__':
