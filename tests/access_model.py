@@ -127,6 +127,29 @@ def quad_tile_accesses(rowptr, cols, rowblocks):
     return lo, hi, last_loaded
 
 
+def cols16_tables(rowptr, cols, rowblocks):
+    '''pmg_cols16_kernel (pmg_kernels.hip) in numpy: per row block its lowest
+    column (0 for an empty block) and per nonzero the offset from it --
+    (cbase, offsets, fits): `fits` = every offset fits in 16 bits.  The kernels
+    that read flow_pmg_level.cols16 or the packed streams (flow_mass.packed16,
+    flow_pmg_level.packed) rebuild the column as cbase[tile] + offset: with
+    these tables that IS the int32 column, so the access sets of
+    quad_tile_accesses hold for them unchanged.'''
+    rowptr = numpy.asarray(rowptr, dtype=numpy.int64)
+    cols = numpy.asarray(cols, dtype=numpy.int64)
+    rb = numpy.asarray(rowblocks, dtype=numpy.int64)
+    k0, k1 = rowptr[rb[:-1]], rowptr[rb[1:]]
+    nnz = int(rowptr[-1])
+    tile_of = numpy.repeat(numpy.arange(len(k0)), k1 - k0)
+    lo, hi = int(k0[0]), int(k1[-1])
+    cbase = numpy.full(len(k0), numpy.iinfo(numpy.int64).max)
+    numpy.minimum.at(cbase, tile_of, cols[lo:hi])
+    cbase[k0 >= k1] = 0
+    off = numpy.zeros(nnz, dtype=numpy.int64)
+    off[lo:hi] = cols[lo:hi] - cbase[tile_of]
+    return cbase, off, bool((off <= 0xffff).all() and (off >= 0).all())
+
+
 def window(rowptr, cols, rowblocks, variant='stream'):
     '''[min, max] of x indices over all tiles, or None when nothing is read.'''
     lo, hi = tile_accesses(rowptr, cols, rowblocks, variant)

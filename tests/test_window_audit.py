@@ -276,3 +276,12 @@ def test_mass_solver_tiles_stay_inside_the_vector(host_structs):
             lo, hi, last = am.quad_tile_accesses(lay.pattern('rowptr'), cols, rb)
             assert lo.min() >= 0 and hi.max() < lay.N
             assert last.max() < lay.nnz + 4
+            # the packed streams (flow_mass.packed16, flow_pmg_level.cols16 /
+            # .packed on the same row blocks): every column offset from the
+            # tile's lowest column fits in 16 bits, base + offset IS the column
+            cbase, off, fits = am.cols16_tables(lay.pattern('rowptr'),
+                                                lay.pattern('cols'), rb)
+            assert fits, (name, degree, int(off.max()))
+            tile = numpy.repeat(numpy.arange(len(rb) - 1), numpy.diff(
+                lay.pattern('rowptr').astype(numpy.int64)[rb]))
+            assert numpy.array_equal(cbase[tile] + off, lay.pattern('cols'))
