@@ -30,6 +30,14 @@ int check_operator(const flow_operator* A);
 int fill(int n, double value, double* y, hipStream_t st);
 // Krylov scalar slots in HBM (a solver's S = work + 3*kRedBlocks); read_state:
 // all of them -> host with ONE synchronisation (through the mailbox)
+// The CSR-stream tile functions call early(row, has_row) as soon as a lane knows
+// its row: a kernel issues its epilogue's loads there (NoEarly: nothing), so
+// that they travel with the tile's own loads instead of adding a link to the
+// chain of dependent loads behind the row sum.
+struct NoEarly {
+  __device__ __forceinline__ void operator()(int, bool) const {}
+};
+
 enum Slot {
   kGamma = 0, kAlpha, kBeta, kRes2, kB2, kRho, kOmega, kRhoNew, kTmp,
   kBreak, kTarget2, kDone, kConvIt, kIter, kNumSlots = 16

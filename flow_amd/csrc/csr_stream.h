@@ -25,10 +25,11 @@ static_assert(FLOW_SPMV_NNZ_PER_BLOCK == kTile2 - 2, "tile minus alignment slack
 // The rows [r0, r1) of one workgroup (<= kBlock rows, <= kTile - 2 nonzeros): the
 // products go through LDS (prod, kTile doubles), then lane i sums row r0 + i.
 // Returns that row's sum (0 for a lane without a row).
+template <class Early = NoEarly>
 __device__ __forceinline__ double stream_rows_sum(
     int r0, int r1, const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals, const double* __restrict__ x,
-    double* __restrict__ prod) {
+    double* __restrict__ prod, Early early = Early()) {
   const int k0 = rowptr[r0];
   const int k1 = rowptr[r1];
   // 16-byte value loads / 8-byte index loads: every lane owns PAIRS pairs of
@@ -36,6 +37,7 @@ __device__ __forceinline__ double stream_rows_sum(
   // planes start 16-B aligned and the host caps a block at kTile-2 nonzeros).
   const int ka = k0 & ~1;
   const int r = r0 + threadIdx.x;
+  early(r, r < r1);
   int a = 0, b = 0;
   if (r < r1) {
     a = rowptr[r] - ka;
@@ -92,15 +94,17 @@ __device__ __forceinline__ double stream_rows_sum(
 // One tile of the CSR stream -- the rows [r0, r1) of workgroup blockIdx.x (XCD-
 // aware tile mapping, common.h).  Returns the lane's row sum; r / r1 tell the
 // caller whether the lane has a row.
+template <class Early = NoEarly>
 __device__ __forceinline__ double stream_tile_row_sum(
     const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals, const int* __restrict__ rowblocks,
-    const double* __restrict__ x, double* __restrict__ prod, int& r, int& r1) {
+    const double* __restrict__ x, double* __restrict__ prod, int& r, int& r1,
+    Early early = Early()) {
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int r0 = rowblocks[tile];
   r1 = rowblocks[tile + 1];
   r = r0 + threadIdx.x;
-  return stream_rows_sum(r0, r1, rowptr, cols, vals, x, prod);
+  return stream_rows_sum(r0, r1, rowptr, cols, vals, x, prod, early);
 }
 
 // The same tile with ONE value plane applied to both components of a
@@ -109,11 +113,12 @@ __device__ __forceinline__ double stream_tile_row_sum(
 // 1022-nonzero tile that still leaves the 8 workgroups per CU the wave limit
 // allows), both row sums out of ONE pass over the segment.  A block of a square
 // operator is never empty.  Returns (sum of component 0, sum of component 1).
+template <class Early = NoEarly>
 __device__ __forceinline__ double2 stream_tile_pair_row_sum(
     const int* __restrict__ rowptr, const int* __restrict__ cols,
     const double* __restrict__ vals, const int* __restrict__ rowblocks,
     const double* __restrict__ x, int xs, double2* __restrict__ prod, int& r,
-    int& r1) {
+    int& r1, Early early = Early()) {
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int r0 = rowblocks[tile];
   r1 = rowblocks[tile + 1];
@@ -121,6 +126,7 @@ __device__ __forceinline__ double2 stream_tile_pair_row_sum(
   const int k1 = rowptr[r1];
   const int ka = k0 & ~1;
   r = r0 + threadIdx.x;
+  early(r, r < r1);
   int a = 0, b = 0;
   if (r < r1) {
     a = rowptr[r] - ka;

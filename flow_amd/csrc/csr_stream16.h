@@ -40,11 +40,16 @@ __device__ __forceinline__ void vzero(float2& s) { s = make_float2(0.f, 0.f); }
 // before the first use; products through LDS, lane i sums row r0 + i.
 // Window-safe like stream_tile_row_sum: g is only dereferenced for the tile's
 // own nonzeros (slack and idle lanes gather the tile's first column).
-template <class V>
+// early(row, has_row) is called as soon as the lane knows its row: the caller
+// issues its epilogue's loads there, so that they travel with the tile's own
+// loads instead of adding a link to the chain of dependent loads.
+// (NoEarly: common.h)
+template <class V, class Early = NoEarly>
 __device__ __forceinline__ V mass_tile_row_sum(
     const int* __restrict__ rowptr, const int* __restrict__ cols,
     const __half* __restrict__ vals, const int* __restrict__ rowblocks,
-    const V* __restrict__ g, V* __restrict__ prod, int& r, int& r1) {
+    const V* __restrict__ g, V* __restrict__ prod, int& r, int& r1,
+    Early early = Early()) {
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int r0 = rowblocks[tile];
   r1 = rowblocks[tile + 1];
@@ -52,6 +57,7 @@ __device__ __forceinline__ V mass_tile_row_sum(
   const int k1 = rowptr[r1];
   const int ka = k0 & ~3;
   r = r0 + threadIdx.x;
+  early(r, r < r1);
   int a = 0, b = 0;
   if (r < r1) {
     a = rowptr[r] - ka;
@@ -107,11 +113,12 @@ __device__ __forceinline__ V mass_tile_row_sum(
 // load (4 B per nonzero instead of 6, half the stream-load instructions).
 // Possible whenever a tile's columns span < 65536 (any banded numbering; the
 // host checks and falls back to the plain stream otherwise).
-template <class V>
+template <class V, class Early = NoEarly>
 __device__ __forceinline__ V mass_tile_row_sum_packed(
     const int* __restrict__ rowptr, const unsigned* __restrict__ packed,
     const int* __restrict__ cbase, const int* __restrict__ rowblocks,
-    const V* __restrict__ g, V* __restrict__ prod, int& r, int& r1) {
+    const V* __restrict__ g, V* __restrict__ prod, int& r, int& r1,
+    Early early = Early()) {
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int r0 = rowblocks[tile];
   r1 = rowblocks[tile + 1];
@@ -120,6 +127,7 @@ __device__ __forceinline__ V mass_tile_row_sum_packed(
   const int k1 = rowptr[r1];
   const int ka = k0 & ~3;
   r = r0 + threadIdx.x;
+  early(r, r < r1);
   int a = 0, b = 0;
   if (r < r1) {
     a = rowptr[r] - ka;

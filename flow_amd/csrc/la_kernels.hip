@@ -70,12 +70,16 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
   x += static_cast<size_t>(blockIdx.y) * n;
   y += static_cast<size_t>(blockIdx.y) * n;
   int r, r1;
+  double xi = 0.0;
+  auto early = [&](int row, bool has) {
+    if (DOT && has) xi = x[row];
+  };
   const double s =
-      stream_tile_row_sum(rowptr, cols, vals, rowblocks, x, prod, r, r1);
+      stream_tile_row_sum(rowptr, cols, vals, rowblocks, x, prod, r, r1, early);
   double t = 0.0;
   if (r < r1) {
     y[r] = s;
-    if (DOT) t = s * x[r];
+    if (DOT) t = s * xi;
   }
   if (DOT) {
     t = block_sum_once(t);
@@ -144,12 +148,16 @@ __global__ __launch_bounds__(kBlock) void mg_up2_kernel(
   const int r0 = rowblocks[tile];
   const int r1 = rowblocks[tile + 1];
   const int r = r0 + threadIdx.x;
+  double ci = 0.0, di = 0.0;       // (early: with the tiles' own loads)
+  if (r < r1) {
+    ci = c[r];
+    di = dinv[r];
+  }
   const double sp = stream_rows_sum(r0, r1, p_rowptr, p_cols, p_vals, xc, prod_p);
   const double sa = stream_rows_sum(r0, r1, a_rowptr, a_cols, a_vals, c, prod_a);
   double g = 0.0, rr = 0.0;
   if (r < r1) {
-    const double ci = c[r];
-    const double yi = sp + omega * dinv[r] * (2.0 * ci - sa);
+    const double yi = sp + omega * di * (2.0 * ci - sa);
     y[r] = yi;
     if (DOTS) {
       g = ci * yi;

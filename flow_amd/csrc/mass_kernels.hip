@@ -35,9 +35,16 @@ __global__ __launch_bounds__(kBlock) void mass_residual_kernel(
   __shared__ double prod[kTile];
   if (stopped(stop)) return;
   int r, r1;
+  double bi = 0.0, di = 0.0;
+  auto early = [&](int row, bool has) {
+    if (has) {
+      bi = b[row];
+      di = dinv[row];
+    }
+  };
   const double s =
-      stream_tile_row_sum(rowptr, cols, vals, rowblocks, x, prod, r, r1);
-  if (r < r1) rho0[r] = static_cast<float>(dinv[r] * (b[r] - s));
+      stream_tile_row_sum(rowptr, cols, vals, rowblocks, x, prod, r, r1, early);
+  if (r < r1) rho0[r] = static_cast<float>(di * (bi - s));
 }
 
 // one plane, both components, identity rows by mask (kind 4); x: component
@@ -51,15 +58,26 @@ __global__ __launch_bounds__(kBlock) void mass_residual_pair_kernel(
   __shared__ double2 prod[kTile2];
   if (stopped(stop)) return;
   int r, r1;
-  const double2 s =
-      stream_tile_pair_row_sum(rowptr, cols, vals, rowblocks, x, xs, prod, r, r1);
+  double b0 = 0.0, b1 = 0.0, d0 = 0.0, d1 = 0.0, x0 = 0.0, x1 = 0.0;
+  bool m0 = true, m1 = true;
+  auto early = [&](int row, bool has) {
+    if (!has) return;
+    b0 = b[row];
+    b1 = b[static_cast<size_t>(n) + row];
+    d0 = dinv[row];
+    d1 = dinv[static_cast<size_t>(n) + row];
+    m0 = mask[row] != 0;
+    m1 = mask[n + row] != 0;
+    x0 = x[row];
+    x1 = x[xs + row];
+  };
+  const double2 s = stream_tile_pair_row_sum(rowptr, cols, vals, rowblocks, x, xs,
+                                             prod, r, r1, early);
   if (r < r1) {
-    const double s0 = mask[r] ? s.x : x[r];
-    const double s1 = mask[n + r] ? s.y : x[xs + r];
-    rho0[r] = make_float2(
-        static_cast<float>(dinv[r] * (b[r] - s0)),
-        static_cast<float>(dinv[static_cast<size_t>(n) + r] *
-                           (b[static_cast<size_t>(n) + r] - s1)));
+    const double s0 = m0 ? s.x : x0;
+    const double s1 = m1 ? s.y : x1;
+    rho0[r] = make_float2(static_cast<float>(d0 * (b0 - s0)),
+                          static_cast<float>(d1 * (b1 - s1)));
   }
 }
 
@@ -111,22 +129,42 @@ __device__ __forceinline__ float2 vaxpby(float a, float2 x, float b, float2 y) {
 }
 // x += z, returns (z.z, y.y) of the row, y = x [+ base: x is then the increment
 // of a solve around `base`, and the norm in the stopping test is the whole
-// solution's]
-__device__ __forceinline__ double2 add_to_x(double* x, const double* base, int xs,
+// solution's].  The old x and base values are loaded EARLY (XRow, below), with
+// the tile's own loads.
+struct XRow {
+  double x0 = 0.0, x1 = 0.0, b0 = 0.0, b1 = 0.0;
+};
+__device__ __forceinline__ void load_xrow(XRow& q, const double* x,
+                                          const double* base, int xs, int r,
+                                          float) {
+  q.x0 = x[r];
+  if (base) q.b0 = base[r];
+}
+__device__ __forceinline__ void load_xrow(XRow& q, const double* x,
+                                          const double* base, int xs, int r,
+                                          float2) {
+  q.x0 = x[r];
+  q.x1 = x[xs + r];
+  if (base) {
+    q.b0 = base[r];
+    q.b1 = base[xs + r];
+  }
+}
+__device__ __forceinline__ double2 add_to_x(double* x, const XRow& q, int xs,
                                            int r, float z) {
-  const double xn = x[r] + static_cast<double>(z);
+  const double xn = q.x0 + static_cast<double>(z);
   x[r] = xn;
-  const double y = base ? base[r] + xn : xn;
+  const double y = q.b0 + xn;
   return make_double2(static_cast<double>(z) * z, y * y);
 }
-__device__ __forceinline__ double2 add_to_x(double* x, const double* base, int xs,
+__device__ __forceinline__ double2 add_to_x(double* x, const XRow& q, int xs,
                                            int r, float2 z) {
-  const double x0 = x[r] + static_cast<double>(z.x);
-  const double x1 = x[xs + r] + static_cast<double>(z.y);
+  const double x0 = q.x0 + static_cast<double>(z.x);
+  const double x1 = q.x1 + static_cast<double>(z.y);
   x[r] = x0;
   x[xs + r] = x1;
-  const double y0 = base ? base[r] + x0 : x0;
-  const double y1 = base ? base[xs + r] + x1 : x1;
+  const double y0 = q.b0 + x0;
+  const double y1 = q.b1 + x1;
   return make_double2(static_cast<double>(z.x) * z.x + static_cast<double>(z.y) * z.y,
                       y0 * y0 + y1 * y1);
 }
@@ -145,16 +183,30 @@ __global__ __launch_bounds__(kBlock) void mass_cheb_kernel(
   if (stopped(stop)) return;
   // (PACKED: `vals` is the packed stream, `cols` the tiles' base columns)
   int r, r1;
+  // the epilogue's operands, loaded as soon as the lane knows its row
+  V own, rho_old, acc_old;
+  vzero(own);
+  vzero(rho_old);
+  vzero(acc_old);
+  XRow xr;
+  auto early = [&](int row, bool has) {
+    if (!has) return;
+    own = g[row];
+    if (MODE >= 1) {
+      rho_old = rho_in[row];
+      acc_old = acc[row];
+    }
+    if (MODE == 2) load_xrow(xr, x, xbase, xs, row, V());
+  };
   V s = PACKED
             ? mass_tile_row_sum_packed<V>(rowptr,
                                           static_cast<const unsigned*>(vals), cols,
-                                          rowblocks, g, prod, r, r1)
+                                          rowblocks, g, prod, r, r1, early)
             : mass_tile_row_sum<V>(rowptr, cols,
                                    static_cast<const __half*>(vals), rowblocks, g,
-                                   prod, r, r1);
+                                   prod, r, r1, early);
   double2 dots = make_double2(0.0, 0.0);
   if (r < r1) {
-    const V own = g[r];
     apply_mask(mask, n, r, own, s);
     if (MODE == 0) {
       const V rho = vaxpby(1.f, own, -c0, s);
@@ -163,14 +215,14 @@ __global__ __launch_bounds__(kBlock) void mass_cheb_kernel(
       d_out[r] = d;
       acc[r] = vaxpby(c0, own, 1.f, d);
     } else {
-      const V rho = vaxpby(1.f, rho_in[r], -1.f, s);
+      const V rho = vaxpby(1.f, rho_old, -1.f, s);
       const V d = vaxpby(c1, own, c2, rho);
       if (MODE == 1) {
         rho_out[r] = rho;
         d_out[r] = d;
-        acc[r] = vaxpby(1.f, acc[r], 1.f, d);
+        acc[r] = vaxpby(1.f, acc_old, 1.f, d);
       } else {
-        dots = add_to_x(x, xbase, xs, r, vaxpby(1.f, acc[r], 1.f, d));
+        dots = add_to_x(x, xr, xs, r, vaxpby(1.f, acc_old, 1.f, d));
         // (K15: the sums only count the rank's OWN rows; the ghost rows it
         // also advances are counted by their owners)
         if (r < own_lo || r >= own_hi) dots = make_double2(0.0, 0.0);

@@ -64,12 +64,17 @@ static_assert(sizeof(Half2x4) == 16, "packed quad");
 // own nonzeros (slack and idle lanes gather the tile's first column).
 // C16: the column indices are 16-bit offsets from the tile's lowest column
 // (cols16 / cbase of flow_pmg_level: 6 B per nonzero instead of 8).
-template <bool C16>
+// early(r, has_row): called as soon as the lane knows its row -- the caller
+// issues the loads of its epilogue there, so that they travel with the tile's
+// own loads instead of forming one more link of the dependent chain behind
+// the row sum (a workgroup lives ~6 us, a link of the chain is ~1 us of it).
+template <bool C16, class Early>
 __device__ __forceinline__ float2 pmg_tile_row_sum(
     const int* __restrict__ rowptr, const void* __restrict__ cols_any,
     const int* __restrict__ cbase,
     const __half2* __restrict__ vals, const int* __restrict__ rowblocks,
-    const float2* __restrict__ g, float2* __restrict__ prod, int& r, int& r1) {
+    const float2* __restrict__ g, float2* __restrict__ prod, int& r, int& r1,
+    Early early) {
   const int* __restrict__ cols = static_cast<const int*>(cols_any);
   const unsigned short* __restrict__ cols16 =
       static_cast<const unsigned short*>(cols_any);
@@ -81,6 +86,7 @@ __device__ __forceinline__ float2 pmg_tile_row_sum(
   const int k1 = rowptr[r1];
   const int ka = k0 & ~3;
   r = r0 + threadIdx.x;
+  early(r, r < r1);
   int a = 0, b = 0;
   if (r < r1) {
     a = rowptr[r] - ka;
@@ -173,10 +179,20 @@ __global__ __launch_bounds__(kBlock) void pmg_cheb_kernel(
   if (stopped(stop)) return;
   int r, r1;
   float2 s;
+  // the epilogue's operands, loaded as soon as the row is known
+  float2 rho = f2(0.f, 0.f), own = f2(0.f, 0.f), acc = f2(0.f, 0.f),
+         extra = f2(0.f, 0.f);
+  auto early = [&](int row, bool has) {
+    if (!has) return;
+    rho = rho_in[row];
+    if (d_own) own = d_own[row];
+    if (MODE >= 1 && x) acc = x[row];
+    if (MODE == 2 && d_extra) extra = d_extra[row];
+  };
   if (FMT == 2) {
     s = mass_tile_row_sum_packed<float2>(rowptr,
                                          static_cast<const unsigned*>(vals),
-                                         cbase, rowblocks, g, prod, r, r1);
+                                         cbase, rowblocks, g, prod, r, r1, early);
     if (r < r1 && idrows) {
       if (idrows[r]) s.x = g[r].x;
       if (idrows[static_cast<size_t>(n) + r]) s.y = g[r].y;
@@ -184,25 +200,21 @@ __global__ __launch_bounds__(kBlock) void pmg_cheb_kernel(
   } else {
     s = pmg_tile_row_sum<FMT == 1>(rowptr, cols, cbase,
                                    static_cast<const __half2*>(vals), rowblocks,
-                                   g, prod, r, r1);
+                                   g, prod, r, r1, early);
   }
   if (r >= r1) return;
-  float2 rho = rho_in[r];
   rho.x -= s.x;
   rho.y -= s.y;
   if (MODE == 0) {
     if (d_own) {
-      const float2 q = d_own[r];
-      rho.x *= q.x;
-      rho.y *= q.y;
+      rho.x *= own.x;
+      rho.y *= own.y;
     }
     rho_out[r] = rho;
     return;
   }
   float2 d = f2(c2 * rho.x, c2 * rho.y);
-  float2 own = f2(0.f, 0.f);
   if (d_own) {
-    own = d_own[r];
     d.x += c1 * own.x;
     d.y += c1 * own.y;
   }
@@ -210,21 +222,14 @@ __global__ __launch_bounds__(kBlock) void pmg_cheb_kernel(
     if (rho_out) rho_out[r] = rho;
     d_out[r] = d;
     if (x) {
-      float2 acc = x[r];
       acc.x += d.x;
       acc.y += d.y;
       x[r] = acc;
     }
     return;
   }
-  float2 acc = x[r];
-  acc.x += own.x + d.x;
-  acc.y += own.y + d.y;
-  if (d_extra) {
-    const float2 e = d_extra[r];
-    acc.x += e.x;
-    acc.y += e.y;
-  }
+  acc.x += own.x + d.x + extra.x;
+  acc.y += own.y + d.y + extra.y;
   double zx = acc.x, zy = acc.y;
   if (bc) {
     if (bc[r]) zx = rin[r];
