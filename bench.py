@@ -498,9 +498,11 @@ def main():
             'cfl_projection_cg_iterations': [
                 i.get('projection_iterations', 0) for i in infos],
             'substep_s': tim,
+            # (counted at the all-reduce callback; the library-issued
+            # ncclAllReduce of FLOW_AMD_RCCL_DIRECT=1 does not pass there)
             'collectives_per_step': (
                 infos[0]['collectives_in_window'] / float(len(infos))
-                if 'collectives_in_window' in infos[0] else None),
+                if infos[0].get('collectives_in_window') else None),
             }
 
     # everything that is built once and cached (operators, hierarchy, ILU
@@ -718,7 +720,7 @@ def main():
     out['config']['start_vectors'] = (
         "mode 'parity' starts the Newton linear solve, the pressure CG and the "
         "velocity correction from the previous steps' increments extrapolated "
-        "in time (3-point Lagrange; navier_stokes.solver_parameters: "
+        "in time (least-squares cubic through five; navier_stokes.solver_parameters: "
         "linear_start / start / increment_start): start vectors only -- every "
         "solve converges to the same stopping test, the Newton iteration still "
         "starts from u0; 40-step trajectories agree with the zero-start run to "
