@@ -208,16 +208,31 @@ def read_mesh(path):
 
 # -- XDMF time series ---------------------------------------------------------
 class XDMFFile(object):
-    '''`with XDMFFile(mpi_comm_world(), 'karman.xdmf') as f: f.write(u, t)`.
-    Vertex values of the field are written (what dolfin's XDMFFile.write does
-    for a P2 function as well); data items are inline XML.'''
+    """`with XDMFFile(mpi_comm_world(), 'karman.xdmf') as f: f.write(u, t)`
+    (reference driver: tests/test_karman_vortex_street.py:214-227).  Vertex
+    values of the field are written (what dolfin's XDMFFile.write does for a
+    P2 function as well).
+
+    parameters['heavy_data']: 'hdf5' -- the arrays go to `<stem>.h5` beside the
+    XML (datasets /Mesh/<k>/mesh/geometry, /Mesh/<k>/mesh/topology,
+    /VisualisationVector/<k>, as dolfin lays them out), through the HDF5 C
+    library (flow_amd/fem/hdf5.py) --, 'xml' -- inline data items --, or 'auto'
+    (default): 'hdf5' where the library is found.  With
+    'rewrite_function_mesh' False the mesh is stored once and every time step
+    refers to it; 'flush_output' rewrites the XML (and flushes the HDF5 file)
+    at every write, so that a run can be looked at while it lasts."""
 
     def __init__(self, comm_or_path, path=None):
         self.path = path if path is not None else comm_or_path
         self.parameters = {'flush_output': False,
-                           'rewrite_function_mesh': True}
-        self._steps = []          # (t, name, ncomp, values (Nv, ncomp))
+                           'rewrite_function_mesh': True,
+                           'heavy_data': 'auto'}
+        self._steps = []          # (t, name, ncomp, values or dataset path)
         self._mesh = None
+        self._h5 = None
+        self._heavy = None        # decided at the first write
+        self._mesh_sets = []      # [(geometry, topology)] dataset paths
+        self._nsets = 0
 
     def __enter__(self):
         return self
@@ -226,6 +241,26 @@ class XDMFFile(object):
         self.close()
         return False
 
+    # -- heavy data ----------------------------------------------------------------
+    def _h5_name(self):
+        stem = self.path[:-5] if self.path.endswith('.xdmf') else self.path
+        return stem + '.h5'
+
+    def _decide(self):
+        if self._heavy is None:
+            from . import hdf5
+            want = self.parameters.get('heavy_data', 'auto')
+            if want not in ('auto', 'hdf5', 'xml'):
+                raise ValueError("heavy_data: 'auto', 'hdf5' or 'xml'")
+            if want == 'hdf5' and not hdf5.available():
+                raise IOError('heavy_data = hdf5: no HDF5 library found '
+                              '(FLOW_AMD_HDF5_LIB)')
+            self._heavy = 'hdf5' if want == 'hdf5' or (
+                want == 'auto' and hdf5.available()) else 'xml'
+            if self._heavy == 'hdf5':
+                self._h5 = hdf5.File(self._h5_name(), 'w')
+        return self._heavy
+
     def write(self, u, t=0.0):
         V = u.function_space()
         mesh = V.mesh()
@@ -233,49 +268,88 @@ class XDMFFile(object):
         self._mesh = mesh
         arr = u.array().reshape(V.dim, V.N)
         vals = arr[:, V.layout.vertex_dofs].T.copy()
-        self._steps.append((float(t), u.name(), V.dim, vals))
+        nv = mesh.num_vertices()
+        if V.dim > 1:           # (XDMF vectors have three components)
+            vals = numpy.concatenate([vals, numpy.zeros((nv, 1))], axis=1)
+        if self._decide() == 'hdf5':
+            new_time = not self._steps or self._steps[-1][0] != float(t)
+            if not self._mesh_sets or (
+                    new_time and self.parameters.get('rewrite_function_mesh')):
+                k = len(self._mesh_sets)
+                names = ('/Mesh/%d/mesh/geometry' % k,
+                         '/Mesh/%d/mesh/topology' % k)
+                self._h5.write(names[0], numpy.asarray(mesh.points, dtype=float))
+                self._h5.write(names[1], numpy.asarray(mesh.cell_vertices,
+                                                       dtype=numpy.int64))
+                self._mesh_sets.append(names)
+            name = '/VisualisationVector/%d' % self._nsets
+            self._nsets += 1
+            self._h5.write(name, vals)
+            self._steps.append((float(t), u.name(), V.dim, name,
+                                len(self._mesh_sets) - 1))
+        else:
+            self._steps.append((float(t), u.name(), V.dim, vals, 0))
         if self.parameters.get('flush_output'):
-            self.close()
+            self._write_xml()
+            if self._h5 is not None:
+                self._h5.flush()
 
     def close(self):
         if self._mesh is None:
             return
+        self._write_xml()
+        if self._h5 is not None:
+            self._h5.close()
+            self._h5 = None
+
+    # -- light data ----------------------------------------------------------------
+    def _item(self, dims, number_type, payload):
+        """A DataItem: `payload` a dataset path (heavy data in the HDF5 file)
+        or the text of an inline item."""
+        nt = 'NumberType="Int"' if number_type == 'Int' else \
+            'NumberType="Float" Precision="8"'
+        if self._heavy == 'hdf5':
+            return ('<DataItem Format="HDF" Dimensions="%s" %s>%s:%s</DataItem>'
+                    % (dims, nt, os.path.basename(self._h5_name()), payload))
+        return ('<DataItem Format="XML" Dimensions="%s" %s>\n%s\n    </DataItem>'
+                % (dims, nt, payload))
+
+    def _write_xml(self):
         mesh = self._mesh
         nv, nc = mesh.num_vertices(), mesh.num_cells()
         out = ['<?xml version="1.0"?>', '<Xdmf Version="3.0">', ' <Domain>',
                '  <Grid Name="TimeSeries" GridType="Collection" '
                'CollectionType="Temporal">']
-        topo = '\n'.join(' '.join(str(v) for v in c)
-                         for c in mesh.cell_vertices)
-        geom = '\n'.join('%.17g %.17g' % (x, y) for x, y in mesh.points)
+        if self._heavy == 'hdf5':
+            topo = geom = None
+        else:
+            topo = '\n'.join(' '.join(str(v) for v in c)
+                             for c in mesh.cell_vertices)
+            geom = '\n'.join('%.17g %.17g' % (x, y) for x, y in mesh.points)
         times = sorted(set(s[0] for s in self._steps))
         for t in times:
+            mine = [s for s in self._steps if s[0] == t]
+            if self._heavy == 'hdf5':
+                geom, topo = self._mesh_sets[mine[0][4]]
             out.append('   <Grid Name="mesh" GridType="Uniform">')
             out.append('    <Time Value="%.17g"/>' % t)
             out.append('    <Topology TopologyType="Triangle" '
-                       'NumberOfElements="%d"><DataItem Format="XML" '
-                       'Dimensions="%d 3" NumberType="Int">' % (nc, nc))
-            out.append(topo)
-            out.append('    </DataItem></Topology>')
-            out.append('    <Geometry GeometryType="XY"><DataItem Format="XML" '
-                       'Dimensions="%d 2">' % nv)
-            out.append(geom)
-            out.append('    </DataItem></Geometry>')
-            for (ts, name, ncomp, vals) in self._steps:
-                if ts != t:
-                    continue
-                if ncomp == 1:
-                    atype, dims, rows = 'Scalar', '%d' % nv, vals[:, 0:1]
+                       'NumberOfElements="%d">%s</Topology>'
+                       % (nc, self._item('%d 3' % nc, 'Int', topo)))
+            out.append('    <Geometry GeometryType="XY">%s</Geometry>'
+                       % self._item('%d 2' % nv, 'Float', geom))
+            for (ts, name, ncomp, vals, _m) in mine:
+                atype = 'Scalar' if ncomp == 1 else 'Vector'
+                dims = '%d' % nv if ncomp == 1 else '%d 3' % nv
+                if self._heavy == 'hdf5':
+                    dims = '%d 1' % nv if ncomp == 1 else dims
+                    payload = vals
                 else:
-                    atype, dims = 'Vector', '%d 3' % nv
-                    rows = numpy.concatenate(
-                        [vals, numpy.zeros((nv, 1))], axis=1)
+                    payload = '\n'.join(' '.join('%.17g' % v for v in r)
+                                        for r in vals)
                 out.append('    <Attribute Name="%s" AttributeType="%s" '
-                           'Center="Node"><DataItem Format="XML" '
-                           'Dimensions="%s">' % (name, atype, dims))
-                out.append('\n'.join(' '.join('%.17g' % v for v in r)
-                                     for r in rows))
-                out.append('    </DataItem></Attribute>')
+                           'Center="Node">%s</Attribute>'
+                           % (name, atype, self._item(dims, 'Float', payload)))
             out.append('   </Grid>')
         out += ['  </Grid>', ' </Domain>', '</Xdmf>']
         with open(self.path, 'w') as fh:
@@ -283,18 +357,41 @@ class XDMFFile(object):
 
 
 def read_xdmf_series(path):
-    '''[(t, {name: values})] of a file written by XDMFFile (tests).'''
+    """[(t, {name: values})] of a file written by XDMFFile (tests); heavy data
+    in an HDF5 file beside it is read through flow_amd/fem/hdf5.py."""
     root = ET.parse(path).getroot()
+    files = {}
+
+    def data(item):
+        dims = [int(d) for d in item.get('Dimensions').split()]
+        if item.get('Format') == 'HDF':
+            fname, dset = item.text.strip().split(':', 1)
+            if fname not in files:
+                from . import hdf5
+                files[fname] = hdf5.File(
+                    os.path.join(os.path.dirname(path) or '.', fname))
+            arr = files[fname].read(dset)
+            assert list(arr.shape) == dims, (dset, arr.shape, dims)
+            return arr
+        kind = int if item.get('NumberType') == 'Int' else float
+        return numpy.array(item.text.split(), dtype=kind).reshape(dims)
+
     series = []
-    for grid in root.iter('Grid'):
-        if grid.get('GridType') != 'Uniform':
-            continue
-        t = float(grid.find('Time').get('Value'))
-        fields = {}
-        for att in grid.findall('Attribute'):
-            item = att.find('DataItem')
-            dims = [int(d) for d in item.get('Dimensions').split()]
-            fields[att.get('Name')] = numpy.array(
-                item.text.split(), dtype=float).reshape(dims)
-        series.append((t, fields))
+    try:
+        for grid in root.iter('Grid'):
+            if grid.get('GridType') != 'Uniform':
+                continue
+            t = float(grid.find('Time').get('Value'))
+            fields = {}
+            for att in grid.findall('Attribute'):
+                vals = data(att.find('DataItem'))
+                if att.get('AttributeType') == 'Scalar':
+                    vals = vals.reshape(-1)
+                fields[att.get('Name')] = vals
+            fields['_topology'] = data(grid.find('Topology').find('DataItem'))
+            fields['_geometry'] = data(grid.find('Geometry').find('DataItem'))
+            series.append((t, fields))
+    finally:
+        for f in files.values():
+            f.close()
     return series

@@ -79,7 +79,18 @@ def test_binary_msh_with_other_element_types(tmp_path):
         assert mesh.cell_areas().sum() == pytest.approx(1.0)
 
 
-def test_xdmf_time_series(tmp_path):
+@pytest.mark.parametrize('heavy', ['xml', 'hdf5'])
+@pytest.mark.parametrize('rewrite_mesh', [False, True])
+def test_xdmf_time_series(tmp_path, heavy, rewrite_mesh):
+    """The reference driver's output loop (tests/test_karman_vortex_street.py:
+    214-227) with inline data and with the heavy data in an HDF5 file beside
+    the XML, laid out as dolfin does."""
+    import os
+    import shutil
+    import subprocess
+    from flow_amd.fem import hdf5
+    if heavy == 'hdf5' and not hdf5.available():
+        pytest.skip('no HDF5 library in this environment')
     mesh = fem.UnitSquareMesh(3, 3)
     W = fem.VectorFunctionSpace(mesh, 'CG', 2)
     P = fem.FunctionSpace(mesh, 'CG', 1)
@@ -90,13 +101,16 @@ def test_xdmf_time_series(tmp_path):
     path = str(tmp_path / 'out.xdmf')
     with io.XDMFFile(io.mpi_comm_world(), path) as xf:
         xf.parameters['flush_output'] = True
-        xf.parameters['rewrite_function_mesh'] = False
+        xf.parameters['rewrite_function_mesh'] = rewrite_mesh
+        xf.parameters['heavy_data'] = heavy
         for k, t in enumerate((0.0, 0.5)):
             x = W.layout.dof_coords
             u.set_array(numpy.concatenate([x[:, 0] + t, x[:, 1] * (k + 1)]))
             p.set_array(mesh.points[:, 0] * t)
             xf.write(u, t)
             xf.write(p, t)
+            # flush_output: the files are complete after every write
+            assert len(io.read_xdmf_series(path)) == k + 1
     series = io.read_xdmf_series(path)
     assert [s[0] for s in series] == [0.0, 0.5]
     vel = series[1][1]['velocity']
@@ -104,3 +118,48 @@ def test_xdmf_time_series(tmp_path):
     assert numpy.allclose(vel[:, 0], mesh.points[:, 0] + 0.5)
     assert numpy.allclose(vel[:, 1], mesh.points[:, 1] * 2)
     assert numpy.allclose(series[1][1]['pressure'], mesh.points[:, 0] * 0.5)
+    for _t, fields in series:
+        assert numpy.array_equal(fields['_topology'], mesh.cell_vertices)
+        assert numpy.array_equal(fields['_geometry'], mesh.points)
+    h5 = str(tmp_path / 'out.h5')
+    if heavy == 'xml':
+        assert not os.path.exists(h5)
+        return
+    with hdf5.File(h5) as f:
+        assert f.exists('/Mesh/0/mesh/geometry')
+        assert f.exists('/Mesh/0/mesh/topology')
+        assert f.exists('/Mesh/1/mesh/topology') == rewrite_mesh
+        assert f.exists('/VisualisationVector/3')
+        assert not f.exists('/VisualisationVector/4')
+        assert f.read('/Mesh/0/mesh/topology').dtype == numpy.int64
+    # an independent reader, where the image has one
+    tool = shutil.which('h5dump') or '/opt/conda/bin/h5dump'
+    if os.path.exists(tool):
+        head = subprocess.run([tool, '-H', h5], capture_output=True, text=True,
+                              check=True).stdout
+        assert 'DATASET "geometry"' in head and 'H5T_IEEE_F64LE' in head
+        assert 'DATASET "topology"' in head and 'H5T_STD_I64LE' in head
+        assert head.count('DATASET') == (8 if rewrite_mesh else 6)
+
+
+def test_hdf5_binding_round_trip(tmp_path):
+    from flow_amd.fem import hdf5
+    if not hdf5.available():
+        pytest.skip('no HDF5 library in this environment')
+    rng = numpy.random.RandomState(0)
+    arrays = {'/a/b/c': rng.standard_normal((5, 3)),
+              '/a/ints': rng.randint(0, 1000, size=7).astype(numpy.int32),
+              '/top': numpy.arange(4, dtype=numpy.int64)}
+    path = str(tmp_path / 'x.h5')
+    with hdf5.File(path, 'w') as f:
+        for name, a in arrays.items():
+            f.write(name, a)
+        with pytest.raises(TypeError):
+            f.write('/bad', numpy.zeros(3, dtype=numpy.float32))
+    with hdf5.File(path) as f:
+        for name, a in arrays.items():
+            got = f.read(name)
+            assert got.dtype == a.dtype and numpy.array_equal(got, a)
+        assert not f.exists('/a/b/d')
+    with pytest.raises(IOError):
+        hdf5.File(str(tmp_path / 'missing.h5'))
