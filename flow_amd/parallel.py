@@ -806,13 +806,33 @@ def mass_solve(solver, b, x, rtol, atol=0.0, maxit=50, tag=None, xbase=None,
     increment form, b the defect of xbase, delta0 an optional start of the
     increment; x = xbase + increment on the own + ghost rows.'''
     from .fem import ops
+    from .message import info
     c = comm()
     key = ('mass_strips', c.world, c.rank)
     if key not in solver.__dict__:
-        solver.__dict__[key] = MassStrips(solver, strips(solver.A.layout.mesh),
-                                          c.rank)
+        try:
+            solver.__dict__[key] = MassStrips(
+                solver, strips(solver.A.layout.mesh), c.rank)
+        except ValueError as e:
+            # (a decomposition is thin for every rank or for none: the deep
+            # ranges are built for all ranks before the assertion)
+            info('mass solves on these strips by Jacobi-CG: %s' % e)
+            solver.__dict__[key] = None
     ms = solver.__dict__[key]
     n = solver.A.size
+    if ms is None:
+        # strips thinner than the halo: Jacobi-CG, one collective per iteration
+        if xbase is None:
+            return cg(solver.A, solver.dinv, b, x, rtol, atol, maxit=1000,
+                      check_every=2, tag=tag)
+        # M delta = g from delta0 (or zero); (not ops.work: cg's own buffer)
+        delta = _hip.clone(delta0) if delta0 is not None else device.zeros(n)
+        sol = cg(solver.A, solver.dinv, b, delta, rtol, atol, maxit=1000,
+                 check_every=2, tag=tag)
+        if x.data_ptr() != xbase.data_ptr():
+            ops.copy(x, xbase)
+        ops.axpby(1.0, delta, 1.0, x)
+        return sol
     c.ensure(4 + solver.ncomp * ms.rows.nhalo)
     head = _hip.REDUCE_WORK + 2 * ms.nlast
     wk = ops.work(head + 2 + (n if xbase is not None else 0))

@@ -606,6 +606,68 @@ def _count_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _thin_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LOCAL_RANK'] = '0'
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from flow_amd import parallel, device, fem
+        from flow_amd.fem import ops
+        from flow_amd.fem.mass import MassSolver
+        mesh = fem.karman_channel(16, 6)
+        V = fem.FunctionSpace(mesh, 'CG', 2)
+        lay = V.layout
+        n = lay.N
+        rng = numpy.random.RandomState(2)
+        full = rng.standard_normal(2 * n)
+        M = ops.assemble_mass(V)
+        free = numpy.ones(2 * n, dtype=numpy.uint8)
+        bdofs = rng.choice(2 * n, 12, replace=False)
+        free[bdofs] = 0
+        Mrows = ops.Matrix(lay, 4, M.vals, rowmask=device.to_device(free))
+        solver = MassSolver(Mrows, Mrows.diag_inv())
+        b = device.to_device(full)
+        idx = torch.from_numpy(bdofs).to(device.get())
+        start = device.zeros(2 * n)
+        start[idx] = b[idx]
+        ref = start.clone()
+        solver.solve(b, ref, 1e-12)
+        g = device.zeros(2 * n)
+        Mrows.apply(start, g)
+        ops.axpby(1.0, b, -1.0, g)
+        parallel.enable(dist.group.WORLD, force=True)
+        x = start.clone()
+        t1 = parallel.mass_solve(solver, b, x, 1e-12)
+        y = device.zeros(2 * n)
+        t2 = parallel.mass_solve(solver, g, y, 1e-12, xbase=start)
+        refh = device.to_host(ref).numpy()
+        out[rank] = dict(
+            method=(t1.method, t2.method),
+            err=(_rel(device.to_host(parallel.gather_field(x.clone(), lay, 2)
+                                     ).numpy(), refh),
+                 _rel(device.to_host(parallel.gather_field(y.clone(), lay, 2)
+                                     ).numpy(), refh)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_thin_strips_fall_back_to_cg(hip):
+    """Strips thinner than the mass solver's halo (16 vertex columns on 3
+    ranks against 6 coupling layers): `parallel.mass_solve` runs Jacobi-CG
+    there, both forms, and says so."""
+    world = 3
+    manager = mp.get_context('spawn').Manager()
+    out = manager.dict()
+    mp.spawn(_thin_worker, args=(world, _free_port(), out), nprocs=world,
+             join=True)
+    for r in range(world):
+        assert all('cg' in m for m in out[r]['method']), out[r]
+        assert max(out[r]['err']) < 1e-9, out[r]
+
+
 def test_collectives_per_time_step(hip):
     '''What one settled time step costs in collectives on the strips (counted at
     the all-reduce callback, every halo and every reduction is one): two per
