@@ -353,6 +353,11 @@ class NotConverged(RuntimeError):
     reference catch exactly that (tests/test_boussinesq.py:254).'''
 
 
+# flow_abi_version() of the library these bindings describe (the structs above
+# and SYMBOLS): a stale libflow_hip.so is refused at load time
+ABI_VERSION = 23
+
+
 def load_library():
     '''dlopen the in-tree library and set the prototypes (no GPU needed).'''
     global _LIB
@@ -370,6 +375,12 @@ def load_library():
             fn = getattr(lib, name)
             fn.restype = ctypes.c_int
             fn.argtypes = argtypes
+        got = lib.flow_abi_version()
+        if got != ABI_VERSION:
+            raise HipError(
+                '%s is ABI version %d, these bindings are version %d: '
+                'rebuild it (`make -C flow_amd/csrc`)'
+                % (LIB_PATH, got, ABI_VERSION))
         _LIB = lib
     return _LIB
 
