@@ -18,21 +18,48 @@ from .. import device
 from .. import parallel
 
 
-def age(pre, kind, rebuilt, its, applications, npar):
+def age(pre, kind, rebuilt, its, applications, npar, it=0):
     """When is a lagged preconditioner rebuilt?  The ILU(0): when a solve needs
     more than twice the (BiCGStab-equivalent) iterations the fresh factors
     needed.  The p-multigrid cycle ages gently (13 -> 16 applications over 200
-    plateau steps of the 10 M-DoF run) and a rebuild costs half a time step
-    (Jacobian assembly, packing, 2 x 32 power-method products): it is rebuilt as
-    soon as a solve needs 2 applications (or 15 %) more than the fresh one."""
+    plateau steps of the 10 M-DoF run) and a rebuild costs most of a time step
+    (Jacobian assembly, packing, 2 x 32 power-method products: 8.5 ms): it is
+    rebuilt when a solve needs 2 applications (or 15 %) more than the fresh
+    one -- not within `pmg_min_solves` of the last rebuild: the counts also
+    move with the quality of the start vectors and with the Newton iteration
+    the solve belongs to (each has its own yardstick), and a rebuild resets it
+    -- and in any case after `pmg_refresh` solves where the solves are long
+    (`pmg_refresh_min` applications on average since the rebuild: a rebuild
+    costs as much as ten applications, and where a solve takes four there is
+    little a fresh cycle could save): the linearisation state the cycle was
+    built on drifts away without any single solve showing it.  Developed
+    vortex street (tools/developed_flow.py): 17.8 applications per step with a
+    cycle built on the symmetric start-up flow 2000 steps earlier, 15.4 when
+    it is rebuilt every 50 solves; 23.5 -> 21.5 ms per step.  (Tried and not
+    kept as the trigger: the relative change of dt u since the build -- it
+    grows fastest on the early plateau, where the counts do not move at
+    all.)"""
+    pre.uses = 0 if rebuilt else getattr(pre, 'uses', 0) + 1
     if rebuilt:
         pre.base_its = max(its, npar['check_every'])
-        pre.base_applications = applications
-    elif kind == 'pmg':
-        fresh = getattr(pre, 'base_applications', applications)
-        if applications >= fresh + max(2, int(round(0.15 * fresh))):
+        pre.base_applications = {}
+    if kind == 'pmg':
+        # (the yardstick of Newton iteration `it`: its first solve with the
+        # fresh cycle -- the second iteration's systems are shorter solves)
+        base = getattr(pre, 'base_applications', None)
+        if not isinstance(base, dict):
+            base = pre.base_applications = {}
+        fresh = base.setdefault(it, applications)
+        pre.work = (0 if rebuilt else getattr(pre, 'work', 0)) + applications
+        refresh = int(npar.get('pmg_refresh', 50))
+        if refresh and pre.uses >= refresh and \
+                pre.work >= float(npar.get('pmg_refresh_min', 6.0)) * (
+                    pre.uses + 1):
             pre.stale = True
-    elif its > 2 * pre.base_its:
+        elif pre.uses >= int(npar.get('pmg_min_solves', 10)) and \
+                applications >= fresh + max(2, int(round(0.15 * fresh))):
+            pre.stale = True
+    elif not rebuilt and its > 2 * pre.base_its:
         pre.stale = True
 
 

@@ -115,6 +115,11 @@ solver_parameters = {
                # products only (flow_amd/fem/pmg.py) -- 14-15 applications per
                # solve where the multicolour ILU(0) needs 33
                'preconditioner': 'pmg', 'ilu_lag': 8.0,
+               # (the cycle is rebuilt after `pmg_refresh` solves where they
+               # average `pmg_refresh_min` applications or more, and not
+               # within `pmg_min_solves` of a rebuild because of one long
+               # solve: newton_preconditioner.age)
+               'pmg_refresh': 50, 'pmg_min_solves': 10, 'pmg_refresh_min': 6.0,
                # (Chebyshev steps before / after the coarse correction and
                # on the P1 level; intervals [lam_max / ratio, 1.1 lam_max].
                # r4, with the start vectors extrapolated in time -- the
@@ -303,12 +308,14 @@ def extrapolation_weights(dts, dt, power=1, degree=None):
 
 
 def _extrapolated_increment(lay, dt, dx, points=2, key='newton_increments',
-                            power=1, degree=None):
+                            power=1, degree=None, stamp=None):
     '''dx <- the increment this call is likely to find, extrapolated in time
     from the increments of the previous calls (extrapolation_weights).  Only
     ever the START VECTOR of a linear solve that is then converged to the same
     tolerance as from zero.  Returns False (dx untouched) without a
-    history.'''
+    history.  stamp: the number of this call -- only entries remembered under
+    the stamps just before it, without a gap, count (a history that is not
+    written on every call: the second Newton iteration's).'''
     hist = []
     for h in lay._dev.get(key, []):
         # only while the step size is settled: through the start-up ramp of a
@@ -318,6 +325,8 @@ def _extrapolated_increment(lay, dt, dx, points=2, key='newton_increments',
         # true one in proportion to the largest residual it has seen)
         if h[0].numel() != dx.numel() or not (1.0 / 1.5 <= dt / h[1] <= 1.5) \
                 or len(hist) >= min(points, 6):
+            break
+        if stamp is not None and (len(h) < 3 or h[2] != stamp - 1 - len(hist)):
             break
         hist.append(h)
     if not hist:
@@ -345,7 +354,8 @@ def _remainder_tolerance(lay, npar, lin_atol, nrm, tol):
                              npar.get('linear_atol_cap', 1.0e-4) * tol))
 
 
-def _remember_increment(lay, dt, dx, keep_points=6, key='newton_increments'):
+def _remember_increment(lay, dt, dx, keep_points=6, key='newton_increments',
+                        stamp=None):
     hist = lay._dev.setdefault(key, [])
     hist[:] = [h for h in hist if h[0].numel() == dx.numel()]
     if len(hist) >= keep_points:
@@ -353,7 +363,19 @@ def _remember_increment(lay, dt, dx, keep_points=6, key='newton_increments'):
         ops.copy(keep, dx)
     else:
         keep = _hip.clone(dx)
-    hist.insert(0, (keep, dt))
+    hist.insert(0, (keep, dt, stamp))
+
+
+def _newton_history(lay, it):
+    '''(key, stamp) of the increment history of Newton iteration `it` of this
+    call: the first iteration of a time loop's calls has its own since round
+    4; so have the second and the third (a developed vortex street takes two
+    iterations per step: ||F|| after the first is 1.3-2.9e-10 there) -- those
+    are only written on the calls that get that far, hence the stamps.'''
+    if it > 2:
+        return None, None
+    key = 'newton_increments' if it == 0 else ('newton_increments', it)
+    return key, lay._dev.get('newton_call', 0)
 
 
 def _compute_tentative_velocity(
@@ -369,6 +391,9 @@ def _compute_tentative_velocity(
     assert time_step_method in _THETA, time_step_method
     theta_i, theta_e = _THETA[time_step_method]
     alpha = 1.0
+    # (the number of this call: stamps the Newton increments it remembers)
+    lay0 = u[0].function_space().layout
+    lay0._dev['newton_call'] = lay0._dev.get('newton_call', 0) + 1
     if parallel.active():
         return _tentative_velocity_on_strips(
             u, p0, f, u_bcs, theta_i, theta_e, rho, mu, dt, tol), alpha
@@ -516,10 +541,12 @@ def _compute_tentative_velocity(
 
         ops.fill(dx, 0.0)
         dx_is_zero = True
-        if it == 0 and npar.get('linear_start') == 'extrapolated':
+        hkey, hstamp = _newton_history(lay, it)
+        if hkey is not None and npar.get('linear_start') == 'extrapolated':
             dx_is_zero = not _extrapolated_increment(
                 lay, dt, dx, int(npar.get('linear_start_points', 5)),
-                degree=npar.get('linear_start_degree'))
+                key=hkey, degree=npar.get('linear_start_degree'),
+                stamp=hstamp)
         pre = None
         kind = npar.get('preconditioner', 'jacobi')
         use_gmres = npar.get('linear_solver', 'gmres') == 'gmres'
@@ -564,6 +591,10 @@ def _compute_tentative_velocity(
                 return kind, pre, False
             if matfree:
                 assemble_jacobian()
+            # (how often that happens: cumulative, reported with every step)
+            lay._dev['newton_rebuilds'] = lay._dev.get('newton_rebuilds', 0) + 1
+            last_step_info['newton_preconditioner_rebuilds'] = \
+                lay._dev['newton_rebuilds']
             if kind == 'pmg':
                 if pre is None:
                     from ..fem.pmg import Pmg
@@ -666,9 +697,9 @@ def _compute_tentative_velocity(
         linear_its.append(its)
         last_step_info['newton_preconditioner'] = kind
         if pre is not None:
-            _age(pre, kind, refactored, its, sol.iterations, npar)
-        if it == 0 and npar.get('linear_start') == 'extrapolated':
-            _remember_increment(lay, dt, dx)
+            _age(pre, kind, refactored, its, sol.iterations, npar, it=it)
+        if hkey is not None and npar.get('linear_start') == 'extrapolated':
+            _remember_increment(lay, dt, dx, key=hkey, stamp=hstamp)
         ops.axpby(-1.0, dx, 1.0, ui.data)
         it += 1
     del keep0, keep1
@@ -828,12 +859,14 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
         lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
         ops.fill(dx, 0.0)
         dx_is_zero = True
-        if it == 0 and npar.get('linear_start') == 'extrapolated':
+        hkey, hstamp = _newton_history(lay, it)
+        if hkey is not None and npar.get('linear_start') == 'extrapolated':
             # (every rank keeps the increments of its own rows: the same
             # history length and step sizes everywhere)
             dx_is_zero = not _extrapolated_increment(
                 lay, dt, dx, int(npar.get('linear_start_points', 5)),
-                degree=npar.get('linear_start_degree'))
+                key=hkey, degree=npar.get('linear_start_degree'),
+                stamp=hstamp)
         # (the count of the previous call's Newton iteration `it`: the same
         # number on every rank -- they all ran the same solve)
         expected = lay._dev.setdefault('gmres_expected_strip', {})
@@ -862,9 +895,9 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
         applications.append(sol.iterations)
         linear_its.append(its)
         last_step_info['newton_preconditioner'] = kind + ' (block Jacobi)'
-        _age(pre, kind, refactored, its, sol.iterations, npar)
-        if it == 0 and npar.get('linear_start') == 'extrapolated':
-            _remember_increment(lay, dt, dx)
+        _age(pre, kind, refactored, its, sol.iterations, npar, it=it)
+        if hkey is not None and npar.get('linear_start') == 'extrapolated':
+            _remember_increment(lay, dt, dx, key=hkey, stamp=hstamp)
         # (dx is zero outside the owned rows)
         ops.axpby(-1.0, dx, 1.0, ui.data)
         parallel.halo(ui.data, lay, 2)

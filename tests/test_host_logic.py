@@ -330,3 +330,58 @@ def test_message(capsys):
         message.set_log_active(False)
     out = capsys.readouterr().out.splitlines()
     assert out == ['outer', '  inner']
+
+
+def test_newton_preconditioner_ageing_rule():
+    """newton_preconditioner.age (host logic): when the lagged p-multigrid
+    cycle is rebuilt -- a long solve (per Newton iteration yardsticks, not
+    within pmg_min_solves of a rebuild), or pmg_refresh solves where they
+    average pmg_refresh_min applications; never on short solves."""
+    from types import SimpleNamespace
+    from flow_amd.navier_stokes.newton_preconditioner import age
+    npar = {'check_every': 1, 'pmg_refresh': 50, 'pmg_min_solves': 10,
+            'pmg_refresh_min': 6.0}
+
+    def fresh():
+        pre = SimpleNamespace(stale=False)
+        age(pre, 'pmg', True, 5, 9, npar, it=0)
+        assert not pre.stale and pre.uses == 0
+        return pre
+
+    # the second Newton iteration's shorter solves have their own yardstick:
+    # 6 then 9 (first iteration: 9) is no ageing
+    pre = fresh()
+    for k in range(24):
+        age(pre, 'pmg', False, 3, 6, npar, it=1)
+        age(pre, 'pmg', False, 5, 9 + (k % 2), npar, it=0)
+        assert not pre.stale, k
+    # one long solve right after a rebuild does not start a rebuild storm ...
+    pre = fresh()
+    age(pre, 'pmg', False, 6, 12, npar, it=0)
+    assert not pre.stale
+    # ... ten solves later it does
+    for _ in range(9):
+        age(pre, 'pmg', False, 5, 9, npar, it=0)
+    assert not pre.stale
+    age(pre, 'pmg', False, 6, 11, npar, it=0)
+    assert pre.stale
+    # long solves: refreshed after pmg_refresh of them whatever the counts do
+    pre = fresh()
+    for k in range(49):
+        age(pre, 'pmg', False, 5, 9, npar, it=0)
+    assert not pre.stale
+    age(pre, 'pmg', False, 5, 9, npar, it=0)
+    assert pre.stale
+    # short solves (the early plateau: 4 applications): never by the clock
+    pre = SimpleNamespace(stale=False)
+    age(pre, 'pmg', True, 2, 4, npar, it=0)
+    for k in range(300):
+        age(pre, 'pmg', False, 2, 4 + (k % 2), npar, it=0)
+    assert not pre.stale
+    # the ILU(0) rule is the old one: twice the fresh iterations
+    pre = SimpleNamespace(stale=False)
+    age(pre, 'ilu0', True, 8, 16, npar)
+    age(pre, 'ilu0', False, 16, 32, npar)
+    assert not pre.stale
+    age(pre, 'ilu0', False, 17, 34, npar)
+    assert pre.stale

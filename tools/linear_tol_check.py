@@ -31,17 +31,17 @@ def main():
     hist = {}
     lay, play = prob.W.layout, prob.P.layout
     for key in ('newton_increments', 'correction_increments'):
-        hist[key] = [(h[0].clone(), h[1]) for h in lay._dev.get(key, [])]
+        hist[key] = [(h[0].clone(),) + tuple(h[1:]) for h in lay._dev.get(key, [])]
     hist['pressure_increments'] = [
-        (h[0].clone(), h[1]) for h in play._dev.get('pressure_increments', [])]
+        (h[0].clone(),) + tuple(h[1:]) for h in play._dev.get('pressure_increments', [])]
     umag = list(prob._umag_hist)
 
     def run(factor):
         prob.restore(snap)
         for key in ('newton_increments', 'correction_increments'):
-            lay._dev[key] = [(h[0].clone(), h[1]) for h in hist[key]]
+            lay._dev[key] = [(h[0].clone(),) + tuple(h[1:]) for h in hist[key]]
         play._dev['pressure_increments'] = [
-            (h[0].clone(), h[1]) for h in hist['pressure_increments']]
+            (h[0].clone(),) + tuple(h[1:]) for h in hist['pressure_increments']]
         prob._umag_hist = list(umag)
         navsto.solver_parameters['newton']['linear_atol_factor'] = \
             factor if factor else 1.0e-6
