@@ -142,6 +142,7 @@ solver_parameters = {
                # preconditioner was applied
                'ilu_vector': 'fp32',
                'adaptive_forcing': False, 'matrix_free': True,
+               'intermediate_fraction': 0.1, 'intermediate_margin': 1.0,
                # start vector of the FIRST Newton iteration's linear solve:
                # 'extrapolated' = the Newton increments of the previous calls,
                # extrapolated linearly in time (a time loop's steps differ
@@ -647,8 +648,10 @@ def _compute_tentative_velocity(
         quad_c = lay._dev.get('newton_quad_C')
         if quad_c is not None and npar.get('adaptive_forcing', True):
             predicted = quad_c * nrm * nrm
-            if predicted > tol:
-                lin_atol = max(lin_atol, min(0.1 * predicted, 1.0e-2 * nrm))
+            if predicted > npar.get('intermediate_margin', 1.0) * tol:
+                lin_atol = max(lin_atol, min(
+                    npar.get('intermediate_fraction', 0.1) * predicted,
+                    1.0e-2 * nrm))
         lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
         if use_gmres:
             # GMRES(restart): one Jacobian action + one preconditioner

@@ -63,6 +63,18 @@ def main():
     print('  rebuilds of the Newton preconditioner in the window: %d'
           % (navsto.last_step_info.get('newton_preconditioner_rebuilds', 0)
              - rebuilds0))
+    cmp_path = os.environ.get('COMPARE')
+    if cmp_path:
+        import torch
+        if os.path.exists(cmp_path):
+            ref = torch.load(cmp_path)
+            print('  against %s: u %.3e  p %.3e (rel-L2)' % (
+                cmp_path,
+                float((prob.u0.data - ref['u']).norm() / ref['u'].norm()),
+                float((prob.p0.data - ref['p']).norm() / ref['p'].norm())))
+        else:
+            torch.save({'u': prob.u0.data.clone(), 'p': prob.p0.data.clone()},
+                       cmp_path)
     print('  dt %.3e .. %.3e; |u|inf %.4f .. %.4f; |F0| %.2e .. %.2e; |F1| %.2e .. %.2e'
           % (min(i['dt'] for i in infos), max(i['dt'] for i in infos),
              min(i['unorm'] for i in infos), max(i['unorm'] for i in infos),
