@@ -24,11 +24,11 @@ def age(pre, kind, rebuilt, its, applications, npar, it=0):
     needed.  The p-multigrid cycle ages gently (13 -> 16 applications over 200
     plateau steps of the 10 M-DoF run) and a rebuild costs most of a time step
     (Jacobian assembly, packing, 2 x 32 power-method products: 8.5 ms): it is
-    rebuilt when a solve needs 2 applications (or 15 %) more than the fresh
-    one -- not within `pmg_min_solves` of the last rebuild: the counts also
-    move with the quality of the start vectors and with the Newton iteration
-    the solve belongs to (each has its own yardstick), and a rebuild resets it
-    -- and in any case after `pmg_refresh` solves where the solves are long
+    rebuilt when the solves need 2 applications (or 15 %) more than the best
+    one since the rebuild -- a smoothed count, and not within `pmg_min_solves`
+    of the rebuild: the counts also move with the quality of the start vectors
+    and with the Newton iteration the solve belongs to (each has its own
+    yardstick) -- and in any case after `pmg_refresh` solves where the solves are long
     (`pmg_refresh_min` applications on average since the rebuild: a rebuild
     costs as much as ten applications, and where a solve takes four there is
     little a fresh cycle could save): the linearisation state the cycle was
@@ -49,15 +49,20 @@ def age(pre, kind, rebuilt, its, applications, npar, it=0):
         base = getattr(pre, 'base_applications', None)
         if not isinstance(base, dict):
             base = pre.base_applications = {}
-        fresh = base.setdefault(it, applications)
+        # [fewest applications since the rebuild, smoothed count]: one long
+        # solve (a poor start vector, a step-size jump) is not ageing
+        best, smooth = base.get(it, (applications, float(applications)))
+        best = min(best, applications)
+        smooth = 0.6 * smooth + 0.4 * applications
+        base[it] = (best, smooth)
         pre.work = (0 if rebuilt else getattr(pre, 'work', 0)) + applications
         refresh = int(npar.get('pmg_refresh', 50))
         if refresh and pre.uses >= refresh and \
                 pre.work >= float(npar.get('pmg_refresh_min', 6.0)) * (
                     pre.uses + 1):
             pre.stale = True
-        elif pre.uses >= int(npar.get('pmg_min_solves', 10)) and \
-                applications >= fresh + max(2, int(round(0.15 * fresh))):
+        elif pre.uses >= int(npar.get('pmg_min_solves', 3)) and \
+                smooth >= best + max(2, int(round(0.15 * best))) - 0.25:
             pre.stale = True
     elif not rebuilt and its > 2 * pre.base_its:
         pre.stale = True

@@ -119,7 +119,7 @@ solver_parameters = {
                # average `pmg_refresh_min` applications or more, and not
                # within `pmg_min_solves` of a rebuild because of one long
                # solve: newton_preconditioner.age)
-               'pmg_refresh': 50, 'pmg_min_solves': 10, 'pmg_refresh_min': 6.0,
+               'pmg_refresh': 50, 'pmg_min_solves': 3, 'pmg_refresh_min': 6.0,
                # (Chebyshev steps before / after the coarse correction and
                # on the P1 level; intervals [lam_max / ratio, 1.1 lam_max].
                # r4, with the start vectors extrapolated in time -- the
