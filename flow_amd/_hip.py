@@ -284,7 +284,7 @@ SYMBOLS = {
     'flow_pmg_pack1': [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                        _VP, _VP, _VP, _VP],
     'flow_pmg_cols16': [_I, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
-    'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _P(_D), _VP],
+    'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _VP, _P(_D), _VP],
     'flow_pmg_apply': [_P(PmgS), _VP, _VP, _VP],
     'flow_mass_pack': [_I, _VP, _VP, _VP, _VP, _VP],
     'flow_mass_pack16': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
@@ -355,7 +355,7 @@ class NotConverged(RuntimeError):
 
 # flow_abi_version() of the library these bindings describe (the structs above
 # and SYMBOLS): a stale libflow_hip.so is refused at load time
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 def load_library():

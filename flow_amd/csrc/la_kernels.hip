@@ -1279,7 +1279,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 23; }
+extern "C" int flow_abi_version(void) { return 24; }
 
 // nonzeros a CSR-stream row block of an operator of `kind` may hold (the host
 // builds the row blocks: flow_amd/fem/space.py)

@@ -487,6 +487,36 @@ __global__ __launch_bounds__(kBlock) void pmg_scale_kernel(int n, float a,
   }
 }
 
+// the norm out of the block partials, on the device (one workgroup): out[0] =
+// |w|, so that the power iteration runs without a read-back per step
+__global__ __launch_bounds__(kBlock) void pmg_norm_finish_kernel(
+    int nparts, const double* __restrict__ partial, double* __restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) s += load_scalar(partial + i);
+  s = block_sum(s);
+  if (threadIdx.x == 0) out[0] = sqrt(s);
+}
+
+// v *= 1 / *nrm (the norm the launch before left on the device)
+__global__ __launch_bounds__(kBlock) void pmg_scale_dev_kernel(
+    int n, const double* __restrict__ nrm, float2* __restrict__ v) {
+  const float a = static_cast<float>(1.0 / load_scalar(nrm));
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    float2 t = v[i];
+    t.x *= a;
+    t.y *= a;
+    v[i] = t;
+  }
+}
+
+__global__ void pmg_copy_kernel(int n, const float2* __restrict__ src,
+                                float2* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(kBlock) void pmg_seed_kernel(int n,
                                                          float2* __restrict__ v) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -725,7 +755,7 @@ extern "C" int flow_pmg_cols16(int nblocks, const int* rowblocks,
 }
 
 extern "C" int flow_pmg_lambda_max(const flow_pmg_level* L, int iterations,
-                                   float* work, double* dwork,
+                                   float* work, double* dwork, float* start,
                                    double* result_host, void* stream) {
   FLOW_REQUIRE(L && L->n > 0 && L->rowptr && L->cols && L->rowblocks &&
                    (L->vals || L->packed) && work && dwork && result_host &&
@@ -737,33 +767,59 @@ extern "C" int flow_pmg_lambda_max(const flow_pmg_level* L, int iterations,
   float2* w = v + n;
   float2* zero = w + n;
   float2* const none = nullptr;
+  float2* const keep = reinterpret_cast<float2*>(start);
   const int g = grid_for(n);
   const int gr = grid_for(n, kBlock, kRedBlocks);
+  double* nrm = dwork + kRedBlocks;    // (behind the partials; S: 3 kRedBlocks)
+  // start: the fixed full-spectrum vector, or the iterate the previous call
+  // left (flagged by a nonzero first entry of its norm slot: `start` is
+  // zero-initialised by the caller)
   hipLaunchKernelGGL(pmg_seed_kernel, dim3(g), dim3(kBlock), 0, st, n, v);
   hipLaunchKernelGGL(pmg_zero_kernel, dim3(g), dim3(kBlock), 0, st, n, zero);
+  if (keep) {
+    // |keep|^2 == 0: never written -> stay with the seed
+    hipLaunchKernelGGL(pmg_norm_kernel, dim3(gr), dim3(kBlock), 0, st, n, keep,
+                       dwork);
+    FLOW_CHECK_LAUNCH();
+    double have = 0.0;
+    int rc = flow::sum_partials_host(dwork, gr, &have, st);
+    if (rc) return rc;
+    if (have == have && have > 0.0)
+      hipLaunchKernelGGL(pmg_copy_kernel, dim3(g), dim3(kBlock), 0, st, n, keep, v);
+  }
   double lam = 0.0;
   for (int it = 0; it < iterations; ++it) {
-    // w = 0 - (D^-1 A) v and |w|^2
+    // w = 0 - (D^-1 A) v, |w| and w / |w|; |v| = 1 on entry (after the first
+    // pass): the growth is the estimate.  Only the last pass reads its norm
+    // back; the others normalise on the device.
     launch_cheb<0>(L, v, zero, w, none, 0.f, 0.f, none, none, none,
                    static_cast<double*>(nullptr),
                    static_cast<const unsigned char*>(nullptr),
                    static_cast<const double*>(nullptr),
                    static_cast<const double*>(nullptr), st);
     hipLaunchKernelGGL(pmg_norm_kernel, dim3(gr), dim3(kBlock), 0, st, n, w, dwork);
-    FLOW_CHECK_LAUNCH();
-    double nrm2 = 0.0;
-    int rc = flow::sum_partials_host(dwork, gr, &nrm2, st);
-    if (rc) return rc;
-    FLOW_REQUIRE(nrm2 == nrm2 && nrm2 > 0.0, "power iteration broke down");
-    // |v| = 1 on entry (after the first pass): the growth is the estimate
-    const double nw = sqrt(nrm2);
-    if (it > 0) lam = nw;
-    hipLaunchKernelGGL(pmg_scale_kernel, dim3(g), dim3(kBlock), 0, st, n,
-                       static_cast<float>(1.0 / nw), w);
+    if (it + 1 < iterations) {
+      hipLaunchKernelGGL(pmg_norm_finish_kernel, dim3(1), dim3(kBlock), 0, st, gr,
+                         dwork, nrm);
+      hipLaunchKernelGGL(pmg_scale_dev_kernel, dim3(g), dim3(kBlock), 0, st, n,
+                         nrm, w);
+    } else {
+      FLOW_CHECK_LAUNCH();
+      double nrm2 = 0.0;
+      int rc = flow::sum_partials_host(dwork, gr, &nrm2, st);
+      if (rc) return rc;
+      FLOW_REQUIRE(nrm2 == nrm2 && nrm2 > 0.0, "power iteration broke down");
+      lam = sqrt(nrm2);
+      hipLaunchKernelGGL(pmg_scale_kernel, dim3(g), dim3(kBlock), 0, st, n,
+                         static_cast<float>(1.0 / lam), w);
+    }
     float2* t = v;
     v = w;
     w = t;
   }
+  if (keep)
+    hipLaunchKernelGGL(pmg_copy_kernel, dim3(g), dim3(kBlock), 0, st, n, v, keep);
+  FLOW_CHECK_LAUNCH();
   *result_host = lam;
   return FLOW_OK;
 }

@@ -238,12 +238,22 @@ class _Level(object):
             _hip.f16(self.vals, 2 * nnz), _hip.f32(self.diag, 2 * n),
             _hip.f32(self.dinv, 2 * n), _hip.stream()))
 
-    def lambda_max(self, work, iterations=32):
+    def lambda_max(self, work, iterations=32, warm_iterations=10):
+        '''Spectral radius of D^-1 A by the power method: `iterations` steps
+        from a fixed vector the first time, `warm_iterations` from the iterate
+        of the previous call afterwards (a rebuild of the same level some time
+        steps later: the dominant eigenvector has hardly moved).'''
+        first = getattr(self, '_eigvec', None) is None
+        if first:
+            self._eigvec = torch.zeros(2 * self.n, dtype=torch.float32,
+                                       device=device.get())
         res = ctypes.c_double(0.0)
         _hip.check(_hip.lib().flow_pmg_lambda_max(
-            ctypes.byref(self.struct), int(iterations),
+            ctypes.byref(self.struct),
+            int(iterations if first else warm_iterations),
             _hip.f32(work, 6 * self.n),
-            _hip.f64(ops.work(_hip.REDUCE_WORK)), ctypes.byref(res),
+            _hip.f64(ops.work(_hip.REDUCE_WORK)),
+            _hip.f32(self._eigvec, 2 * self.n), ctypes.byref(res),
             _hip.stream()))
         return res.value
 

@@ -23,7 +23,8 @@ def age(pre, kind, rebuilt, its, applications, npar, it=0):
     more than twice the (BiCGStab-equivalent) iterations the fresh factors
     needed.  The p-multigrid cycle ages gently (13 -> 16 applications over 200
     plateau steps of the 10 M-DoF run) and a rebuild costs most of a time step
-    (Jacobian assembly, packing, 2 x 32 power-method products: 8.5 ms): it is
+    (Jacobian assembly, packing, 2 x 10 power-method products from the
+    previous rebuild's iterate: ~5 ms): it is
     rebuilt when the solves need 2 applications (or 15 %) more than the best
     one since the rebuild -- a smoothed count, and not within `pmg_min_solves`
     of the rebuild: the counts also move with the quality of the start vectors

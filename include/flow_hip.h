@@ -404,9 +404,14 @@ int flow_pmg_cols16(int nblocks, const int* rowblocks, const int* rowptr,
                     const int* cols, int* cbase, void* cols16,
                     int* overflow_dev, void* stream);
 /* spectral radius of D^-1 A of a level by `iterations` (>= 2) steps of the
- * power method.  work: 6*n floats, dwork: FLOW_REDUCE_WORK doubles. */
+ * power method (normalised on the device: one read-back, at the end).  work:
+ * 6*n floats, dwork: FLOW_REDUCE_WORK doubles.  start (optional, 2*n floats,
+ * zero before the first call): the iterate the previous call left there is
+ * where this one starts (a rebuild of the same level a few time steps later
+ * needs a few iterations, not 32) and leaves its own. */
 int flow_pmg_lambda_max(const flow_pmg_level* level, int iterations, float* work,
-                        double* dwork, double* result_host, void* stream);
+                        double* dwork, float* start, double* result_host,
+                        void* stream);
 /* z = M^-1 r (r, z: 2*fine.n doubles, component-blocked) */
 int flow_pmg_apply(const flow_pmg* pmg, const double* r, double* z, void* stream);
 
