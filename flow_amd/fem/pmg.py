@@ -243,7 +243,8 @@ class _Level(object):
         from a fixed vector the first time, `warm_iterations` from the iterate
         of the previous call afterwards (a rebuild of the same level some time
         steps later: the dominant eigenvector has hardly moved).'''
-        first = getattr(self, '_eigvec', None) is None
+        first = getattr(self, '_eigvec', None) is None or \
+            os.environ.get('FLOW_AMD_PMG_COLD_POWER') == '1'
         if first:
             self._eigvec = torch.zeros(2 * self.n, dtype=torch.float32,
                                        device=device.get())
