@@ -110,7 +110,9 @@ def describe(world, nrows=None):
                 'preconditioner', 'ilu0')
         return ('x-strips x%d: every sub-step sharded (GMRES + %s, row-sharded '
                 'V-cycle CG, %s mass solves); collectives: %s' % (
-                    world, pre, MASS_SOLVER_ON_STRIPS,
+                    world, pre,
+                    'Jacobi-CG (strips thinner than the mass solver\'s halo)'
+                    if _MASS_FALLBACK[0] else MASS_SOLVER_ON_STRIPS,
                     'ncclAllReduce issued by the library on its stream'
                     if comm().direct is not None else
                     'torch.distributed.all_reduce (%s)' % (
@@ -122,6 +124,7 @@ def describe(world, nrows=None):
 
 # what parallel.cg-based mass solves are (bench.py's parallelism line)
 MASS_SOLVER_ON_STRIPS = 'defect-correction (deep halo)'
+_MASS_FALLBACK = [False]      # mass_solve fell back to Jacobi-CG (thin strips)
 
 
 # -- communicator ---------------------------------------------------------------
@@ -818,6 +821,7 @@ def mass_solve(solver, b, x, rtol, atol=0.0, maxit=50, tag=None, xbase=None,
             # ranges are built for all ranks before the assertion)
             info('mass solves on these strips by Jacobi-CG: %s' % e)
             solver.__dict__[key] = None
+            _MASS_FALLBACK[0] = True
     ms = solver.__dict__[key]
     n = solver.A.size
     if ms is None:
