@@ -11,7 +11,7 @@ CPU: the extrapolation weights themselves.
 import numpy
 import pytest
 
-from flow_amd.navier_stokes.pressure_correction import extrapolation_weights
+from flow_amd.navier_stokes.start_vectors import extrapolation_weights
 
 
 def test_extrapolation_weights_reproduce_polynomials():
@@ -111,42 +111,42 @@ def test_start_vectors_do_not_move_the_trajectory(hip):
 @pytest.mark.gpu
 def test_stamped_histories_only_count_without_gaps(hip):
     '''The increment histories of the second / third Newton iteration are only
-    written by the calls that get that far: `_extrapolated_increment` with a
+    written by the calls that get that far: `extrapolated_increment` with a
     stamp uses the entries of the calls just before this one and stops at the
     first gap (an older entry would be extrapolated over a time it does not
     belong to).'''
     from types import SimpleNamespace
     from flow_amd import device
-    from flow_amd.navier_stokes import pressure_correction as pc
+    from flow_amd.navier_stokes import start_vectors as sv
     lay = SimpleNamespace(_dev={})
     n = 1000
     dt = 0.03
     key = ('newton_increments', 1)
     # calls 1..4 wrote t, 2t, 3t, 4t (a linear rate: exactly extrapolated)
     for call in (1, 2, 3, 4):
-        pc._remember_increment(lay, dt, device.to_device(
+        sv.remember_increment(lay, dt, device.to_device(
             numpy.full(n, float(call))), key=key, stamp=call)
     out = device.zeros(n)
-    assert pc._extrapolated_increment(lay, dt, out, 5, key=key, degree=3,
+    assert sv.extrapolated_increment(lay, dt, out, 5, key=key, degree=3,
                                       stamp=5)
     assert numpy.allclose(device.to_host(out).numpy(), 5.0)
     # call 5 did not get to this Newton iteration: at call 6 the history has a
     # gap right at its head -> nothing to start from
     out = device.zeros(n)
-    assert not pc._extrapolated_increment(lay, dt, out, 5, key=key, degree=3,
+    assert not sv.extrapolated_increment(lay, dt, out, 5, key=key, degree=3,
                                           stamp=6)
     assert (device.to_host(out).numpy() == 0.0).all()
     # calls 6 and 7 write again: at call 8 only those two count (a straight
     # line through them: 6, 7 -> 8), the older four lie behind the gap
     for call in (6, 7):
-        pc._remember_increment(lay, dt, device.to_device(
+        sv.remember_increment(lay, dt, device.to_device(
             numpy.full(n, float(call))), key=key, stamp=call)
     out = device.zeros(n)
-    assert pc._extrapolated_increment(lay, dt, out, 5, key=key, degree=3,
+    assert sv.extrapolated_increment(lay, dt, out, 5, key=key, degree=3,
                                       stamp=8)
     assert numpy.allclose(device.to_host(out).numpy(), 8.0)
     # without a stamp (the first iteration's history, written on every call)
     # all entries within the step-size rule count, as before
     out = device.zeros(n)
-    assert pc._extrapolated_increment(lay, dt, out, 2, key=key)
+    assert sv.extrapolated_increment(lay, dt, out, 2, key=key)
     assert numpy.allclose(device.to_host(out).numpy(), 8.0)
