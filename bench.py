@@ -469,10 +469,12 @@ def main():
         _hip.check(_hip.lib().flow_profile_marker(1, _hip.stream()))
         barrier()
         calls0 = parallel.comm().calls if parallel.active() else 0
+        launches0 = _hip.launch_count()
         t0 = time.perf_counter()
         infos = [prob.step(tol=args.tol) for _ in range(args.steps)]
         barrier()
         elapsed = time.perf_counter() - t0
+        infos[0]['launches_in_window'] = _hip.launch_count() - launches0
         if parallel.active():
             # (every halo and every reduction of the strips is one all-reduce)
             infos[0]['collectives_in_window'] = parallel.comm().calls - calls0
@@ -505,6 +507,9 @@ def main():
             'cfl_projection_cg_iterations': [
                 i.get('projection_iterations', 0) for i in infos],
             'substep_s': tim,
+            # kernel launches of the library per step (flow_launch_count)
+            'launches_per_step': infos[0].get('launches_in_window', 0)
+            / float(len(infos)),
             # (counted at the all-reduce callback; the library-issued
             # ncclAllReduce of FLOW_AMD_RCCL_DIRECT=1 does not pass there)
             'collectives_per_step': (

@@ -253,6 +253,7 @@ _D = ctypes.c_double
 _P = ctypes.POINTER
 SYMBOLS = {
     'flow_abi_version': [],
+    'flow_launch_count': [_P(ctypes.c_ulonglong)],
     'flow_xcd_tile_host': [_I, _I],
     'flow_spmv_tile_nnz': [_I],
     'flow_operator_apply': [_P(Operator), _VP, _VP, _VP],
@@ -355,7 +356,7 @@ class NotConverged(RuntimeError):
 
 # flow_abi_version() of the library these bindings describe (the structs above
 # and SYMBOLS): a stale libflow_hip.so is refused at load time
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 def load_library():
@@ -383,6 +384,13 @@ def load_library():
                 % (LIB_PATH, got, ABI_VERSION))
         _LIB = lib
     return _LIB
+
+
+def launch_count():
+    '''Kernel launches the library has issued so far (no GPU needed to ask).'''
+    n = ctypes.c_ulonglong(0)
+    check(load_library().flow_launch_count(ctypes.byref(n)))
+    return int(n.value)
 
 
 def spmv_tile_nnz(kind=0):

@@ -7,6 +7,21 @@
 
 #include "../../include/flow_hip.h"
 
+// Every kernel launch of the library is counted (flow_launch_count: what a time
+// step costs in launches is what bounds it where the kernels are small -- the
+// 8-GPU rank): the launch macro of hip_runtime.h with one increment in front.
+namespace flow {
+extern unsigned long long g_launches;
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock,        \
+                           streamId, ...)                                       \
+  do {                                                                          \
+    ++flow::g_launches;                                                         \
+    (kernelName)<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(     \
+        __VA_ARGS__);                                                           \
+  } while (0)
+
 namespace flow {
 
 void set_error(const char* fmt, ...);

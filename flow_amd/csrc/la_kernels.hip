@@ -1279,7 +1279,16 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 24; }
+extern "C" int flow_abi_version(void) { return 25; }
+
+namespace flow {
+unsigned long long g_launches = 0;
+}
+extern "C" int flow_launch_count(unsigned long long* count_host) {
+  FLOW_REQUIRE(count_host != nullptr, "flow_launch_count argument");
+  *count_host = flow::g_launches;
+  return FLOW_OK;
+}
 
 // nonzeros a CSR-stream row block of an operator of `kind` may hold (the host
 // builds the row blocks: flow_amd/fem/space.py)

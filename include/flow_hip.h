@@ -50,6 +50,9 @@ int flow_spmv_tile_nnz(int kind);
 
 const char* flow_last_error(void);
 int flow_abi_version(void);
+/* Kernel launches the library has issued so far in this process (all entry
+ * points, all streams): differences over a window give launches per step. */
+int flow_launch_count(unsigned long long* count_host);
 /* Host copy of the workgroup -> tile mapping the CSR-stream kernels use
  * (XCD-aware, a permutation of [0, nblocks)); for tests. */
 int flow_xcd_tile_host(int block, int nblocks);
