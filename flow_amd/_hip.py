@@ -229,6 +229,7 @@ class MgShardS(ctypes.Structure):
         ('Ah0', Operator), ('Ps0', Operator), ('Rg', Operator),
         ('Cg', Operator),
         ('up_rowblocks0', ctypes.c_void_p), ('up_nblocks0', ctypes.c_int),
+        ('z_lo', ctypes.c_int), ('z_hi', ctypes.c_int),
         ]
 
 
@@ -356,7 +357,7 @@ class NotConverged(RuntimeError):
 
 # flow_abi_version() of the library these bindings describe (the structs above
 # and SYMBOLS): a stale libflow_hip.so is refused at load time
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 
 def load_library():

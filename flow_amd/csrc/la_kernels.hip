@@ -140,7 +140,8 @@ __global__ __launch_bounds__(kBlock) void mg_up2_kernel(
     const double* __restrict__ a_vals, const double* __restrict__ xc,
     const double* __restrict__ c, const double* __restrict__ dinv, double omega,
     double* __restrict__ y, double* __restrict__ gpart,
-    double* __restrict__ rpart, const double* __restrict__ stop) {
+    double* __restrict__ rpart, const double* __restrict__ stop,
+    int own_lo = 0, int own_hi = 0x7fffffff) {
   __shared__ double prod_p[kTile];
   __shared__ double prod_a[kTile];
   if (stopped(stop)) return;
@@ -159,7 +160,9 @@ __global__ __launch_bounds__(kBlock) void mg_up2_kernel(
   if (r < r1) {
     const double yi = sp + omega * di * (2.0 * ci - sa);
     y[r] = yi;
-    if (DOTS) {
+    // (K15: a rank that also forms y on its first ghost layer counts its OWN
+    // rows only; the ghost rows are counted by their owners)
+    if (DOTS && r >= own_lo && r < own_hi) {
       g = ci * yi;
       rr = yi * yi;
     }
@@ -1279,7 +1282,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 25; }
+extern "C" int flow_abi_version(void) { return 26; }
 
 namespace flow {
 unsigned long long g_launches = 0;
@@ -2854,7 +2857,8 @@ static int shard_up0(const ShardCg& c, const double* r, double* z, double* gpart
       hipLaunchKernelGGL(mg_up2_kernel<true>, grid, dim3(kBlock), 0, c.st,
                          c.G->up_rowblocks0, P0->rowptr, P0->cols, P0->vals[0],
                          A0->rowptr, A0->cols, A0->vals[0], M->x[1], c.sh(r),
-                         M->dinv[0], M->omega, c.sh(z), gpart, rpart, stop);
+                         M->dinv[0], M->omega, c.sh(z), gpart, rpart, stop,
+                         c.R->r0, c.R->r1);
     else
       hipLaunchKernelGGL(mg_up2_kernel<false>, grid, dim3(kBlock), 0, c.st,
                          c.G->up_rowblocks0, P0->rowptr, P0->cols, P0->vals[0],
@@ -2991,6 +2995,10 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
                      R->r0 - R->e0, R->r1 - R->e0, c.own);
   if ((rc = fill(kNumSlots, 0.0, c.S, st))) return rc;
   if ((rc = fill(3 * L, 0.0, c.w, st))) return rc;          // w, p, s
+  // one collective per iteration: z is formed on the first ghost layer too and
+  // never exchanged (rows further out stay zero)
+  const bool z_local = G && shard_two_launch(G) && G->z_hi > G->z_lo;
+  if (z_local && (rc = fill(L, 0.0, c.z, st))) return rc;
   FLOW_CHECK_LAUNCH();
 
   // |B b|^2 over the owned rows -> S[kB2] (this rank's share)
@@ -3020,7 +3028,7 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
     if ((rc = shard_vcycle(c, c.r, c.z, none, none, nullptr, nullptr,
                            two ? rc_r : nullptr)))
       return rc;
-    if ((rc = halo(C, R, 1, c.sh(c.z), me, st))) return rc;
+    if (!z_local && (rc = halo(C, R, 1, c.sh(c.z), me, st))) return rc;
     if (two && (rc = fill(n1, 0.0, rc_s, st))) return rc;
   } else {
     hipLaunchKernelGGL(vmul_kernel, dim3(gl), dim3(kBlock), 0, st, L, 1.0, c.dc,
@@ -3100,7 +3108,7 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
                                       stop))) {
           return rc;
         }
-        if ((rc = halo(C, R, 1, c.sh(c.z), me, st))) return rc;
+        if (!z_local && (rc = halo(C, R, 1, c.sh(c.z), me, st))) return rc;
         gpart = c.mpart;
         rpart = c.mpart + nm;
       } else {
@@ -3147,9 +3155,15 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
       return FLOW_NOT_CONVERGED;
     }
   }
-  // x on the owned AND ghost rows (the recurrences ran there too)
-  hipLaunchKernelGGL(shard_expand_kernel, dim3(gl), dim3(kBlock), 0, st, ncomp, me,
-                     R->e0, n, c.xc, x);
+  // x on the owned AND ghost rows (the recurrences ran there too; z_local: on
+  // the first ghost layer -- further out the search directions are zero)
+  if (z_local)
+    hipLaunchKernelGGL(shard_expand_kernel, dim3(grid_for(G->z_hi - G->z_lo)),
+                       dim3(kBlock), 0, st, 1, G->z_hi - G->z_lo, G->z_lo, n,
+                       c.xc + (G->z_lo - R->e0), x);
+  else
+    hipLaunchKernelGGL(shard_expand_kernel, dim3(gl), dim3(kBlock), 0, st, ncomp,
+                       me, R->e0, n, c.xc, x);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -3491,6 +3505,11 @@ extern "C" int flow_shard_mgcg_solve(
                  "sharded hierarchy: two-launch form");
     need += mgs->Cg.n;
     if (2LL * mgs->Cg.n > need) need = 2LL * mgs->Cg.n;
+    FLOW_REQUIRE(mgs->z_hi <= mgs->z_lo ||
+                     (mgs->z_lo >= rows->e0 && mgs->z_lo <= rows->r0 &&
+                      mgs->z_hi >= rows->r1 && mgs->z_hi <= rows->e1),
+                 "sharded hierarchy: [z_lo, z_hi) must hold the owned rows and "
+                 "lie inside the rows' window");
   }
   if (mgs->Rg.n > need) need = mgs->Rg.n;
   if ((rc = check_comm(comm, need))) return rc;

@@ -122,6 +122,11 @@ def describe(world, nrows=None):
     return 'replicated x%d' % world
 
 
+# collectives per iteration of the sharded V-cycle CG: 1 (default: the halo of
+# w two layers deep, z formed on the first ghost layer by the rank itself), 2
+# (the halo of z exchanged), 3 (round 3: the coarse residual too)
+MGCG_COLLECTIVES = int(os.environ.get('FLOW_AMD_MGCG_COLLECTIVES', '1'))
+
 # what parallel.cg-based mass solves are (bench.py's parallelism line)
 MASS_SOLVER_ON_STRIPS = 'defect-correction (deep halo)'
 _MASS_FALLBACK = [False]      # mass_solve fell back to Jacobi-CG (thin strips)
@@ -636,11 +641,15 @@ class MgShard(object):
     strip (flow_mg_shard): Ah0 / Ps0 with the row blocks of the owned rows, the
     restriction restricted to the owned columns.'''
 
-    def __init__(self, mg, v):
+    def __init__(self, mg, v, rows2=None, zrange=None):
+        '''rows2 / zrange: the one-collective form -- the flow_rows whose ghost
+        ranges reach TWO coupling layers out, and the rows [z_lo, z_hi) (owned +
+        one layer) the up-sweep then covers.'''
         from .fem.multigrid import CsrOperator
         assert mg.nlevels >= 2 and mg.R0_host is not None
         self.mg = mg
         self._keep = []
+        self.rows2 = rows2
         lvl = mg.levels[0]
         Rg = mg.R0_host[:, v.r0:v.r1].tocsr()
         assert Rg.nnz > 0
@@ -651,8 +660,7 @@ class MgShard(object):
         s.Ps0 = owned_operator(lvl['Ps'].op, self._blocks(lvl['Ps'], v))
         s.Rg = self.Rg.op
         self.Cg = None
-        if mg.C0_host is not None and \
-                os.environ.get('FLOW_AMD_MGCG_COLLECTIVES', '2') != '3':
+        if mg.C0_host is not None and MGCG_COLLECTIVES != 3:
             # the two-collective form: C = R (I - Ah) cut to the owned COLUMNS
             # (no ghost rows needed for the rank's share of C r), and row
             # blocks of the owned rows that hold a tile of Ps AND of Ah
@@ -662,12 +670,17 @@ class MgShard(object):
             s.Cg = self.Cg.op
             rps = [device.to_host(lvl[k]._rowptr).numpy().astype(numpy.int64)
                    for k in ('Ps', 'Ah')]
+            z0, z1 = (v.r0, v.r1) if zrange is None else zrange
             rb = csr_stream_rowblocks(
-                [rp[v.r0:v.r1 + 1] - rp[v.r0] for rp in rps]) + v.r0
+                [rp[z0:z1 + 1] - rp[z0] for rp in rps]) + z0
             t = device.to_device(rb.astype(numpy.int32))
             self._keep.append(t)
             s.up_rowblocks0 = _hip.i32(t).value
             s.up_nblocks0 = t.numel() - 1
+            if zrange is not None:
+                assert rows2 is not None
+                assert rows2.e0 <= z0 <= v.r0 and v.r1 <= z1 <= rows2.e1
+                s.z_lo, s.z_hi = int(z0), int(z1)
         self.struct = s
 
     def _blocks(self, op, v):
@@ -687,14 +700,25 @@ def mgcg(A, dinv, mg, b, x, rtol, atol=0.0, maxit=1000, check_every=2,
     v = view(lay)
     key = ('mg_shard', c.world, c.rank)
     if key not in mg.__dict__:
-        mg.__dict__[key] = MgShard(mg, v)
+        rows2 = zrange = None
+        if mg.C0_host is not None and MGCG_COLLECTIVES == 1:
+            # one collective per iteration: ghost ranges two layers deep, z
+            # formed on the first layer by the rank itself
+            st = strips(lay.mesh)
+            try:
+                rows2 = st.deep_blocks(lay, 2).struct(c.rank)
+                zrange = st.deep_ranges(lay, 2)[c.rank][1]
+            except AssertionError:
+                rows2 = zrange = None       # (strips too thin: two collectives)
+        mg.__dict__[key] = MgShard(mg, v, rows2, zrange)
     ms = mg.__dict__[key]
     n1 = ms.struct.Rg.n
     two = ms.Cg is not None
-    c.ensure(max(4 + v.rows.nhalo + (n1 if two else 0), 2 * n1 if two else n1))
+    rows = ms.rows2 if ms.rows2 is not None else v.rows
+    c.ensure(max(4 + rows.nhalo + (n1 if two else 0), 2 * n1 if two else n1))
     op = v.operator(A)
     n = A.size
-    wlen = _hip.REDUCE_WORK + 11 * (v.e1 - v.e0) + op.nblocks \
+    wlen = _hip.REDUCE_WORK + 11 * (rows.e1 - rows.e0) + op.nblocks \
         + 2 * max(ms.struct.Ps0.nblocks, ms.struct.up_nblocks0) + 2 \
         + (3 * n1 + 2 if two else 0)
     wk = ops.work(wlen)
@@ -703,7 +727,7 @@ def mgcg(A, dinv, mg, b, x, rtol, atol=0.0, maxit=1000, check_every=2,
     its = ctypes.c_int(0)
     res = ctypes.c_double(0.0)
     _hip.check(_hip.lib().flow_shard_mgcg_solve(
-        ctypes.byref(c.struct), ctypes.byref(v.rows), ctypes.byref(op),
+        ctypes.byref(c.struct), ctypes.byref(rows), ctypes.byref(op),
         _hip.f64(dinv, n, 'dinv'), ctypes.byref(ms.struct),
         _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
         int(maxit), int(check_every), int(first), _hip.f64(wk), wk.numel(),

@@ -703,6 +703,15 @@ typedef struct {
                                    three-collective form */
   const int* up_rowblocks0;     /* mg->up_rowblocks[0] for the owned rows */
   int up_nblocks0;
+  /* ONE collective per iteration (two-collective form only): z_hi > z_lo --
+   * up_rowblocks0 then covers the rows [z_lo, z_hi) = the owned rows plus ONE
+   * ghost layer, and the flow_rows handed to the solver reach TWO layers out:
+   * the halo of w (in the collective that carries the dots) is two layers
+   * deep, so r is current two layers out, so the up-sweep can form z on the
+   * first ghost layer itself -- every rank recomputing those few rows instead
+   * of asking for them -- and w = A z needs no halo of z.  x comes back on
+   * [z_lo, z_hi). */
+  int z_lo, z_hi;
 } flow_mg_shard;
 int flow_shard_mgcg_solve(const flow_comm* comm, const flow_rows* rows,
                           const flow_operator* A, const double* dinv,

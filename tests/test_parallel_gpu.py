@@ -267,7 +267,10 @@ def test_strip_sharded_solvers_and_step(hip, world):
         calls, its = res['mgcg_calls']
         # (+ one every eighth iteration: the coarse images are recomputed from
         # the vectors they belong to, against the drift of the recurrences)
-        assert calls <= 2 * (its + 2) + 7 + (its + 2) // 8 + 1, (calls, its)
+        # (r4, later: ONE per iteration -- the halo of w is two layers deep,
+        # so that every rank forms z on its first ghost layer itself and the
+        # halo of z is gone, from the start sequence too)
+        assert calls <= (its + 2) + 6 + (its + 2) // 8 + 1, (calls, its)
         st = res['step']
         assert 'x-strips x%d' % world in st['method']
         assert st['ghosts_u'] and st['ghosts_p']
@@ -671,14 +674,15 @@ def test_thin_strips_fall_back_to_cg(hip):
 def test_collectives_per_time_step(hip):
     '''What one settled time step costs in collectives on the strips (counted at
     the all-reduce callback, every halo and every reduction is one): two per
-    GMRES application (halo of the operator's input, Gram-Schmidt sums), two
-    per V-cycle CG iteration (the coarse residual travels by recurrence), one
+    GMRES application (halo of the operator's input, Gram-Schmidt sums), ONE
+    per V-cycle CG iteration (the coarse residual travels by recurrence, z is
+    formed on the first ghost layer by every rank itself), one
     per defect correction of the two mass solves (deep halo: the five
     products of a Chebyshev polynomial run on shrinking ghost ranges), plus
     the starts of the solves and the norms of the Newton iteration and the
     step-size controller -- and, with the start vectors extrapolated in time,
     few iterations of each.  Round 3 counted ~110 per step at the headline
-    size; this small problem takes 60-68 now (two narrow strips cost the
+    size; this small problem takes 49-56 now (two narrow strips cost the
     block-Jacobi cycle more GMRES applications than eight strips of the
     headline mesh do).'''
     world = 2
@@ -690,9 +694,9 @@ def test_collectives_per_time_step(hip):
     for row in out[0]:
         # the budget of a step, from its own iteration counts
         budget = (2 * row['gmres'] + 6 * max(row['newton'], 1) + 2
-                  + 2 * (row['pressure'] + 2) + 7 + (row['pressure'] + 2) // 8 + 1
+                  + (row['pressure'] + 2) + 6 + (row['pressure'] + 2) // 8 + 1
                   + (row['correction'] + 2) + 3
                   + (row['projection'] + 2) + 3 + 2)
         assert row['calls'] <= budget, (row, budget)
     print('collectives per settled step on 2 strips: %r' % (out[0],))
-    assert max(r['calls'] for r in out[0][2:]) <= 72, out[0]
+    assert max(r['calls'] for r in out[0][2:]) <= 60, out[0]

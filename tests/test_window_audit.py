@@ -190,6 +190,35 @@ def test_multigrid_level0_stays_inside_the_window(host_structs, world):
                     (name, world, g, (w0, w1))
         # (the audit has seen the empty-tile path of the kernel)
         assert world == 2 or empty_tiles > 0
+        # the one-collective form: the up-sweep (Ps and Ah tiles over the SAME
+        # row blocks) covers the owned rows plus one ghost layer, the residual
+        # window reaches two layers out; C cut to the owned columns reads the
+        # owned part of a vector in local numbering
+        try:
+            deep = st.deep_blocks(lay, 2)
+        except AssertionError:
+            continue                        # (strips too thin at this size)
+        for g in range(world):
+            v = parallel.View(lay, st, g)
+            rows2 = deep.struct(g)
+            z0, z1 = st.deep_ranges(lay, 2)[g][1]
+            ms = parallel.MgShard(mg, v, rows2, (z0, z1))
+            assert ms.struct.z_lo == z0 and ms.struct.z_hi == z1
+            assert rows2.e0 <= z0 <= v.r0 and v.r1 <= z1 <= rows2.e1
+            up = _host(ms._keep[-1])
+            assert up[0] == z0 and up[-1] == z1
+            for op, (w0, w1) in ((lvl['Ah'], (rows2.e0, rows2.e1)),
+                                 (lvl['Ps'], (0, mg.sizes[1]))):
+                lo_t, hi_t = am.tile_accesses(_host(op._rowptr),
+                                              _host(op._cols), up, 'stream')
+                sel = lo_t <= hi_t
+                assert w0 <= lo_t[sel].min() and hi_t[sel].max() < w1, \
+                    (name, world, g, 'up', (w0, w1))
+            lo_t, hi_t = am.tile_accesses(
+                _host(ms.Cg._rowptr), _host(ms.Cg._cols), _host(ms.Cg._rb),
+                'stream')
+            sel = lo_t <= hi_t
+            assert 0 <= lo_t[sel].min() and hi_t[sel].max() < v.r1 - v.r0
 
 
 @pytest.mark.parametrize('world', WORLDS)
