@@ -17,7 +17,10 @@ All operators are assembled by the HIP kernels of libflow_hip.so (K13/K14):
      (reference :54-58) [+ SUPG terms, :60-86];
   b  rhs(f) = -int source v (UFL's rhs() negates; reference :88).
 The reference solves with sparse LU (:117-121); here BiCGStab + ILU(0) on the
-row-equilibrated system (GMRES(30) first, BiCGStab as the second try).
+row-equilibrated system (GMRES(30) first, BiCGStab as the second try), started
+from the solution of the previous solve on the space (a Banach sweep of the
+Boussinesq driver solves nearly the system of the sweep before: 100 -> 60
+iterations at 1.3 M rows, tools/boussinesq_time.py; the start vector only).
 
 On the strips of flow_amd.parallel (several GPUs) every rank assembles A over
 ITS cells for ITS rows, evaluates on its rows, and the solve is the sharded
@@ -39,7 +42,10 @@ from . import parallel
 from . import stabilization
 
 solver_parameters = {'rtol': 1.0e-13, 'maxit': 2000, 'check_every': 10,
-                     'preconditioner': 'ilu0'}     # 'ilu0' | 'jacobi'
+                     'preconditioner': 'ilu0',     # 'ilu0' | 'jacobi'
+                     # 'previous': the solve starts from the solution of the
+                     # previous solve on the space; 'zero': no history
+                     'start': 'previous'}
 last_solve_info = {}
 
 
@@ -203,17 +209,33 @@ class Heat(object):
             ))
         bvec = ops.vmul(dinv, bvec)
         u = Function(self.V)
-        # warm start is not used: x0 = 0 like a direct solve has no history
+        # Start vector: the solution of the previous solve on this space (the
+        # reference's LU has no history; a Banach sweep of the Boussinesq
+        # driver solves nearly the system of the sweep before, a time loop
+        # nearly the one of the step before) with this call's Dirichlet values
+        # -- a start vector only: the solve runs to the same rtol, a start that
+        # leaves a larger residual than zero is dropped by the GMRES itself.
+        # solver_parameters['start'] = 'zero': as a direct solve.
         par = solver_parameters
+        start = lay._dev.get('heat_start') \
+            if par.get('start', 'previous') == 'previous' else None
+        warm = start is not None and start.numel() == u.data.numel()
+        if warm:
+            ops.copy(u.data, start)
+            if nbc > 0:
+                _hip.check(lib.flow_bc_set_values(
+                    nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(u.data),
+                    st))
         if parallel.active():
             # block-Jacobi ILU(0) GMRES on the strips; the ghost rows of the
             # solution from their owners
             pre = parallel.local_ilu(A)
             info = parallel.gmres(A, pre, bvec, u.data, rtol=par['rtol'],
                                   atol=0.0, maxit=par['maxit'], restart=30,
-                                  x_is_zero=True, verify=True)
+                                  x_is_zero=not warm, verify=True)
             parallel.halo(u.data, lay, 1)
             last_solve_info['heat'] = info
+            self._remember(lay, u.data, warm, start)
             return u
         pre = None
         if par.get('preconditioner', 'ilu0') == 'ilu0':
@@ -227,7 +249,7 @@ class Heat(object):
         try:
             info = ops.krylov_solve(
                 'gmres', A, bvec, u.data, rtol=par['rtol'], atol=0.0,
-                maxit=par['maxit'], ilu=pre, restart=30, x_is_zero=True,
+                maxit=par['maxit'], ilu=pre, restart=30, x_is_zero=not warm,
                 dinv='jacobi' if pre is None else None
                 )
         except _hip.NotConverged:
@@ -237,4 +259,14 @@ class Heat(object):
                 maxit=par['maxit'], check_every=par['check_every'], ilu=pre
                 )
         last_solve_info['heat'] = info
+        self._remember(lay, u.data, warm, start)
         return u
+
+    @staticmethod
+    def _remember(lay, x, warm, start):
+        if solver_parameters.get('start', 'previous') != 'previous':
+            return
+        if warm:
+            ops.copy(start, x)
+        else:
+            lay._dev['heat_start'] = _hip.clone(x)

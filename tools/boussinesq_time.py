@@ -1,0 +1,54 @@
+# -*- coding: utf-8 -*-
+'''BASELINE config 4 (Boussinesq box, coupled N-S + heat) in steady stepping:
+wall time per coupled time step after setup, Banach sweeps per step, where a
+sweep's time goes (heat assemble + solve / N-S step).
+  python tools/boussinesq_time.py [nx] [steps]'''
+from __future__ import print_function
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    nx = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    from flow_amd import fem, boussinesq, device, heat
+    import flow_amd.navier_stokes as navsto
+    mesh = fem.heater_box(nx, fitted=nx >= 12)
+    t0 = time.time()
+    stepper = boussinesq.FixedPointStepper(boussinesq.HeaterBox(mesh), 1.0e-2)
+    device.synchronize()
+    print('setup %.1f s' % (time.time() - t0))
+    tim = {'heat_init': 0.0, 'heat_solve': 0.0, 'ns': 0.0}
+    orig_init, orig_solve = heat.Heat.__init__, heat.Heat.solve_alpha_M_beta_F
+
+    def timed(name, fn):
+        def wrapper(*a, **kw):
+            device.synchronize()
+            t = time.time()
+            out = fn(*a, **kw)
+            device.synchronize()
+            tim[name] += time.time() - t
+            return out
+        return wrapper
+    heat.Heat.__init__ = timed('heat_init', orig_init)
+    heat.Heat.solve_alpha_M_beta_F = timed('heat_solve', orig_solve)
+    for k in range(steps):
+        for key in tim:
+            tim[key] = 0.0
+        device.synchronize()
+        t = time.time()
+        stepper.advance()
+        device.synchronize()
+        wall = time.time() - t
+        row = stepper.log[-1]
+        print('step %2d  dt %.3e  sweeps %s  wall %.1f ms  (heat assembly %.1f, '
+              'heat solve %.1f [%s])'
+              % (k + 1, row['dt'], row.get('sweeps'), 1e3 * wall,
+                 1e3 * tim['heat_init'], 1e3 * tim['heat_solve'],
+                 heat.last_solve_info.get('heat')))
+
+
+if __name__ == '__main__':
+    main()
