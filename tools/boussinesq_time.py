@@ -2,7 +2,7 @@
 '''BASELINE config 4 (Boussinesq box, coupled N-S + heat) in steady stepping:
 wall time per coupled time step after setup, Banach sweeps per step, where a
 sweep's time goes (heat assemble + solve / N-S step).
-  python tools/boussinesq_time.py [nx] [steps]'''
+  python tools/boussinesq_time.py [nx] [steps] [group.key=value ...]'''
 from __future__ import print_function
 import os
 import sys
@@ -15,6 +15,12 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     from flow_amd import fem, boussinesq, device, heat
     import flow_amd.navier_stokes as navsto
+    for kv in sys.argv[3:]:            # e.g. newton.linear_start=zero
+        key, val = kv.split('=')
+        grp, name = key.split('.')
+        old = navsto.solver_parameters[grp][name]
+        navsto.solver_parameters[grp][name] = \
+            val if isinstance(old, str) else type(old)(float(val))
     mesh = fem.heater_box(nx, fitted=nx >= 12)
     t0 = time.time()
     stepper = boussinesq.FixedPointStepper(boussinesq.HeaterBox(mesh), 1.0e-2)
@@ -34,9 +40,25 @@ def main():
         return wrapper
     heat.Heat.__init__ = timed('heat_init', orig_init)
     heat.Heat.solve_alpha_M_beta_F = timed('heat_solve', orig_solve)
+    flows = []
+    orig_flow = boussinesq.CoupledStep.flow
+
+    def flow(self):
+        device.synchronize()
+        t = time.time()
+        out = orig_flow(self)
+        device.synchronize()
+        i = navsto.last_step_info
+        flows.append((1e3 * (time.time() - t), len(i['newton_residuals']) - 1,
+                      sum(i['newton_linear_applications']),
+                      i['pressure'].iterations, i['correction'].iterations,
+                      i.get('newton_preconditioner')))
+        return out
+    boussinesq.CoupledStep.flow = flow
     for k in range(steps):
         for key in tim:
             tim[key] = 0.0
+        del flows[:]
         device.synchronize()
         t = time.time()
         stepper.advance()
@@ -45,9 +67,12 @@ def main():
         row = stepper.log[-1]
         print('step %2d  dt %.3e  sweeps %s  wall %.1f ms  (heat assembly %.1f, '
               'heat solve %.1f [%s])'
-              % (k + 1, row['dt'], row.get('sweeps'), 1e3 * wall,
+              % (k + 1, row['dt'], row.get('banach_steps'), 1e3 * wall,
                  1e3 * tim['heat_init'], 1e3 * tim['heat_solve'],
                  heat.last_solve_info.get('heat')))
+        print('         N-S steps (ms, Newton its, GMRES applications, pressure, '
+              'corrections, preconditioner): %s'
+              % ', '.join('(%.1f, %d, %d, %d, %d, %s)' % f for f in flows))
 
 
 if __name__ == '__main__':
