@@ -18,9 +18,10 @@ def main():
     for kv in sys.argv[3:]:            # e.g. newton.linear_start=zero
         key, val = kv.split('=')
         grp, name = key.split('.')
-        old = navsto.solver_parameters[grp][name]
-        navsto.solver_parameters[grp][name] = \
-            val if isinstance(old, str) else type(old)(float(val))
+        where = heat.solver_parameters if grp == 'heat' \
+            else navsto.solver_parameters[grp]
+        old = where[name]
+        where[name] = val if isinstance(old, str) else type(old)(float(val))
     mesh = fem.heater_box(nx, fitted=nx >= 12)
     t0 = time.time()
     stepper = boussinesq.FixedPointStepper(boussinesq.HeaterBox(mesh), 1.0e-2)
