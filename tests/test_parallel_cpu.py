@@ -110,6 +110,65 @@ def test_strips_too_thin_are_refused():
         parallel.Strips(mesh, 150).blocks(scalar_layout(mesh, 2))
 
 
+@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('degree,depth', [(1, 2), (2, 6)])
+def test_deep_ghost_ranges(world, degree, depth):
+    """The deep halos (round 4): ghost ranges `depth` coupling layers out -- two
+    for the pressure solve with one collective per iteration, six for the mass
+    solver's five products per collective.  Layer d + 1 holds every column of
+    the rows of layer d; the halo slots of the deep blocks exchange exactly
+    the ghost rows; k products on shrinking ranges reproduce the whole
+    matrix' k-th power on the owned rows."""
+    mesh = fem.karman_channel(72, 9)
+    lay = scalar_layout(mesh, degree)
+    st = parallel.Strips(mesh, world)
+    rowptr = lay.pattern('rowptr').astype(numpy.int64)
+    cols = lay.pattern('cols').astype(numpy.int64)
+    ranges = st.deep_ranges(lay, depth)
+    deep = st.deep_blocks(lay, depth)
+    n = lay.N
+    import scipy.sparse as sp
+    A = sp.csr_matrix((numpy.ones(len(cols)), cols, rowptr), shape=(n, n))
+    A = sp.diags(1.0 / numpy.asarray(A.sum(axis=1)).ravel()).dot(A).tocsr()
+    x = numpy.random.RandomState(0).standard_normal(n)
+    # the exchange buffer as the all-reduce leaves it: every rank's send slots
+    structs = [deep.struct(g) for g in range(world)]
+    buf = numpy.zeros(deep.nhalo)
+    for s in structs:
+        for side in (0, 1):
+            row, ln, slot = s.send_row[side], s.send_len[side], s.send_slot[side]
+            buf[slot:slot + ln] += x[row:row + ln]
+    want = x.copy()
+    for _ in range(depth - 1):
+        want = A.dot(want)
+    for g, s in enumerate(structs):
+        rng = ranges[g]
+        assert rng[0] == (s.r0, s.r1) and rng[depth] == (s.e0, s.e1)
+        for d in range(depth):
+            (lo, hi), (lo1, hi1) = rng[d], rng[d + 1]
+            assert lo1 <= lo and hi <= hi1
+            seg = cols[rowptr[lo]:rowptr[hi]]
+            assert lo1 <= seg.min() and seg.max() < hi1
+        # the rank's window: own rows + what the neighbours sent
+        win = numpy.full(n, numpy.nan)
+        win[s.r0:s.r1] = x[s.r0:s.r1]
+        for side in (0, 1):
+            row, ln, slot = s.recv_row[side], s.recv_len[side], s.recv_slot[side]
+            win[row:row + ln] = buf[slot:slot + ln]
+        assert numpy.array_equal(win[s.e0:s.e1], x[s.e0:s.e1])
+        # depth - 1 products, product j on the rows of layer depth - 1 - j
+        v = win
+        for j in range(depth - 1):
+            lo, hi = rng[depth - 1 - j]
+            nxt = numpy.full(n, numpy.nan)
+            nxt[lo:hi] = A[lo:hi].dot(numpy.nan_to_num(v, nan=1e300))
+            assert numpy.isfinite(nxt[lo:hi]).all() and \
+                abs(nxt[lo:hi]).max() < 1e100, 'a product read outside its layer'
+            v = nxt
+        assert numpy.allclose(v[s.r0:s.r1], want[s.r0:s.r1], rtol=1e-12,
+                              atol=1e-14)
+
+
 # -- the sharded CG loop under gloo ------------------------------------------------
 class NumpyShardCg(object):
     '''What flow_shard_cg_solve does on one rank, in numpy: ext-compact vectors,
