@@ -289,3 +289,134 @@ def test_sharded_cg_pattern_under_gloo(world, degree):
         _, e0, e1, r0, r1, x, _ = out[r]
         # the recurrences on the ghost rows reproduce the owners' values
         assert numpy.array_equal(x, full[e0:e1]), 'ghost rows = owners, bitwise'
+
+
+# -- the sharded defect-correction mass solver under gloo ---------------------------
+class NumpyShardMass(object):
+    '''What flow_shard_mass_solve does on one rank, in numpy (fp64 throughout:
+    the communication pattern is the subject, not the mixed precision): per
+    correction the scaled defect on the OWN rows, ONE all-reduce of [the norms
+    of the correction before | the deep halo of the defect], then the Chebyshev
+    polynomial's products on shrinking ghost ranges; the verdict on correction
+    k arrives with the collective of pass k + 1.'''
+
+    def __init__(self, M, ranges, s, comm, steps, lo, hi):
+        self.M, self.rng, self.s, self.comm = M, ranges, s, comm
+        self.steps, self.lo, self.hi = steps, lo, hi
+        d = M.diagonal()
+        import scipy.sparse as sp
+        self.A = sp.diags(1.0 / d).dot(M).tocsr()
+        self.dinv = 1.0 / d
+
+    def exchange(self, head, rho):
+        s, b = self.s, self.comm.buf.numpy()
+        count = 4 + s.nhalo
+        b[:4] = head
+        b[4:count] = 0.0
+        for side in (0, 1):
+            row, ln, slot = s.send_row[side], s.send_len[side], s.send_slot[side]
+            b[4 + slot:4 + slot + ln] = rho[row:row + ln]
+        assert self.comm._allreduce(None, count) == 0
+        for side in (0, 1):
+            row, ln, slot = s.recv_row[side], s.recv_len[side], s.recv_slot[side]
+            rho[row:row + ln] = b[4 + slot:4 + slot + ln]
+        return b[:4].copy()
+
+    def polynomial(self, rho0):
+        '''z = p(D^-1 M) rho0 on the own rows; rho0 valid on the deepest range,
+        product j on the rows of layer steps - 1 - j.'''
+        theta, delta = 0.5 * (self.hi + self.lo), 0.5 * (self.hi - self.lo)
+        sigma = theta / delta
+        rk = 1.0 / sigma
+        n = len(rho0)
+        rho = rho0.copy()
+        d = rho / theta
+        acc = d.copy()
+        for j in range(self.steps - 1):
+            lo, hi = self.rng[self.steps - 1 - j]
+            nxt = numpy.full(n, numpy.nan)
+            nxt[lo:hi] = rho[lo:hi] - self.A[lo:hi].dot(numpy.nan_to_num(
+                d, nan=1e300))
+            assert abs(nxt[lo:hi]).max() < 1e100, 'read outside the layer'
+            rn = 1.0 / (2.0 * sigma - rk)
+            dn = numpy.full(n, numpy.nan)
+            dn[lo:hi] = rn * rk * d[lo:hi] + 2.0 * rn / delta * nxt[lo:hi]
+            rk = rn
+            acc[lo:hi] = acc[lo:hi] + dn[lo:hi]
+            rho, d = nxt, dn
+        return acc
+
+    def solve(self, b, rtol, contraction, maxit=30):
+        s = self.s
+        n = self.M.shape[0]
+        x = numpy.zeros(n)
+        zz = xx = 0.0
+        for k in range(maxit + 1):
+            rho = numpy.full(n, numpy.nan)
+            rho[s.r0:s.r1] = self.dinv[s.r0:s.r1] * (
+                b[s.r0:s.r1] - self.M[s.r0:s.r1].dot(numpy.nan_to_num(x)))
+            head = self.exchange([zz, xx, 0.0, 0.0], rho)
+            # the verdict on correction k - 1 (its norms summed over the ranks)
+            if k > 0 and contraction * numpy.sqrt(head[0]) <= \
+                    rtol * numpy.sqrt(head[1]):
+                return x, k
+            z = self.polynomial(rho)
+            lo1, hi1 = self.rng[1]
+            # (x is advanced on the own rows and the first ghost layer: the
+            # next defect on the own rows reads it there)
+            x[lo1:hi1] += z[lo1:hi1]
+            zz = float(z[s.r0:s.r1].dot(z[s.r0:s.r1]))
+            xx = float(x[s.r0:s.r1].dot(x[s.r0:s.r1]))
+        raise AssertionError('no convergence')
+
+
+def _mass_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        parallel.enable(dist.group.WORLD, force=True)
+        comm = parallel.comm()
+        mesh = fem.karman_channel(72, 9)
+        S = H.oracle_space(mesh, 2)
+        M = orc.mass_matrix(S).tocsr()
+        lay = scalar_layout(mesh, 2)
+        steps = 6
+        st = parallel.strips(mesh)
+        rng = st.deep_ranges(lay, steps)[rank]
+        s = st.deep_blocks(lay, steps).struct(rank)
+        comm.ensure(4 + s.nhalo)
+        b = M.dot(numpy.random.RandomState(4).standard_normal(M.shape[0]))
+        from flow_amd.fem import mass as fmass
+        lo, hi = fmass.WATHEN[2]
+        bound = 1.5 * fmass.chebyshev_contraction(lo, hi, steps)
+        x, k = NumpyShardMass(M, rng, s, comm, steps, lo, hi).solve(
+            b, 1e-10, bound)
+        out[rank] = (k, s.r0, s.r1, x[s.r0:s.r1], comm.calls)
+    finally:
+        parallel.disable()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_mass_solver_pattern_under_gloo(world):
+    '''k corrections cost k + 1 collectives (the last one carries the verdict);
+    every rank takes the same number; the own rows assemble the direct
+    solution.'''
+    mesh = fem.karman_channel(72, 9)
+    M = orc.mass_matrix(H.oracle_space(mesh, 2)).tocsr()
+    xref = numpy.random.RandomState(4).standard_normal(M.shape[0])
+    manager = mp.get_context('spawn').Manager()
+    out = manager.dict()
+    mp.spawn(_mass_worker, args=(world, _free_port(), out), nprocs=world,
+             join=True)
+    ks = {out[r][0] for r in range(world)}
+    assert len(ks) == 1
+    k = ks.pop()
+    assert 3 <= k <= 8
+    full = numpy.full(M.shape[0], numpy.nan)
+    for r in range(world):
+        _k, r0, r1, x, calls = out[r]
+        full[r0:r1] = x
+        assert calls == k + 1, (calls, k)
+    assert numpy.linalg.norm(full - xref) < 1e-9 * numpy.linalg.norm(xref)
