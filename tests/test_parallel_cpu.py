@@ -420,3 +420,198 @@ def test_sharded_mass_solver_pattern_under_gloo(world):
         full[r0:r1] = x
         assert calls == k + 1, (calls, k)
     assert numpy.linalg.norm(full - xref) < 1e-9 * numpy.linalg.norm(xref)
+
+
+# -- the sharded two-level CG with ONE collective per iteration, under gloo --------
+def _two_level(A, agg=6, omega=0.6):
+    '''A two-level cycle in the product's algebra (flow_mg): Ah = A w D^-1,
+    C = R (I - Ah), Ps = (I - w D^-1 A) P;  B r = Ps x' + w D^-1 (2 r - Ah r),
+    x' = (P^T A P)^-1 C r.  P: piecewise constant over `agg` consecutive rows
+    (any P exercises the pattern).'''
+    import scipy.sparse as sp
+    n = A.shape[0]
+    nc = (n + agg - 1) // agg
+    P = sp.csr_matrix((numpy.ones(n), (numpy.arange(n), numpy.arange(n) // agg)),
+                      shape=(n, nc))
+    wd = omega / A.diagonal()
+    Ah = A.dot(sp.diags(wd)).tocsr()
+    Ps = (P - sp.diags(wd).dot(A).dot(P)).tocsr()
+    C = (P.T - P.T.dot(Ah)).tocsr()
+    coarse = spla.splu(P.T.dot(A).dot(P).tocsc())
+    return dict(wd=wd, Ah=Ah, Ps=Ps, C=C, coarse=coarse, nc=nc)
+
+
+def _apply_two_level(T, r):
+    x1 = T['coarse'].solve(T['C'].dot(r))
+    return T['Ps'].dot(x1) + T['wd'] * (2.0 * r - T['Ah'].dot(r))
+
+
+class NumpyShardMgCg(object):
+    '''What flow_shard_mgcg_solve does on one rank in its one-collective form
+    (flow_mg_shard.z_lo / z_hi), in numpy on GLOBAL-length vectors with NaN
+    outside what the rank may know: ghost ranges two layers deep; r current
+    two layers out through the halo of w that rides with the dots; z formed on
+    the owned rows and the FIRST ghost layer; the coarse residual carried by
+    CG's own recurrences, its collective part C[:, own] w_own summed in the
+    same all-reduce.'''
+
+    def __init__(self, A, T, rng, s, comm):
+        self.A, self.T, self.rng, self.s, self.comm = A, T, rng, s, comm
+        self.nc = T['nc']
+
+    def exchange(self, head, w, coarse_part):
+        s, b = self.s, self.comm.buf.numpy()
+        off = 4 + s.nhalo
+        count = off + self.nc
+        b[:4] = head
+        b[4:off] = 0.0
+        for side in (0, 1):
+            row, ln, slot = s.send_row[side], s.send_len[side], s.send_slot[side]
+            b[4 + slot:4 + slot + ln] = w[row:row + ln]
+        b[off:count] = coarse_part
+        assert self.comm._allreduce(None, count) == 0
+        for side in (0, 1):
+            row, ln, slot = s.recv_row[side], s.recv_len[side], s.recv_slot[side]
+            w[row:row + ln] = b[4 + slot:4 + slot + ln]
+        return b[:4].copy(), b[off:count].copy()
+
+    def solve(self, b, rtol, maxit):
+        s, T, A = self.s, self.T, self.A
+        n = A.shape[0]
+        r0, r1 = s.r0, s.r1
+        z0, z1 = self.rng[1]                    # owned + first ghost layer
+        e0, e1 = s.e0, s.e1                     # two layers out
+        own = slice(r0, r1)
+        known = numpy.zeros(n, dtype=bool)
+        known[e0:e1] = True
+
+        def form_z(r, rc):
+            # the up-sweep on [z0, z1): needs r two layers out
+            xc = T['coarse'].solve(rc)
+            rr = numpy.where(known, r, 1e300)
+            z = numpy.zeros(n)
+            z[z0:z1] = T['Ps'][z0:z1].dot(xc) + T['wd'][z0:z1] * (
+                2.0 * r[z0:z1] - T['Ah'][z0:z1].dot(rr))
+            assert abs(z[z0:z1]).max() < 1e100, 'z read r outside two layers'
+            return z
+
+        def A_own(z):
+            zz = numpy.zeros(n) + 1e300
+            zz[z0:z1] = z[z0:z1]
+            w = numpy.zeros(n)
+            w[own] = A[own].dot(zz)
+            assert abs(w[own]).max() < 1e100, 'A z read z outside one layer'
+            return w
+
+        zero = numpy.zeros(self.nc)
+        # start (x = 0): r = b on the own rows, its halo; the coarse residual
+        # and |B b| need collectives of their own -- start-up, not the loop
+        r = numpy.zeros(n)
+        r[own] = b[own]
+        _h, _c = self.exchange(numpy.zeros(4), r, zero)
+        _h, rc_r = self.exchange(numpy.zeros(4), numpy.zeros(n),
+                                 T['C'][:, own].dot(r[own]))
+        z = form_z(r, rc_r)
+        head, _c = self.exchange([0.0, 0.0, 0.0, z[own].dot(z[own])],
+                                 numpy.zeros(n), zero)
+        target2 = rtol**2 * head[3]
+        x = numpy.zeros(n)
+        p = numpy.zeros(n)
+        sv = numpy.zeros(n)
+        rc_s = numpy.zeros(self.nc)
+        w = A_own(z)
+        head, rc_w = self.exchange(
+            [r[own].dot(z[own]), z[own].dot(w[own]), z[own].dot(z[own]), 0.0],
+            w, T['C'][:, own].dot(w[own]))
+        gamma, alpha = head[0], head[0] / head[1]
+        beta = 0.0
+        it = 0
+        while head[2] > target2 and it < maxit:
+            p = z + beta * p
+            sv = w + beta * sv
+            x += alpha * p
+            r[e0:e1] -= alpha * sv[e0:e1]
+            rc_s = rc_w + beta * rc_s
+            rc_r = rc_r - alpha * rc_s
+            z = form_z(r, rc_r)
+            w = A_own(z)
+            head, rc_w = self.exchange(
+                [r[own].dot(z[own]), z[own].dot(w[own]), z[own].dot(z[own]),
+                 0.0], w, T['C'][:, own].dot(w[own]))
+            beta = head[0] / gamma
+            alpha = head[0] / (head[1] - beta * head[0] / alpha)
+            gamma = head[0]
+            it += 1
+        return x, it
+
+
+def _reference_two_level_cg(A, T, b, rtol, maxit):
+    '''The same recurrences on the whole system (one process).'''
+    x = numpy.zeros_like(b)
+    r = b.copy()
+    z = _apply_two_level(T, r)
+    zb = z.copy()
+    target2 = rtol**2 * zb.dot(zb)
+    w = A.dot(z)
+    g, d = r.dot(z), z.dot(w)
+    gamma, alpha, beta = g, g / d, 0.0
+    p = numpy.zeros_like(b)
+    sv = numpy.zeros_like(b)
+    it = 0
+    while z.dot(z) > target2 and it < maxit:
+        p = z + beta * p
+        sv = w + beta * sv
+        x += alpha * p
+        r -= alpha * sv
+        z = _apply_two_level(T, r)
+        w = A.dot(z)
+        g, d = r.dot(z), z.dot(w)
+        beta = g / gamma
+        alpha = g / (d - beta * g / alpha)
+        gamma = g
+        it += 1
+    return x, it
+
+
+def _mgcg_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        parallel.enable(dist.group.WORLD, force=True)
+        comm = parallel.comm()
+        mesh, A, b = _system(1)
+        lay = scalar_layout(mesh, 1)
+        T = _two_level(A)
+        st = parallel.strips(mesh)
+        rng = st.deep_ranges(lay, 2)[rank]
+        s = st.deep_blocks(lay, 2).struct(rank)
+        comm.ensure(4 + s.nhalo + T['nc'])
+        x, its = NumpyShardMgCg(A, T, rng, s, comm).solve(b, 1e-10, 500)
+        out[rank] = (its, s.r0, s.r1, rng[1], x, comm.calls)
+    finally:
+        parallel.disable()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_one_collective_two_level_cg_pattern_under_gloo(world):
+    '''The one-collective form of the sharded V-cycle CG as an algorithm: the
+    same iterates as the whole-system recurrences (same count, same solution),
+    ONE collective per iteration + the start-up ones, x valid on the owned rows
+    and the first ghost layer.'''
+    _mesh_, A, b = _system(1)
+    T = _two_level(A)
+    xref, its_ref = _reference_two_level_cg(A, T, b, 1e-10, 500)
+    direct = spla.splu(A.tocsc()).solve(b)
+    assert numpy.linalg.norm(xref - direct) < 1e-8 * numpy.linalg.norm(direct)
+    manager = mp.get_context('spawn').Manager()
+    out = manager.dict()
+    mp.spawn(_mgcg_worker, args=(world, _free_port(), out), nprocs=world,
+             join=True)
+    for r in range(world):
+        its, r0, r1, (z0, z1), x, calls = out[r]
+        assert its == its_ref, (its, its_ref)
+        assert calls == its + 4, (calls, its)
+        # owned rows and the first ghost layer carry the solution
+        assert numpy.allclose(x[z0:z1], xref[z0:z1], rtol=1e-9, atol=1e-12)
