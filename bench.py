@@ -291,6 +291,37 @@ def oracle_step_timing(target_dofs=None):
     return out, fit
 
 
+def launch_ranks(n):
+    '''`python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port P bench.py <the same arguments>` as
+    a child process; its stdout (rank 0's JSON line) is passed through.
+    Returns the child's exit code.'''
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    last = None
+    for raw in proc.stdout:
+        line = raw.decode('utf-8', 'replace').rstrip('\n')
+        if line.startswith('{') and '"metric"' in line:
+            last = line
+        else:
+            # (anything else a rank wrote to stdout: not this program's line)
+            sys.stderr.write(line + '\n')
+    code = proc.wait()
+    if last is not None:
+        print(last)
+        sys.stdout.flush()
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -364,12 +395,15 @@ def main():
         args.initial = 'stokes' if args.velocity_degree == 2 else 'profile'
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    if world == 1 and args.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` as written: start the N ranks as a CHILD
+        # process (never exec: nothing in this process has touched torch or
+        # the GPU yet, and nothing will), relay its one JSON line and its exit
+        # code.  The driver's own launch line (python -m torch.distributed.run
+        # ... bench.py --gpus N) sets RANK / WORLD_SIZE and comes in below.
+        sys.exit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(
-                'launch N > 1 with: python -m torch.distributed.run --nnodes=1 '
-                '--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N'
-                )
+        raise SystemExit('--gpus %d, but WORLD_SIZE = %d' % (args.gpus, world))
     import numpy
     import torch
     import torch.distributed as dist

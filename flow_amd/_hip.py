@@ -271,10 +271,15 @@ SYMBOLS = {
     'flow_vmul': [_I, _D, _VP, _VP, _VP, _VP],
     'flow_fill': [_I, _D, _VP, _VP],
     'flow_lincomb': [_I, _I, _P(_D), _P(_VP), _VP, _VP],
+    'flow_fingerprint': [_I, _P(_VP), _P(_I), _VP, _VP, _VP],
+    'flow_read_doubles': [_VP, _I, _P(_D), _VP],
     'flow_extrapolation_weights': [_I, _P(_D), _D, _I, _I, _P(_D)],
     'flow_scale_rows': [_I, _VP, _VP, _VP, _VP],
     'flow_cg_solve': [_P(Operator), _VP, _P(CoarseS), _P(MgS), _VP, _VP, _D, _D,
                       _I, _I, _I, _VP, ctypes.c_size_t, _P(_I), _P(_D), _VP],
+    'flow_cg_solve_guarded': [_P(Operator), _VP, _P(CoarseS), _P(MgS), _VP, _VP,
+                              _VP, _D, _D, _I, _I, _I, _VP, ctypes.c_size_t,
+                              _P(_I), _P(_D), _P(_I), _VP],
     'flow_mg_apply': [_P(MgS), _I, _VP, _VP, _VP],
     'flow_two_level_apply': [_P(CoarseS), _VP, _VP, _VP, _VP, _VP],
     'flow_bicgstab_solve': [_P(Operator), _VP, _P(IluS), _VP, _VP, _D, _D, _I,
@@ -357,7 +362,7 @@ class NotConverged(RuntimeError):
 
 # flow_abi_version() of the library these bindings describe (the structs above
 # and SYMBOLS): a stale libflow_hip.so is refused at load time
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 
 def load_library():

@@ -538,8 +538,23 @@ __global__ __launch_bounds__(kScalarBlock) void cg_scalar_kernel(
       // the stopping test of the whole solve, in the PRECONDITIONED norm like
       // PETSc's KSPCG (its default, which the reference's `solve` runs with):
       // |B r| <= max(rtol |B b|, atol), z = B r, S[kB2] = |B b|^2
-      store_scalar(S + kTarget2, fmax(rtol2 * load_scalar(S + kB2), atol2));
+      const double b2 = load_scalar(S + kB2);
+      store_scalar(S + kTarget2, fmax(rtol2 * b2, atol2));
       store_scalar(S + kIter, 0.0);
+      // a guarded start (first == 2: flow_cg_solve_guarded) that leaves a
+      // LARGER preconditioned residual than the zero start would, |B r0| >
+      // |B b|, is rejected: S[kDone] = 5 turns everything behind this kernel
+      // into no-ops -- x still holds the start --, the host swaps in the
+      // fallback.  (What a far start costs these recurrences is attainable
+      // accuracy: the recurrence residual drifts from the true one in
+      // proportion to the largest residual seen, and from zero -- the
+      // reference's start -- that is |b|.)
+      if (first == 2 && rr > b2) {
+        store_scalar(S + kConvIt, 0.0);
+        store_scalar(S + kRes2, rr);
+        store_scalar(S + kDone, 5.0);
+        return;
+      }
     } else {
       const double g_old = load_scalar(S + kGamma);
       const double a_old = load_scalar(S + kAlpha);
@@ -972,7 +987,10 @@ static int cg(const flow_operator* A, const double* dinv,
               const flow_coarse* C, const flow_mg* M, const double* b,
               double* x, double rtol, double atol, int maxit, int check_every,
               int first_check, double* work, int* iters_host,
-              double* resid_host, hipStream_t st) {
+              double* resid_host, hipStream_t st, bool* rejected = nullptr) {
+  // rejected != nullptr: the start vector is guarded (cg_scalar_kernel); when
+  // it is rejected, *rejected = true, x is the start still, FLOW_OK
+  if (rejected) *rejected = false;
   const int N = op_size(A);
   const int nd = dot_parts(A);
   double* partial = work;
@@ -1020,8 +1038,8 @@ static int cg(const flow_operator* A, const double* dinv,
   if ((rc = apply(A, z, w, st, dpart))) return rc;
   if ((rc = dots(N, 3, r, z, z, w, z, z, partial, &np, st))) return rc;
   hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kScalarBlock), 0, st, np,
-                     nd, 1, partial, partial + 2 * kRedBlocks, dpart, rtol2,
-                     atol2, S);
+                     nd, rejected ? 2 : 1, partial, partial + 2 * kRedBlocks,
+                     dpart, rtol2, atol2, S);
   FLOW_CHECK_LAUNCH();
 
   // Iterations are enqueued in batches; the device decides which iterate
@@ -1069,6 +1087,12 @@ static int cg(const flow_operator* A, const double* dinv,
     }
     if (state[kDone] == 1.0) {
       *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = sqrt(res2);
+      return FLOW_OK;
+    }
+    if (state[kDone] == 5.0 && rejected) {
+      *rejected = true;
+      *iters_host = 0;
       *resid_host = sqrt(res2);
       return FLOW_OK;
     }
@@ -1282,7 +1306,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 26; }
+extern "C" int flow_abi_version(void) { return 27; }
 
 namespace flow {
 unsigned long long g_launches = 0;
@@ -1689,6 +1713,107 @@ extern "C" int flow_lincomb(int n, int nterms, const double* coef_host,
     case 5: hipLaunchKernelGGL(lincomb_kernel<5>, grid, blk, 0, st, n, t, y); break;
     default: hipLaunchKernelGGL(lincomb_kernel<6>, grid, blk, 0, st, n, t, y); break;
   }
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Fingerprints of fields: which trajectory does a call continue?  The start
+// vectors of a time loop (flow_amd/navier_stokes/start_vectors.py) belong to
+// the trajectory whose last step RETURNED the fields this call is handed; the
+// caller copies them (`u0.assign(u1)`, tests/test_karman_vortex_street.py:
+// 241-242), so identity is a matter of values.  64-bit sum of the entries' bit
+// patterns times odd multipliers of their index, modulo 2^64: integer
+// arithmetic, so the order of summation does not matter and equal fields give
+// equal fingerprints bit for bit.  Fields beyond 2^22 entries are sampled by
+// whole 64-byte lines (every k-th), at most 32 MB read per field.
+// ---------------------------------------------------------------------------
+constexpr int kFingerprintFields = 2;
+struct FingerprintArgs {
+  const double* x[kFingerprintFields];
+  int n[kFingerprintFields];
+  int line_stride[kFingerprintFields];
+  int sampled[kFingerprintFields];     // entries visited
+};
+
+__global__ __launch_bounds__(kBlock) void fingerprint_kernel(
+    FingerprintArgs a, unsigned long long* __restrict__ part) {
+  __shared__ unsigned long long wave_part[kBlock / 64];
+  const int f = blockIdx.y;
+  const double* __restrict__ x = a.x[f];
+  const int n = a.n[f], k = a.line_stride[f], m = a.sampled[f];
+  unsigned long long h = 0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < m;
+       e += gridDim.x * blockDim.x) {
+    const long long idx = static_cast<long long>(e >> 3) * k * 8 + (e & 7);
+    if (idx < n) {
+      const unsigned long long bits =
+          static_cast<unsigned long long>(__double_as_longlong(x[idx]));
+      h += (bits ^ (bits >> 29)) *
+           ((2ull * static_cast<unsigned long long>(idx) + 1ull) *
+            0x9E3779B97F4A7C15ull);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off, 64);
+  if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    h = 0;
+    for (int w = 0; w < kBlock / 64; ++w) h += wave_part[w];
+    part[static_cast<size_t>(f) * kRedBlocks + blockIdx.x] = h;
+  }
+}
+
+// one block per field: slots[2f] = low 32 bits, slots[2f+1] = high 32 bits of
+// the sum of the partials, as doubles (exact integers: they travel through the
+// double-typed mailbox unharmed)
+__global__ __launch_bounds__(kBlock) void fingerprint_finish_kernel(
+    int nparts, const unsigned long long* __restrict__ part,
+    double* __restrict__ slots) {
+  __shared__ unsigned long long wave_part[kBlock / 64];
+  const int f = blockIdx.x;
+  unsigned long long h = 0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock)
+    h += part[static_cast<size_t>(f) * kRedBlocks + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off, 64);
+  if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    h = 0;
+    for (int w = 0; w < kBlock / 64; ++w) h += wave_part[w];
+    store_scalar(slots + 2 * f, static_cast<double>(h & 0xffffffffull));
+    store_scalar(slots + 2 * f + 1, static_cast<double>(h >> 32));
+  }
+}
+
+extern "C" int flow_fingerprint(int nfields, const double* const* x_host,
+                                const int* n_host, double* work, double* slots,
+                                void* stream) {
+  FLOW_REQUIRE(nfields >= 1 && nfields <= kFingerprintFields && x_host &&
+                   n_host && work && slots,
+               "fingerprint arguments (1 or 2 fields)");
+  FingerprintArgs a = {};
+  int most = 0;
+  for (int f = 0; f < nfields; ++f) {
+    FLOW_REQUIRE(x_host[f] != nullptr && n_host[f] > 0, "fingerprint field");
+    const long long lines = (static_cast<long long>(n_host[f]) + 7) / 8;
+    const long long cap = (1ll << 22) / 8;
+    const long long k = (lines + cap - 1) / cap;
+    a.x[f] = x_host[f];
+    a.n[f] = n_host[f];
+    a.line_stride[f] = static_cast<int>(k);
+    a.sampled[f] = static_cast<int>(((lines + k - 1) / k) * 8);
+    if (a.sampled[f] > most) most = a.sampled[f];
+  }
+  hipStream_t st = as_stream(stream);
+  const int g = grid_for(most, kBlock * 4, kRedBlocks);
+  unsigned long long* part = reinterpret_cast<unsigned long long*>(work);
+  hipLaunchKernelGGL(fingerprint_kernel, dim3(g, nfields), dim3(kBlock), 0, st,
+                     a, part);
+  hipLaunchKernelGGL(fingerprint_finish_kernel, dim3(nfields), dim3(kBlock), 0,
+                     st, g, part, slots);
   FLOW_CHECK_LAUNCH();
   return FLOW_OK;
 }
@@ -2390,6 +2515,64 @@ extern "C" int flow_cg_solve(const flow_operator* A, const double* dinv,
             first_check, work, iters_host, resid_host, as_stream(stream));
 }
 
+// The same solve from a GUARDED start vector: a start that leaves a larger
+// preconditioned residual than x = 0 would (|B(b - A x)| > |B b|, decided on
+// the device from the numbers the first iteration forms anyway) is dropped
+// for `x_fallback` (guarded as well; NULL: none), and that for zero -- the
+// reference's start (a fresh Function, pressure_correction.py:313).
+extern "C" int flow_cg_solve_guarded(
+    const flow_operator* A, const double* dinv, const flow_coarse* coarse,
+    const flow_mg* mg, const double* b, double* x, const double* x_fallback,
+    double rtol, double atol, int maxit, int check_every, int first_check,
+    double* work, size_t work_len, int* iters_host, double* resid_host,
+    int* starts_dropped_host, void* stream) {
+  FLOW_REQUIRE(starts_dropped_host != nullptr, "starts_dropped_host is NULL");
+  *starts_dropped_host = 0;
+  // (argument checks: those of the unguarded solve, which does no work before
+  // they have passed)
+  int rc = check_solver_args(A, b, x, rtol, atol, maxit, check_every,
+                             first_check, work, work_len, 5, iters_host,
+                             resid_host);
+  if (rc) return rc;
+  FLOW_REQUIRE(A->kind != 3, "CG: assembled (symmetric) operators only");
+  if (coarse) {
+    FLOW_REQUIRE(dinv != nullptr, "two-level preconditioner needs dinv");
+    FLOW_REQUIRE(A->kind == 0, "two-level preconditioner: scalar operators");
+    if ((rc = check_coarse(coarse, A->n))) return rc;
+  }
+  if (mg) {
+    FLOW_REQUIRE(coarse == nullptr, "multigrid and two-level are exclusive");
+    FLOW_REQUIRE(dinv != nullptr && A->kind == 0,
+                 "multigrid preconditioner: scalar operators with dinv");
+    if ((rc = check_mg(mg, A->n))) return rc;
+    FLOW_REQUIRE(mg->nlevels >= 2, "multigrid: at least two levels");
+  }
+  FLOW_REQUIRE(work_len >= cg_work_len(A, coarse, mg),
+               "solver workspace too small");
+  FLOW_REQUIRE(reinterpret_cast<uintptr_t>(work) % 16 == 0,
+               "solver workspace must be 16-byte aligned");
+  FLOW_REQUIRE(x_fallback != x, "the fallback start must not alias x");
+  hipStream_t st = as_stream(stream);
+  const int N = op_size(A);
+  bool rejected = false;
+  rc = cg(A, dinv, coarse, mg, b, x, rtol, atol, maxit, check_every,
+          first_check, work, iters_host, resid_host, st, &rejected);
+  if (rc || !rejected) return rc;
+  *starts_dropped_host = 1;
+  if (x_fallback) {
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(N)), dim3(kBlock), 0, st, N,
+                       1.0, x_fallback, 0.0, x);
+    FLOW_CHECK_LAUNCH();
+    rc = cg(A, dinv, coarse, mg, b, x, rtol, atol, maxit, check_every, 0, work,
+            iters_host, resid_host, st, &rejected);
+    if (rc || !rejected) return rc;
+    *starts_dropped_host = 2;
+  }
+  if ((rc = fill(N, 0.0, x, st))) return rc;
+  return cg(A, dinv, coarse, mg, b, x, rtol, atol, maxit, check_every, 0, work,
+            iters_host, resid_host, st);
+}
+
 // z = V-cycle(r): one application of the multigrid preconditioner (tests, and
 // callers that drive their own Krylov loop)
 extern "C" int flow_mg_apply(const flow_mg* mg, int n, const double* r,
@@ -2642,6 +2825,17 @@ static int read_values(const double* dev, int n, double* host, hipStream_t st) {
   for (int i = 0; i < n; ++i) host[i] = static_cast<volatile double*>(mailbox)[i];
   return FLOW_OK;
 }
+
+}  // namespace flow
+// n <= 64 doubles of device memory -> the host, in stream order (one
+// synchronisation through the calling thread's mailbox)
+extern "C" int flow_read_doubles(const double* dev, int n, double* host,
+                                 void* stream) {
+  FLOW_REQUIRE(dev && host && n >= 1 && n <= flow::kMailbox,
+               "read_doubles arguments (1..64 values)");
+  return flow::read_values(dev, n, host, flow::as_stream(stream));
+}
+namespace flow {
 
 // buf[k] = (k == rank) ? max(v[0..nv)) : 0, k < world
 __global__ void shard_rank_slot_kernel(int world, int rank, int nv,

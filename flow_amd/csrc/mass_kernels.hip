@@ -284,7 +284,21 @@ __global__ __launch_bounds__(kMassScalarBlock) void mass_scalar_kernel(
   if (nan || contraction2 * zz <= fmax(rtol2 * xx, atol2)) {
     store_scalar(S + kConvIt, k);
     store_scalar(S + kDone, nan ? 2.0 : 1.0);
+  } else {
+    // The stopping test rests on the A-PRIORI contraction |I - B M| (spectral
+    // bounds of the scaled element matrix): watch what the iteration actually
+    // does.  z_{k+1} = (I - B M) z_k, so |z_{k+1}| > contraction |z_k| --
+    // above the floor fp64 leaves in the defect -- says the bound does not hold
+    // for this matrix (not the mass matrix of straight P1 / P2 triangles?):
+    // S[kDone] = 3, the caller falls back to Jacobi-CG.
+    const double prev = load_scalar(S + kGamma);
+    if (k > 1.0 && zz > contraction2 * prev && zz > 1.0e-26 * xx) {
+      store_scalar(S + kConvIt, k);
+      store_scalar(S + kTmp, sqrt(zz / prev));
+      store_scalar(S + kDone, 3.0);
+    }
   }
+  store_scalar(S + kGamma, zz);
   store_scalar(S + kIter, k);
   store_scalar(S + kRes2, zz);
   store_scalar(S + kB2, xx);
@@ -526,6 +540,14 @@ static int mass_solve(const flow_mass* M, const double* b, double* x,
       *resid_host = sqrt(zz);
       return FLOW_OK;
     }
+    if (state[kDone] == 3.0) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = sqrt(zz);
+      set_error("mass solve: correction %d contracted by %.3f, the vouched "
+                "bound is %.3f (not the mass matrix of straight P1/P2 "
+                "triangles?)", *iters_host, state[kTmp], M->contraction);
+      return FLOW_NOT_CONVERGED;
+    }
     if (launched >= maxit) {
       *iters_host = launched;
       *resid_host = sqrt(zz);
@@ -631,7 +653,17 @@ __global__ void shard_mass_unpack_kernel(flow_rows R, int ncomp, int first,
   if (nan || contraction2 * zz <= fmax(rtol2 * xx, atol2)) {
     store_scalar(S + kConvIt, static_cast<double>(applied));
     store_scalar(S + kDone, nan ? 2.0 : 1.0);
+  } else {
+    // (the run-time watch on the a-priori contraction: mass_scalar_kernel;
+    // the sums are the same on every rank, so is the verdict)
+    const double prev = load_scalar(S + kGamma);
+    if (applied > 1 && zz > contraction2 * prev && zz > 1.0e-26 * xx) {
+      store_scalar(S + kConvIt, static_cast<double>(applied));
+      store_scalar(S + kTmp, sqrt(zz / prev));
+      store_scalar(S + kDone, 3.0);
+    }
   }
+  store_scalar(S + kGamma, zz);
   store_scalar(S + kIter, static_cast<double>(applied));
   store_scalar(S + kRes2, zz);
   store_scalar(S + kB2, xx);
@@ -727,6 +759,14 @@ static int shard_mass_solve(const flow_comm* C, const flow_rows* R,
       *iters_host = static_cast<int>(state[kConvIt]);
       *resid_host = sqrt(zz);
       return FLOW_OK;
+    }
+    if (state[kDone] == 3.0) {
+      *iters_host = static_cast<int>(state[kConvIt]);
+      *resid_host = sqrt(zz);
+      set_error("sharded mass solve: correction %d contracted by %.3f, the "
+                "vouched bound is %.3f", *iters_host, state[kTmp],
+                M->contraction);
+      return FLOW_NOT_CONVERGED;
     }
     if (k > maxit) {
       *iters_host = maxit;

@@ -52,6 +52,11 @@ class MassSolver(object):
         self.dinv = dinv
         self.ncomp = 2 if A.kind == 4 else 1
         n, nnz = lay.N, lay.nnz
+        if lay.degree not in WATHEN:
+            raise ValueError(
+                'MassSolver: no spectral bounds for Lagrange degree %r on '
+                'triangles (known: %s); use the Jacobi-CG (ops.krylov_solve)'
+                % (lay.degree, sorted(WATHEN)))
         lo, hi = WATHEN[lay.degree]
         lo, hi = _PAD[0] * lo, _PAD[1] * hi
         # (readable three halves past nnz: quads of nonzeros per lane)
@@ -107,11 +112,43 @@ class MassSolver(object):
 
     @classmethod
     def cached(cls, A, dinv, **kw):
-        key = ('mass_solver', tuple(sorted(kw.items())))
+        # (the fp16 copy is made from A.vals as they are now: a matrix whose
+        # values are replaced or rewritten in place gets a new solver)
+        key = ('mass_solver', tuple(sorted(kw.items())), A.vals.data_ptr(),
+               getattr(A.vals, '_version', 0))
         held = A.__dict__.setdefault('_mass_solvers', {})
+        for old in [k for k in held if k[:2] == key[:2] and k != key]:
+            del held[old]
         if key not in held:
             held[key] = cls(A, dinv, **kw)
         return held[key]
+
+    # The stopping test rests on an a-priori contraction; the device watches
+    # the observed one (mass_scalar_kernel) and reports a violation -- or a
+    # NaN, or maxit -- as non-convergence.  guard: fall back to the Jacobi-CG
+    # (flow_cg_solve: PETSc's test on the preconditioned residual) with a
+    # message instead of failing the caller's step.
+    # (Running into the caller's `maxit` stays an error like the Krylov
+    # solvers', and dolfin's 'error_on_nonconvergence'.)
+    guard = True
+
+    def _bound_failed(self, err):
+        msg = str(err)
+        return self.guard and ('contracted by' in msg or 'broke down' in msg)
+
+    def _fallback(self, err, b, x, rtol, atol):
+        from ..message import info
+        info('mass solve: %s -- falling back to Jacobi-CG' % err)
+        self.fallbacks = getattr(self, 'fallbacks', 0) + 1
+        if self.ncomp == 2:
+            # (the identity-row form needs the boundary values in x on the
+            # masked rows: they are what b carries there)
+            mask = self.A.rowmask == 0
+            x[mask] = b[mask]
+        sol = ops.krylov_solve('cg', self.A, b, x, rtol=rtol, atol=atol,
+                               maxit=10000, dinv=self.dinv, check_every=5)
+        sol.method = 'defect correction -> ' + sol.method
+        return sol
 
     def solve_increment(self, g, xbase, x, rtol, atol=0.0, maxit=50, tag=None,
                         first_check=0, delta0=None):
@@ -125,14 +162,26 @@ class MassSolver(object):
             first_check = self.history[tag]
         its = ctypes.c_int(0)
         res = ctypes.c_double(0.0)
-        _hip.check(_hip.lib().flow_mass_solve_increment(
-            ctypes.byref(self.struct), _hip.f64(g, n, 'g'),
-            _hip.f64(xbase, n, 'xbase'),
-            _hip.f64(delta0, n, 'delta0') if delta0 is not None else None,
-            _hip.f64(x, n, 'x'),
-            float(rtol), float(atol), int(maxit), int(first_check),
-            _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
-            _hip.stream()))
+        base = _hip.clone(xbase) if x.data_ptr() == xbase.data_ptr() \
+            and self.guard else xbase
+        try:
+            _hip.check(_hip.lib().flow_mass_solve_increment(
+                ctypes.byref(self.struct), _hip.f64(g, n, 'g'),
+                _hip.f64(xbase, n, 'xbase'),
+                _hip.f64(delta0, n, 'delta0') if delta0 is not None else None,
+                _hip.f64(x, n, 'x'),
+                float(rtol), float(atol), int(maxit), int(first_check),
+                _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
+                _hip.stream()))
+        except _hip.NotConverged as err:
+            if not self._bound_failed(err):
+                raise
+            # M increment = g by Jacobi-CG from zero, x = xbase + increment
+            delta = _hip.fill(device.empty(n), 0.0)
+            sol = self._fallback(err, g, delta, rtol, atol)
+            ops.copy(x, base)
+            ops.axpby(1.0, delta, 1.0, x)
+            return sol
         if tag is not None:
             self.history[tag] = its.value
         return ops.SolveInfo(its.value, res.value,
@@ -150,11 +199,21 @@ class MassSolver(object):
             first_check = self.history[tag]
         its = ctypes.c_int(0)
         res = ctypes.c_double(0.0)
-        _hip.check(_hip.lib().flow_mass_solve(
-            ctypes.byref(self.struct), _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'),
-            float(rtol), float(atol), int(maxit), int(first_check),
-            _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
-            _hip.stream()))
+        try:
+            _hip.check(_hip.lib().flow_mass_solve(
+                ctypes.byref(self.struct), _hip.f64(b, n, 'b'),
+                _hip.f64(x, n, 'x'),
+                float(rtol), float(atol), int(maxit), int(first_check),
+                _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
+                _hip.stream()))
+        except _hip.NotConverged as err:
+            if not self._bound_failed(err):
+                raise
+            # (x holds the last iterate: a start vector like any other -- the
+            # CG below only ever moves it on the free rows)
+            if not bool(torch.isfinite(x).all()):
+                _hip.fill(x, 0.0)
+            return self._fallback(err, b, x, rtol, atol)
         if tag is not None:
             self.history[tag] = its.value
         return ops.SolveInfo(its.value, res.value,

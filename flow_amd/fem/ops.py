@@ -511,7 +511,7 @@ class SolveInfo(object):
 def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
                  check_every=None, coarse=None, ilu=None, mg=None,
                  first_check=0, tag=None, restart=20, x_is_zero=False,
-                 pmg=None, verify=True):
+                 pmg=None, verify=True, guard=None):
     '''Solve A x = b on the device; x holds the initial guess.  Raises
     _hip.NotConverged (a RuntimeError) like dolfin's
     'error_on_nonconvergence'.  first_check > 0: iterations before the first
@@ -526,7 +526,12 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     (that many Arnoldi steps are enqueued before the first read-back);
     verify: check the accepted iterate with the true residual (one more
     operator application; off for the Newton systems, whose outer iteration
-    recomputes the nonlinear residual anyway).'''
+    recomputes the nonlinear residual anyway).
+    guard (CG): x is a start vector the caller does not vouch for (one
+    extrapolated from earlier calls): False / a device vector = its fallback
+    (none / that vector).  A start that leaves a larger preconditioned residual
+    than zero is dropped on the device for the fallback, and that for zero
+    (flow_cg_solve_guarded); `starts_dropped` of the returned info counts.'''
     lib = _hip.lib()
     n = A.size
     if isinstance(dinv, str):
@@ -554,7 +559,19 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
         history = A.__dict__.setdefault('_solve_history', {})
         if first_check == 0 and tag in history:
             first_check = history[tag] + 1
-    if method == 'cg':
+    dropped = ctypes.c_int(0)
+    if method == 'cg' and guard is not None:
+        fallback = None if guard is False else _hip.f64(guard, n, 'x_fallback')
+        rc = lib.flow_cg_solve_guarded(
+            ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
+            ctypes.byref(coarse.struct) if coarse is not None else None,
+            ctypes.byref(mg.struct) if mg is not None else None,
+            _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), fallback, float(rtol),
+            float(atol), int(maxit), int(check_every), int(first_check),
+            _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
+            ctypes.byref(dropped), _hip.stream()
+            )
+    elif method == 'cg':
         rc = lib.flow_cg_solve(
             ctypes.byref(A.operator()), _hip.f64(dinv, n, 'dinv'),
             ctypes.byref(coarse.struct) if coarse is not None else None,
@@ -589,11 +606,13 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     _hip.check(rc)
     if history is not None:
         history[tag] = its.value
-    return SolveInfo(its.value, res.value,
-                     method + ('+2level' if coarse is not None else '')
-                     + ('+mg%d' % mg.nlevels if mg is not None else '')
-                     + ('+ilu0' if ilu is not None else '')
-                     + ('+pmg' if pmg is not None else ''))
+    out = SolveInfo(its.value, res.value,
+                    method + ('+2level' if coarse is not None else '')
+                    + ('+mg%d' % mg.nlevels if mg is not None else '')
+                    + ('+ilu0' if ilu is not None else '')
+                    + ('+pmg' if pmg is not None else ''))
+    out.starts_dropped = dropped.value
+    return out
 
 
 # -- load vectors, projection, norms -----------------------------------------

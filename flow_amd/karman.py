@@ -112,11 +112,7 @@ class KarmanProblem(object):
         self._umag_start = fem.ops.StartChooser()
         self.W.layout._dev.pop('step_history', None)
         self.W.layout._dev.pop('newton_quad_C', None)
-        self.W.layout._dev.pop('newton_increments', None)
-        for it in (1, 2):
-            self.W.layout._dev.pop(('newton_increments', it), None)
-        self.W.layout._dev.pop('correction_increments', None)
-        self.P.layout._dev.pop('pressure_increments', None)
+        navier_stokes.forget_history(self.W)
         return
 
     def prepare(self):

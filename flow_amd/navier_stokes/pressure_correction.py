@@ -68,11 +68,12 @@ from ..message import Message, info
 from .. import _hip
 from .. import device
 from .. import parallel
+from . import start_vectors
 from .start_vectors import (                                # noqa: F401
-    extrapolation_weights,
+    extrapolation_weights, forget_history,
     extrapolated_increment as _extrapolated_increment,
     remember_increment as _remember_increment,
-    newton_history as _newton_history,
+    newton_key as _newton_key,
     )
 from .newton_preconditioner import (
     age as _age, contraction as _contraction,
@@ -81,7 +82,7 @@ from .newton_preconditioner import (
     )
 
 __all__ = ['Chorin', 'IPCS', 'Rotational', 'solver_parameters',
-           'last_step_info', 'set_mode']
+           'last_step_info', 'set_mode', 'forget_history']
 
 # Jacobi-preconditioned Krylov needs more iterations than the reference's AMG
 # (maxit 100/1000, reference :335,422,460): limits are scaled up, everything
@@ -226,6 +227,16 @@ def _uses_history():
             or solver_parameters['correction'].get('extrapolate', False))
 
 
+def _uses_start_vectors():
+    return (solver_parameters['newton'].get('linear_start') == 'extrapolated'
+            or solver_parameters['pressure'].get('start') == 'extrapolated'
+            or (solver_parameters['correction'].get('increment_start')
+                == 'extrapolated'
+                and solver_parameters['correction'].get('method',
+                                                         'chebyshev')
+                == 'chebyshev'))
+
+
 def _history(lay):
     '''The previous call's fields, when this call continues its trajectory
     (u[0] IS the velocity it returned) and a setting that uses them is on;
@@ -321,9 +332,6 @@ def _compute_tentative_velocity(
     assert time_step_method in _THETA, time_step_method
     theta_i, theta_e = _THETA[time_step_method]
     alpha = 1.0
-    # (the number of this call: stamps the Newton increments it remembers)
-    lay0 = u[0].function_space().layout
-    lay0._dev['newton_call'] = lay0._dev.get('newton_call', 0) + 1
     if parallel.active():
         return _tentative_velocity_on_strips(
             u, p0, f, u_bcs, theta_i, theta_e, rho, mu, dt, tol), alpha
@@ -471,12 +479,11 @@ def _compute_tentative_velocity(
 
         ops.fill(dx, 0.0)
         dx_is_zero = True
-        hkey, hstamp = _newton_history(lay, it)
+        hkey = _newton_key(it)
         if hkey is not None and npar.get('linear_start') == 'extrapolated':
             dx_is_zero = not _extrapolated_increment(
                 lay, dt, dx, int(npar.get('linear_start_points', 5)),
-                key=hkey, degree=npar.get('linear_start_degree'),
-                stamp=hstamp)
+                key=hkey, degree=npar.get('linear_start_degree'))
         pre = None
         kind = npar.get('preconditioner', 'jacobi')
         use_gmres = npar.get('linear_solver', 'gmres') == 'gmres'
@@ -631,7 +638,7 @@ def _compute_tentative_velocity(
         if pre is not None:
             _age(pre, kind, refactored, its, sol.iterations, npar, it=it)
         if hkey is not None and npar.get('linear_start') == 'extrapolated':
-            _remember_increment(lay, dt, dx, key=hkey, stamp=hstamp)
+            _remember_increment(lay, dt, dx, key=hkey)
         ops.axpby(-1.0, dx, 1.0, ui.data)
         it += 1
     del keep0, keep1
@@ -791,14 +798,14 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
         lin_rtol = max(npar['linear_rtol'], lin_atol / nrm)
         ops.fill(dx, 0.0)
         dx_is_zero = True
-        hkey, hstamp = _newton_history(lay, it)
+        hkey = _newton_key(it)
         if hkey is not None and npar.get('linear_start') == 'extrapolated':
             # (every rank keeps the increments of its own rows: the same
-            # history length and step sizes everywhere)
+            # history length and step sizes everywhere -- the ranks agree on
+            # the trajectory a call belongs to, start_vectors._resolve)
             dx_is_zero = not _extrapolated_increment(
                 lay, dt, dx, int(npar.get('linear_start_points', 5)),
-                key=hkey, degree=npar.get('linear_start_degree'),
-                stamp=hstamp)
+                key=hkey, degree=npar.get('linear_start_degree'))
         # (the count of the previous call's Newton iteration `it`: the same
         # number on every rank -- they all ran the same solve)
         expected = lay._dev.setdefault('gmres_expected_strip', {})
@@ -829,7 +836,7 @@ def _tentative_velocity_on_strips(u, p0, f, u_bcs, theta_i, theta_e, rho, mu,
         last_step_info['newton_preconditioner'] = kind + ' (block Jacobi)'
         _age(pre, kind, refactored, its, sol.iterations, npar, it=it)
         if hkey is not None and npar.get('linear_start') == 'extrapolated':
-            _remember_increment(lay, dt, dx, key=hkey, stamp=hstamp)
+            _remember_increment(lay, dt, dx, key=hkey)
         # (dx is zero outside the owned rows)
         ops.axpby(-1.0, dx, 1.0, ui.data)
         parallel.halo(ui.data, lay, 2)
@@ -860,13 +867,15 @@ def _bicgstab_with_restarts(A, b, x, rtol, pre, npar):
                 raise
 
 
-def _pressure_cg(A, dinv, prec, b, x, tol, par):
+def _pressure_cg(A, dinv, prec, b, x, tol, par, fallback=False):
     '''CG for the pressure system: rtol = tol, atol = 0 (reference :332-335,
     :420-422), preconditioned with the multigrid V-cycle, with Jacobi + the
     aggregate coarse space, or with Jacobi alone (`prec` from
     _preconditioner); row-sharded over the GPUs of the node when
     flow_amd.parallel is enabled and the system is large enough for that to pay
-    (parallel.min_rows()).'''
+    (parallel.min_rows()).  fallback: what the guarded start x is dropped for
+    when it leaves a larger preconditioned residual than zero would (a vector,
+    or False: zero at once; ops.krylov_solve `guard`).'''
     coarse, mg = prec
     if parallel.active():
         if mg is not None:
@@ -879,7 +888,7 @@ def _pressure_cg(A, dinv, prec, b, x, tol, par):
     return ops.krylov_solve(
         'cg', A, b, x, rtol=tol, atol=0.0, maxit=par['maxit'], dinv=dinv,
         check_every=2 if mg is not None else par['check_every'],
-        coarse=coarse, mg=mg, tag='pressure'
+        coarse=coarse, mg=mg, tag='pressure', guard=fallback
         )
 
 
@@ -941,15 +950,20 @@ def _compute_pressure(
     # from step to step, and still exact on a state of rest.
     ops.copy(p1.data, p0.data)
     phi_start = None
+    plain = None      # the start without the extrapolated increment
     if hist is None and par.get('start') == 'extrapolated':
-        # ... plus the previous calls' pressure increments p1 - p0 extrapolated
-        # in time (3-point, as the Newton increments: a start vector only; on
-        # the strips every rank extrapolates its own + ghost rows)
-        phi_start = device.empty(P.N)
-        if _extrapolated_increment(lay, dt, phi_start,
+        # ... plus the pressure increments p1 - p0 of the trajectory's earlier
+        # time levels extrapolated in time (start_vectors: a start vector only,
+        # guarded by the solver; on the strips every rank extrapolates its own
+        # + ghost rows)
+        phi_start = lay._dev.get('pressure_phi_scratch')
+        if phi_start is None:
+            phi_start = lay._dev['pressure_phi_scratch'] = device.empty(P.N)
+        if _extrapolated_increment(W.layout, dt, phi_start,
                                    int(par.get('start_points', 5)),
                                    key='pressure_increments', power=1,
                                    degree=par.get('start_degree')):
+            plain = _hip.clone(p0.data)
             ops.axpby(1.0, phi_start, 1.0, p1.data)
     if not p_bcs:
         one = lay._dev.get('ones')
@@ -957,9 +971,12 @@ def _compute_pressure(
             one = _zeros(P.N)
             ops.fill(one, 1.0)
             lay._dev['ones'] = one
-        total = parallel.dot(one, p1.data, lay) if parallel.active() \
-            else ops.dot(one, p1.data)
-        ops.axpby(-total / P.N, one, 1.0, p1.data)
+        for vec in (p1.data, plain):
+            if vec is None:
+                continue
+            total = parallel.dot(one, vec, lay) if parallel.active() \
+                else ops.dot(one, vec)
+            ops.axpby(-total / P.N, one, 1.0, vec)
     if hist is not None and 'p_in' in hist and 0.7 <= dt / hist['dt'] <= 1.5:
         # ... extrapolated through the previous pressures when this call
         # continues the previous step's trajectory at a settled step size
@@ -1022,7 +1039,12 @@ def _compute_pressure(
         _hip.check(lib.flow_bc_set_values(
             nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(p1.data), st
             ))
-        sol = _pressure_cg(Kbc, dinv, coarse, b, p1.data, tol, par)
+        if plain is not None:
+            _hip.check(lib.flow_bc_set_values(
+                nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(plain), st
+                ))
+        sol = _pressure_cg(Kbc, dinv, coarse, b, p1.data, tol, par,
+                           fallback=plain if plain is not None else False)
     else:
         # pure Neumann problem: singular but consistent, no null-space
         # handling (reference :340-432); start: see above
@@ -1030,11 +1052,13 @@ def _compute_pressure(
         if key not in lay._dev:
             lay._dev[key] = K.diag_inv()
         coarse = _preconditioner(lay, key, K, None, True, par)
-        sol = _pressure_cg(K, lay._dev[key], coarse, b, p1.data, tol, par)
+        sol = _pressure_cg(K, lay._dev[key], coarse, b, p1.data, tol, par,
+                           fallback=plain if plain is not None else False)
     if phi_start is not None:
         ops.copy(phi_start, p1.data)
         ops.axpby(-1.0, p0.data, 1.0, phi_start)
-        _remember_increment(lay, dt, phi_start, key='pressure_increments')
+        _remember_increment(W.layout, dt, phi_start, key='pressure_increments')
+    last_step_info['pressure_starts_dropped'] = getattr(sol, 'starts_dropped', 0)
     if verbose:
         info('pressure: %r' % sol)
     last_step_info['pressure'] = sol
@@ -1142,7 +1166,9 @@ def _compute_velocity_correction(
             # p_t: smooth from step to step) -- a start vector only
             d0 = None
             if par.get('increment_start') == 'extrapolated':
-                d0 = device.empty(n2)
+                d0 = lay._dev.get('correction_d0_scratch')
+                if d0 is None:
+                    d0 = lay._dev['correction_d0_scratch'] = device.empty(n2)
                 if not _extrapolated_increment(
                         lay, dt, d0, int(par.get('start_points', 5)),
                         key='correction_increments', power=2,
@@ -1165,7 +1191,7 @@ def _compute_velocity_correction(
                     b, u1.data, u1.data, tol, maxit=min(par['maxit'], 100),
                     tag='correction', delta0=d0)
             if par.get('increment_start') == 'extrapolated':
-                d0 = d0 if d0 is not None else device.empty(n2)
+                d0 = lay._dev['correction_d0_scratch']
                 ops.copy(d0, u1.data)
                 ops.axpby(-1.0, ui_keep, 1.0, d0)
                 _remember_increment(lay, dt, d0, key='correction_increments')
@@ -1197,9 +1223,12 @@ def _step(
         rotational_form=False,
         verbose=True,
         tol=1.0e-10,
+        p_identity=None,
         ):
     '''Incremental pressure correction scheme as described in section 3.4 of
-    Guermond, Minev, Shen (2006); reference :468-518.'''
+    Guermond, Minev, Shen (2006); reference :468-518.  p_identity: the pressure
+    the caller handed in when p0 is not it (Chorin drops it, :545): what
+    identifies the trajectory this call continues (start_vectors).'''
     # dt, mu are Constant()s; rho may be a Constant or a plain float
     dt_ = scalar_value(dt)
     mu_ = scalar_value(mu)
@@ -1215,6 +1244,15 @@ def _step(
         ops.axpby(-1.0, hist['u_out'], 1.0, tmp)
         hist['continuing'] = ops.vector_norm(tmp, 'linf') == 0.0
         del tmp
+
+    # the start vectors of the linear solves belong to the trajectory whose
+    # last step returned the fields this call is handed (start_vectors)
+    tracked = _uses_start_vectors()
+    if tracked:
+        start_vectors.begin_step(
+            lay, u[0].data, (p_identity if p_identity is not None else p0).data)
+    else:
+        lay._dev.pop('start_vector_state', None)
 
     t_0 = time.perf_counter()
     with Message('Computing tentative velocity'):
@@ -1249,6 +1287,8 @@ def _step(
         'correction_s': t_3 - t_2,
         }
     last_step_info['tentative_velocity'] = ui
+    if tracked:
+        start_vectors.end_step(lay, u1.data, p1.data)
     if _uses_history():
         hist = lay._dev.setdefault('step_history', {})
         if 'ui' not in hist:
@@ -1288,11 +1328,13 @@ class _PressureCorrection(object):
 
     def step(self, dt, u, p0, u_bcs, p_bcs, rho, mu, f, verbose=True,
              tol=1.0e-10):
+        p_in = None
         if self.drop_pressure:
-            p0 = Function(p0.function_space())
+            p_in, p0 = p0, Function(p0.function_space())
         return _step(
             dt, u, p0, u_bcs, p_bcs, rho, mu, self.time_step_method, f,
-            rotational_form=self.rotational_form, verbose=verbose, tol=tol
+            rotational_form=self.rotational_form, verbose=verbose, tol=tol,
+            p_identity=p_in
             )
 
 

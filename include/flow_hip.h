@@ -143,6 +143,20 @@ int flow_axpby(int n, double a, const double* x, double b, double* y,
 int flow_vmul(int n, double a, const double* x, const double* y, double* out,
               void* stream);                        /* out = a x .* y */
 int flow_fill(int n, double value, double* y, void* stream);   /* y = value */
+/* 64-bit fingerprints of nfields <= 2 device vectors (sum of the entries' bit
+ * patterns times odd multipliers of their index, modulo 2^64 -- integer
+ * arithmetic: equal values give equal fingerprints bit for bit; beyond 2^22
+ * entries every k-th 64-byte line): which trajectory a call continues is a
+ * matter of the VALUES of the fields it is handed (callers copy what a step
+ * returns: `u0.assign(u1)`, tests/test_karman_vortex_street.py:241-242).
+ * Asynchronous: slots (device, 2*nfields doubles) receive the low and the high
+ * 32 bits of each fingerprint as exact integers; x_host / n_host are HOST
+ * arrays; work: FLOW_REDUCE_WORK doubles.  flow_read_doubles brings n <= 64
+ * doubles of device memory to the host in stream order (one synchronisation). */
+int flow_fingerprint(int nfields, const double* const* x_host,
+                     const int* n_host, double* work, double* slots,
+                     void* stream);
+int flow_read_doubles(const double* dev, int n, double* host, void* stream);
 /* y = sum_k coef_host[k] * x_host[k], k < nterms <= 6, in one pass (coef_host
  * and the pointer list x_host are HOST arrays; y must not be one of the x): the
  * start vectors a time loop extrapolates from its previous increments */
@@ -540,6 +554,23 @@ int flow_cg_solve(const flow_operator* A, const double* dinv,
                   double rtol, double atol, int maxit, int check_every,
                   int first_check, double* work, size_t work_len,
                   int* iters_host, double* resid_host, void* stream);
+/* flow_cg_solve from a GUARDED start vector (the start vectors a time loop
+ * extrapolates from its previous calls, flow_amd/navier_stokes/
+ * start_vectors.py; the reference starts every solve from a fresh, zero
+ * Function, pressure_correction.py:313).  A start that leaves a larger
+ * preconditioned residual than x = 0 would, ||B(b - A x)|| > ||B b|| --
+ * decided on the device by the kernel that forms the first iteration's scalars,
+ * from numbers it forms anyway; everything enqueued behind the verdict returns
+ * at once, x still holds the start -- is dropped for x_fallback (guarded the
+ * same way; NULL: none; must not alias x) and that for zero.
+ * *starts_dropped_host: 0, 1 or 2.  Everything else as flow_cg_solve. */
+int flow_cg_solve_guarded(const flow_operator* A, const double* dinv,
+                          const flow_coarse* coarse, const flow_mg* mg,
+                          const double* b, double* x, const double* x_fallback,
+                          double rtol, double atol, int maxit, int check_every,
+                          int first_check, double* work, size_t work_len,
+                          int* iters_host, double* resid_host,
+                          int* starts_dropped_host, void* stream);
 int flow_bicgstab_solve(const flow_operator* A, const double* dinv,
                         const flow_ilu* ilu, const double* b, double* x,
                         double rtol, double atol, int maxit, int check_every,

@@ -292,6 +292,18 @@ def momentum_rhs(W, P, U, p0, f, rho, mu, want_jacobian=True):
     return Rv, Jm
 
 
+def _identity_rows(A, dofs):
+    '''`bc.apply(A)`: the rows of the Dirichlet dofs replaced by rows of the
+    identity (row scaling with 0/1 + a unit diagonal: the same entries as
+    assigning them one by one, in time linear in the nonzeros).'''
+    keep = numpy.ones(A.shape[0])
+    keep[dofs] = 0.0
+    A = sp.diags(keep).dot(A.tocsr()) + sp.diags(1.0 - keep)
+    A = A.tocsr()
+    A.eliminate_zeros()
+    return A
+
+
 _THETA = {
     'forward euler': (0.0, 1.0),
     'backward euler': (1.0, 0.0),
@@ -328,10 +340,7 @@ def tentative_velocity(W, P, u0, p0, f0, f1, bc_dofs, bc_vals, method,
             return ui, history
         if it == max_it:
             break
-        J = J.tolil()
-        J[bc_dofs, :] = 0.0
-        J[bc_dofs, bc_dofs] = 1.0
-        ui = ui - spla.splu(J.tocsc()).solve(F)
+        ui = ui - spla.splu(_identity_rows(J, bc_dofs).tocsc()).solve(F)
     raise RuntimeError('Newton solver did not converge: %r' % history)
 
 
@@ -428,11 +437,12 @@ def velocity_correction(W, P, ui, p1, p0, bc_dofs, bc_vals, rho, mu, dt,
 
 
 def step(W, P, u0, p0, f0, f1, u_bc, p_bc, rho, mu, dt,
-         scheme='ipcs', method='backward euler'):
+         scheme='ipcs', method='backward euler', info=None):
     '''`_step` (pressure_correction.py:468-518) with the scheme flags of
     Chorin (:545-548), IPCS (:575-584), Rotational (:607-617).
     u_bc / p_bc: (dofs, values) tuples; p_bc None or empty -> Neumann branch.
-    Returns (u1, p1, ui).'''
+    Returns (u1, p1, ui); a dict handed in as `info` receives the Newton
+    iteration's residual norms.'''
     assert dt > 0.0 and mu > 0.0
     rotational = False
     if scheme == 'chorin':
@@ -442,9 +452,11 @@ def step(W, P, u0, p0, f0, f1, u_bc, p_bc, rho, mu, dt,
         rotational = True
     else:
         assert scheme == 'ipcs'
-    ui, _ = tentative_velocity(
+    ui, history = tentative_velocity(
         W, P, u0, p0, f0, f1, u_bc[0], u_bc[1], method, rho, mu, dt
         )
+    if info is not None:
+        info['newton_history'] = history
     b = pressure_rhs(W, P, ui, p0, 1.0, rho, mu, dt, rotational)
     if p_bc is not None and len(p_bc[0]) > 0:
         p1 = solve_pressure(P, b, p_bc[0], p_bc[1])
@@ -542,10 +554,8 @@ def heat_solve(M, A, alpha, beta, b, bc_dofs, bc_vals):
     '''`Heat.solve_alpha_M_beta_F` (flow/heat.py:103-122): (alpha M + beta A) u
     = b with `bc.apply(A, b)` (row replacement), sparse LU.  The reference
     computes `right_hand_side` but solves with the raw `b` (:109-121).'''
-    S = (alpha * M + beta * A).tolil()
+    S = _identity_rows(alpha * M + beta * A, bc_dofs)
     b = b.copy()
-    S[bc_dofs, :] = 0.0
-    S[bc_dofs, bc_dofs] = 1.0
     b[bc_dofs] = bc_vals
     return spla.splu(S.tocsc()).solve(b)
 

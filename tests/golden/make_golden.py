@@ -5,7 +5,16 @@ Generates the golden fixtures under tests/golden/ with the CPU oracle
 so these vectors come from the oracle, which is pinned by the reference's
 analytic known-answer tests (tests/test_oracle_pinning.py).
 
-    python tests/golden/make_golden.py [--force]
+    python tests/golden/make_golden.py [--force] [--large [name ...]]
+
+--large writes the fixtures ns_large_<name>.npz instead (tests/large_cases.py:
+one Rotational step, backward Euler and Crank-Nicolson, of the Karman channel
+problem at BASELINE config 2's size and on a Taylor-Hood channel of 0.76 M DoF
+-- minutes of sparse LU each, run in the build container; the GPU box only
+reads them).  Such a fixture holds the generator's arguments, a fingerprint of
+the generated inputs and, of each output field, every 87th dof and the l2 /
+max norms per component: the inputs are analytic and rebuilt where they are
+needed.
 
 Existing fixtures are left alone unless --force is given: they carry their own
 mesh arrays, and the ones written before the generators numbered cells x-major
@@ -34,6 +43,7 @@ import mms                                                 # noqa: E402
 
 
 FORCE = '--force' in sys.argv[1:]
+LARGE = '--large' in sys.argv[1:]
 
 
 def _wanted(filename):
@@ -117,7 +127,44 @@ def heat_fixture():
     numpy.savez_compressed(path, **data)
 
 
+def large_fixture(name):
+    import time
+    import large_cases
+    path = _wanted('ns_large_%s.npz' % name)
+    if path is None:
+        return
+    args = large_cases.LARGE[name]
+    case = large_cases.KarmanStepCase(**args)
+    data = {'fingerprint': case.fingerprint(), 'stride': large_cases.STRIDE,
+            'dt': case.dt, 'num_dofs': case.num_dofs()}
+    for k, v in case.args.items():
+        data['arg_' + k] = v
+    for method in ('backward euler', 'crank-nicolson'):
+        info = {}
+        t0 = time.time()
+        u1, p1, ui = case.oracle_step(method, info=info)
+        key = method.replace(' ', '_').replace('-', '_')
+        data[key + '_oracle_seconds'] = time.time() - t0
+        data[key + '_newton_history'] = numpy.array(info['newton_history'])
+        for fname, field, ncomp in (('ui', ui, 2), ('p1', p1, 1), ('u1', u1, 2)):
+            sample, l2, linf = large_cases.summary(field, ncomp)
+            data['%s_%s_sample' % (key, fname)] = sample
+            data['%s_%s_l2' % (key, fname)] = l2
+            data['%s_%s_linf' % (key, fname)] = linf
+        print('  %s: %d DoF, %s, %.0f s, Newton %s' % (
+            name, case.num_dofs(), method, data[key + '_oracle_seconds'],
+            ' '.join('%.2e' % r for r in info['newton_history'])), flush=True)
+    numpy.savez_compressed(path, **data)
+
+
 if __name__ == '__main__':
+    if LARGE:
+        import large_cases
+        names = [a for a in sys.argv[1:] if a in large_cases.LARGE] \
+            or sorted(large_cases.LARGE)
+        for name in names:
+            large_fixture(name)
+        sys.exit(0)
     # C1: the reference's plumbing configuration (tests/test_navier_stokes.py:
     # 403-410): UnitSquareMesh(8, 8, 'crossed'), P2-P1, guermond2
     ns_fixture('c1_unit_square', fem.UnitSquareMesh(8, 8, 'crossed'), 2, 'all',
