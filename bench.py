@@ -345,6 +345,14 @@ def main():
                          'where a step takes two Newton iterations; the '
                          'default window is the early plateau, as in rounds '
                          '2-3')
+    ap.add_argument('--developed', type=int, default=None, metavar='STEPS',
+                    help='N = 1: a second window in the DEVELOPED vortex '
+                         'street -- that many untimed steps behind the settled '
+                         'plateau (setup), then --warmup / --steps as for the '
+                         'headline window; reported as config.developed and '
+                         'value_developed.  Default: 2400 at the headline size '
+                         '(t ~ 75: the wake sheds, a step takes two Newton '
+                         'iterations), 0 = off otherwise')
     ap.add_argument('--nx', type=int, default=2182,
                     help='cells along the channel (2182 x 509: ~10 M DoF)')
     ap.add_argument('--ny', type=int, default=None)
@@ -393,6 +401,11 @@ def main():
 
     if args.initial is None:
         args.initial = 'stokes' if args.velocity_degree == 2 else 'profile'
+    if args.developed is None:
+        args.developed = 2400 if (
+            args.nx == 2182 and args.ny is None and args.velocity_degree == 2
+            and args.gpus == 1 and not args.no_settle and not args.spin_up
+            and args.mode == 'parity') else 0
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world == 1 and args.gpus > 1 and 'RANK' not in os.environ:
@@ -643,6 +656,42 @@ def main():
         for g, vals in saved.items():
             navsto.solver_parameters[g].update(vals)
 
+    # --- the developed vortex street (N = 1): the regime the metric names ---
+    # The windows above sit on the early plateau, a few steps behind the CFL
+    # controller's ramp: symmetric flow, one Newton iteration per step.  Once
+    # the wake sheds (t > ~55) ||F(u0)|| is 1e-8 instead of 5e-10, the first
+    # Newton iterate is left just above `tol`, every step takes two Newton
+    # iterations and longer solves -- for the reference as for this build.
+    developed = None
+    if world == 1 and args.developed > 0 and settled:
+        navsto.set_mode(args.mode)
+        apply_overrides()
+        prob.restore(settled['state'])
+        t_spin = time.perf_counter()
+        for _ in range(args.developed):
+            prob.step(tol=args.tol)
+        device.synchronize()
+        spin_s = time.perf_counter() - t_spin
+        plateau_state = settled['state']
+        settled['state'] = prob.snapshot()
+        # (restore() forgets the start-vector histories: the window's warm-up
+        # steps refill them; at least 8, so that the timed steps see full ones)
+        keep_warmup = args.warmup
+        args.warmup = max(args.warmup, 8)
+        d_infos, d_elapsed = window(args.mode)
+        args.warmup = keep_warmup
+        developed = summary(d_infos, d_elapsed)
+        developed['spin_up_steps'] = args.developed
+        developed['spin_up_s'] = spin_s
+        developed['t'] = settled['state']['t']
+        developed['unorm'] = [i.get('unorm') for i in d_infos]
+        developed['note'] = (
+            '%d untimed steps behind the settled plateau (setup, %.1f s), then '
+            '%d warm-up + %d timed steps in mode %r: the developed vortex '
+            'street' % (args.developed, spin_s, max(args.warmup, 8),
+                        args.steps, args.mode))
+        settled['state'] = plateau_state
+
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -763,6 +812,11 @@ def main():
         }
     out['config'].update({k: v for k, v in head.items()
                           if k not in ('steps_per_s', 'ms_per_step')})
+    if developed is not None:
+        # co-headline: the same metric in the regime a Karman run lives in
+        out['value_developed'] = developed['steps_per_s']
+        out['ms_per_step_developed'] = developed['ms_per_step']
+        out['config']['developed'] = developed
     if fast is not None:
         out['config']['fast_mode'] = fast
     if zero_start is not None:

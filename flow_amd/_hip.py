@@ -314,10 +314,10 @@ SYMBOLS = {
                                _P(_D), _VP],
     'flow_shard_cg_solve': [_P(CommS), _P(RowsS), _P(Operator), _VP, _VP, _VP,
                             _D, _D, _I, _I, _I, _VP, ctypes.c_size_t, _P(_I),
-                            _P(_D), _VP],
+                            _P(_D), _P(_I), _VP],
     'flow_shard_mgcg_solve': [_P(CommS), _P(RowsS), _P(Operator), _VP,
                               _P(MgShardS), _VP, _VP, _D, _D, _I, _I, _I, _VP,
-                              ctypes.c_size_t, _P(_I), _P(_D), _VP],
+                              ctypes.c_size_t, _P(_I), _P(_D), _P(_I), _VP],
     'flow_shard_mass_solve': [_P(CommS), _P(RowsS), _P(MassS), _P(MassStripsS),
                               _VP, _VP, _VP, _VP, _D, _D, _I, _I, _VP,
                               ctypes.c_size_t, _P(_I), _P(_D), _VP],

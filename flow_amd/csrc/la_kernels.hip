@@ -2945,6 +2945,14 @@ __global__ void shard_scalar_unpack_kernel(flow_rows R, int ncomp, int first,
     store_scalar(S + kB2, load_scalar(buf + 3));
     store_scalar(S + kTarget2, fmax(rtol2 * load_scalar(buf + 3), atol2));
     store_scalar(S + kIter, 0.0);
+    // first == 2: the guarded start of cg_scalar_kernel -- the sums are the
+    // same on every rank, so is the verdict
+    if (first == 2 && rr > load_scalar(buf + 3)) {
+      store_scalar(S + kConvIt, 0.0);
+      store_scalar(S + kRes2, rr);
+      store_scalar(S + kDone, 5.0);
+      return;
+    }
   } else {
     const double g_old = load_scalar(S + kGamma);
     const double a_old = load_scalar(S + kAlpha);
@@ -3133,7 +3141,11 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
                     const flow_mg_shard* G, const double* b, double* x,
                     double rtol, double atol, int maxit, int check_every,
                     int first_check, double* work, int* iters_host,
-                    double* resid_host, hipStream_t st) {
+                    double* resid_host, hipStream_t st,
+                    int* rejected = nullptr) {
+  // rejected != nullptr: the start vector is guarded; when it is rejected,
+  // *rejected = 1, x is untouched, FLOW_OK (the caller swaps in its fallback)
+  if (rejected) *rejected = 0;
   ShardCg c;
   c.C = C;
   c.R = R;
@@ -3257,8 +3269,8 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
   if (two && grid_for(n1) > gs) gs = grid_for(n1);
   // alpha, beta and the verdict on the start; ghost rows of w; rc_w
   hipLaunchKernelGGL(shard_scalar_unpack_kernel, dim3(gs), dim3(kBlock), 0, st, *R,
-                     ncomp, 1, rtol2, atol2, C->buf, c.S, c.sh(c.w), me, n1, coff,
-                     rc_w);
+                     ncomp, rejected ? 2 : 1, rtol2, atol2, C->buf, c.S,
+                     c.sh(c.w), me, n1, coff, rc_w);
   FLOW_CHECK_LAUNCH();
   double state[kNumSlots];
   int launched = 0;
@@ -3340,6 +3352,12 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
       *iters_host = static_cast<int>(state[kConvIt]);
       *resid_host = sqrt(res2);
       break;
+    }
+    if (state[kDone] == 5.0 && rejected) {
+      *rejected = 1;
+      *iters_host = 0;
+      *resid_host = sqrt(res2);
+      return FLOW_OK;
     }
     if (launched >= maxit) {
       *iters_host = launched;
@@ -3651,7 +3669,8 @@ extern "C" int flow_shard_cg_solve(const flow_comm* comm, const flow_rows* rows,
                                    double atol, int maxit, int check_every,
                                    int first_check, double* work,
                                    size_t work_len, int* iters_host,
-                                   double* resid_host, void* stream) {
+                                   double* resid_host,
+                                   int* start_rejected_host, void* stream) {
   int rc = check_shard_solver(comm, rows, A, b, x, rtol, atol, maxit, work,
                               iters_host, resid_host);
   if (rc) return rc;
@@ -3665,7 +3684,7 @@ extern "C" int flow_shard_cg_solve(const flow_comm* comm, const flow_rows* rows,
                "sharded CG workspace too small");
   return shard_cg(comm, rows, A, dinv, nullptr, b, x, rtol, atol, maxit,
                   check_every, first_check, work, iters_host, resid_host,
-                  as_stream(stream));
+                  as_stream(stream), start_rejected_host);
 }
 
 extern "C" int flow_shard_mgcg_solve(
@@ -3673,7 +3692,7 @@ extern "C" int flow_shard_mgcg_solve(
     const double* dinv, const flow_mg_shard* mgs, const double* b, double* x,
     double rtol, double atol, int maxit, int check_every, int first_check,
     double* work, size_t work_len, int* iters_host, double* resid_host,
-    void* stream) {
+    int* start_rejected_host, void* stream) {
   int rc = check_shard_solver(comm, rows, A, b, x, rtol, atol, maxit, work,
                               iters_host, resid_host);
   if (rc) return rc;
@@ -3710,7 +3729,8 @@ extern "C" int flow_shard_mgcg_solve(
   FLOW_REQUIRE(work_len >= shard_cg_work_len(rows, A, mgs),
                "sharded multigrid CG workspace too small");
   return shard_cg(comm, rows, A, dinv, mgs, b, x, rtol, atol, maxit, check_every,
-                  first_check, work, iters_host, resid_host, as_stream(stream));
+                  first_check, work, iters_host, resid_host, as_stream(stream),
+                  start_rejected_host);
 }
 
 extern "C" int flow_shard_gmres_solve(

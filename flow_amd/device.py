@@ -115,6 +115,24 @@ def stream_handle():
     return _HANDLE
 
 
+def check_stream():
+    '''The library enqueues on the package's stream (the cached handle above);
+    torch operations of the host code -- masks, uploads, index assignments --
+    go to torch's CURRENT stream.  The two are the same stream unless a caller
+    has switched torch's (`with torch.cuda.stream(s)`): then nothing orders
+    them any more.  Called once per time step: refuse that instead of racing
+    (FLOW_AMD_FOLLOW_TORCH_STREAM=1 makes the library follow instead).'''
+    if not on_gpu() or _FOLLOW_TORCH or _STREAM is None:
+        return
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream != _STREAM.cuda_stream:
+        raise RuntimeError(
+            "flow_amd: torch's current stream (%#x) is not the stream the HIP "
+            'library enqueues on (%#x) -- leave the `with torch.cuda.stream(...)` '
+            'block, or set FLOW_AMD_FOLLOW_TORCH_STREAM=1 before importing '
+            'flow_amd' % (cur.cuda_stream, _STREAM.cuda_stream))
+
+
 def synchronize():
     if on_gpu():
         torch.cuda.synchronize()

@@ -18,7 +18,7 @@ import os
 
 import numpy
 
-_H5F_ACC_RDONLY, _H5F_ACC_TRUNC = 0, 2
+_H5F_ACC_RDONLY, _H5F_ACC_RDWR, _H5F_ACC_TRUNC = 0, 1, 2
 _H5P_DEFAULT, _H5S_ALL = 0, 0
 _hid = ctypes.c_int64          # hid_t of HDF5 >= 1.10
 
@@ -120,7 +120,7 @@ def _check(rc, what):
 
 class File(object):
     '''`with File(path, 'w') as f: f.write('/Mesh/0/mesh/geometry', x)`; mode
-    'r' for `read`.'''
+    'r' for `read`, 'a' to add datasets to an existing file.'''
 
     def __init__(self, path, mode='r'):
         lib = _lib()
@@ -133,11 +133,13 @@ class File(object):
                                      _H5P_DEFAULT)
         elif mode == 'r':
             self._id = lib.H5Fopen(bpath, _H5F_ACC_RDONLY, _H5P_DEFAULT)
+        elif mode == 'a':
+            self._id = lib.H5Fopen(bpath, _H5F_ACC_RDWR, _H5P_DEFAULT)
         else:
             raise ValueError(mode)
         _check(self._id, 'opening %s' % path)
         self._lcpl = None
-        if mode == 'w':
+        if mode in ('w', 'a'):
             self._lcpl = _check(
                 lib.H5Pcreate(_global('H5P_CLS_LINK_CREATE_ID_g')), 'H5Pcreate')
             _check(lib.H5Pset_create_intermediate_group(self._lcpl, 1),

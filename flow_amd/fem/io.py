@@ -220,7 +220,15 @@ class XDMFFile(object):
     (default): 'hdf5' where the library is found.  With
     'rewrite_function_mesh' False the mesh is stored once and every time step
     refers to it; 'flush_output' rewrites the XML (and flushes the HDF5 file)
-    at every write, so that a run can be looked at while it lasts."""
+    at every write, so that a run can be looked at while it lasts (in 'xml'
+    mode that is the whole inline data again at every write -- the arrays are
+    formatted once, the file grows quadratically: use 'hdf5' for long runs).
+    A write after close() opens the heavy-data file again and adds to it.  On
+    the strips of flow_amd.parallel the field is gathered and rank 0 alone
+    writes.  Differences from dolfin's files: the topology is stored as
+    int64 in the HDF5 file (dolfin: uint64; declared `UInt` in the XML either
+    way), one `Grid` per time value holds every field written at that time,
+    and only vertex values are written."""
 
     def __init__(self, comm_or_path, path=None):
         self.path = path if path is not None else comm_or_path
@@ -259,14 +267,32 @@ class XDMFFile(object):
                 want == 'auto' and hdf5.available()) else 'xml'
             if self._heavy == 'hdf5':
                 self._h5 = hdf5.File(self._h5_name(), 'w')
+        elif self._heavy == 'hdf5' and self._h5 is None:
+            # a write after close(): the heavy-data file is opened again and
+            # added to (the XML is rewritten from what this object remembers)
+            from . import hdf5
+            self._h5 = hdf5.File(self._h5_name(), 'a')
         return self._heavy
 
     def write(self, u, t=0.0):
+        '''Vertex values of `u` at time `t` (dolfin: XDMFFile.write(u, t)).
+        On the strips of flow_amd.parallel every rank calls this: the field is
+        made whole (owners' rows summed over the ranks) and RANK 0 ALONE
+        writes -- one file, one writer.'''
+        from .. import parallel
         V = u.function_space()
         mesh = V.mesh()
         assert self._mesh is None or self._mesh is mesh
+        if parallel.active():
+            from .. import _hip, device
+            whole = _hip.clone(u.data)
+            parallel.gather_field(whole, V.layout, V.dim)
+            if parallel.comm().rank != 0:
+                return
+            arr = device.to_host(whole).numpy().reshape(V.dim, V.N)
+        else:
+            arr = u.array().reshape(V.dim, V.N)
         self._mesh = mesh
-        arr = u.array().reshape(V.dim, V.N)
         vals = arr[:, V.layout.vertex_dofs].T.copy()
         nv = mesh.num_vertices()
         if V.dim > 1:           # (XDMF vectors have three components)
@@ -288,7 +314,9 @@ class XDMFFile(object):
             self._steps.append((float(t), u.name(), V.dim, name,
                                 len(self._mesh_sets) - 1))
         else:
-            self._steps.append((float(t), u.name(), V.dim, vals, 0))
+            # (formatted once: flush_output rewrites the XML after every write)
+            text = '\n'.join(' '.join('%.17g' % v for v in r) for r in vals)
+            self._steps.append((float(t), u.name(), V.dim, text, 0))
         if self.parameters.get('flush_output'):
             self._write_xml()
             if self._h5 is not None:
@@ -306,7 +334,7 @@ class XDMFFile(object):
     def _item(self, dims, number_type, payload):
         """A DataItem: `payload` a dataset path (heavy data in the HDF5 file)
         or the text of an inline item."""
-        nt = 'NumberType="Int"' if number_type == 'Int' else \
+        nt = 'NumberType="UInt"' if number_type == 'Int' else \
             'NumberType="Float" Precision="8"'
         if self._heavy == 'hdf5':
             return ('<DataItem Format="HDF" Dimensions="%s" %s>%s:%s</DataItem>'
@@ -323,9 +351,12 @@ class XDMFFile(object):
         if self._heavy == 'hdf5':
             topo = geom = None
         else:
-            topo = '\n'.join(' '.join(str(v) for v in c)
-                             for c in mesh.cell_vertices)
-            geom = '\n'.join('%.17g %.17g' % (x, y) for x, y in mesh.points)
+            if getattr(self, '_mesh_text', None) is None:
+                self._mesh_text = (
+                    '\n'.join(' '.join(str(v) for v in c)
+                              for c in mesh.cell_vertices),
+                    '\n'.join('%.17g %.17g' % (x, y) for x, y in mesh.points))
+            topo, geom = self._mesh_text
         times = sorted(set(s[0] for s in self._steps))
         for t in times:
             mine = [s for s in self._steps if s[0] == t]
@@ -345,8 +376,7 @@ class XDMFFile(object):
                     dims = '%d 1' % nv if ncomp == 1 else dims
                     payload = vals
                 else:
-                    payload = '\n'.join(' '.join('%.17g' % v for v in r)
-                                        for r in vals)
+                    payload = vals
                 out.append('    <Attribute Name="%s" AttributeType="%s" '
                            'Center="Node">%s</Attribute>'
                            % (name, atype, self._item(dims, 'Float', payload)))
@@ -373,7 +403,7 @@ def read_xdmf_series(path):
             arr = files[fname].read(dset)
             assert list(arr.shape) == dims, (dset, arr.shape, dims)
             return arr
-        kind = int if item.get('NumberType') == 'Int' else float
+        kind = int if item.get('NumberType') in ('Int', 'UInt') else float
         return numpy.array(item.text.split(), dtype=kind).reshape(dims)
 
     series = []

@@ -257,12 +257,15 @@ class MomentumJacobian(object):
         if not bc_dofs.numel():
             return None
         held = getattr(self, '_mask', None)
-        if held is None or held[0] is not bc_dofs:
+        # (the same tensor, not rewritten in place since: identity alone would
+        # keep a stale mask after an in-place update of the dof list)
+        stamp = (bc_dofs.data_ptr(), bc_dofs.numel(), bc_dofs._version)
+        if held is None or held[0] is not bc_dofs or held[2] != stamp:
             mask = torch.zeros(self.size, dtype=torch.uint8,
                                device=bc_dofs.device)
             mask[bc_dofs.long()] = 1
             device.synchronize()
-            self._mask = held = (bc_dofs, mask)
+            self._mask = held = (bc_dofs, mask, stamp)
         return _hip.u8(held[1], self.size, 'bc_mask')
 
     def rebind(self, bfmask, ui, prm, bc_dofs):

@@ -881,10 +881,11 @@ def _pressure_cg(A, dinv, prec, b, x, tol, par, fallback=False):
         if mg is not None:
             # the same V-cycle, finest level cut into the ranks' strips
             return parallel.mgcg(A, dinv, mg, b, x, tol, 0.0, par['maxit'],
-                                 check_every=2, tag='pressure')
+                                 check_every=2, tag='pressure', guard=fallback)
         # (a system too small to coarsen: plain Jacobi-CG on the strips)
         return parallel.cg(A, dinv, b, x, tol, 0.0, par['maxit'],
-                           check_every=par['check_every'], tag='pressure')
+                           check_every=par['check_every'], tag='pressure',
+                           guard=fallback)
     return ops.krylov_solve(
         'cg', A, b, x, rtol=tol, atol=0.0, maxit=par['maxit'], dinv=dinv,
         check_every=2 if mg is not None else par['check_every'],
@@ -1235,6 +1236,7 @@ def _step(
     rho_ = scalar_value(rho)
     assert dt_ > 0.0
     assert mu_ > 0.0
+    device.check_stream()
 
     lay = u[0].function_space().layout
     hist = lay._dev.get('step_history') if _uses_history() else None

@@ -303,6 +303,13 @@ class Comm(object):
 
 
 # -- partition (pure host logic, CPU-testable) ------------------------------------
+class StripsTooThin(ValueError):
+    '''A ghost range would reach past the immediate neighbour: the caller
+    picks the algorithm with the shallower halo (raised explicitly -- not an
+    assert: the choice must not depend on `python -O`, and a genuine invariant
+    failure must not be mistaken for it).'''
+
+
 class RowBlocks(object):
     '''Contiguous row blocks of ONE scalar space over the ranks, with the ghost
     ranges [lo_g, r0_g) and [r1_g, hi_g) each rank needs and the layout of the
@@ -319,11 +326,11 @@ class RowBlocks(object):
         for g in range(self.world):
             r0, r1 = self.rows(g)
             assert self.lo[g] <= r0 and self.hi[g] >= r1
-            # ghost rows must belong to the immediate neighbours only
-            left = self.bounds[g - 1] if g > 0 else 0
-            right = self.bounds[g + 2] if g + 2 <= self.world else n
-            assert self.lo[g] >= left and self.hi[g] <= right, \
-                'strips too thin: a ghost range reaches past the neighbour'
+        if not self.fits(self.bounds, self.lo, self.hi):
+            # (decided over ALL ranks before anything is raised: every rank
+            # sees the same verdict)
+            raise StripsTooThin(
+                'strips too thin: a ghost range reaches past the neighbour')
         slot = {}
         off = 0
         for q in range(self.world):
@@ -332,6 +339,19 @@ class RowBlocks(object):
                 off += ln
         self.nhalo = off
         self._slot = slot
+
+    @staticmethod
+    def fits(bounds, lo, hi):
+        '''Do the ghost ranges [lo_g, hi_g) stay within the immediate
+        neighbours' rows, for every rank?'''
+        world = len(bounds) - 1
+        n = int(bounds[-1])
+        for g in range(world):
+            left = bounds[g - 1] if g > 0 else 0
+            right = bounds[g + 2] if g + 2 <= world else n
+            if lo[g] < left or hi[g] > right:
+                return False
+        return True
 
     def rows(self, g):
         return int(self.bounds[g]), int(self.bounds[g + 1])
@@ -608,9 +628,36 @@ def _solve_info(its, res, name):
     return SolveInfo(its, res, '%s[x-strips x%d]' % (name, comm().world))
 
 
-def cg(A, dinv, b, x, rtol, atol=0.0, maxit=1000, check_every=2, tag=None):
+def _guarded(solve, x, guard):
+    '''The fallback chain of ops.krylov_solve(guard=...) around a sharded CG:
+    solve(rejected) runs the library's loop from x (rejected: a c_int to
+    receive the verdict on the start, or None: unguarded).  Returns the number
+    of starts dropped.'''
+    from .fem import ops
+    if guard is None:
+        solve(None)
+        return 0
+    rejected = ctypes.c_int(0)
+    solve(rejected)
+    if not rejected.value:
+        return 0
+    dropped = 1
+    if guard is not False:
+        ops.copy(x, guard)
+        solve(rejected)
+        if not rejected.value:
+            return dropped
+        dropped = 2
+    ops.fill(x, 0.0)
+    solve(None)
+    return dropped
+
+
+def cg(A, dinv, b, x, rtol, atol=0.0, maxit=1000, check_every=2, tag=None,
+       guard=None):
     '''Jacobi-CG on the strips (operator kind 0 or 4); b valid on the owned
-    rows, x on the owned rows (start) -> owned + ghost rows (solution).'''
+    rows, x on the owned rows (start) -> owned + ghost rows (solution).
+    guard: as ops.krylov_solve.'''
     from .fem import ops
     c = comm()
     lay = A.layout
@@ -625,15 +672,21 @@ def cg(A, dinv, b, x, rtol, atol=0.0, maxit=1000, check_every=2, tag=None):
     first = history[tag] + 1 if history is not None and tag in history else 0
     its = ctypes.c_int(0)
     res = ctypes.c_double(0.0)
-    _hip.check(_hip.lib().flow_shard_cg_solve(
-        ctypes.byref(c.struct), ctypes.byref(v.rows), ctypes.byref(op),
-        _hip.f64(dinv, n, 'dinv'), _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'),
-        float(rtol), float(atol), int(maxit), int(check_every), int(first),
-        _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
-        _hip.stream()))
+
+    def solve(rejected):
+        _hip.check(_hip.lib().flow_shard_cg_solve(
+            ctypes.byref(c.struct), ctypes.byref(v.rows), ctypes.byref(op),
+            _hip.f64(dinv, n, 'dinv'), _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'),
+            float(rtol), float(atol), int(maxit), int(check_every), int(first),
+            _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
+            ctypes.byref(rejected) if rejected is not None else None,
+            _hip.stream()))
+    dropped = _guarded(solve, x, guard)
     if history is not None:
         history[tag] = its.value
-    return _solve_info(its.value, res.value, 'cg')
+    out = _solve_info(its.value, res.value, 'cg')
+    out.starts_dropped = dropped
+    return out
 
 
 class MgShard(object):
@@ -692,8 +745,9 @@ class MgShard(object):
 
 
 def mgcg(A, dinv, mg, b, x, rtol, atol=0.0, maxit=1000, check_every=2,
-         tag=None):
-    '''CG + the strip-sharded V-cycle (the pressure solve).'''
+         tag=None, guard=None):
+    '''CG + the strip-sharded V-cycle (the pressure solve).  guard: as
+    ops.krylov_solve.'''
     from .fem import ops
     c = comm()
     lay = A.layout
@@ -708,8 +762,8 @@ def mgcg(A, dinv, mg, b, x, rtol, atol=0.0, maxit=1000, check_every=2,
             try:
                 rows2 = st.deep_blocks(lay, 2).struct(c.rank)
                 zrange = st.deep_ranges(lay, 2)[c.rank][1]
-            except AssertionError:
-                rows2 = zrange = None       # (strips too thin: two collectives)
+            except StripsTooThin:
+                rows2 = zrange = None       # (two collectives per iteration)
         mg.__dict__[key] = MgShard(mg, v, rows2, zrange)
     ms = mg.__dict__[key]
     n1 = ms.struct.Rg.n
@@ -726,15 +780,22 @@ def mgcg(A, dinv, mg, b, x, rtol, atol=0.0, maxit=1000, check_every=2,
     first = history[tag] + 1 if history is not None and tag in history else 0
     its = ctypes.c_int(0)
     res = ctypes.c_double(0.0)
-    _hip.check(_hip.lib().flow_shard_mgcg_solve(
-        ctypes.byref(c.struct), ctypes.byref(rows), ctypes.byref(op),
-        _hip.f64(dinv, n, 'dinv'), ctypes.byref(ms.struct),
-        _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
-        int(maxit), int(check_every), int(first), _hip.f64(wk), wk.numel(),
-        ctypes.byref(its), ctypes.byref(res), _hip.stream()))
+
+    def solve(rejected):
+        _hip.check(_hip.lib().flow_shard_mgcg_solve(
+            ctypes.byref(c.struct), ctypes.byref(rows), ctypes.byref(op),
+            _hip.f64(dinv, n, 'dinv'), ctypes.byref(ms.struct),
+            _hip.f64(b, n, 'b'), _hip.f64(x, n, 'x'), float(rtol), float(atol),
+            int(maxit), int(check_every), int(first), _hip.f64(wk), wk.numel(),
+            ctypes.byref(its), ctypes.byref(res),
+            ctypes.byref(rejected) if rejected is not None else None,
+            _hip.stream()))
+    dropped = _guarded(solve, x, guard)
     if history is not None:
         history[tag] = its.value
-    return _solve_info(its.value, res.value, 'cg+mg%d' % mg.nlevels)
+    out = _solve_info(its.value, res.value, 'cg+mg%d' % mg.nlevels)
+    out.starts_dropped = dropped
+    return out
 
 
 def gmres(Jop, pre, b, x, rtol, atol=0.0, maxit=1000, restart=20,
@@ -786,8 +847,8 @@ class MassStrips(object):
         rng = st.deep_ranges(lay, steps)[rank]
         try:
             self.rows = st.deep_blocks(lay, steps).struct(rank)
-        except AssertionError as e:
-            raise ValueError(
+        except StripsTooThin as e:
+            raise StripsTooThin(
                 'the mass solver\'s halo is %d coupling layers deep, a strip '
                 'of this decomposition is thinner (%s): fewer ranks, or '
                 "solver_parameters['correction']['method'] = 'cg' and "
@@ -840,9 +901,9 @@ def mass_solve(solver, b, x, rtol, atol=0.0, maxit=50, tag=None, xbase=None,
         try:
             solver.__dict__[key] = MassStrips(
                 solver, strips(solver.A.layout.mesh), c.rank)
-        except ValueError as e:
-            # (a decomposition is thin for every rank or for none: the deep
-            # ranges are built for all ranks before the assertion)
+        except StripsTooThin as e:
+            # (a decomposition is thin for every rank or for none: RowBlocks
+            # looks at all ranks before it raises)
             info('mass solves on these strips by Jacobi-CG: %s' % e)
             solver.__dict__[key] = None
             _MASS_FALLBACK[0] = True

@@ -697,6 +697,10 @@ int flow_shard_reduce_host(const flow_comm* comm, const flow_rows* rows,
  * products and the halo of w; stopping test, device-side convergence flag and
  * the meaning of first_check / check_every as flow_cg_solve.  Every rank runs
  * the same number of iterations (the sums are bitwise identical).
+ * start_rejected_host != NULL: the start vector is guarded as in
+ * flow_cg_solve_guarded -- ||B(b - A x)|| > ||B b|| (sums over all ranks: the
+ * same verdict everywhere) leaves x untouched, sets *start_rejected_host = 1
+ * and returns FLOW_OK: the caller swaps in its fallback and calls again.
  * work (16-B aligned): FLOW_REDUCE_WORK + 10 * ncomp * (e1 - e0) + A->nblocks
  * + 2 doubles, ncomp = 1 (kind 0) or 2 (kind 4). */
 int flow_shard_cg_solve(const flow_comm* comm, const flow_rows* rows,
@@ -704,7 +708,8 @@ int flow_shard_cg_solve(const flow_comm* comm, const flow_rows* rows,
                         const double* b, double* x, double rtol, double atol,
                         int maxit, int check_every, int first_check,
                         double* work, size_t work_len, int* iters_host,
-                        double* resid_host, void* stream);
+                        double* resid_host, int* start_rejected_host,
+                        void* stream);
 
 /* The pressure solve on the strips: CG preconditioned with the SAME smoothed-
  * aggregation V(1,1) cycle as flow_cg_solve (same iteration counts).  The
@@ -749,7 +754,8 @@ int flow_shard_mgcg_solve(const flow_comm* comm, const flow_rows* rows,
                           const flow_mg_shard* mgs, const double* b, double* x,
                           double rtol, double atol, int maxit, int check_every,
                           int first_check, double* work, size_t work_len,
-                          int* iters_host, double* resid_host, void* stream);
+                          int* iters_host, double* resid_host,
+                          int* start_rejected_host, void* stream);
 
 /* The mass solver of K18 on the strips.  A correction's polynomial reaches
  * steps - 1 matrix hops: with the scaled defect known on a ghost zone `steps`

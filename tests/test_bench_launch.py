@@ -16,7 +16,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ARGS = ['--gpus', '2', '--backend', 'gloo', '--nx', '96', '--steps', '2',
+ARGS = ['--gpus', '2', '--backend', 'gloo', '--nx', '192', '--steps', '2',
         '--warmup', '1', '--no-cpu-baseline', '--no-hbm-resident',
         '--no-fast-leg', '--spmv-reps', '5']
 

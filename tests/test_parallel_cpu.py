@@ -106,8 +106,11 @@ def test_strips_cover_the_mesh_and_halo_slots_are_consistent(world):
 
 def test_strips_too_thin_are_refused():
     mesh = _mesh()
-    with pytest.raises(AssertionError):
+    with pytest.raises(parallel.StripsTooThin):
         parallel.Strips(mesh, 150).blocks(scalar_layout(mesh, 2))
+    # (a ValueError of its own, so that callers can choose the algorithm with
+    # the shallower halo without catching genuine invariant failures)
+    assert issubclass(parallel.StripsTooThin, ValueError)
 
 
 @pytest.mark.parametrize('world', [2, 3])

@@ -196,7 +196,7 @@ def test_multigrid_level0_stays_inside_the_window(host_structs, world):
         # owned part of a vector in local numbering
         try:
             deep = st.deep_blocks(lay, 2)
-        except AssertionError:
+        except parallel.StripsTooThin:
             continue                        # (strips too thin at this size)
         for g in range(world):
             v = parallel.View(lay, st, g)

@@ -39,14 +39,22 @@ def main():
         prob.step()
     fields = (('newton', prob.W.layout, 'newton_increments', 1),
               ('newton#2', prob.W.layout, ('newton_increments', 1), 1),
-              ('pressure', prob.P.layout, 'pressure_increments', 1),
+              ('pressure', prob.W.layout, 'pressure_increments', 1),
               ('correction', prob.W.layout, 'correction_increments', 2))
+
+    def history(lay, key):
+        # (round 5: the histories belong to the trajectory of the run,
+        # flow_amd/navier_stokes/start_vectors.py)
+        st = lay._dev.get('start_vector_state')
+        if st is None or not st.trajectories:
+            return []
+        return max(st.trajectories, key=lambda t: t.used).hist.get(key, [])
     errs = {f[0]: {c: [] for c in CANDIDATES} for f in fields}
     counts = []
     for k in range(steps):
         preds = {}
         for name, lay, key, power in fields:
-            hist = lay._dev.get(key, [])
+            hist = history(lay, key)
             for (m, q) in CANDIDATES:
                 if len(hist) < m:
                     continue
@@ -64,9 +72,9 @@ def main():
                        info['pressure'].iterations,
                        info['correction'].iterations))
         for name, lay, key, power in fields:
-            if not lay._dev.get(key):
+            if not history(lay, key):
                 continue
-            actual = lay._dev[key][0][0]
+            actual = history(lay, key)[0][0]
             na = ops.vector_norm(actual)
             for (m, q) in CANDIDATES:
                 p = preds.get((name, m, q))
