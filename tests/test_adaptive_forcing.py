@@ -1,0 +1,131 @@
+# -*- coding: utf-8 -*-
+'''
+Loose linear solves for Newton iterations that cannot be the last one
+(navier_stokes.solver_parameters['newton']['adaptive_forcing'], mode 'parity'):
+the reference solves every Newton system exactly (LU, flow/navier_stokes/
+pressure_correction.py:224-254); here an iterate the quadratic model says
+cannot pass the Newton test only serves as the next linearisation point, and
+what its loose solve leaves the next Newton step removes.  What must hold:
+
+  * an iterate that IS accepted always comes from a tight solve -- also when
+    the prediction was wrong (the loose solve is then continued: `finish`);
+  * the accepted fields are those of the run with every solve tight.
+GPU only.
+'''
+import numpy
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem():
+    from flow_amd import karman
+    import flow_amd.navier_stokes as navsto
+    navsto.solver_parameters['pressure']['mg_coarsest'] = 200
+    prob = karman.KarmanProblem(193, 45, mu=0.0226)
+    prob.prepare()
+    prob.reset(1.0e-5)
+    prob.set_initial_stokes()
+    navsto.set_mode('parity')
+    prob.settle()
+    return prob
+
+
+def test_a_wrong_prediction_never_lets_a_loose_solve_be_accepted(hip):
+    '''The margin of the quadratic model is set absurdly low on a settled
+    flow: the model says no iterate can pass, every system is solved loosely
+    -- and the last iterate passes.  The
+    solve is continued to the tight tolerance: same Newton count, same fields
+    as with adaptive forcing off, and the path is reported.'''
+    from flow_amd import device
+    import flow_amd.navier_stokes as navsto
+    saved = dict(navsto.solver_parameters['newton'])
+    try:
+        prob = _problem()
+        snap = prob.snapshot()
+        out = {}
+        for mode in ('off', 'wrong'):
+            navsto.solver_parameters['newton']['adaptive_forcing'] = mode != 'off'
+            if mode == 'wrong':
+                # "cannot pass" as soon as the predicted remainder exceeds
+                # 1e-6 * tol, and then only half of it asked for: also the
+                # LAST iterate of a step comes from a loose solve
+                navsto.solver_parameters['newton']['intermediate_margin'] = 1e-6
+                navsto.solver_parameters['newton']['intermediate_fraction'] = 0.5
+            prob.restore(snap)
+            rows = []
+            for k in range(4):
+                before = navsto.last_step_info.get(
+                    'newton_finished_loose_solves', 0)
+                info = prob.step()
+                rows.append(dict(
+                    u=device.to_host(prob.u0.data).numpy().copy(),
+                    p=device.to_host(prob.p0.data).numpy().copy(),
+                    newton=len(info['newton_residuals']) - 1,
+                    last=info['newton_linear_residuals'][-1],
+                    first=info['newton_linear_residuals'][0],
+                    finished=navsto.last_step_info.get(
+                        'newton_finished_loose_solves', 0) - before))
+            out[mode] = rows
+    finally:
+        navsto.solver_parameters['newton'].clear()
+        navsto.solver_parameters['newton'].update(saved)
+    for a, b in zip(out['off'], out['wrong']):
+        assert a['newton'] == b['newton'] >= 1
+        assert a['finished'] == 0
+        # (fraction 0.5 is three and a half decades looser than the default:
+        # what the next Newton step does not remove of it stays below 1e-7)
+        assert numpy.linalg.norm(a['u'] - b['u']) < 1e-7 * numpy.linalg.norm(a['u'])
+        assert numpy.linalg.norm(a['p'] - b['p']) < 1e-7 * numpy.linalg.norm(a['p'])
+        # the accepted iterate's linear system was solved to the tight
+        # tolerance (1e-6 of the Newton tolerance 1e-10) in both runs
+        assert a['last'] <= 1.0e-16 and b['last'] <= 1.0e-16
+    # (the first step has no model yet; afterwards every step ends that way)
+    assert [r['finished'] for r in out['wrong'][1:]] == [1, 1, 1]
+    # ... and the intermediate solves really were loose
+    assert all(r['first'] > 1.0e-14 for r in out['wrong'][1:])
+
+
+def test_loose_intermediate_solves_do_not_move_multi_iteration_steps(hip):
+    '''Steps that take several Newton iterations (the 160 x 37 channel with
+    the viscosity scaled to the headline's cell Peclet number, from a state that
+    is not a solution of anything), 6 of them in a row so that
+    the quadratic model is known: with adaptive forcing the intermediate
+    solves are loose and cheaper, the accepted fields agree with the all-tight
+    run to 1e-8, the Newton counts are the same.'''
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import large_cases
+    import flow_amd.navier_stokes as navsto
+    saved = dict(navsto.solver_parameters['newton'])
+    case = large_cases.KarmanStepCase(160, 37, mu=0.02)
+    out = {}
+    try:
+        for mode in (False, True):
+            navsto.solver_parameters['newton']['adaptive_forcing'] = mode
+            navsto.forget_history(case.W)
+            case.W.layout._dev.pop('newton_quad_C', None)
+            u, p = case.u0, case.p0
+            rows = []
+            for k in range(6):
+                u, p, _ = case.product_step(u0=u, p0=p)
+                rows.append((u.copy(), p.copy(),
+                             list(navsto.last_step_info['newton_residuals']),
+                             list(navsto.last_step_info[
+                                 'newton_linear_applications'])))
+            out[mode] = rows
+    finally:
+        navsto.solver_parameters['newton'].clear()
+        navsto.solver_parameters['newton'].update(saved)
+    loose_apps = tight_apps = 0
+    for (ua, pa, ra, aa), (ub, pb, rb, ab) in zip(out[False], out[True]):
+        assert len(ra) == len(rb), (ra, rb)
+        assert numpy.linalg.norm(ua - ub) < 1e-8 * numpy.linalg.norm(ua)
+        assert numpy.linalg.norm(pa - pb) < 1e-8 * numpy.linalg.norm(pa)
+        tight_apps += sum(aa)
+        loose_apps += sum(ab)
+    print('GMRES applications over 6 steps: all solves tight %d, loose '
+          'intermediate solves %d' % (tight_apps, loose_apps))
+    assert any(len(r[2]) > 2 for r in out[True])
+    assert loose_apps < tight_apps
