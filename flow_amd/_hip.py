@@ -130,6 +130,7 @@ class PmgS(ctypes.Structure):
         ('rptr', ctypes.c_void_p), ('rsrc', ctypes.c_void_p),
         ('bc_fine', ctypes.c_void_p), ('bc_coarse', ctypes.c_void_p),
         ('work', ctypes.c_void_p),
+        ('scalar', ctypes.c_int),
         ]
 
 

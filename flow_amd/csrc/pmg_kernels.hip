@@ -163,9 +163,11 @@ __device__ __forceinline__ float2 pmg_tile_row_sum(
 // (`vals`: a 32-bit word per nonzero, fp16 value | 16-bit column offset) --
 // rows flagged in idrows (component-blocked, stride n) are identity rows of
 // their component.
+// zs: component stride of z and rin (n; 0 in scalar mode -- both components
+// then carry the same numbers and z has n entries)
 template <int MODE, int FMT>
 __global__ __launch_bounds__(kBlock) void pmg_cheb_kernel(
-    int n, const int* __restrict__ rowptr, const void* __restrict__ cols,
+    int n, int zs, const int* __restrict__ rowptr, const void* __restrict__ cols,
     const int* __restrict__ cbase,
     const void* __restrict__ vals, const unsigned char* __restrict__ idrows,
     const int* __restrict__ rowblocks,
@@ -233,17 +235,17 @@ __global__ __launch_bounds__(kBlock) void pmg_cheb_kernel(
   double zx = acc.x, zy = acc.y;
   if (bc) {
     if (bc[r]) zx = rin[r];
-    if (bc[n + r]) zy = rin[static_cast<size_t>(n) + r];
+    if (bc[n + r]) zy = rin[static_cast<size_t>(zs) + r];
   }
   z[r] = zx;
-  z[static_cast<size_t>(n) + r] = zy;
+  if (zs) z[static_cast<size_t>(zs) + r] = zy;
 }
 
 // start of the cycle: the fp64 component-blocked input becomes the scaled
 // residual rho0 = D^-1 r (kept for the post-smoothing), rho = rho0 and
 // d0 = rho0 / theta
 __global__ __launch_bounds__(kBlock) void pmg_init_kernel(
-    int n, const double* __restrict__ r, const float2* __restrict__ dinv,
+    int n, int rs, const double* __restrict__ r, const float2* __restrict__ dinv,
     float inv_theta, float2* __restrict__ rho0, float2* __restrict__ rho,
     float2* __restrict__ d, const double* __restrict__ stop) {
   if (stopped(stop)) return;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void pmg_init_kernel(
        i += gridDim.x * blockDim.x) {
     const float2 di = dinv[i];
     const float2 v = f2(static_cast<float>(r[i]) * di.x,
-                        static_cast<float>(r[static_cast<size_t>(n) + i]) * di.y);
+                        static_cast<float>(r[static_cast<size_t>(rs) + i]) * di.y);
     rho0[i] = v;
     rho[i] = v;
     d[i] = f2(inv_theta * v.x, inv_theta * v.y);
@@ -561,10 +563,11 @@ int pmg_check(const flow_pmg* M, int op_size) {
   int rc = check_level(&M->fine, "fine level of flow_pmg");
   if (rc) return rc;
   if ((rc = check_level(&M->coarse, "coarse level of flow_pmg"))) return rc;
-  FLOW_REQUIRE(2 * M->fine.n == op_size, "flow_pmg does not match the operator");
+  FLOW_REQUIRE((M->scalar ? 1 : 2) * M->fine.n == op_size,
+               "flow_pmg does not match the operator");
   FLOW_REQUIRE(M->pre >= 1 && M->post >= 1 && M->coarse_steps >= 1 &&
-                   M->pre <= 3 && M->post <= 3 && M->coarse_steps <= 32,
-               "Chebyshev step counts (pre, post: 1..3; coarse: 1..32)");
+                   M->pre <= 3 && M->post <= 3 && M->coarse_steps <= 64,
+               "Chebyshev step counts (pre, post: 1..3; coarse: 1..64)");
   FLOW_REQUIRE(M->ends && M->rptr && M->rsrc && M->work, "flow_pmg pointers");
   FLOW_REQUIRE(reinterpret_cast<uintptr_t>(M->work) % 16 == 0,
                "flow_pmg work must be 16-byte aligned");
@@ -593,23 +596,24 @@ void launch_cheb(const flow_pmg_level* L, const float2* g, const float2* rho_in,
                  float2* rho_out, const float2* d_own, float c1, float c2,
                  float2* d_out, float2* x, const float2* d_extra, double* z,
                  const unsigned char* bc, const double* rin, const double* stop,
-                 hipStream_t st) {
+                 hipStream_t st, int zstride = -1) {
+  const int zs = zstride < 0 ? L->n : zstride;
   if (L->packed)
     hipLaunchKernelGGL((pmg_cheb_kernel<MODE, 2>), dim3(L->nblocks), dim3(kBlock),
-                       0, st, L->n, L->rowptr, static_cast<const void*>(nullptr),
+                       0, st, L->n, zs, L->rowptr, static_cast<const void*>(nullptr),
                        L->cbase, L->packed, L->idrows, L->rowblocks, g, rho_in,
                        rho_out, d_own, c1, c2, d_out, x, d_extra, z, bc, rin,
                        stop);
   else if (L->cols16)
     hipLaunchKernelGGL((pmg_cheb_kernel<MODE, 1>), dim3(L->nblocks), dim3(kBlock),
-                       0, st, L->n, L->rowptr,
+                       0, st, L->n, zs, L->rowptr,
                        static_cast<const void*>(L->cols16), L->cbase, L->vals,
                        static_cast<const unsigned char*>(nullptr), L->rowblocks,
                        g, rho_in, rho_out, d_own, c1, c2, d_out, x, d_extra, z,
                        bc, rin, stop);
   else
     hipLaunchKernelGGL((pmg_cheb_kernel<MODE, 0>), dim3(L->nblocks), dim3(kBlock),
-                       0, st, L->n, L->rowptr, static_cast<const void*>(L->cols),
+                       0, st, L->n, zs, L->rowptr, static_cast<const void*>(L->cols),
                        L->cbase, L->vals,
                        static_cast<const unsigned char*>(nullptr), L->rowblocks,
                        g, rho_in, rho_out, d_own, c1, c2, d_out, x, d_extra, z,
@@ -643,8 +647,10 @@ int pmg_apply(const flow_pmg* M, const double* r, double* z, hipStream_t st,
 
   // pre-smoothing from x = 0: d[0 .. pre-1]
   Cheb pre(F->lam_min, F->lam_max);
-  hipLaunchKernelGGL(pmg_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, r,
-                     fdinv, pre.first(), rho0, rho, d[0], stop);
+  // (scalar mode: ONE fp64 component in and out, carried in both lanes)
+  const int zs = M->scalar ? 0 : n;
+  hipLaunchKernelGGL(pmg_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, zs,
+                     r, fdinv, pre.first(), rho0, rho, d[0], stop);
   for (int j = 1; j < M->pre; ++j) {
     pre.next(&c1, &c2);
     launch_cheb<1>(F, d[j - 1], rho, rho, d[j - 1], c1, c2, d[j], none, none, nod,
@@ -675,7 +681,7 @@ int pmg_apply(const flow_pmg* M, const double* r, double* z, hipStream_t st,
   Cheb post(F->lam_min, F->lam_max);
   if (M->post == 1) {
     launch_cheb<2>(F, x, rho0, none, none, 0.f, post.first(), none, x, none, z,
-                   M->bc_fine, r, stop, st);
+                   M->bc_fine, r, stop, st, zs);
   } else {
     launch_cheb<1>(F, x, rho0, rho, none, 0.f, post.first(), d[0], none, none, nod,
                    nob, nod, stop, st);
@@ -683,7 +689,7 @@ int pmg_apply(const flow_pmg* M, const double* r, double* z, hipStream_t st,
       post.next(&c1, &c2);
       if (j + 1 == M->post)
         launch_cheb<2>(F, d[j - 1], rho, none, d[j - 1], c1, c2, none, x,
-                       j == 2 ? d[0] : none, z, M->bc_fine, r, stop, st);
+                       j == 2 ? d[0] : none, z, M->bc_fine, r, stop, st, zs);
       else
         launch_cheb<1>(F, d[j - 1], rho, rho, d[j - 1], c1, c2, d[j], none, none,
                        nod, nob, nod, stop, st);
@@ -827,7 +833,7 @@ extern "C" int flow_pmg_lambda_max(const flow_pmg_level* L, int iterations,
 extern "C" int flow_pmg_apply(const flow_pmg* M, const double* r, double* z,
                               void* stream) {
   FLOW_REQUIRE(M != nullptr && r && z, "flow_pmg_apply arguments");
-  int rc = pmg_check(M, 2 * M->fine.n);
+  int rc = pmg_check(M, (M->scalar ? 1 : 2) * M->fine.n);
   if (rc) return rc;
   return pmg_apply(M, r, z, as_stream(stream), nullptr);
 }

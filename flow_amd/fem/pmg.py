@@ -210,10 +210,22 @@ class _Level(object):
         self._fill_struct(self.rowptr, self._cols, self._rb)
 
     def pack(self, J):
-        '''Diagonal blocks (planes 0 and 3) of a kind-2 Matrix on this layout.'''
+        '''Diagonal blocks (planes 0 and 3) of a kind-2 Matrix on this layout;
+        a scalar Matrix (kind 0) fills both planes (flow_pmg.scalar).'''
         lay = self.lay
-        assert J.layout is lay and J.kind == 2
+        assert J.layout is lay and J.kind in (0, 2)
         n, nnz, k0 = self.n, self.nnz, self.offset
+        if J.kind == 0:
+            assert self._packed is None
+            a = J.vals[k0:k0 + nnz]
+            _hip.check(_hip.lib().flow_pmg_pack(
+                n, nnz, _hip.i32(self.rowptr, n + 1, 'rowptr'),
+                _hip.i32(self.diag_idx, n, 'diag_idx'),
+                _hip.f64(a, nnz), _hip.f64(a, nnz),
+                _hip.u8(self.keep, nnz) if self.keep is not None else None,
+                _hip.f16(self.vals, 2 * nnz), _hip.f32(self.diag, 2 * n),
+                _hip.f32(self.dinv, 2 * n), _hip.stream()))
+            return
         if self._packed is not None:
             pk, idr = self._packed
             rb, cb = self._rb_used, self._cols16[1]
@@ -270,12 +282,25 @@ class Pmg(object):
     flat optimum).'''
 
     def __init__(self, W, pre=1, post=2, coarse_steps=6, ratio_fine=5.0,
-                 ratio_coarse=12.0, safety=1.1, rows=None, vrows=None):
+                 ratio_coarse=12.0, safety=1.1, rows=None, vrows=None,
+                 scalar=False, coarse_auto=False, coarse_max=48):
         '''rows / vrows = (r0, r1) / (v0, v1): block Jacobi on a strip -- the
         cycle on the diagonal block of those P2 / P1 rows in local numbering,
-        couplings that leave the block dropped (flow_amd/parallel.py).'''
+        couplings that leave the block dropped (flow_amd/parallel.py).
+        scalar: W is a scalar P2 space, the operator a scalar one (the heat
+        system): `refactor` takes kind-0 matrices, `apply` vectors of W.N
+        entries, `set_bcs` scalar dof numbers.
+        coarse_auto: the Chebyshev treatment of the P1 level is sized from an
+        estimate of its condition number at every `refactor` (`mass_share`):
+        the hand-tuned steps at CFL-sized time steps, more of them -- with the
+        square root of the estimate, at most coarse_max -- where the level is
+        a diffusion problem (dt >> h^2 / nu).'''
         lay = W.layout
-        assert lay.degree == 2, 'the p-multigrid needs a P2 velocity space'
+        assert lay.degree == 2, 'the p-multigrid needs a P2 space'
+        self.scalar = bool(scalar)
+        self.coarse_auto = bool(coarse_auto)
+        self.coarse_max = int(coarse_max)
+        self.coarse_steps0, self.ratio_coarse0 = int(coarse_steps), ratio_coarse
         self.lay = lay
         self.lay1 = scalar_layout(lay.mesh, 1)
         self.rows, self.vrows = rows, vrows
@@ -309,6 +334,7 @@ class Pmg(object):
         s.bc_fine = _hip.u8(k['bc_fine'], 2 * n).value
         s.bc_coarse = _hip.u8(k['bc_coarse'], 2 * n1).value
         s.work = _hip.f32(k['work'], 12 * n + 8 * n1 + 2).value
+        s.scalar = int(self.scalar)
         assert k['work'].data_ptr() % 16 == 0
         self.struct = s
         self._bc_key = None
@@ -333,6 +359,11 @@ class Pmg(object):
         if key == self._bc_key:
             return self._bc1
         n, n1 = self.lay.N, self.lay1.N
+        if self.scalar:
+            # (both lanes carry the one component: the masks are duplicated;
+            # the coarse dof list that is returned is the scalar one)
+            d = numpy.asarray(bc_dofs_host, dtype=numpy.int64)
+            bc_dofs_host = numpy.concatenate([d, n + d])
         m0 = numpy.zeros(2 * n, dtype=numpy.uint8)
         m0[bc_dofs_host] = 1
         bc1 = self.coarse_bc_dofs(bc_dofs_host)
@@ -346,17 +377,48 @@ class Pmg(object):
         self._keep['bc_coarse'].copy_(torch.from_numpy(m1))
         device.synchronize()
         self._bc_key = key
-        self._bc1 = (bc1, device.to_device(bc1))
+        if self.scalar:
+            bc1 = bc1[bc1 < n1]
+        self._bc1 = (bc1, device.to_device(bc1) if len(bc1) else None)
         return self._bc1
 
     # -- numbers -------------------------------------------------------------------
-    def refactor(self, J, J1):
+    def refactor(self, J, J1, mass_share=None):
+        '''mass_share (coarse_auto): a lower bound for the share of the mass
+        term in the diagonal of the P1 operator, min_i (alpha M)_ii / (J1)_ii
+        over its free rows.  The operator is the mass term plus a (nearly)
+        positive semi-definite rest, so lam_min(D^-1 J1) >= lam_min(D_M^-1 M)
+        * mass_share ~ 0.4 * mass_share: the condition number the Chebyshev
+        steps on that level face.'''
         self.fine.pack(J)
         self.coarse.pack(J1)
         work = self._keep['work']
         lam0 = self.fine.lambda_max(work)
         lam1 = self.coarse.lambda_max(work)
         self.lam = (lam0, lam1)
+        if self.coarse_auto and mass_share is not None:
+            # The hand-tuned pair (coarse_steps, ratio_coarse) belongs to
+            # CFL-sized steps, where this estimate of the condition number
+            # reads ~70 (tools/debug_pmg_auto.py: 69 on the 160 x 37 channel at
+            # diffusion number 0.5 -- the bound is pessimistic, the Krylov
+            # method deals with the low end).  Up to three times that nothing
+            # changes (a longer polynomial over a wider interval is WORSE
+            # there: contraction 0.38 instead of 0.24, and it amplifies the
+            # complex eigenvalues of the convection term).  Beyond -- dt >>
+            # h^2 / nu -- the interval grows with the estimate and the step
+            # count with its square root, which keeps the quality of the
+            # tuned point; with the count capped the interval is cut to what
+            # those steps cover.
+            est = self.safety * lam1 / max(0.4 * mass_share, 1e-6)
+            scale = est / 70.0
+            steps, ratio = self.coarse_steps0, self.ratio_coarse0
+            if scale > 3.0:
+                steps = int(numpy.ceil(self.coarse_steps0 * numpy.sqrt(scale)))
+                steps = min(steps, self.coarse_max)
+                ratio = self.ratio_coarse0 * (
+                    steps / float(self.coarse_steps0))**2
+            self.ratio_coarse = ratio
+            self.struct.coarse_steps = steps
         for lvl, lam, ratio in ((self.fine, lam0, self.ratio_fine),
                                 (self.coarse, lam1, self.ratio_coarse)):
             lvl.struct.lam_max = self.safety * lam
@@ -369,7 +431,7 @@ class Pmg(object):
     def apply(self, r, z):
         '''z = M^-1 r (tests / direct use); on a block: vectors of the block's
         rows, component stride = its size.'''
-        n2 = 2 * self.fine.n
+        n2 = (1 if self.scalar else 2) * self.fine.n
         _hip.check(_hip.lib().flow_pmg_apply(
             ctypes.byref(self.struct), _hip.f64(r, n2, 'r'), _hip.f64(z, n2, 'z'),
             _hip.stream()))

@@ -42,7 +42,19 @@ from . import parallel
 from . import stabilization
 
 solver_parameters = {'rtol': 1.0e-13, 'maxit': 2000, 'check_every': 10,
-                     'preconditioner': 'ilu0',     # 'ilu0' | 'jacobi'
+                     # 'pmg' (P2 spaces on one GPU; else 'ilu0'): the two-level
+                     # p-multigrid cycle of flow_amd/fem/pmg.py in its scalar
+                     # mode -- Chebyshev smoothing on the P2 operator, the P1
+                     # discretisation of the same operator (assembled by the P1
+                     # instance of the heat kernel) as the coarse level, treated
+                     # with as many Chebyshev steps as its condition number
+                     # asks for -- where one cycle contracts (`pmg_accept`),
+                     # else the multicolour ILU(0); | 'ilu0' | 'jacobi'
+                     'preconditioner': 'pmg', 'pmg_accept': 0.7,
+                     'pmg_maxit': 30, 'pmg_retry': 8,
+                     'pmg': {'pre': 1, 'post': 2, 'coarse_steps': 6,
+                             'ratio_fine': 8.0, 'ratio_coarse': 12.0,
+                             'coarse_auto': True, 'coarse_max': 48},
                      # 'previous': the solve starts from the solution of the
                      # previous solve on the space; 'zero': no history
                      'start': 'previous'}
@@ -76,6 +88,10 @@ class Heat(object):
         nc = mesh.num_cells()
         rho_cp = float(rho) * float(cp)
         kappa = float(kappa)
+        # (what the P1 coarse level of the solver's preconditioner is
+        # assembled from, on demand)
+        self._form = (conv, kappa, rho_cp, bool(supg_stabilization))
+        self._coarse = None
 
         lumped = ops.assemble_scalar_matrix(lay, ops.LUMPED_MASS)
         self.A = ops.Matrix(lay, 0)
@@ -199,6 +215,16 @@ class Heat(object):
         # the Krylov solve gets diag(A)^-1 A x = diag(A)^-1 b, where a relative
         # residual is a relative error to within the conditioning of a
         # diagonally scaled M-matrix-like operator.
+        pmg_ready = None
+        rejected = lay._dev.get('heat_pmg_rejected', 0)
+        if rejected > 0:
+            lay._dev['heat_pmg_rejected'] = rejected - 1
+        if solver_parameters.get('preconditioner') == 'pmg' \
+                and lay.degree == 2 and not parallel.active() \
+                and rejected <= 0:
+            # (packed from the UNSCALED operator: the rediscretised P1 level
+            # goes with the finite-element scaling of the rows)
+            pmg_ready = self._pmg(A, float(alpha), float(beta), dofs)
         dinv = A.diag_inv()
         if parallel.active():
             # (rows the rank does not own are empty here: keep them finite)
@@ -238,21 +264,61 @@ class Heat(object):
             self._remember(lay, u.data, warm, start)
             return u
         pre = None
-        if par.get('preconditioner', 'ilu0') == 'ilu0':
+        kind = par.get('preconditioner', 'ilu0')
+        pmg = None
+        if kind == 'pmg':
+            pmg = pmg_ready
+            kind = 'pmg' if pmg is not None else 'ilu0'
+        if pmg is not None:
+            # one application of the error propagation on a fixed full-
+            # spectrum vector: the cycle is used where it contracts.
+            # Chebyshev smoothing assumes a spectrum near the real axis; the
+            # skew convection term puts imaginary parts ~ |conv| dt / h there:
+            # beyond CFL ~ 3 the cycle amplifies -- first locally (a plume),
+            # where this probe does not see it yet: a solve that has not
+            # converged after `pmg_maxit` iterations goes on with the ILU(0);
+            # a rejection stands for the next `pmg_retry` solves
+            c = self._contraction(pmg, A, dofs)
+            last_solve_info['heat_pmg_contraction'] = c
+            last_solve_info['heat_pmg_coarse_steps'] = pmg.struct.coarse_steps
+            if not c < par.get('pmg_accept', 0.8):
+                pmg, kind = None, 'ilu0'
+                lay._dev['heat_pmg_rejected'] = int(par.get('pmg_retry', 8))
+        if kind == 'ilu0':
             # The zero-mass edge rows and the skew convection make the diagonal
             # a poor preconditioner; the reference solves with LU (:116-121).
             from .fem import ilu
             pre = ilu.Ilu0(A)
-        # GMRES(30) + ILU(0) (minimises the residual monotonically; BiCGStab
-        # stagnates on very coarse meshes, where most rows are zero-mass edge
-        # rows), BiCGStab as the second try
+        # GMRES(30) with the cycle or the ILU(0) (minimises the residual
+        # monotonically; BiCGStab stagnates on very coarse meshes, where most
+        # rows are zero-mass edge rows), BiCGStab + ILU(0) as the second try
         try:
             info = ops.krylov_solve(
                 'gmres', A, bvec, u.data, rtol=par['rtol'], atol=0.0,
-                maxit=par['maxit'], ilu=pre, restart=30, x_is_zero=not warm,
-                dinv='jacobi' if pre is None else None
+                maxit=par['maxit'] if pmg is None
+                else min(par['maxit'], int(par.get('pmg_maxit', 30))),
+                ilu=pre, pmg=pmg, restart=30, x_is_zero=not warm,
+                dinv='jacobi' if pre is None and pmg is None else None
                 )
         except _hip.NotConverged:
+            if pmg is not None:
+                # (the cycle passed the probe and GMRES stalled all the same:
+                # the ILU(0) goes on from the iterate it left)
+                from .fem import ilu
+                pre = ilu.Ilu0(A)
+                lay._dev['heat_pmg_rejected'] = int(par.get('pmg_retry', 8))
+                if not bool(torch.isfinite(u.data).all()):
+                    ops.fill(u.data, 0.0)
+                try:
+                    info = ops.krylov_solve(
+                        'gmres', A, bvec, u.data, rtol=par['rtol'], atol=0.0,
+                        maxit=par['maxit'], ilu=pre, restart=30,
+                        x_is_zero=False)
+                    last_solve_info['heat'] = info
+                    self._remember(lay, u.data, warm, start)
+                    return u
+                except _hip.NotConverged:
+                    pass
             ops.fill(u.data, 0.0)
             info = ops.krylov_solve(
                 'bicgstab', A, bvec, u.data, rtol=par['rtol'], atol=0.0,
@@ -261,6 +327,89 @@ class Heat(object):
         last_solve_info['heat'] = info
         self._remember(lay, u.data, warm, start)
         return u
+
+    # -- the p-multigrid preconditioner of the solve ---------------------------
+    def _coarse_operators(self, lay1):
+        '''M and A of the same form on the P1 space of the mesh (the P1
+        instance of the heat kernel), once per Heat object.'''
+        if self._coarse is None:
+            conv, kappa, rho_cp, supg = self._form
+            lib = _hip.lib()
+            mesh = self.V.mesh()
+            W = conv.function_space()
+            nc = mesh.num_cells()
+            M1 = ops.assemble_scalar_matrix(lay1, ops.LUMPED_MASS)
+            A1 = ops.Matrix(lay1, 0)
+            msupg = ops.value_plane(lay1) if supg else None
+            status = device.zeros(1, dtype=torch.int32)
+            buf = ops.scratch(mesh, 2 * lay1.nloc**2 * nc)
+            _hip.check(lib.flow_assemble_heat(
+                ctypes.byref(ops.mesh_struct(mesh)),
+                ctypes.byref(ops.space_struct(lay1)),
+                ctypes.byref(ops.space_struct(W.layout)),
+                _hip.f64(conv.data, W.size()), kappa, rho_cp, int(supg),
+                _hip.f64(buf), _hip.f64(A1.vals), _hip.f64(msupg), None,
+                _hip.i32(status), _hip.stream()))
+            if supg:
+                ops.axpby(1.0, M1.vals, 1.0, msupg)
+                M1 = ops.Matrix(lay1, 0, msupg)
+            self._coarse = (M1, A1)
+        return self._coarse
+
+    def _pmg(self, S, alpha, beta, bc_dofs_host):
+        '''The cycle for S = alpha M + beta A (unscaled, Dirichlet rows already
+        identity rows) -- as the right preconditioner of the ROW-SCALED system
+        the Krylov method sees: M^-1 r~ = cycle(D r~), i.e. the cycle is fed
+        the scaled residual as its scaled residual (the fine level's own
+        row scaling in its first kernel is switched off).'''
+        import numpy
+        from .fem.pmg import Pmg
+        lib = _hip.lib()
+        lay = self.V.layout
+        held = lay._dev.get('heat_pmg')
+        if held is None:
+            held = lay._dev['heat_pmg'] = Pmg(
+                self.V, scalar=True, **solver_parameters.get('pmg', {}))
+        pmg = held
+        lay1 = pmg.lay1
+        M1, A1 = self._coarse_operators(lay1)
+        S1 = lay._dev.get('heat_pmg_S1')
+        if S1 is None:
+            S1 = lay._dev['heat_pmg_S1'] = ops.Matrix(lay1, 0)
+        ops.axpby(alpha, M1.vals, 0.0, S1.vals)
+        ops.axpby(beta, A1.vals, 1.0, S1.vals)
+        bc1_host, bc1 = pmg.set_bcs(numpy.asarray(bc_dofs_host))
+        if len(bc1_host):
+            _hip.check(lib.flow_bc_identity_rows(
+                ctypes.byref(S1.operator()), _hip.f64(S1.vals),
+                _hip.i32(lay1.dev('diag_idx')), len(bc1_host), _hip.i32(bc1),
+                _hip.stream()))
+        # share of the mass term in the diagonal of the P1 operator (free rows)
+        di = lay1.dev('diag_idx').long()
+        share = alpha * M1.vals[di] / S1.vals[di]
+        if len(bc1_host):
+            share[bc1.long()] = 1.0
+        share = float(device.to_host(share.min()))
+        if not (share > 0.0):
+            return None       # (not a mass term plus a positive rest)
+        pmg.refactor(S, S1, mass_share=share)
+        pmg.fine.dinv.fill_(1.0)
+        return pmg
+
+    def _contraction(self, pmg, A, bc_dofs_host):
+        import numpy
+        lay = self.V.layout
+        n = lay.N
+        hold = lay._dev.setdefault('heat_pmg_probe', {})
+        key = hash(numpy.asarray(bc_dofs_host).tobytes())
+        if hold.get('key') != key:
+            v = numpy.random.RandomState(7).standard_normal(n)
+            v[bc_dofs_host] = 0.0
+            hold.update(key=key, v=device.to_device(v), w=device.empty(n),
+                        z=device.empty(n))
+        v, w, z = hold['v'], hold['w'], hold['z']
+        from .navier_stokes.newton_preconditioner import power_probe
+        return power_probe(A.apply, pmg.apply, v, w, z, sweeps=1)
 
     @staticmethod
     def _remember(lay, x, warm, start):

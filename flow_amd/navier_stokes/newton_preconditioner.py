@@ -69,11 +69,13 @@ def age(pre, kind, rebuilt, its, applications, npar, it=0):
         pre.stale = True
 
 
-def contraction(pre, operator, lay, bc_dofs_host):
+def contraction(pre, operator, lay, bc_dofs_host, sweeps=1):
     """|v - M^-1 J v| / |v| for the preconditioner `pre` of the operator J on a
     fixed full-spectrum vector v that vanishes on the Dirichlet dofs (as the
-    Krylov vectors of the Newton systems do): < 1 where one application is a
-    convergent iteration, NaN / > 1 where it amplifies."""
+    Krylov vectors of the Newton systems do) -- and, for sweeps > 1, the same
+    ratio for the next applications of the error propagation (power_probe):
+    < 1 where one application is a convergent iteration, NaN / > 1 where it
+    amplifies."""
     n2 = 2 * lay.N
     hold = lay._dev.setdefault('pmg_probe', {})
     bkey = hash(bc_dofs_host.tobytes())
@@ -83,13 +85,39 @@ def contraction(pre, operator, lay, bc_dofs_host):
         hold.update(key=bkey, v=device.to_device(v), w=device.empty(n2),
                     z=device.empty(n2))
     v, w, z = hold['v'], hold['w'], hold['z']
-    operator.apply(v, w)
-    pre.apply(w, z)
-    ops.axpby(1.0, v, -1.0, z)
-    num = ops.vector_norm(z)
+    return power_probe(operator.apply, pre.apply, v, w, z, sweeps)
+
+
+def power_probe(apply_operator, apply_preconditioner, v, w, z, sweeps=3):
+    """max_k |E^k v| / |E^(k-1) v|, k = 1 .. sweeps, E = I - M^-1 A: the
+    first ratio is the contraction of one application on the full-spectrum
+    vector v; the later ones home in on the dominant eigenvalue of E -- a cycle
+    that amplifies only LOCALLY (a plume, a shear layer at CFL >> 1: a handful
+    of modes a random vector carries little of) shows up there, where the
+    first ratio still reads 0.15.  (Not the acceptance test by default: a
+    rediscretised coarse level leaves E a few eigenvalues of modulus 2-3 even
+    where the cycle is an excellent GMRES preconditioner -- outliers of M^-1 A
+    far from 0 cost an iteration each, no more; measured: 2.8 on the Newton
+    system of tests/test_pmg.py, which GMRES solves in 14 applications.  The
+    solvers cap the iterations of a solve with the cycle instead and hand a
+    stalled one to the ILU(0).)  z holds the last E^k v on return."""
+    worst = 0.0
+    cur = v
     den = ops.vector_norm(v)
-    ratio = num / den
-    return ratio if numpy.isfinite(ratio) else float('inf')
+    for _ in range(max(1, int(sweeps))):
+        apply_operator(cur, w)
+        apply_preconditioner(w, z)
+        ops.axpby(1.0, cur, -1.0, z)          # z = cur - M^-1 A cur
+        num = ops.vector_norm(z)
+        ratio = num / den if den > 0.0 else float('inf')
+        if not numpy.isfinite(ratio):
+            return float('inf')
+        worst = max(worst, ratio)
+        if cur is v:
+            cur = device.empty(v.numel())
+        ops.copy(cur, z)
+        den = num
+    return worst
 
 
 def contraction_on_strips(pre, Jop, lay, bc_dofs_host):
@@ -120,6 +148,33 @@ def contraction_on_strips(pre, Jop, lay, bc_dofs_host):
     num, den = [float(x) for x in device.to_host(sums)]
     ratio = numpy.sqrt(num / den) if den > 0.0 else float('inf')
     return ratio if numpy.isfinite(ratio) else float('inf')
+
+
+def mass_share(pre, J1):
+    """A lower bound for the share of the mass term in the diagonal of the P1
+    Jacobian `J1` (kind 2: the diagonal blocks are planes 0 and 3) over its
+    free rows, min_i M_ii / (J1)_ii: what sizes the Chebyshev treatment of the
+    coarse level (Pmg.refactor, `coarse_auto`).  At CFL-sized steps the level
+    is mass-dominated (share ~ 0.5, a handful of steps); at dt >> h^2 / nu --
+    the Boussinesq driver at dt = 1 -- it is a diffusion problem (share ~
+    1e-2) and wants ~ sqrt(1 / share) of them."""
+    lay1 = pre.lay1
+    hold = lay1._dev.setdefault('pmg_mass_diag', {})
+    if 'm' not in hold:
+        M1 = ops.assemble_scalar_matrix(lay1, ops.MASS)
+        hold['m'] = M1.vals[lay1.dev('diag_idx').long()].clone()
+    m = hold['m']
+    di = lay1.dev('diag_idx').long()
+    share = None
+    for plane in (0, 3):
+        d = J1.plane(plane)[di]
+        s = m / d
+        # (Dirichlet rows are identity rows: d = 1, tiny share -- not counted)
+        s = s[d != 1.0]
+        if s.numel():
+            v = float(device.to_host(s.min()))
+            share = v if share is None else min(share, v)
+    return share if share is not None and share > 0.0 else None
 
 
 def coarse_jacobian(pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host,

@@ -78,7 +78,7 @@ from .start_vectors import (                                # noqa: F401
 from .newton_preconditioner import (
     age as _age, contraction as _contraction,
     contraction_on_strips as _contraction_on_strips,
-    coarse_jacobian as _coarse_jacobian,
+    coarse_jacobian as _coarse_jacobian, mass_share as _mass_share,
     )
 
 __all__ = ['Chorin', 'IPCS', 'Rotational', 'solver_parameters',
@@ -134,8 +134,14 @@ solver_parameters = {
                # application --: one fine product less and two cheap coarse
                # ones more, tools/pmg_param_sweep.sh: 9.15 against 10.15
                # ms/step with 2 / 2 / 4 and ratios 8 / 8)
+               # coarse_auto: where the P1 level is not mass-dominated (dt >>
+               # h^2 / nu: the Boussinesq driver's steps) its Chebyshev
+               # treatment grows with the level's condition number, up to
+               # coarse_max steps (Pmg.refactor; at CFL-sized steps the rule
+               # asks for fewer than `coarse_steps` and changes nothing)
                'pmg': {'pre': 1, 'post': 2, 'coarse_steps': 6,
-                       'ratio_fine': 5.0, 'ratio_coarse': 12.0},
+                       'ratio_fine': 5.0, 'ratio_coarse': 12.0,
+                       'coarse_auto': True, 'coarse_max': 48},
                # ... used where one cycle contracts a full-spectrum vector by
                # at least this factor (else: ILU(0)), and a GMRES that has not
                # converged after `pmg_maxit` applications is redone with ILU(0)
@@ -571,8 +577,11 @@ def _compute_tentative_velocity(
                     from ..fem.pmg import Pmg
                     pre = Pmg(W, **npar.get('pmg', {}))
                     lay._dev[slot] = pre
-                pre.refactor(J, _coarse_jacobian(
-                    pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host))
+                J1 = _coarse_jacobian(
+                    pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host)
+                pre.refactor(J, J1, mass_share=_mass_share(pre, J1)
+                             if pre.coarse_auto else None)
+                last_step_info['pmg_coarse_steps'] = pre.struct.coarse_steps
                 pre.dt, pre.key, pre.stale = dt, key, False
                 # Chebyshev smoothing assumes a spectrum near the real axis:
                 # on an under-resolved convection-dominated problem (cell

@@ -21,9 +21,9 @@ p0 on the device (flow_fingerprint), `end_step` the returned fields:
   * input == a trajectory's last INPUT: the same time level again (a Banach
     sweep of a coupled problem repeats the step with another forcing,
     tests/test_boussinesq.py:202-289; a driver redoes a step with a smaller dt,
-    :254-264) -- the increments extrapolate from the levels BEFORE it, and what
-    this call finds replaces the entry of the first attempt instead of counting
-    as a time step;
+    :254-264) -- the solves start from what the attempt before found (nearly
+    the same system), and what this call finds replaces that entry instead of
+    counting as a time step;
   * neither: a new trajectory without history (another problem on the same
     function space, a restart from a checkpoint, a hand-modified field).  The
     least recently used one beyond MAX_TRAJECTORIES is dropped.
@@ -46,6 +46,10 @@ from .. import parallel
 
 MAX_TRAJECTORIES = 3
 KEEP_POINTS = 6
+# a repeated step starts its solves from what the attempt before found
+# ('previous_attempt') or, like the first attempt, from the extrapolation of
+# the earlier time levels ('extrapolated')
+REDO_START = 'previous_attempt'
 
 
 class Trajectory(object):
@@ -226,7 +230,17 @@ def extrapolated_increment(lay, dt, dx, points=2, key='newton_increments',
     tr = _resolve(st)
     hist = []
     for h in tr.entries(key):
-        if h[2] >= tr.level:         # this level's first attempt (a redo)
+        if h[2] >= tr.level:
+            # this time level's earlier attempt (the call repeats the step: a
+            # Banach sweep with another forcing, a redo): what it found is the
+            # best start there is -- nearly the same system
+            if tr.redo and REDO_START == 'previous_attempt' \
+                    and h[0].numel() == dx.numel() \
+                    and (1.0 / 1.5 <= dt / h[1] <= 1.5):
+                ops.copy(dx, h[0])
+                if dt != h[1]:
+                    ops.axpby(0.0, dx, (dt / h[1])**power, dx)
+                return True
             continue
         # only while the step size is settled: through the start-up ramp of a
         # controller that doubles dt the rates are not smooth in time, and a

@@ -386,6 +386,11 @@ typedef struct {
   float* work;                     /* 12*fine.n + 8*coarse.n + 2 floats, 16-B
                                       aligned; the LAST float2 must be zero and
                                       is never written (dummy coarse row) */
+  int scalar;                      /* != 0: a SCALAR operator of size fine.n (the
+                                      heat system, flow/heat.py:103-122): both
+                                      planes of the levels hold the same matrix,
+                                      r and z have fine.n entries, the masks are
+                                      duplicated; 0: the two velocity blocks */
 } flow_pmg;
 /* vals[k] = half2((a00, a11)[k] / their diagonal entries of row(k)), 0 where
  * keep[k] == 0 (keep = NULL: everything is kept);

@@ -168,7 +168,7 @@ def test_histories_only_count_without_gaps(hip):
 def test_trajectories_are_told_apart_by_the_fields_they_are_handed(hip):
     """A call continues the trajectory whose last step RETURNED its input
     fields (by value); the same input again is a repetition of that time level
-    (its entry is replaced, the extrapolation looks at the levels before it);
+    (it starts from what the first attempt found, whose entry it replaces);
     anything else starts a new trajectory without history; interleaved
     trajectories on one layout keep their own histories."""
     from flow_amd import device
@@ -196,11 +196,11 @@ def test_trajectories_are_told_apart_by_the_fields_they_are_handed(hip):
     step(b[0], b[1], 10.0, None)
     step(a[1], a[2], 2.0, 1.0)          # (one point: the rate is carried on)
     step(b[1], b[2], 20.0, 10.0)
-    step(a[2], a[3], 3.0, 3.0)          # linear through 1, 2
+    step(a[2], a[3], 3.2, 3.0)          # linear through 1, 2; finds 3.2
     step(b[2], b[3], 30.0, 30.0)
-    # a repetition of A's last step (same input): extrapolated from the levels
-    # before it, as the first attempt was; its entry is replaced, not added
-    step(a[2], a[3], 3.5, 3.0)
+    # a repetition of A's last step (same input): started from what the first
+    # attempt found (nearly the same system); its entry is replaced, not added
+    step(a[2], a[3], 3.5, 3.2)
     tr = [t for t in lay._dev['start_vector_state'].trajectories
           if t.fp_in is not None and len(t.hist[key]) == 3
           and abs(float(device.to_host(t.hist[key][0][0])[0]) - 3.5) < 1e-12]
