@@ -8,7 +8,7 @@ GPU box, so the counterpart drivers import these names from here instead.
 '''
 from .mesh import (                                             # noqa: F401
     Mesh, Point, RectangleMesh, UnitSquareMesh, rectangle_with_hole,
-    karman_channel, heater_box, heater_box_coarse,
+    karman_channel, karman_channel_graded, heater_box, heater_box_coarse,
     )
 from .space import (                                            # noqa: F401
     FunctionSpace, VectorFunctionSpace, FiniteElement, VectorElement,

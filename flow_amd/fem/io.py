@@ -196,14 +196,20 @@ def write_dolfin_xml(path, mesh):
         fh.write('    </cells>\n  </mesh>\n</dolfin>\n')
 
 
-def read_mesh(path):
-    '''`Mesh('test.xml')` / the `.msh` cache of the reference drivers.'''
+def read_mesh(path, reorder=True):
+    '''`Mesh('test.xml')` / the `.msh` cache of the reference drivers
+    (tests/test_karman_vortex_street.py:29-33, 52-53).  reorder: a loaded mesh
+    is renumbered along its longest axis like the generators' meshes
+    (Mesh.reordered: what the packed streams, the strips and the cell kernels'
+    coalescing lean on); `vertex_origin` maps back to the file's ids.'''
     ext = os.path.splitext(path)[1].lower()
     if ext == '.msh':
-        return read_msh(path)
-    if ext == '.xml':
-        return read_dolfin_xml(path)
-    raise ValueError('unknown mesh format %r' % ext)
+        mesh = read_msh(path)
+    elif ext == '.xml':
+        mesh = read_dolfin_xml(path)
+    else:
+        raise ValueError('unknown mesh format %r' % ext)
+    return mesh.reordered() if reorder else mesh
 
 
 # -- XDMF time series ---------------------------------------------------------

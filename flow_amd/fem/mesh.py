@@ -29,12 +29,17 @@ class Mesh(object):
       bfacet_cell  (Nb,), bfacet_local (Nb,)  the cell and its local facet index
     '''
     def __init__(self, points, cells=None):
+        # (ids the vertices had in the file / in the mesh this one was
+        # renumbered from: `reordered`; None: this numbering is the original)
+        self.vertex_origin = None
         if isinstance(points, str):
             # Mesh('test.xml') / Mesh('karman.msh') as the reference drivers do
-            # (tests/test_karman_vortex_street.py:52-53)
+            # (tests/test_karman_vortex_street.py:52-53); renumbered along the
+            # longest axis like the generators' meshes (io.read_mesh)
             from . import io
             loaded = io.read_mesh(points)
             points, cells = loaded.points, loaded.cell_vertices
+            self.vertex_origin = loaded.vertex_origin
         self.points = numpy.ascontiguousarray(points, dtype=numpy.float64)
         self.cell_vertices = numpy.ascontiguousarray(cells, dtype=numpy.int32)
         assert self.points.ndim == 2 and self.points.shape[1] == 2
@@ -44,6 +49,39 @@ class Mesh(object):
         self._topology = None
         self._cache = {}
         return
+
+    # -- numbering -------------------------------------------------------------
+    def reordered(self):
+        '''The same mesh numbered the way the generators number theirs, which
+        is what the fast path leans on: vertices sorted along the LONGEST axis
+        of the bounding box (ties: the other coordinate) -- every operator is
+        then banded with a bandwidth of about one cross-section of vertices,
+        x[col] gathers stay in cache, the 16-bit column offsets of the packed
+        streams hold, and a strip of the domain is a contiguous range of rows
+        (flow_amd/parallel.py) --, cells in the order of their lowest vertex,
+        so that neighbouring threads of the cell kernels touch neighbouring
+        dofs and a strip is a contiguous cell range.  A mesh from a generic
+        generator (gmsh numbers boundary curves first, then the interior in
+        the order of its front) has none of that.  `vertex_origin[k]` = the id
+        vertex k had before.'''
+        p = self.points
+        ext = p.max(axis=0) - p.min(axis=0)
+        major = int(numpy.argmax(ext))
+        order = numpy.lexsort((p[:, 1 - major], p[:, major]))
+        new_id = numpy.empty(len(p), dtype=numpy.int64)
+        new_id[order] = numpy.arange(len(p))
+        cells = new_id[self.cell_vertices.astype(numpy.int64)]
+        corder = numpy.lexsort((cells.max(axis=1), cells.min(axis=1)))
+        out = Mesh(p[order], cells[corder].astype(numpy.int32))
+        origin = order if self.vertex_origin is None \
+            else numpy.asarray(self.vertex_origin)[order]
+        out.vertex_origin = origin.astype(numpy.int64)
+        return out
+
+    def bandwidth(self):
+        '''Largest difference of two vertex ids within a cell.'''
+        c = self.cell_vertices.astype(numpy.int64)
+        return int((c.max(axis=1) - c.min(axis=1)).max())
 
     # -- dolfin-flavoured accessors ------------------------------------------
     def num_vertices(self):
@@ -404,3 +442,110 @@ def heater_box_coarse(nsides=9, side_points=1):
         - (p[:, 2, 0] - p[:, 0, 0]) * (p[:, 1, 1] - p[:, 0, 1])
     cells[det < 0] = cells[det < 0][:, [0, 2, 1]]
     return Mesh(pts, cells.astype(numpy.int32))
+
+
+def karman_channel_graded(lcar=5.0e-3, lcar_far=None, seed=0, smoothing=10):
+    '''The Karman channel as the reference's driver meshes it with gmsh
+    (tests/test_karman_vortex_street.py:26-53: rectangle [0, 0.6] x [-0.07,
+    0.07] minus the disk of radius 0.02 at (0.1, 0.01), characteristic length
+    `lcar`), without gmsh: an UNSTRUCTURED Delaunay triangulation, graded --
+    cells of size `lcar` at the cylinder growing to `lcar_far` (default
+    4 lcar) over a distance of 0.1 --, in the numbering it was generated in
+    (boundary curves first, interior points in lattice order: nothing the fast
+    path could lean on; `.reordered()` gives it that).  Deterministic for a
+    given seed.  Points: the boundary curves at the local size, a thinned
+    hexagonal lattice inside (density ~ 1 / h^2), `smoothing` rounds of
+    Laplacian smoothing with re-triangulation.'''
+    from scipy.spatial import Delaunay
+    x0, x1, y0, y1 = 0.0, 0.6, -0.07, 0.07
+    cx, cy, r = 0.1, 0.01, 0.02
+    h0 = float(lcar)
+    h1 = float(lcar_far) if lcar_far is not None else 4.0 * h0
+
+    def size(p):
+        d = numpy.hypot(p[..., 0] - cx, p[..., 1] - cy) - r
+        t = numpy.clip(d / 0.1, 0.0, 1.0)
+        return h0 + (h1 - h0) * t
+
+    def walk(a, b):
+        """Points from a to b (b excluded), spaced by the local size: equal
+        steps of the arc length measured in units of h."""
+        a, b = numpy.asarray(a, float), numpy.asarray(b, float)
+        L = numpy.linalg.norm(b - a)
+        t = numpy.linspace(0.0, 1.0, 4001)
+        hh = size(a[None, :] + (b - a)[None, :] * t[:, None])
+        m = numpy.concatenate([[0.0], numpy.cumsum(
+            0.5 * (1.0 / hh[1:] + 1.0 / hh[:-1]) * (L / 4000.0))])
+        n = max(1, int(round(m[-1])))
+        tk = numpy.interp(numpy.arange(n) * m[-1] / n, m, t)
+        return a[None, :] + (b - a)[None, :] * tk[:, None]
+
+    corners = [(x0, y0), (x1, y0), (x1, y1), (x0, y1)]
+    boundary = [walk(corners[k], corners[(k + 1) % 4]) for k in range(4)]
+    nc = max(12, int(round(2.0 * numpy.pi * r / h0)))
+    ang = 2.0 * numpy.pi * numpy.arange(nc) / nc
+    circle = numpy.stack([cx + r * numpy.cos(ang), cy + r * numpy.sin(ang)], axis=1)
+    fixed = numpy.concatenate(boundary + [circle])
+    nfixed = len(fixed)
+    # interior: hexagonal lattice at the finest size, thinned to the local one
+    rng = numpy.random.RandomState(seed)
+    s0 = h0
+    rows = int((y1 - y0) / (0.866 * s0)) + 1
+    cols = int((x1 - x0) / s0) + 1
+    J, I = numpy.meshgrid(numpy.arange(rows), numpy.arange(cols), indexing='ij')
+    cand = numpy.stack([(x0 + (I + 0.5 * (J % 2)) * s0).ravel(),
+                        (y0 + J * 0.866 * s0).ravel()], axis=1)
+    h = size(cand)
+    keep = rng.uniform(size=len(cand)) < (s0 / h)**2
+    d_wall = numpy.minimum.reduce([cand[:, 0] - x0, x1 - cand[:, 0],
+                                   cand[:, 1] - y0, y1 - cand[:, 1]])
+    d_cyl = numpy.hypot(cand[:, 0] - cx, cand[:, 1] - cy) - r
+    keep &= (d_wall > 0.6 * h) & (d_cyl > 0.6 * h)
+    pts = numpy.concatenate([fixed, cand[keep]])
+
+    def triangulate(pts):
+        tri = Delaunay(pts).simplices
+        cen = pts[tri].mean(axis=1)
+        # inside the hole: the centroid test, and any triangle of circle points
+        # only (three neighbours on the polygon: its centroid lies within
+        # rounding of the polygon's edge)
+        inside = numpy.hypot(cen[:, 0] - cx, cen[:, 1] - cy) < r * numpy.cos(
+            numpy.pi / nc) * 0.999
+        inside |= ((tri >= nfixed - nc) & (tri < nfixed)).all(axis=1)
+        tri = tri[~inside]
+        p = pts[tri]
+        det = (p[:, 1, 0] - p[:, 0, 0]) * (p[:, 2, 1] - p[:, 0, 1]) \
+            - (p[:, 2, 0] - p[:, 0, 0]) * (p[:, 1, 1] - p[:, 0, 1])
+        # (slivers of collinear boundary points)
+        tri = tri[numpy.abs(det) > 1e-14]
+        det = det[numpy.abs(det) > 1e-14]
+        tri[det < 0] = tri[det < 0][:, [0, 2, 1]]
+        return tri
+
+    for _ in range(int(smoothing)):
+        tri = triangulate(pts)
+        # Laplacian smoothing of the interior points: mean of the neighbours
+        a = numpy.concatenate([tri[:, 0], tri[:, 1], tri[:, 2],
+                               tri[:, 1], tri[:, 2], tri[:, 0]])
+        b = numpy.concatenate([tri[:, 1], tri[:, 2], tri[:, 0],
+                               tri[:, 0], tri[:, 1], tri[:, 2]])
+        acc = numpy.zeros_like(pts)
+        cnt = numpy.zeros(len(pts))
+        numpy.add.at(acc, a, pts[b])
+        numpy.add.at(cnt, a, 1.0)
+        new = acc / numpy.maximum(cnt, 1.0)[:, None]
+        move = numpy.arange(len(pts)) >= nfixed
+        move &= cnt > 0
+        # (a point stays clear of the walls and of the cylinder by half the
+        # local size: no flat triangles on the boundary)
+        hn = size(new)
+        ok = (numpy.minimum.reduce([new[:, 0] - x0, x1 - new[:, 0],
+                                    new[:, 1] - y0, y1 - new[:, 1]]) > 0.5 * hn) \
+            & (numpy.hypot(new[:, 0] - cx, new[:, 1] - cy) - r > 0.5 * hn)
+        move &= ok
+        pts[move] = 0.5 * pts[move] + 0.5 * new[move]
+    tri = triangulate(pts)
+    used = numpy.zeros(len(pts), dtype=bool)
+    used[tri.ravel()] = True
+    new_id = numpy.cumsum(used) - 1
+    return Mesh(pts[used], new_id[tri].astype(numpy.int32))

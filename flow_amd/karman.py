@@ -56,13 +56,25 @@ class ObstacleBoundary(fem.SubDomain):
 
 
 class KarmanProblem(object):
-    def __init__(self, nx, ny=None, velocity_degree=2, mu=0.002,
-                 rho=RHO_WATER_293K, scheme='rotational', fitted=True):
+    def __init__(self, nx=None, ny=None, velocity_degree=2, mu=0.002,
+                 rho=RHO_WATER_293K, scheme='rotational', fitted=True,
+                 mesh=None):
         # body-fitted obstacle (fem/mesh.py: rectangle_with_fitted_hole); the
         # staircase variant (fitted=False) leaves one-cell notches in which,
         # at the controller's step size, a node-scale velocity spike grows
-        # once the wake becomes unsteady
-        self.mesh = fem.karman_channel(nx, ny, fitted=fitted)
+        # once the wake becomes unsteady.
+        # mesh: any triangulation of the channel instead (a file name, or a
+        # Mesh: the reference's driver reads the one gmsh made,
+        # tests/test_karman_vortex_street.py:26-53); renumbered along the
+        # channel unless it already is (Mesh.reordered)
+        if mesh is not None:
+            if isinstance(mesh, str):
+                mesh = fem.Mesh(mesh)
+            elif mesh.bandwidth() > 8 * int(mesh.num_vertices()**0.5) + 64:
+                mesh = mesh.reordered()
+            self.mesh = mesh
+        else:
+            self.mesh = fem.karman_channel(nx, ny, fitted=fitted)
         self.W = fem.VectorFunctionSpace(self.mesh, 'Lagrange', velocity_degree)
         self.P = fem.FunctionSpace(self.mesh, 'Lagrange', 1)
         self.mu = mu

@@ -59,10 +59,12 @@ def force(x, t):
 
 
 class KarmanStepCase(object):
-    def __init__(self, nx, ny, vdeg=2, dt=None, mu=0.002,
-                 rho=karman.RHO_WATER_293K, fitted=True):
+    def __init__(self, nx=None, ny=None, vdeg=2, dt=None, mu=0.002,
+                 rho=karman.RHO_WATER_293K, fitted=True, mesh=None):
         self.args = dict(nx=nx, ny=ny, vdeg=vdeg, mu=mu, rho=rho, fitted=fitted)
-        self.mesh = mesh = fem.karman_channel(nx, ny, fitted=fitted)
+        if mesh is None:
+            mesh = fem.karman_channel(nx, ny, fitted=fitted)
+        self.mesh = mesh
         self.vdeg = vdeg
         self.mu, self.rho = mu, rho
         self.W = W = fem.VectorFunctionSpace(mesh, 'Lagrange', vdeg)

@@ -24,14 +24,20 @@ from oracle import fem_oracle as orc
 import oracle_harness as H
 
 
-def _mesh():
-    return fem.karman_channel(36, 9)
+def _mesh(world=2):
+    '''The channel, long enough for `world` strips (6 and 8 ranks -- a whole
+    node -- get strips of 20 cell columns: room for the deep halos).'''
+    return fem.karman_channel(36 if world <= 3 else 20 * world, 9)
 
 
-def _system(degree=1):
+def _long_mesh(world=2):
+    return fem.karman_channel(72 if world <= 3 else 24 * world, 9)
+
+
+def _system(degree=1, world=2):
     '''SPD system on the channel: stiffness + mass (P1) or mass (P2), as the
     pressure / correction systems; pattern = the layout's pattern.'''
-    mesh = _mesh()
+    mesh = _mesh(world)
     S = H.oracle_space(mesh, degree)
     A = orc.mass_matrix(S)
     if degree == 1:
@@ -42,9 +48,9 @@ def _system(degree=1):
     return mesh, A, rng.standard_normal(S.N)
 
 
-@pytest.mark.parametrize('world', [1, 2, 3, 5])
+@pytest.mark.parametrize('world', [1, 2, 3, 5, 6, 8])
 def test_strips_cover_the_mesh_and_halo_slots_are_consistent(world):
-    mesh = _mesh()
+    mesh = _mesh(world if world > 5 else 2)
     st = parallel.Strips(mesh, world)
     nv = mesh.num_vertices()
     assert st.vbounds[0] == 0 and st.vbounds[-1] == nv
@@ -113,7 +119,7 @@ def test_strips_too_thin_are_refused():
     assert issubclass(parallel.StripsTooThin, ValueError)
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 6, 8])
 @pytest.mark.parametrize('degree,depth', [(1, 2), (2, 6)])
 def test_deep_ghost_ranges(world, degree, depth):
     """The deep halos (round 4): ghost ranges `depth` coupling layers out -- two
@@ -122,7 +128,7 @@ def test_deep_ghost_ranges(world, degree, depth):
     the rows of layer d; the halo slots of the deep blocks exchange exactly
     the ghost rows; k products on shrinking ranges reproduce the whole
     matrix' k-th power on the owned rows."""
-    mesh = fem.karman_channel(72, 9)
+    mesh = _long_mesh(world)
     lay = scalar_layout(mesh, degree)
     st = parallel.Strips(mesh, world)
     rowptr = lay.pattern('rowptr').astype(numpy.int64)
@@ -259,7 +265,7 @@ def _worker(rank, world, port, degree, out):
         parallel.enable(dist.group.WORLD, force=True)
         comm = parallel.comm()
         assert comm.rank == rank and comm.world == world and comm.staged
-        mesh, A, b = _system(degree)
+        mesh, A, b = _system(degree, world)
         lay = scalar_layout(mesh, degree)
         s = parallel.strips(mesh).blocks(lay).struct(rank)
         comm.ensure(4 + s.nhalo)
@@ -270,9 +276,10 @@ def _worker(rank, world, port, degree, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,degree', [(2, 1), (3, 1), (2, 2), (3, 2)])
+@pytest.mark.parametrize('world,degree', [(2, 1), (3, 1), (2, 2), (3, 2),
+                                          (6, 2), (8, 1)])
 def test_sharded_cg_pattern_under_gloo(world, degree):
-    _mesh_, A, b = _system(degree)
+    _mesh_, A, b = _system(degree, world)
     ref = spla.splu(A.tocsc()).solve(b)
     manager = mp.get_context('spawn').Manager()
     out = manager.dict()
@@ -380,7 +387,7 @@ def _mass_worker(rank, world, port, out):
     try:
         parallel.enable(dist.group.WORLD, force=True)
         comm = parallel.comm()
-        mesh = fem.karman_channel(72, 9)
+        mesh = _long_mesh(world)
         S = H.oracle_space(mesh, 2)
         M = orc.mass_matrix(S).tocsr()
         lay = scalar_layout(mesh, 2)
@@ -401,12 +408,12 @@ def _mass_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_sharded_mass_solver_pattern_under_gloo(world):
     '''k corrections cost k + 1 collectives (the last one carries the verdict);
     every rank takes the same number; the own rows assemble the direct
     solution.'''
-    mesh = fem.karman_channel(72, 9)
+    mesh = _long_mesh(world)
     M = orc.mass_matrix(H.oracle_space(mesh, 2)).tocsr()
     xref = numpy.random.RandomState(4).standard_normal(M.shape[0])
     manager = mp.get_context('spawn').Manager()
@@ -583,7 +590,7 @@ def _mgcg_worker(rank, world, port, out):
     try:
         parallel.enable(dist.group.WORLD, force=True)
         comm = parallel.comm()
-        mesh, A, b = _system(1)
+        mesh, A, b = _system(1, world)
         lay = scalar_layout(mesh, 1)
         T = _two_level(A)
         st = parallel.strips(mesh)
@@ -597,13 +604,13 @@ def _mgcg_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 6])
 def test_one_collective_two_level_cg_pattern_under_gloo(world):
     '''The one-collective form of the sharded V-cycle CG as an algorithm: the
     same iterates as the whole-system recurrences (same count, same solution),
     ONE collective per iteration + the start-up ones, x valid on the owned rows
     and the first ghost layer.'''
-    _mesh_, A, b = _system(1)
+    _mesh_, A, b = _system(1, world)
     T = _two_level(A)
     xref, its_ref = _reference_two_level_cg(A, T, b, 1e-10, 500)
     direct = spla.splu(A.tocsc()).solve(b)
