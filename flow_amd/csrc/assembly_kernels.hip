@@ -14,6 +14,8 @@
 //            contributions through the host-built contribution map, fixed
 //            order, coalesced stores of the CSR values.
 // Everything here is HBM-bound integer/fp64 streaming; no MFMA.
+#include <cstdlib>
+
 #include "fem_device.h"
 
 namespace flow {
@@ -509,6 +511,119 @@ __global__ __launch_bounds__(kBlock) void momentum_jvp_kernel(
 #pragma unroll
     for (int i = 0; i < NL; ++i)
       scratch[static_cast<size_t>(a * NL + i) * nc + c] = acc[a][i];
+}
+
+// The same action with TWO LANES PER CELL (P2): lane 2k + a of a wavefront
+// works on velocity component a of cell k of its tile.  Each lane holds ONE
+// component of the linearisation state and of the direction (12 doubles
+// instead of 24) and accumulates the six test functions of ITS component (6
+// doubles instead of 12); per quadrature point the two lanes swap the three
+// numbers the other needs -- u_b, v_b and the cross derivative d_a v_b --
+// through DPP (__shfl_xor 1).  No work is done twice except the geometry.  What
+// it is for: the one-lane kernel runs at 148 VGPRs = 3 waves per SIMD, its
+// counters read 31 % of the wave cycles waiting for the dof gathers
+// (profiles/counters_r04.md); with the state split over two lanes the kernel
+// fits 5 waves per SIMD (96 VGPRs).  Measured: slower (123 against 108 us),
+// see momentum_jvp_apply -- kept behind FLOW_AMD_JVP_PAIR=1 for the record and
+// the counters.
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void momentum_jvp_pair_kernel(
+    int nc, int cb, int ce, const double* __restrict__ xy,
+    const int* __restrict__ cdu, int nu, int nv,
+    const int* __restrict__ bfmask, const double* __restrict__ ui,
+    const double* __restrict__ v, flow_ns_params prm,
+    double* __restrict__ scratch, const double* __restrict__ stop) {
+  constexpr int NL = Elem<DEG>::NL;
+  constexpr int NQ = Elem<DEG>::NQ;
+  if (stopped(stop)) return;
+  const int t = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  const int c = cb + (t >> 1);
+  const int a = t & 1;                 // this lane's velocity component
+  if (c >= ce) return;                 // (both lanes of a pair leave together)
+  const Geom g = load_geom(xy, nc, c);
+  double U[NL], V[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int d = cdu[i * nc + c];
+    U[i] = ui[static_cast<size_t>(a) * nu + d];
+    V[i] = v[static_cast<size_t>(a) * nv + d];
+  }
+  const int mask = bfmask[c];
+  const double ci = -prm.dt / prm.rho * prm.theta_i;
+  const double hr = 0.5 * prm.rho;
+  const double mu = prm.mu;
+  double acc[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) acc[i] = 0.0;
+
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double L[3] = {qpoint<DEG>(q, 0), qpoint<DEG>(q, 1), qpoint<DEG>(q, 2)};
+    const double w = 0.5 * qweight<DEG>(q) * g.adet;
+    const double uq = eval_at<DEG>(U, L);
+    const double vq = eval_at<DEG>(V, L);
+    double gur[3], gvr[3], gu[2], gv[2];
+    ref_gradient<DEG>(U, L, gur);
+    ref_gradient<DEG>(V, L, gvr);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      gu[d] = gur[0] * g.gl[0][d] + gur[1] * g.gl[1][d] + gur[2] * g.gl[2][d];
+      gv[d] = gvr[0] * g.gl[0][d] + gvr[1] * g.gl[1][d] + gvr[2] * g.gl[2][d];
+    }
+    // the partner's component b = 1 - a: u_b, v_b, d_a v_b
+    const double uo = __shfl_xor(uq, 1, 64);
+    const double vo = __shfl_xor(vq, 1, 64);
+    const double cross = __shfl_xor(a == 0 ? gv[1] : gv[0], 1, 64);
+    const double u0 = a == 0 ? uq : uo, u1 = a == 0 ? uo : uq;
+    const double v0 = a == 0 ? vq : vo, v1 = a == 0 ? vo : vq;
+    // as momentum_jvp_kernel, for component a:
+    //   S0 = w (v_a - ci rho/2 dconv),  dconv = (grad v_a).u + (grad u_a).v
+    //   S1[d] = w ci (rho/2 (v_d u_a + u_d v_a) - mu (d_d v_a + d_a v_d))
+    const double dconv = gv[0] * u0 + gv[1] * u1 + gu[0] * v0 + gu[1] * v1;
+    const double s0 = w * (vq - ci * hr * dconv);
+    // d_a v_d: d = a is this lane's own gv[a], d = b the partner's
+    const double t0 = a == 0 ? gv[0] : cross;     // d_a v_0
+    const double t1 = a == 0 ? cross : gv[1];     // d_a v_1
+    double S1[2];
+    S1[0] = w * ci * (hr * (v0 * uq + u0 * vq) - mu * (gv[0] + t0));
+    S1[1] = w * ci * (hr * (v1 * uq + u1 * vq) - mu * (gv[1] + t1));
+    double T[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) T[k] = g.gl[k][0] * S1[0] + g.gl[k][1] * S1[1];
+    test_accumulate<DEG>(L, s0, T, acc);
+  }
+  if (mask && ci != 0.0) {
+    // exterior facets, p = 0:  mu ((grad v)^T n)_a = mu sum_b d_a v_b n_b
+    // (add_rhs_weak_facets; both lanes of the pair are here: same cell)
+    for (int lf = 0; lf < 3; ++lf) {
+      if (!((mask >> lf) & 1)) continue;
+      const int f0 = facet_v0(lf), f1 = facet_v1(lf);
+      const double nL[2] = {-g.gl[lf][0] * g.adet, -g.gl[lf][1] * g.adet};
+      for (int gq = 0; gq < 2; ++gq) {
+        const double sg = gq == 0 ? FLOW_G2A : FLOW_G2B;
+        double L[3] = {0.0, 0.0, 0.0};
+        L[f0] = 1.0 - sg;
+        L[f1] = sg;
+        double gvr[3], gv[2];
+        ref_gradient<DEG>(V, L, gvr);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+          gv[d] = gvr[0] * g.gl[0][d] + gvr[1] * g.gl[1][d] + gvr[2] * g.gl[2][d];
+        const double cross = __shfl_xor(a == 0 ? gv[1] : gv[0], 1, 64);
+        // d_a v_0 n_0 + d_a v_1 n_1
+        const double tn = a == 0 ? gv[0] * nL[0] + cross * nL[1]
+                                 : cross * nL[0] + gv[1] * nL[1];
+        const double wt = 0.5 * ci * mu * tn;
+        double phi[NL], dphi[NL][3];
+        basis<DEG>(L, phi, dphi);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) acc[i] += wt * phi[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+    scratch[static_cast<size_t>(a * NL + i) * nc + c] = acc[i];
 }
 
 // out[d] = v[d] on the Dirichlet dofs (identity rows) whose row lies in
@@ -1079,6 +1194,7 @@ using namespace flow;
 
 static inline dim3 cell_grid(int nc) { return dim3((nc + kBlock - 1) / kBlock); }
 
+
 extern "C" int flow_assemble_scalar_matrix(int kind, const flow_mesh* mesh,
                                            const flow_space* V, double* scratch,
                                            double* vals, void* stream) {
@@ -1228,9 +1344,28 @@ int flow::momentum_jvp_apply(const flow_momentum_jvp* J, const double* v,
   const int os = out_stride ? out_stride : W->n;
   const CellRange cr(mesh);
   int rc;
-  FLOW_DISPATCH_DEG(W->deg, momentum_jvp_kernel, cell_grid(cr.count()), st,
-                    mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n, vs,
-                    J->bfmask, J->ui, v, J->prm, J->scratch, stop);
+  // P2, FLOW_AMD_JVP_PAIR=1 in the environment: two lanes per cell
+  // (momentum_jvp_pair_kernel).  Measured on the 9.87 M-DoF workload and NOT
+  // the default: 96 VGPRs / 5 waves per SIMD instead of 148 / 3, bit-identical
+  // results -- and 123 us per launch instead of 108: the kernel is bound by
+  // fp64 issue, and the swaps, selects and the second copy of the geometry
+  // and index loads add instructions where the extra waves only hide latency
+  // 
+  static const bool pair = [] {
+    const char* e = getenv("FLOW_AMD_JVP_PAIR");
+    return e && e[0] == '1';
+  }();
+  if (W->deg == 2 && pair) {
+    hipLaunchKernelGGL(momentum_jvp_pair_kernel<2>, cell_grid(2 * cr.count()),
+                       dim3(kBlock), 0, st, mesh->nc, cr.cb, cr.ce, mesh->xy,
+                       W->cell_dofs, W->n, vs, J->bfmask, J->ui, v, J->prm,
+                       J->scratch, stop);
+    FLOW_CHECK_LAUNCH();
+  } else {
+    FLOW_DISPATCH_DEG(W->deg, momentum_jvp_kernel, cell_grid(cr.count()), st,
+                      mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n, vs,
+                      J->bfmask, J->ui, v, J->prm, J->scratch, stop);
+  }
   // (Dirichlet rows are identity rows: with the byte mask the gather writes
   // them itself; without it a copy kernel follows)
   if ((rc = gather(W->n, 2, W->vptr, W->vsrc, J->scratch,

@@ -548,3 +548,54 @@ def test_newton_failure_raises_runtime_error(hip):
         navsto.IPCS().step(f.Constant(-1.0), {0: u0}, p0, [], [],
                            f.Constant(1.0), f.Constant(1.0),
                            f={0: f.Constant((0, 0)), 1: f.Constant((0, 0))})
+
+
+_PAIR_SNIPPET = r'''
+import sys, numpy, scipy.sparse as sp
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+from flow_amd import fem, _hip, device
+from flow_amd.fem import ops
+from flow_amd.navier_stokes import pressure_correction as pc
+from oracle import fem_oracle as orc
+import cases
+worst = 0.0
+for mesh in (fem.karman_channel(30, 10, fitted=True), fem.heater_box(12, fitted=True)):
+    for method in ('backward euler', 'crank-nicolson'):
+        case = cases.Case(mesh, vdeg=2, dt=0.07, rho=1.3, mu=0.4, f_degree=3, seed=5)
+        W, P = case.oracle_spaces()
+        rng = numpy.random.RandomState(6)
+        ui = case.u0 + 0.1 * rng.standard_normal(len(case.u0))
+        th_i, th_e = pc._THETA[method]
+        Mo = sp.block_diag([orc.mass_matrix(W)] * 2, format='csr')
+        Ri, dRi = orc.momentum_rhs(W, P, ui, case.p0, case.lattice(case.f1), case.rho, case.mu)
+        J_ref = Mo - case.dt / case.rho * th_i * dRi
+        lay = case.W.layout
+        prm = _hip.NsParams(case.dt, case.rho, case.mu, th_i, th_e)
+        bfm = device.to_device(mesh.cell_bfacet_mask())
+        v = rng.standard_normal(2 * lay.N)
+        bc = numpy.unique(rng.randint(0, 2 * lay.N, size=7)).astype(numpy.int32)
+        Jop = ops.MomentumJacobian(case.W, bfm, device.to_device(ui), prm, device.to_device(bc))
+        out = device.empty(2 * lay.N)
+        Jop.apply(device.to_device(v), out)
+        ref = J_ref.dot(v); ref[bc] = v[bc]
+        worst = max(worst, abs(device.to_host(out).numpy() - ref).max() / abs(ref).max())
+print('PAIR_ERR %%.3e' %% worst)
+'''
+
+
+def test_two_lanes_per_cell_jacobian_action(hip):
+    '''momentum_jvp_pair_kernel (FLOW_AMD_JVP_PAIR=1: read once per process,
+    hence the child process -- a plain script, not the test runner): the same
+    action as the oracle's Jacobian to 1e-12, boundary facets included.'''
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, FLOW_AMD_JVP_PAIR='1')
+    out = subprocess.run(
+        [sys.executable, '-c', _PAIR_SNIPPET % dict(
+            tests=here, root=os.path.dirname(here))],
+        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith('PAIR_ERR')]
+    assert line and float(line[0].split()[1]) < 1e-12, out.stdout.decode()
