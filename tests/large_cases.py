@@ -162,12 +162,13 @@ LARGE = {
     # multigrid levels under the pressure solve
     'p2p1_1091x255': dict(nx=1091, ny=255, vdeg=2),
     }
-STRIDE = 87          # every 87th dof of each field is stored
+STRIDE = 87          # every 87th dof of each field is stored (a fixture
+                     # says which stride it was written with)
 
 
-def summary(field, ncomp):
+def summary(field, ncomp, stride=STRIDE):
     '''What a fixture keeps of a field: a strided sample, the l2 and max norm
     per component.'''
     f = numpy.asarray(field).reshape(ncomp, -1)
-    return (f[:, ::STRIDE].copy(),
+    return (f[:, ::stride].copy(),
             numpy.sqrt((f**2).sum(axis=1)), abs(f).max(axis=1))

@@ -20,7 +20,7 @@ The step comparisons of tests/test_hip_parity.py run on a few hundred cells
     XCD tile map, the 16-bit column offsets, the packed fp16 streams, 3+-level
     V-cycles and the p-multigrid at the workload's cell Peclet number are all
     under the comparison.  The fixtures hold every 87th dof and the norms of
-    the oracle's fields; the inputs are analytic (tests/large_cases.py) and
+    the oracle's fields (every 261st at 2.5 M DoF); the inputs are analytic (tests/large_cases.py) and
     rebuilt here, checked against the fixture's fingerprint.
 
 Tolerance: 1e-7 relative l2 (north star: 1e-6), Krylov tolerances 1e-13 as in
@@ -83,11 +83,11 @@ def test_karman_step_against_the_offline_oracle(hip, name, method):
     # between the hosts' numpy builds)
     fp, fpg = case.fingerprint(), gold['fingerprint']
     assert numpy.allclose(fp, fpg, rtol=1e-9, atol=1e-12), (fp, fpg)
-    assert int(gold['stride']) == large_cases.STRIDE
+    stride = int(gold['stride'])
     key = method.replace(' ', '_').replace('-', '_')
     u1, p1, ui = case.product_step(method)
     for fname, field, ncomp in (('ui', ui, 2), ('p1', p1, 1), ('u1', u1, 2)):
-        sample, l2, linf = large_cases.summary(field, ncomp)
+        sample, l2, linf = large_cases.summary(field, ncomp, stride)
         gs = gold['%s_%s_sample' % (key, fname)]
         gl2 = gold['%s_%s_l2' % (key, fname)]
         glinf = gold['%s_%s_linf' % (key, fname)]
