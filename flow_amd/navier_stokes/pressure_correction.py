@@ -165,12 +165,24 @@ solver_parameters = {
                # C' |u_k - u*| ~ 4e-4 in the developed vortex street).  An
                # iterate that PASSES the Newton test against the prediction
                # is never accepted from a loose solve: that solve is first
-               # continued to the tight tolerance (see `finish`).  Developed
-               # street, tools/developed_lab.py: fraction 1e-2 / 1e-3 / 1e-4 /
-               # 1e-5 / 3e-6: 21.9 / 20.4 / 18.6 / 19.2 / 20.0 ms per step
-               # (off: 22.3): the first solve of a step drops from 10 to 3
-               # applications, the second grows from 6 to 9.
-               'adaptive_forcing': True, 'matrix_free': True,
+               # continued to the tight tolerance (see `finish`).  OFF in mode
+               # 'parity' (on in mode 'fast'), by measurement: in the burst
+               # phases of the developed street (tools/developed_lab.py, t ~
+               # 74: fraction 1e-2 / 1e-3 / 1e-4 / 1e-5 / 3e-6: 21.9 / 20.4 /
+               # 18.6 / 19.2 / 20.0 ms per step, off: 22.3 -- the first solve
+               # of a step drops from 10 to 3 applications, the second grows
+               # from 6 to 9) it pays; over a whole run it does not
+               # (tools/long_run.py, 4000 steps to t = 122: 32.1 k GMRES
+               # applications, 13.0 ms per step with it against 29.6 k, 12.2
+               # ms without).  What a loose solve finds goes into the history
+               # the start vectors are extrapolated from; in the calmer phases
+               # the tight solves live on starts that are good to 1e-5 (3 + 3
+               # applications per step) and the loosely solved increments
+               # cost them that (15).  No signal separates the phases without
+               # a tight solve from a clean history: the Newton residuals and
+               # max|u| do not (long_run: F1 = 2.9e-10 costs 4 + 3 at t = 70,
+               # 10 + 7 at t = 74).
+               'adaptive_forcing': False, 'matrix_free': True,
                'intermediate_fraction': 1.0e-4, 'intermediate_margin': 1.25,
                # start vector of the FIRST Newton iteration's linear solve:
                # 'extrapolated' = the Newton increments of the previous calls,
@@ -215,7 +227,7 @@ _MODES = {
     'parity': {
         'newton': {'initial_guess': 'previous', 'linear_atol_factor': 1.0e-6,
                    'linear_remainder_fraction': 0.0,
-                   'forcing': 0.0, 'adaptive_forcing': True,
+                   'forcing': 0.0, 'adaptive_forcing': False,
                    'intermediate_fraction': 1.0e-4, 'intermediate_margin': 1.25,
                    'linear_start': 'extrapolated'},
         'pressure': {'extrapolate': False, 'start': 'extrapolated'},

@@ -1,7 +1,9 @@
 # -*- coding: utf-8 -*-
 '''
 Loose linear solves for Newton iterations that cannot be the last one
-(navier_stokes.solver_parameters['newton']['adaptive_forcing'], mode 'parity'):
+(navier_stokes.solver_parameters['newton']['adaptive_forcing']: an option of
+mode 'parity', off by default -- it pays in the burst phases of the vortex
+street and loses over a whole run, pressure_correction.py; on in mode 'fast'):
 the reference solves every Newton system exactly (LU, flow/navier_stokes/
 pressure_correction.py:224-254); here an iterate the quadratic model says
 cannot pass the Newton test only serves as the next linearisation point, and

@@ -36,10 +36,12 @@ for k in range(nsteps):
         tot_lin += its
     if k % 10 == 9 or k == nsteps - 1:
         device.synchronize()
-        print('step %4d  t %.4f  dt %.3e  |u|inf %.4f  newton %d  applications %2d (%s)  cg(p) %3d  cg(corr) %d  wall %.1f s'
+        print('step %4d  t %.4f  dt %.3e  |u|inf %.4f  newton %d  applications %2d (%s)  cg(p) %3d  cg(corr) %d  wall %.1f s  F %s  apps %s'
               % (k + 1, prob.t, info['dt'], info['unorm'], len(info['newton_linear_iterations']), its,
                  info.get('newton_preconditioner', '-'),
-                 info['pressure'].iterations, info['correction'].iterations, time.time() - t0), flush=True)
+                 info['pressure'].iterations, info['correction'].iterations, time.time() - t0,
+                 ' '.join('%.2e' % r for r in info['newton_residuals']),
+                 '+'.join(str(a) for a in info['newton_linear_applications'])), flush=True)
 assert numpy.isfinite(info['unorm'])
 device.synchronize()
 if t20 is not None:
