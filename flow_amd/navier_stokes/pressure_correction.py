@@ -184,6 +184,7 @@ solver_parameters = {
                # 10 + 7 at t = 74).
                'adaptive_forcing': False, 'matrix_free': True,
                'intermediate_fraction': 1.0e-4, 'intermediate_margin': 1.25,
+               'finish_loose_solves': True,
                # start vector of the FIRST Newton iteration's linear solve:
                # 'extrapolated' = the Newton increments of the previous calls,
                # extrapolated linearly in time (a time loop's steps differ
@@ -229,6 +230,7 @@ _MODES = {
                    'linear_remainder_fraction': 0.0,
                    'forcing': 0.0, 'adaptive_forcing': False,
                    'intermediate_fraction': 1.0e-4, 'intermediate_margin': 1.25,
+                   'finish_loose_solves': True,
                    'linear_start': 'extrapolated'},
         'pressure': {'extrapolate': False, 'start': 'extrapolated'},
         'correction': {'extrapolate': False},
@@ -238,6 +240,10 @@ _MODES = {
                    'linear_remainder_fraction': 0.0,
                    'forcing': 1.0e-4, 'adaptive_forcing': True,
                    'intermediate_fraction': 0.1, 'intermediate_margin': 1.0,
+                   # (mode 'fast' accepts an iterate from a loose solve: its
+                   # linear tolerance is a fraction of the Newton tolerance
+                   # anyway)
+                   'finish_loose_solves': False,
                    'linear_start': 'zero'},
         'pressure': {'extrapolate': True, 'start': 'zero'},
         'correction': {'extrapolate': True},
@@ -493,7 +499,8 @@ def _compute_tentative_velocity(
             nrm, first_nrm = first_nrm, None
         else:
             nrm = residual()
-        if nrm < tol and finish is not None:
+        if nrm < tol and finish is not None and \
+                npar.get('finish_loose_solves', True):
             # The quadratic model said this iterate could not pass the Newton
             # test, so its linear system was only solved loosely
             # ('adaptive_forcing') -- and it passes.  An accepted iterate must

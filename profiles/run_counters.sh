@@ -12,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-hbm-resident --no-fast-leg --spmv-reps 5 $@"
+ARGS="--steps 4 --warmup 2 --developed 0 --no-cpu-baseline --no-hbm-resident --no-fast-leg --spmv-reps 5 $@"
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 20 --no-cpu-baseline --no-hbm-resident --no-fast-leg --spmv-reps 50"
+ARGS="--steps 10 --warmup 20 --developed 0 --no-cpu-baseline --no-hbm-resident --no-fast-leg --spmv-reps 50"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 echo trace done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
