@@ -82,6 +82,35 @@ def _bin_aggregates(x, free, width):
     return agg, len(ukey)
 
 
+def _kd_aggregates(x, free, target):
+    '''Aggregates of about `target` free points each by recursive median
+    splits along the longer axis of a group's bounding box (a k-d tree's
+    leaves): spatially compact and of equal COUNT whatever the local mesh
+    size -- for graded meshes, where bins of one width hold hundreds of points
+    at the fine end and none at the coarse one.'''
+    idx = numpy.nonzero(free)[0]
+    agg = numpy.full(len(x), -1, dtype=numpy.int64)
+    nagg = 0
+    stack = [idx]
+    while stack:
+        g = stack.pop()
+        if len(g) <= 1.5 * target:
+            agg[g] = nagg
+            nagg += 1
+            continue
+        p = x[g]
+        ext = p.max(axis=0) - p.min(axis=0)
+        axis = int(numpy.argmax(ext))
+        # (split into parts that are multiples of the target, as even as that
+        # allows: leaves between target and 1.5 target points)
+        k = int(round(len(g) / float(target)))
+        half = (k // 2) * len(g) // k
+        order = numpy.argpartition(p[:, axis], half)
+        stack.append(g[order[:half]])
+        stack.append(g[order[half:]])
+    return agg, nagg
+
+
 class Multigrid(object):
     '''Hierarchy for a scalar SPD Matrix `A` (kind 0).  isbc: Dirichlet dofs
     (identity rows of A); singular: pure Neumann operator -> pseudo-inverse on
@@ -99,7 +128,13 @@ class Multigrid(object):
         isbc = numpy.zeros(n, dtype=bool) if isbc is None else \
             numpy.asarray(isbc, dtype=bool)
         x = lay.dof_coords.copy()
-        width = s * numpy.sqrt(2.0 * lay.mesh.cell_areas().mean())
+        areas = lay.mesh.cell_areas()
+        width = s * numpy.sqrt(2.0 * areas.mean())
+        # a graded mesh (cell sizes a factor 3 apart and more): aggregates of
+        # equal count (s^2 points: what a bin of s widths holds on a uniform
+        # mesh) instead of bins of equal width
+        self.aggregation = 'kd-tree' if numpy.percentile(areas, 99) > \
+            9.0 * numpy.percentile(areas, 1) else 'bins'
         free = ~isbc
         Ah = A.to_scipy().tocsr()
         self.levels = []          # device operators Ah, Ps, R + dinv, t per level
@@ -112,7 +147,10 @@ class Multigrid(object):
         while Ah.shape[0] > coarsest and len(self.levels) < _hip.MG_MAX_LEVELS - 1:
             m = Ah.shape[0]
             D = Ah.diagonal()
-            agg, nc = _bin_aggregates(x, free, width)
+            if self.aggregation == 'kd-tree':
+                agg, nc = _kd_aggregates(x, free, s * s)
+            else:
+                agg, nc = _bin_aggregates(x, free, width)
             if nc < 2 or nc >= m:
                 break
             idx = numpy.nonzero(agg >= 0)[0]

@@ -73,6 +73,7 @@ class _State(object):
         self.pending_out = None   # trajectory whose fp_out is still on the device
         self.current = None       # resolved trajectory of the call in flight
         self.unresolved = False   # begin_step ran, fingerprints not read yet
+        self.agree = None         # device: the ranks' verdicts (strips)
         self.clock = 0
 
 
@@ -135,15 +136,18 @@ def _resolve(st):
     if parallel.active():
         # every rank must take the same decision (a start vector changes
         # which launches and collectives a solve issues): all or none
-        t = device.to_device(torch.tensor(
+        if st.agree is None:
+            st.agree = device.zeros(4)
+        t = st.agree
+        # (a host-to-device copy, the all-reduce and ONE read-back, all in
+        # stream order)
+        t.copy_(torch.tensor(
             [1.0 if code == 1 else 0.0, 1.0 if code == 2 else 0.0,
              float(which if which is not None else -1), 1.0],
             dtype=torch.float64))
         c = parallel.comm()
         c.calls += 1
-        device.synchronize()
         c.allreduce_tensor(t)
-        device.synchronize()
         h = device.to_host(t)
         world = int(round(float(h[3])))
         same_slot = which is not None and \
