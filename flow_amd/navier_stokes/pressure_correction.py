@@ -984,6 +984,26 @@ def _pressure_cg(A, dinv, prec, b, x, tol, par, fallback=False):
         )
 
 
+def _pressure_from(A, dinv, prec, b, x, tol, par, plain, wlay):
+    '''_pressure_cg from the start in x; `plain`: the start without the
+    extrapolated increment (None: x is that start).  A solve that does not
+    converge from an extrapolated start -- the guard has already ruled out
+    that the start was worse than zero -- forgets the trajectory's history and
+    is redone once from the plain start before the error goes to the caller
+    (dolfin: 'error_on_nonconvergence').'''
+    try:
+        return _pressure_cg(A, dinv, prec, b, x, tol, par,
+                            fallback=plain if plain is not None else False)
+    except _hip.NotConverged:
+        if plain is None:
+            raise
+        info('pressure: no convergence from the extrapolated start; history '
+             'dropped, redone from the plain start')
+        start_vectors.drop_current(wlay)
+        ops.copy(x, plain)
+        return _pressure_cg(A, dinv, prec, b, x, tol, par, fallback=False)
+
+
 def _preconditioner(lay, key, A, isbc, singular, par):
     '''(coarse, mg): the smoothed-aggregation multigrid hierarchy (default), or
     the two-level aggregate coarse space -- which is what the row-sharded loop
@@ -1135,8 +1155,8 @@ def _compute_pressure(
             _hip.check(lib.flow_bc_set_values(
                 nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(plain), st
                 ))
-        sol = _pressure_cg(Kbc, dinv, coarse, b, p1.data, tol, par,
-                           fallback=plain if plain is not None else False)
+        sol = _pressure_from(Kbc, dinv, coarse, b, p1.data, tol, par, plain,
+                             W.layout)
     else:
         # pure Neumann problem: singular but consistent, no null-space
         # handling (reference :340-432); start: see above
@@ -1144,8 +1164,8 @@ def _compute_pressure(
         if key not in lay._dev:
             lay._dev[key] = K.diag_inv()
         coarse = _preconditioner(lay, key, K, None, True, par)
-        sol = _pressure_cg(K, lay._dev[key], coarse, b, p1.data, tol, par,
-                           fallback=plain if plain is not None else False)
+        sol = _pressure_from(K, lay._dev[key], coarse, b, p1.data, tol, par,
+                             plain, W.layout)
     if phi_start is not None:
         ops.copy(phi_start, p1.data)
         ops.axpby(-1.0, p0.data, 1.0, phi_start)

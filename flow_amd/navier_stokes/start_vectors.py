@@ -193,6 +193,47 @@ def forget_history(space_or_layout):
     return
 
 
+def snapshot_state(space_or_layout):
+    '''A deep copy of everything kept for a velocity space (development tools:
+    several runs from the same state WITH its histories); None if nothing is.'''
+    lay = getattr(space_or_layout, 'layout', space_or_layout)
+    st = lay._dev.get('start_vector_state')
+    if st is None:
+        return None
+    if st.unresolved:
+        _resolve(st)
+    if st.pending_out is not None:
+        # (the last step's output fingerprint is still on the device)
+        host = (ctypes.c_double * 8)()
+        _hip.check(_hip.lib().flow_read_doubles(
+            _hip.f64(st.slots, 8), 8, host, _hip.stream()))
+        v = [int(x) for x in host]
+        st.pending_out.fp_out = (v[4] | (v[5] << 32), v[6] | (v[7] << 32))
+        st.pending_out = None
+    return _copy_state(st)
+
+
+def _copy_state(st):
+    out = _State()
+    out.clock = st.clock
+    for tr in st.trajectories:
+        c = Trajectory()
+        c.level, c.fp_in, c.fp_out, c.used = tr.level, tr.fp_in, tr.fp_out, tr.used
+        c.hist = {k: [(_hip.clone(h[0]),) + tuple(h[1:]) for h in v]
+                  for k, v in tr.hist.items()}
+        out.trajectories.append(c)
+    return out
+
+
+def restore_state(space_or_layout, snap):
+    '''Install a copy of a snapshot_state() result (the snapshot stays usable).'''
+    lay = getattr(space_or_layout, 'layout', space_or_layout)
+    if snap is None:
+        lay._dev.pop('start_vector_state', None)
+    else:
+        lay._dev['start_vector_state'] = _copy_state(snap)
+
+
 def drop_current(lay):
     '''Forget the history of the trajectory the call in flight belongs to (a
     solve did not converge from an extrapolated start).'''

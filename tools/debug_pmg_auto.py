@@ -1,4 +1,5 @@
-import sys; sys.path.insert(0,'/root/repo')
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from flow_amd import karman
 import flow_amd.navier_stokes as navsto
 for auto in (True, False):

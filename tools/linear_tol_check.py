@@ -28,20 +28,15 @@ def main():
     for _ in range(8):           # (fill the start vectors' history)
         prob.step()
     snap = prob.snapshot()
-    hist = {}
-    lay, play = prob.W.layout, prob.P.layout
-    for key in ('newton_increments', 'correction_increments'):
-        hist[key] = [(h[0].clone(),) + tuple(h[1:]) for h in lay._dev.get(key, [])]
-    hist['pressure_increments'] = [
-        (h[0].clone(),) + tuple(h[1:]) for h in play._dev.get('pressure_increments', [])]
+    from flow_amd.navier_stokes import start_vectors as sv
+    lay = prob.W.layout
+    hist = sv.snapshot_state(lay)
     umag = list(prob._umag_hist)
 
     def run(factor):
         prob.restore(snap)
-        for key in ('newton_increments', 'correction_increments'):
-            lay._dev[key] = [(h[0].clone(),) + tuple(h[1:]) for h in hist[key]]
-        play._dev['pressure_increments'] = [
-            (h[0].clone(),) + tuple(h[1:]) for h in hist['pressure_increments']]
+        # (with the histories of the snapshot: restore_state installs a copy)
+        sv.restore_state(lay, hist)
         prob._umag_hist = list(umag)
         navsto.solver_parameters['newton']['linear_atol_factor'] = \
             factor if factor else 1.0e-6
