@@ -557,11 +557,17 @@ def main():
         barrier()
         calls0 = parallel.comm().calls if parallel.active() else 0
         launches0 = _hip.launch_count()
+        graphs0 = _hip.graph_stats()
         t0 = time.perf_counter()
         infos = [prob.step(tol=args.tol) for _ in range(args.steps)]
         barrier()
         elapsed = time.perf_counter() - t0
         infos[0]['launches_in_window'] = _hip.launch_count() - launches0
+        graphs1 = _hip.graph_stats()
+        infos[0]['graphs_in_window'] = {
+            k: graphs1[k] - graphs0[k] for k in (
+                'captures', 'replays', 'nodes', 'captures_cg', 'captures_gmres',
+                'captures_mass')}
         if parallel.active():
             # (every halo and every reduction of the strips is one all-reduce)
             infos[0]['collectives_in_window'] = parallel.comm().calls - calls0
@@ -597,6 +603,9 @@ def main():
             # kernel launches of the library per step (flow_launch_count)
             'launches_per_step': infos[0].get('launches_in_window', 0)
             / float(len(infos)),
+            # iteration bodies replayed as HIP graphs in the window (off by
+            # default: FLOW_AMD_GRAPHS=1; a replay counts as ONE launch above)
+            'graph_replay': infos[0].get('graphs_in_window'),
             # (counted at the all-reduce callback; the library-issued
             # ncclAllReduce of FLOW_AMD_RCCL_DIRECT=1 does not pass there)
             'collectives_per_step': (

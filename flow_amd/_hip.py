@@ -256,6 +256,8 @@ _P = ctypes.POINTER
 SYMBOLS = {
     'flow_abi_version': [],
     'flow_launch_count': [_P(ctypes.c_ulonglong)],
+    'flow_graph_mode': [_I, ctypes.c_longlong],
+    'flow_graph_stats': [_P(ctypes.c_ulonglong)],
     'flow_xcd_tile_host': [_I, _I],
     'flow_spmv_tile_nnz': [_I],
     'flow_operator_apply': [_P(Operator), _VP, _VP, _VP],
@@ -363,7 +365,7 @@ class NotConverged(RuntimeError):
 
 # flow_abi_version() of the library these bindings describe (the structs above
 # and SYMBOLS): a stale libflow_hip.so is refused at load time
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 
 def load_library():
@@ -398,6 +400,23 @@ def launch_count():
     n = ctypes.c_ulonglong(0)
     check(load_library().flow_launch_count(ctypes.byref(n)))
     return int(n.value)
+
+
+def graph_mode(mode, auto_rows=-1, sites=0):
+    '''Iteration bodies as HIP graphs: 0 never, 1 always, 2 by system size;
+    sites: 1 CG | 2 GMRES | 4 mass solver (0: leave) (include/flow_hip.h:
+    flow_graph_mode).'''
+    check(load_library().flow_graph_mode(int(mode) | (int(sites) << 4),
+                                         int(auto_rows)))
+
+
+def graph_stats():
+    '''dict: graphs kept, captures, replays, kernel nodes replayed.'''
+    v = (ctypes.c_ulonglong * 8)()
+    check(load_library().flow_graph_stats(v))
+    return {'graphs': int(v[0]), 'captures': int(v[1]), 'replays': int(v[2]),
+            'nodes': int(v[3]), 'captures_cg': int(v[4]),
+            'captures_gmres': int(v[5]), 'captures_mass': int(v[6])}
 
 
 def spmv_tile_nnz(kind=0):

@@ -443,6 +443,7 @@ __global__ __launch_bounds__(kBlock) void momentum_jvp_kernel(
     const int* __restrict__ cdu, int nu, int nv,
     const int* __restrict__ bfmask, const double* __restrict__ ui,
     const double* __restrict__ v, flow_ns_params prm,
+    const double* __restrict__ prm_dev,
     double* __restrict__ scratch, const double* __restrict__ stop) {
   constexpr int NL = Elem<DEG>::NL;
   constexpr int NQ = Elem<DEG>::NQ;
@@ -454,9 +455,12 @@ __global__ __launch_bounds__(kBlock) void momentum_jvp_kernel(
   load_local<NL>(ui, nu, cdu, nc, c, 2, U);
   load_local<NL>(v, nv, cdu, nc, c, 2, V);
   const int mask = bfmask[c];
-  const double ci = -prm.dt / prm.rho * prm.theta_i;
-  const double hr = 0.5 * prm.rho;
-  const double mu = prm.mu;
+  // (prm_dev: the three numbers below in device memory, written by
+  // jvp_params_kernel -- a replayed graph cannot carry the step size by value)
+  const double ci = prm_dev ? load_scalar(prm_dev)
+                            : -prm.dt / prm.rho * prm.theta_i;
+  const double hr = prm_dev ? load_scalar(prm_dev + 1) : 0.5 * prm.rho;
+  const double mu = prm_dev ? load_scalar(prm_dev + 2) : prm.mu;
   double acc[2][NL];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -532,6 +536,7 @@ __global__ __launch_bounds__(kBlock) void momentum_jvp_pair_kernel(
     const int* __restrict__ cdu, int nu, int nv,
     const int* __restrict__ bfmask, const double* __restrict__ ui,
     const double* __restrict__ v, flow_ns_params prm,
+    const double* __restrict__ prm_dev,
     double* __restrict__ scratch, const double* __restrict__ stop) {
   constexpr int NL = Elem<DEG>::NL;
   constexpr int NQ = Elem<DEG>::NQ;
@@ -549,9 +554,10 @@ __global__ __launch_bounds__(kBlock) void momentum_jvp_pair_kernel(
     V[i] = v[static_cast<size_t>(a) * nv + d];
   }
   const int mask = bfmask[c];
-  const double ci = -prm.dt / prm.rho * prm.theta_i;
-  const double hr = 0.5 * prm.rho;
-  const double mu = prm.mu;
+  const double ci = prm_dev ? load_scalar(prm_dev)
+                            : -prm.dt / prm.rho * prm.theta_i;
+  const double hr = prm_dev ? load_scalar(prm_dev + 1) : 0.5 * prm.rho;
+  const double mu = prm_dev ? load_scalar(prm_dev + 2) : prm.mu;
   double acc[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) acc[i] = 0.0;
@@ -1334,9 +1340,25 @@ int flow::momentum_jvp_check(const flow_momentum_jvp* J) {
 
 // v_stride / out_stride: component strides of v and out (0: W->n); both
 // pointers are indexed by GLOBAL row (callers with compact vectors shift them)
+__global__ void jvp_params_kernel(flow_ns_params prm, double* __restrict__ dst) {
+  if (threadIdx.x == 0) {
+    store_scalar(dst, -prm.dt / prm.rho * prm.theta_i);
+    store_scalar(dst + 1, 0.5 * prm.rho);
+    store_scalar(dst + 2, prm.mu);
+  }
+}
+
+int flow::momentum_jvp_params(const flow_momentum_jvp* J, double* dst,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(jvp_params_kernel, dim3(1), dim3(64), 0, st, J->prm, dst);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
 int flow::momentum_jvp_apply(const flow_momentum_jvp* J, const double* v,
                              double* out, hipStream_t st, int v_stride,
-                             int out_stride, const double* stop) {
+                             int out_stride, const double* stop,
+                             const double* prm_dev) {
   const flow_mesh* mesh = J->mesh;
   const flow_space* W = J->W;
   const int nl = W->deg == 1 ? 3 : 6;
@@ -1359,12 +1381,12 @@ int flow::momentum_jvp_apply(const flow_momentum_jvp* J, const double* v,
     hipLaunchKernelGGL(momentum_jvp_pair_kernel<2>, cell_grid(2 * cr.count()),
                        dim3(kBlock), 0, st, mesh->nc, cr.cb, cr.ce, mesh->xy,
                        W->cell_dofs, W->n, vs, J->bfmask, J->ui, v, J->prm,
-                       J->scratch, stop);
+                       prm_dev, J->scratch, stop);
     FLOW_CHECK_LAUNCH();
   } else {
     FLOW_DISPATCH_DEG(W->deg, momentum_jvp_kernel, cell_grid(cr.count()), st,
                       mesh->nc, cr.cb, cr.ce, mesh->xy, W->cell_dofs, W->n, vs,
-                      J->bfmask, J->ui, v, J->prm, J->scratch, stop);
+                      J->bfmask, J->ui, v, J->prm, prm_dev, J->scratch, stop);
   }
   // (Dirichlet rows are identity rows: with the byte mask the gather writes
   // them itself; without it a copy kernel follows)

@@ -2,8 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
+#include <vector>
 
 #include "../../include/flow_hip.h"
 
@@ -65,9 +68,51 @@ int exchange(const flow_comm* c, int count);
 
 // assembly_kernels.hip: the matrix-free operator (flow_operator kind 3)
 int momentum_jvp_check(const flow_momentum_jvp* J);
+// prm_dev: the step-size dependent factors in device memory (three doubles
+// written by momentum_jvp_params) instead of J->prm by value -- what lets a
+// captured iteration body outlive a change of the step size
 int momentum_jvp_apply(const flow_momentum_jvp* J, const double* v, double* out,
                        hipStream_t st, int v_stride = 0, int out_stride = 0,
-                       const double* stop = nullptr);
+                       const double* stop = nullptr,
+                       const double* prm_dev = nullptr);
+int momentum_jvp_params(const flow_momentum_jvp* J, double* dst, hipStream_t st);
+
+// graph_replay.hip: iteration bodies as HIP graphs (OFF unless FLOW_AMD_GRAPHS
+// / flow_graph_mode says otherwise: measured slower than the launches they
+// replace, see there).  A solver hashes every VALUE that determines the
+// launches of one iteration (KeyHash), asks replay_prepare for the instantiated
+// graph -- on a miss the body is captured once: it must only enqueue on `st`
+// -- and replays it with replay_launch; with *exec == nullptr (capture
+// unavailable, a loop whose bodies never repeat) it launches the body itself.
+// replay_wanted(rows, site): FLOW_AMD_GRAPHS unset / 0 never, 1 always, auto:
+// systems of up to kReplayAutoRows rows (FLOW_AMD_GRAPH_ROWS).
+constexpr long long kReplayAutoRows = 1500000;
+struct KeyHash {
+  unsigned long long h = 1469598103934665603ull;
+  void bytes(const void* p, size_t n) {
+    const unsigned char* c = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) h = (h ^ c[i]) * 1099511628211ull;
+  }
+  template <class T> KeyHash& pod(const T& v) {
+    bytes(&v, sizeof(T));
+    return *this;
+  }
+  template <class T> KeyHash& obj(const T* p) {   // a struct by value, or "none"
+    const unsigned char tag = p ? 1 : 0;
+    bytes(&tag, 1);
+    if (p) bytes(p, sizeof(T));
+    return *this;
+  }
+};
+enum ReplaySite { kReplayCg = 1, kReplayGmres = 2, kReplayMass = 4 };
+bool replay_wanted(long long rows, int site);
+int replay_prepare(unsigned long long key, int site, hipStream_t st,
+                   const std::function<int()>& body, hipGraphExec_t* exec,
+                   int* nodes);
+int replay_launch(hipGraphExec_t exec, int nodes, hipStream_t st);
+// la_kernels.hip; skip_prm: without flow_momentum_jvp.prm (passed through
+// device memory)
+void key_operator(KeyHash& k, const flow_operator* A, bool skip_prm = false);
 
 #define FLOW_CHECK_HIP(expr)                                                 \
   do {                                                                       \

@@ -319,17 +319,27 @@ struct SpmvProfile {
 };
 static SpmvProfile g_spmv_profile;
 
+// every value of an operator that reaches a kernel (graph_replay.hip)
+void key_operator(KeyHash& k, const flow_operator* A, bool skip_prm) {
+  k.obj(A);
+  if (A && A->kind == 3 && A->matfree) {
+    flow_momentum_jvp J = *static_cast<const flow_momentum_jvp*>(A->matfree);
+    if (skip_prm) J.prm = flow_ns_params{0.0, 0.0, 0.0, 0.0, 0.0};
+    k.obj(&J).obj(J.mesh).obj(J.W);
+  }
+}
+
 // y = A x; with dpart != nullptr also the dot_parts(A) workgroup shares of x.y
 // vec_stride: component stride of x and y for the two-component kinds 3 and 4
 // (0: A->n); x and y are indexed by global row either way
 static int apply(const flow_operator* A, const double* x, double* y,
                  hipStream_t st, double* dpart = nullptr,
                  const double* stop = nullptr, int vec_stride = 0,
-                 int out_stride = 0) {
+                 int out_stride = 0, const double* jvp_prm = nullptr) {
   if (A->kind == 3) {
     FLOW_REQUIRE(dpart == nullptr, "matrix-free operators carry no fused dot");
     return momentum_jvp_apply(static_cast<const flow_momentum_jvp*>(A->matfree),
-                              x, y, st, vec_stride, out_stride, stop);
+                              x, y, st, vec_stride, out_stride, stop, jvp_prm);
   }
   const int xs = vec_stride ? vec_stride : A->n;
   const dim3 grid(A->nblocks, A->kind == 1 ? 2 : 1);
@@ -1013,6 +1023,7 @@ static int cg(const flow_operator* A, const double* dinv,
   int np = 0, rc;
 
   const double* stop = S + kDone;
+  double* const r_ = r;     // (for the lambdas below, whose `r` is a status)
   const double rtol2 = rtol * rtol, atol2 = atol * atol;
   if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
   if ((rc = fill(2 * N, 0.0, p, st))) return rc;      // p, s
@@ -1042,6 +1053,45 @@ static int cg(const flow_operator* A, const double* dinv,
                      dpart, rtol2, atol2, S);
   FLOW_CHECK_LAUNCH();
 
+  // one iteration: the same launches with the same arguments every time (the
+  // tolerances only enter the FIRST scalar kernel above)
+  auto body = [&]() -> int {
+    int r;
+    if (C) {
+      hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
+                         st, N, S, dinv, w, z, p, s, x, r_, 0, partial,
+                         static_cast<const double*>(nullptr));
+      if ((r = two_level(C, dinv, r_, z, crc, czc, st, partial, &np, stop)))
+        return r;
+    } else if (M) {
+      hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
+                         st, N, S, dinv, w, z, p, s, x, r_, 0, partial,
+                         static_cast<const double*>(nullptr));
+      if ((r = vcycle(M, r_, z, st, mpart, mpart + nm, &np, stop))) return r;
+    } else {
+      hipLaunchKernelGGL(cg_update_kernel<true>, dim3(gu), dim3(kBlock), 0, st,
+                         N, S, dinv, w, z, p, s, x, r_, 1, partial,
+                         static_cast<const double*>(nullptr));
+      np = gu;
+    }
+    if ((r = apply(A, z, w, st, dpart, stop))) return r;
+    hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kScalarBlock), 0, st,
+                       np, nd, 0, gpart, rpart, dpart, 0.0, 0.0, S);
+    FLOW_CHECK_LAUNCH();
+    return FLOW_OK;
+  };
+  // ... replayed as a HIP graph where the launch rate bounds the iteration
+  // (graph_replay.hip; never while the SpMV is being timed with events)
+  hipGraphExec_t graph = nullptr;
+  int graph_nodes = 0;
+  if (replay_wanted(N, kReplayCg) && g_spmv_profile.ev == nullptr) {
+    KeyHash key;
+    key.pod(0x6367ull);       // "cg"
+    key_operator(key, A);
+    key.obj(C).obj(M).pod(dinv).pod(x).pod(work).pod(N);
+    if ((rc = replay_prepare(key.h, kReplayCg, st, body, &graph, &graph_nodes))) return rc;
+  }
+
   // Iterations are enqueued in batches; the device decides which iterate
   // passes the stopping test (cg_scalar_kernel) and turns everything behind it
   // into no-ops, so a batch may overshoot: the first one is `first_check`
@@ -1054,26 +1104,11 @@ static int cg(const flow_operator* A, const double* dinv,
                                                          : check_every;
     const int todo = (maxit - launched < batch) ? maxit - launched : batch;
     for (int k = 0; k < todo; ++k) {
-      if (C) {
-        hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
-                           st, N, S, dinv, w, z, p, s, x, r, 0, partial,
-                           static_cast<const double*>(nullptr));
-        if ((rc = two_level(C, dinv, r, z, crc, czc, st, partial, &np, stop)))
-          return rc;
-      } else if (M) {
-        hipLaunchKernelGGL(cg_update_kernel<false>, dim3(gv), dim3(kBlock), 0,
-                           st, N, S, dinv, w, z, p, s, x, r, 0, partial,
-                           static_cast<const double*>(nullptr));
-        if ((rc = vcycle(M, r, z, st, mpart, mpart + nm, &np, stop))) return rc;
-      } else {
-        hipLaunchKernelGGL(cg_update_kernel<true>, dim3(gu), dim3(kBlock), 0, st,
-                           N, S, dinv, w, z, p, s, x, r, 1, partial,
-                           static_cast<const double*>(nullptr));
-        np = gu;
+      if (graph) {
+        if ((rc = replay_launch(graph, graph_nodes, st))) return rc;
+      } else if ((rc = body())) {
+        return rc;
       }
-      if ((rc = apply(A, z, w, st, dpart, stop))) return rc;
-      hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(kScalarBlock), 0, st,
-                         np, nd, 0, gpart, rpart, dpart, rtol2, atol2, S);
     }
     FLOW_CHECK_LAUNCH();
     launched += todo;
@@ -1306,7 +1341,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 27; }
+extern "C" int flow_abi_version(void) { return 28; }
 
 namespace flow {
 unsigned long long g_launches = 0;
@@ -1964,7 +1999,8 @@ constexpr int kGCw = kGCoef + kGmresMax;                  //   and the w factor
 constexpr int kGYc = kGCw + 1;                            // update: y_k / |V_k|
 constexpr int kGRot = kGYc + kGmresMax;                   // Givens (cs, sn)[k]
 constexpr int kGRhs = kGRot + 2 * kGmresMax;              // rotated beta e1
-constexpr int kGState = kGRhs + kGmresMax + 1;
+constexpr int kGJvp = kGRhs + kGmresMax + 1;                // momentum_jvp_params
+constexpr int kGState = kGJvp + 3;
 static_assert(kGState <= FLOW_GMRES_STATE, "gmres device state");
 
 // Arnoldi step j of a cycle, the part round 1 did on the host: sums of the
@@ -2314,6 +2350,7 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
   const int gd = grid_for(N, kBlock, kRedBlocks);
   int np = 0, rc;
 
+  const double* jprm = nullptr;   // (set with the graphs below)
   // Z_j = M^-1 V_j (without a preconditioner Z_j is V_j itself)
   const bool precond = pmg || ilu || dinv;
   const double* Zbase = precond ? Z : V;
@@ -2332,7 +2369,8 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
     int r;
     double* w = V + static_cast<size_t>(j + 1) * N;
     if ((r = precondition(j))) return r;
-    if ((r = apply(A, Zbase + static_cast<size_t>(j) * N, w, st, nullptr, stop)))
+    if ((r = apply(A, Zbase + static_cast<size_t>(j) * N, w, st, nullptr, stop, 0,
+                   0, jprm)))
       return r;
     for (int k0 = 0; k0 <= j; k0 += 8) {
       const int chunk = j + 1 - k0 < 8 ? j + 1 - k0 : 8;
@@ -2354,6 +2392,37 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
                                stop, st)))
       return r;
     return FLOW_OK;
+  };
+
+  // Arnoldi step j as a HIP graph where the launch rate bounds it
+  // (graph_replay.hip): one graph per column and `last` flag; the step size
+  // of a matrix-free Jacobian travels through device memory (G + kGJvp), so
+  // the graphs survive the step-size controller
+  const bool replay = replay_wanted(N, kReplayGmres);
+  KeyHash base;
+  if (replay) {
+    base.pod(0x676dull);      // "gm"
+    key_operator(base, A, true);
+    base.pod(dinv).obj(ilu).obj(ilu ? ilu->plan : nullptr).obj(pmg);
+    base.pod(work).pod(N).pod(m);
+    if (A->kind == 3) {
+      jprm = G + kGJvp;
+      if ((rc = momentum_jvp_params(
+               static_cast<const flow_momentum_jvp*>(A->matfree), G + kGJvp, st)))
+        return rc;
+    }
+  }
+  auto arnoldi_replayed = [&](int j, bool last) -> int {
+    if (!replay) return arnoldi(j, -1.0, 0.0, last);
+    KeyHash key = base;
+    key.pod(j).pod(last);
+    hipGraphExec_t graph = nullptr;
+    int nodes = 0, r;
+    if ((r = replay_prepare(key.h, kReplayGmres, st,
+                            [&]() { return arnoldi(j, -1.0, 0.0, last); }, &graph,
+                            &nodes)))
+      return r;
+    return graph ? replay_launch(graph, nodes, st) : arnoldi(j, -1.0, 0.0, last);
   };
 
   if ((rc = fill(kNumSlots, 0.0, S, st))) return rc;
@@ -2424,7 +2493,7 @@ static int gmres(const flow_operator* A, const double* dinv, const flow_ilu* ilu
       if (plan > room) plan = room;
       for (int k = 0; k < plan; ++k, ++enq) {
         const bool last = enq + 1 >= m || it0 + enq + 1 >= maxit;
-        if ((rc = arnoldi(enq, -1.0, 0.0, last))) return rc;
+        if ((rc = arnoldi_replayed(enq, last))) return rc;
       }
       if ((rc = read_state(S, state, st))) return rc;
       cols = static_cast<int>(state[kConvIt]);

@@ -519,13 +519,35 @@ static int mass_solve(const flow_mass* M, const double* b, double* x,
     FLOW_CHECK_LAUNCH();
     return FLOW_OK;
   };
+  // one correction as a HIP graph where the launch rate bounds it
+  // (graph_replay.hip): two bodies -- from x = 0, and the general one
+  const bool replay = replay_wanted(A->n, kReplayMass);
+  KeyHash base;
+  if (replay) {
+    base.pod(0x6d73ull);      // "ms"
+    key_operator(base, A);
+    base.obj(M).pod(b).pod(x).pod(xbase).pod(work).pod(rtol).pod(atol);
+  }
+  auto one_replayed = [&]() -> int {
+    if (!replay) return one();
+    KeyHash key = base;
+    key.pod(x_is_zero);
+    hipGraphExec_t graph = nullptr;
+    int nodes = 0, r;
+    const bool was_zero = x_is_zero;
+    if ((r = replay_prepare(key.h, kReplayMass, st, one, &graph, &nodes))) return r;
+    x_is_zero = was_zero;     // (a capture has run `one` without launching)
+    if (!graph) return one();
+    x_is_zero = false;
+    return replay_launch(graph, nodes, st);
+  };
   double state[kNumSlots];
   int launched = 0;
   while (true) {
     const int batch = (launched == 0 && first_check > 0) ? first_check : 1;
     const int todo = (maxit - launched < batch) ? maxit - launched : batch;
     for (int k = 0; k < todo; ++k)
-      if ((rc = one())) return rc;
+      if ((rc = one_replayed())) return rc;
     launched += todo;
     if ((rc = read_state(S, state, st))) return rc;
     const double zz = state[kRes2];

@@ -298,6 +298,18 @@ _THETA = {
     }
 
 
+def _persistent(lay, name, n):
+    '''A work vector of the layout that keeps its ADDRESS from call to call
+    (uninitialised): the vectors of a solver loop are arguments of its
+    launches, and only a loop whose arguments repeat is replayed as a HIP
+    graph (csrc/graph_replay.hip) instead of being captured again.'''
+    key = ('persistent', name)
+    buf = lay._dev.get(key)
+    if buf is None or buf.numel() != n:
+        buf = lay._dev[key] = device.empty(n)
+    return buf
+
+
 def _zeros(n):
     '''A zeroed work vector; the fill is a kernel of the library on its stream
     (no torch kernels inside a step).'''
@@ -385,7 +397,12 @@ def _compute_tentative_velocity(
     n2 = W.size()
 
     # initial guess: previous velocity (reference :204-220) ...
-    ui = Function(W, _hip.clone(u[0].data))
+    # (in a buffer of the layout, the same for every call: the iterate's
+    # address is an argument of every launch of the Newton-Krylov loop, and a
+    # loop whose arguments do not change is replayed as a HIP graph --
+    # csrc/graph_replay.hip.  The tentative velocity reported in
+    # last_step_info lives until the next call on this space.)
+    ui = Function(W, ops.copy(_persistent(lay, 'newton_iterate', n2), u[0].data))
     # ... or ('initial_guess': 'best'), when this call continues the trajectory
     # of the previous one (u[0] IS the velocity the last step returned), the
     # previous step's TENTATIVE velocity if its residual is smaller (choice (2)
@@ -1204,7 +1221,7 @@ def _compute_velocity_correction(
     increment = (par.get('method', 'chebyshev') == 'chebyshev'
                  and par.get('increment', True)
                  and not par.get('extrapolate', False))
-    b = _zeros(n2) if parallel.active() else device.empty(n2)
+    b = _zeros(n2) if parallel.active() else _persistent(lay, 'correction_rhs', n2)
     buf = ops.scratch(mesh, 2 * lay.nloc * nc)
     _hip.check(lib.flow_assemble_correction_rhs(
         ctypes.byref(_mesh_s(mesh)), ctypes.byref(_space_s(lay)),
@@ -1235,7 +1252,16 @@ def _compute_velocity_correction(
     Mbc, dinv = lay._dev[key]
     nbc = bc_dofs.numel()
     # the tentative velocity is the natural initial guess: u1 - ui = O(dt) ...
-    u1 = Function(W, _hip.clone(ui.data))
+    # (increment form on one GPU: the start lives in a buffer of the layout --
+    # the solver's loop only sees it and its own workspace, the same addresses
+    # every call --, the result base + increment is written to a fresh u1)
+    apart = increment and not parallel.active()
+    if apart:
+        start = ops.copy(_persistent(lay, 'correction_start', n2), ui.data)
+        u1 = Function(W, device.empty(n2))
+    else:
+        u1 = Function(W, _hip.clone(ui.data))
+        start = u1.data
     # ... plus, when this call continues the previous one's trajectory, that
     # step's correction u1 - ui scaled with the step sizes (the correction
     # -dt/rho M^-1 grad(phi) varies slowly once the flow has settled: 6 -> 2-3
@@ -1248,11 +1274,11 @@ def _compute_velocity_correction(
         if solver_parameters['correction'].get('extrapolate', False) else None
     if hist is not None and 'dt' in hist and 0.7 <= dt / hist['dt'] <= 1.5:
         r = dt / hist['dt']
-        ops.axpby(r, hist['u_out'], 1.0, u1.data)
-        ops.axpby(-r, hist['ui'], 1.0, u1.data)
+        ops.axpby(r, hist['u_out'], 1.0, start)
+        ops.axpby(-r, hist['ui'], 1.0, start)
     if nbc > 0:
         _hip.check(lib.flow_bc_set_values(
-            nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(u1.data), st
+            nbc, _hip.i32(bc_dofs), _hip.f64(bc_vals), _hip.f64(start), st
             ))
         if increment:
             # (the increment vanishes on the Dirichlet rows: the start carries
@@ -1300,7 +1326,7 @@ def _compute_velocity_correction(
                     tag='correction', xbase=u1.data, delta0=d0)
             else:
                 sol = solver.solve_increment(
-                    b, u1.data, u1.data, tol, maxit=min(par['maxit'], 100),
+                    b, start, u1.data, tol, maxit=min(par['maxit'], 100),
                     tag='correction', delta0=d0)
             if par.get('increment_start') == 'extrapolated':
                 d0 = lay._dev['correction_d0_scratch']

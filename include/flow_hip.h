@@ -53,6 +53,27 @@ int flow_abi_version(void);
 /* Kernel launches the library has issued so far in this process (all entry
  * points, all streams): differences over a window give launches per step. */
 int flow_launch_count(unsigned long long* count_host);
+/* Iteration bodies as HIP graphs (flow_amd/csrc/graph_replay.hip) -- OFF by
+ * default.  The Krylov and defect-correction loops of this library
+ * (flow_cg_solve*, flow_gmres_solve, flow_mass_solve*) issue the same chain of
+ * launches every iteration; each can be captured once and replayed, with
+ * bit-identical results.  Measured on MI355X / ROCm 7.2 the replay is SLOWER
+ * than the launches it replaces at every size of the workload (2.61 against
+ * 2.38 ms per step on the eighth-size proxy; graph_replay.hip has the table),
+ * hence the default.
+ * mode 0 (default, FLOW_AMD_GRAPHS unset): never; 1 (FLOW_AMD_GRAPHS=1): always;
+ * 2 (FLOW_AMD_GRAPHS=auto): for systems of up to auto_rows rows (< 0: leave;
+ * default 1.5e6, FLOW_AMD_GRAPH_ROWS); mode | (sites << 4) with sites != 0
+ * also chooses the loops (1 CG, 2 GMRES, 4 mass solver; default all).  A graph
+ * is captured the first time a body is seen and kept under a hash of every
+ * value that reaches its kernels (the step size of the matrix-free Jacobian
+ * travels through device memory instead); a replay counts as ONE launch in
+ * flow_launch_count.
+ * flow_graph_stats: stats_host[0..7] = graphs kept, captures so far, replays
+ * so far, kernel nodes those replays carried, captures by loop (CG, GMRES,
+ * mass solver), 0. */
+int flow_graph_mode(int mode, long long auto_rows);
+int flow_graph_stats(unsigned long long* stats_host);
 /* Host copy of the workgroup -> tile mapping the CSR-stream kernels use
  * (XCD-aware, a permutation of [0, nblocks)); for tests. */
 int flow_xcd_tile_host(int block, int nblocks);
