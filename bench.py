@@ -393,6 +393,11 @@ def main():
                          'value_developed.  Default: 2400 at the headline size '
                          '(t ~ 75: the wake sheds, a step takes two Newton '
                          'iterations), 0 = off otherwise')
+    ap.add_argument('--developed-period', type=int, default=400, metavar='STEPS',
+                    help='with --developed: that many further steps behind '
+                         'the timed window, timed as a whole (about one '
+                         'shedding period: bursts and calm phases averaged); '
+                         'reported as value_developed_period; 0 = off')
     ap.add_argument('--nx', type=int, default=2182,
                     help='cells along the channel (2182 x 509: ~10 M DoF)')
     ap.add_argument('--ny', type=int, default=None)
@@ -739,6 +744,34 @@ def main():
             '%d warm-up + %d timed steps in mode %r: the developed vortex '
             'street' % (args.developed, spin_s, max(args.warmup, 8),
                         args.steps, args.mode))
+        # ... and one shedding period on from there (St ~ 0.2: ~12.5 s, ~370
+        # steps): what a step of the street costs averaged over its bursts and
+        # its calm phases -- the window above happens to sit in a burst
+        if args.developed_period > 0:
+            barrier()
+            t_p = time.perf_counter()
+            p_infos = [prob.step(tol=args.tol)
+                       for _ in range(args.developed_period)]
+            barrier()
+            p_elapsed = time.perf_counter() - t_p
+            apps = [sum(i.get('newton_linear_applications', [])) for i in p_infos]
+            developed['period'] = {
+                'steps': args.developed_period,
+                'ms_per_step': 1e3 * p_elapsed / args.developed_period,
+                'steps_per_s': args.developed_period / p_elapsed,
+                't_end': prob.t,
+                'newton_iterations_mean': sum(
+                    len(i['newton_residuals']) - 1 for i in p_infos)
+                / float(len(p_infos)),
+                'newton_linear_applications_mean': sum(apps) / float(len(apps)),
+                'newton_linear_applications_min_max': [min(apps), max(apps)],
+                'pressure_cg_iterations_mean': sum(
+                    i['pressure'].iterations for i in p_infos)
+                / float(len(p_infos)),
+                'note': 'the %d steps behind the timed window, continued '
+                        'without a restart: one shedding period'
+                        % args.developed_period,
+                }
         settled['state'] = plateau_state
 
     if rank != 0:
@@ -865,6 +898,9 @@ def main():
         # co-headline: the same metric in the regime a Karman run lives in
         out['value_developed'] = developed['steps_per_s']
         out['ms_per_step_developed'] = developed['ms_per_step']
+        if 'period' in developed:
+            out['value_developed_period'] = developed['period']['steps_per_s']
+            out['ms_per_step_developed_period'] = developed['period']['ms_per_step']
         out['config']['developed'] = developed
     if fast is not None:
         out['config']['fast_mode'] = fast

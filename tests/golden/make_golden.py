@@ -7,7 +7,8 @@ analytic known-answer tests (tests/test_oracle_pinning.py).
 
     python tests/golden/make_golden.py [--force] [--large [name ...]]
 
---large writes the fixtures ns_large_<name>.npz instead (tests/large_cases.py:
+--large writes the fixtures ns_large_<name>.npz, bq_large_<name>.npz and
+stokes_large_<name>.npz instead (tests/large_cases.py:
 one Rotational step, backward Euler and Crank-Nicolson, of the Karman channel
 problem at BASELINE config 2's size and on a Taylor-Hood channel of 0.76 M DoF
 -- minutes of sparse LU each, run in the build container; the GPU box only
@@ -159,13 +160,78 @@ def large_fixture(name):
     numpy.savez_compressed(path, **data)
 
 
+def _store(data, key, fields, stride):
+    import large_cases
+    for fname, field, ncomp in fields:
+        sample, l2, linf = large_cases.summary(field, ncomp, stride)
+        data['%s%s_sample' % (key, fname)] = sample
+        data['%s%s_l2' % (key, fname)] = l2
+        data['%s%s_linf' % (key, fname)] = linf
+
+
+def boussinesq_fixture(name):
+    '''bq_large_<name>.npz: one coupled sweep (BASELINE config 4).'''
+    import time
+    import large_cases
+    import cases
+    path = _wanted('bq_large_%s.npz' % name)
+    if path is None:
+        return
+    case = large_cases.BoussinesqSweepCase(**large_cases.LARGE_BOUSSINESQ[name])
+    data = {'fingerprint': case.fingerprint(), 'stride': large_cases.STRIDE,
+            'num_dofs': case.num_dofs()}
+    for k, v in case.args.items():
+        data['arg_' + k] = v
+    info = {}
+    t0 = time.time()
+    theta, u, p = case.oracle_sweep(info=info)
+    data['oracle_seconds'] = time.time() - t0
+    data['newton_history'] = numpy.array(info['newton_history'])
+    p = cases.mean_free(p, case.pressure_mass())
+    _store(data, '', (('theta', theta - 293.0, 1), ('u', u, 2), ('p', p, 1)),
+           large_cases.STRIDE)
+    print('  bq %s: %d DoF, %.0f s, Newton %s' % (
+        name, case.num_dofs(), data['oracle_seconds'],
+        ' '.join('%.2e' % r for r in info['newton_history'])), flush=True)
+    numpy.savez_compressed(path, **data)
+
+
+def stokes_fixture(name):
+    '''stokes_large_<name>.npz: the Stokes bootstrap (BASELINE config 5's
+    solver).'''
+    import time
+    import large_cases
+    path = _wanted('stokes_large_%s.npz' % name)
+    if path is None:
+        return
+    case = large_cases.StokesChannelCase(**large_cases.LARGE_STOKES[name])
+    data = {'fingerprint': case.fingerprint(), 'stride': large_cases.STRIDE,
+            'num_dofs': case.num_dofs()}
+    for k, v in case.args.items():
+        data['arg_' + k] = v
+    t0 = time.time()
+    u, p = case.oracle_solve()
+    data['oracle_seconds'] = time.time() - t0
+    _store(data, '', (('u', u, 2), ('p', p, 1)), large_cases.STRIDE)
+    print('  stokes %s: %d DoF, %.0f s' % (name, case.num_dofs(),
+                                          data['oracle_seconds']), flush=True)
+    numpy.savez_compressed(path, **data)
+
+
 if __name__ == '__main__':
     if LARGE:
         import large_cases
-        names = [a for a in sys.argv[1:] if a in large_cases.LARGE] \
-            or sorted(large_cases.LARGE)
-        for name in names:
-            large_fixture(name)
+        asked = [a for a in sys.argv[1:] if not a.startswith('--')]
+        every = not asked
+        for name in sorted(large_cases.LARGE):
+            if every or name in asked:
+                large_fixture(name)
+        for name in sorted(large_cases.LARGE_BOUSSINESQ):
+            if every or name in asked:
+                boussinesq_fixture(name)
+        for name in sorted(large_cases.LARGE_STOKES):
+            if every or name in asked:
+                stokes_fixture(name)
         sys.exit(0)
     # C1: the reference's plumbing configuration (tests/test_navier_stokes.py:
     # 403-410): UnitSquareMesh(8, 8, 'crossed'), P2-P1, guermond2

@@ -172,3 +172,163 @@ def summary(field, ncomp, stride=STRIDE):
     f = numpy.asarray(field).reshape(ncomp, -1)
     return (f[:, ::stride].copy(),
             numpy.sqrt((f**2).sum(axis=1)), abs(f).max(axis=1))
+
+
+class BoussinesqSweepCase(object):
+    '''BASELINE config 4 at a size where the kernels tile: ONE fixed-point
+    sweep of a Boussinesq time step (reference tests/test_boussinesq.py:213-253
+    -- implicit Euler on Heat with the old velocity, then Rotational.step with
+    the buoyancy rho(theta) g) on the body-fitted heater box, from an analytic
+    perturbed state (a warm plume above the heater, a weak swirl that vanishes
+    on the walls), as tests/test_boussinesq_counterpart.py runs it on 12 cells
+    per side.'''
+    def __init__(self, n, dt=0.05, t=12.0):
+        from flow_amd import boussinesq
+        self.args = dict(n=n, dt=dt, t=t)
+        self.mesh = mesh = fem.heater_box(n, fitted=True)
+        self.pb = pb = boussinesq.HeaterBox(mesh)
+        self.dt, self.t = dt, t
+        xq = pb.Q.layout.dof_coords
+        xw = pb.W.layout.dof_coords
+        self.theta0 = 293.0 + 8.0 * numpy.exp(
+            -((xq[:, 0] - 0.05)**2 + (xq[:, 1] - 0.09)**2) / 4e-4)
+        bump = numpy.sin(numpy.pi * xw[:, 0] / 0.1) \
+            * numpy.sin(numpy.pi * xw[:, 1] / 0.2)
+        u = 1.0e-3 * numpy.concatenate([-(xw[:, 1] - 0.1) * bump,
+                                        (xw[:, 0] - 0.05) * bump])
+        self.u_bc = collect(pb.no_slip, pb.W.size())
+        u[self.u_bc[0]] = self.u_bc[1]
+        self.u0 = u
+
+    def num_dofs(self):
+        return self.pb.W.size() + self.pb.P.size() + self.pb.Q.size()
+
+    def fingerprint(self):
+        m = self.mesh
+        w = numpy.cos(numpy.arange(len(self.u0)) * 0.37)
+        return numpy.array([
+            m.num_vertices(), m.num_cells(), self.pb.W.N, self.pb.P.N,
+            m.points.sum(), numpy.dot(w, self.u0),
+            numpy.dot(w[:len(self.theta0)], self.theta0 - 293.0), self.dt])
+
+    def product_sweep(self, flow_tol=1.0e-13):
+        '''(theta, u, p) of flow_amd.boussinesq.CoupledStep.sweep.'''
+        from flow_amd import boussinesq
+        u0, p0, theta0 = self.pb.state_of_rest()
+        theta0.set_array(self.theta0)
+        u0.set_array(self.u0)
+        self.p_rest = p0.array().copy()
+        step = boussinesq.CoupledStep(self.pb, u0, p0, theta0, self.t, self.dt)
+        step.flow_tol = flow_tol
+        dist = step.sweep()
+        assert all(numpy.isfinite(dist)) and step.sweeps == 1
+        return step.theta.array(), step.u.array(), step.p.array()
+
+    def oracle_sweep(self, info=None):
+        from oracle import fem_oracle as orc
+        pb, mesh = self.pb, self.mesh
+        Qo = orc.Space(mesh.points, mesh.cell_vertices, pb.Q.layout.cell_dofs, 2,
+                       pb.Q.N)
+        Wo = orc.Space(mesh.points, mesh.cell_vertices, pb.W.layout.cell_dofs, 2,
+                       pb.W.N)
+        Po = orc.Space(mesh.points, mesh.cell_vertices, pb.P.layout.cell_dofs, 1,
+                       pb.P.N)
+        M, A, _b = orc.heat_operators(Qo, Wo, self.u0, pb.kappa, pb.rho_room,
+                                      pb.cp, 0.0, False)
+        d_t, v_t = collect(pb.temperature_bcs(self.t), pb.Q.size())
+        theta = orc.heat_solve(M.tocsr(), A.tocsr(), 1.0, -self.dt,
+                               M.dot(self.theta0), d_t, v_t)
+        dens = pb.rho(self.theta0)[pb.Q.layout.cell_dofs]
+        f = numpy.stack([numpy.zeros_like(dens), dens * pb.gravity], axis=2)
+        lat = (reference.lattice(2), f)
+        # (hydrostatic pressure of the state of rest: linear, so its P1
+        # projection is its nodal interpolant)
+        p_rest = pb.rho_room * pb.gravity * pb.P.layout.dof_coords[:, 1]
+        u, p, _ui = orc.step(Wo, Po, self.u0, p_rest, lat, lat, self.u_bc,
+                             None, pb.rho_room, pb.mu, self.dt,
+                             scheme='rotational', info=info)
+        return theta, u, p
+
+    def pressure_mass(self):
+        '''P1 mass matrix (scipy): the Neumann pressure is compared mean-free.'''
+        from oracle import fem_oracle as orc
+        pb, mesh = self.pb, self.mesh
+        return orc.mass_matrix(orc.Space(
+            mesh.points, mesh.cell_vertices, pb.P.layout.cell_dofs, 1, pb.P.N))
+
+
+class StokesChannelCase(object):
+    '''The Karman driver's Stokes bootstrap (reference
+    tests/test_karman_vortex_street.py:171-179, flow/stokes.py:13-148) on a
+    body-fitted channel with the analytic body force above: flow_amd.stokes
+    (MINRES + block preconditioner) against the oracle's sparse LU of the
+    saddle-point matrix -- BASELINE config 5's solver at a size where the
+    kernels tile.'''
+    def __init__(self, nx, ny, mu=0.002):
+        self.args = dict(nx=nx, ny=ny, mu=mu)
+        self.mesh = mesh = fem.karman_channel(nx, ny, fitted=True)
+        self.mu = mu
+        self.WP = fem.FunctionSpace(
+            mesh,
+            fem.VectorElement('Lagrange', mesh.ufl_cell(), 2)
+            * fem.FiniteElement('Lagrange', mesh.ufl_cell(), 1))
+        self.W, self.P = W, P = self.WP.sub(0), self.WP.sub(1)
+        prof = '%e * (%e - x[1]) * (x[1] - %e) / %e' % (
+            karman.ENTRANCE_VELOCITY, karman.Y1, karman.Y0,
+            (0.5 * (karman.Y1 - karman.Y0))**2)
+        inflow = fem.Expression(prof, degree=2)
+        self.u_bcs = [
+            fem.DirichletBC(W, (0.0, 0.0), karman.UpperBoundary()),
+            fem.DirichletBC(W, (0.0, 0.0), karman.LowerBoundary()),
+            fem.DirichletBC(W, (0.0, 0.0), karman.ObstacleBoundary()),
+            fem.DirichletBC(W.sub(0), inflow, karman.LeftBoundary()),
+            fem.DirichletBC(W.sub(0), inflow, karman.RightBoundary()),
+            ]
+        self.p_bcs = [fem.DirichletBC(P, 0.0, karman.RightBoundary())]
+        self.force = fem.Expression(lambda x: force(x, 0.3), degree=2)
+
+    def num_dofs(self):
+        return self.W.size() + self.P.N
+
+    def fingerprint(self):
+        m = self.mesh
+        return numpy.array([m.num_vertices(), m.num_cells(), self.W.N, self.P.N,
+                            m.points.sum(), self.mu])
+
+    def product_solve(self, tol=1.0e-13):
+        from flow_amd import stokes
+        u, p = stokes.solve(self.WP, self.u_bcs + self.p_bcs, self.mu, self.force,
+                            verbose=False, tol=tol, max_iter=20000)
+        return u.array(), p.array()
+
+    def oracle_solve(self):
+        from oracle import fem_oracle as orc
+        m = self.mesh
+        Wo = orc.Space(m.points, m.cell_vertices, self.W.layout.cell_dofs, 2,
+                       self.W.N)
+        Po = orc.Space(m.points, m.cell_vertices, self.P.layout.cell_dofs, 1,
+                       self.P.N)
+        X = fem.cell_lattice_points(m, 2)
+        nc, nl = X.shape[:2]
+        v = self.force.eval(X.reshape(-1, 2).T)
+        lat = (reference.lattice(2), numpy.ascontiguousarray(
+            v.reshape(2, nc, nl).transpose(1, 2, 0)))
+        return orc.stokes_solve(Wo, Po, lat, self.mu,
+                                collect(self.u_bcs, self.W.size()),
+                                collect(self.p_bcs, self.P.N))
+
+
+# the configurations of tests/golden/bq_large_*.npz / stokes_large_*.npz
+LARGE_BOUSSINESQ = {
+    # 0.39 M DoF (velocity 2 x 0.12 M, pressure 30 k, temperature 0.12 M)
+    'box_120': dict(n=120),
+    # BASELINE config 4's nominal size: 4.2 M DoF
+    'box_400': dict(n=400),
+    }
+LARGE_STOKES = {
+    # 0.34 M DoF
+    'channel_400x93': dict(nx=400, ny=93),
+    # BASELINE config 5's nominal size: 2.0 M DoF
+    'channel_980x229': dict(nx=980, ny=229),
+    }
+

@@ -113,6 +113,64 @@ def test_karman_step_against_the_offline_oracle(hip, name, method):
              navsto.last_step_info['correction']))
 
 
+def _compare_with_fixture(gold, fields, what):
+    stride = int(gold['stride'])
+    for fname, field, ncomp in fields:
+        sample, l2, linf = large_cases.summary(field, ncomp, stride)
+        gs, gl2, glinf = (gold[fname + '_sample'], gold[fname + '_l2'],
+                          gold[fname + '_linf'])
+        err = numpy.linalg.norm(sample - gs) / numpy.linalg.norm(gs)
+        assert err < 1e-7, (what, fname, err)
+        assert abs(sample - gs).max() < 1e-6 * glinf.max(), (what, fname)
+        assert numpy.allclose(l2, gl2, rtol=1e-8, atol=1e-9 * gl2.max()), \
+            (what, fname, l2, gl2)
+        assert numpy.allclose(linf, glinf, rtol=1e-7,
+                              atol=1e-8 * glinf.max()), (what, fname)
+
+
+@pytest.mark.parametrize('name', sorted(large_cases.LARGE_BOUSSINESQ))
+def test_boussinesq_sweep_against_the_offline_oracle(hip, name):
+    '''BASELINE config 4 above toy size: one coupled sweep (heat with the old
+    velocity, then Rotational.step with the buoyancy; reference
+    tests/test_boussinesq.py:213-253) against the oracle's, computed in the
+    build container (tests/golden/make_golden.py --large): temperature excess,
+    velocity and mean-free pressure to 1e-7, the Newton residuals to the
+    digits the conditioning leaves.'''
+    import flow_amd.navier_stokes as navsto
+    path = os.path.join(GOLDEN, 'bq_large_%s.npz' % name)
+    if not os.path.exists(path):
+        pytest.skip('fixture %s not generated' % os.path.basename(path))
+    gold = numpy.load(path)
+    case = large_cases.BoussinesqSweepCase(**large_cases.LARGE_BOUSSINESQ[name])
+    fp, fpg = case.fingerprint(), gold['fingerprint']
+    assert numpy.allclose(fp, fpg, rtol=1e-9, atol=1e-12), (fp, fpg)
+    theta, u, p = case.product_sweep()
+    p = cases.mean_free(p, case.pressure_mass())
+    _compare_with_fixture(gold, (('theta', theta - 293.0, 1), ('u', u, 2),
+                                 ('p', p, 1)), name)
+    _newton_history_matches(navsto.last_step_info['newton_residuals'],
+                            gold['newton_history'])
+    print('%s: %d DoF, Newton residuals %s, pressure %r' % (
+        name, case.num_dofs(),
+        ' '.join('%.2e' % r for r in navsto.last_step_info['newton_residuals']),
+        navsto.last_step_info['pressure']))
+
+
+@pytest.mark.parametrize('name', sorted(large_cases.LARGE_STOKES))
+def test_stokes_against_the_offline_oracle(hip, name):
+    '''The Stokes solver (BASELINE config 5's; reference flow/stokes.py:13-148)
+    above toy size against the oracle's sparse LU of the saddle-point system.'''
+    path = os.path.join(GOLDEN, 'stokes_large_%s.npz' % name)
+    if not os.path.exists(path):
+        pytest.skip('fixture %s not generated' % os.path.basename(path))
+    gold = numpy.load(path)
+    case = large_cases.StokesChannelCase(**large_cases.LARGE_STOKES[name])
+    fp, fpg = case.fingerprint(), gold['fingerprint']
+    assert numpy.allclose(fp, fpg, rtol=1e-9, atol=1e-12), (fp, fpg)
+    u, p = case.product_solve()
+    _compare_with_fixture(gold, (('u', u, 2), ('p', p, 1)), name)
+
+
 def test_twelve_steps_with_start_vectors_against_the_oracle(hip):
     '''A time loop at 53 k DoF: the oracle and the product each step their own
     trajectory 12 times from the same state (fixed step size, the start
