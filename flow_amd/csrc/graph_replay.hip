@@ -26,6 +26,7 @@
 // graph changes is the dispatch of each node, and that is not cheaper.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <unordered_map>
 
 #include "common.h"
@@ -54,6 +55,9 @@ struct Thrash {
   int misses = 0, pause = 0;
 };
 Thrash g_thrash[8];
+// the cache and its counters (a capture runs under the lock: two threads that
+// solve on two streams take turns capturing, replays only look the graph up)
+std::mutex g_lock;
 
 void read_env() {
   if (g_mode >= 0) return;
@@ -68,6 +72,8 @@ void read_env() {
 }
 
 void drop_all() {
+  if (g_cache.empty()) return;
+  (void)hipDeviceSynchronize();
   for (auto& kv : g_cache) (void)hipGraphExecDestroy(kv.second.exec);
   g_cache.clear();
 }
@@ -87,6 +93,7 @@ int replay_prepare(unsigned long long key, int site, hipStream_t st,
                    int* nodes) {
   *exec = nullptr;
   *nodes = 0;
+  std::lock_guard<std::mutex> guard(g_lock);
   Thrash& th = g_thrash[site & 7];
   auto it = g_cache.find(key);
   if (it != g_cache.end()) {
@@ -110,7 +117,9 @@ int replay_prepare(unsigned long long key, int site, hipStream_t st,
     return FLOW_OK;
   }
   if (g_cache.size() >= kMaxEntries) {
-    // (evict the older half)
+    // (evict the older half -- behind a synchronisation: one of them may
+    // still be executing)
+    (void)hipStreamSynchronize(st);
     std::vector<std::pair<unsigned long long, unsigned long long>> age;
     for (auto& kv : g_cache) age.push_back({kv.second.used, kv.first});
     std::sort(age.begin(), age.end());
@@ -158,6 +167,7 @@ int replay_prepare(unsigned long long key, int site, hipStream_t st,
 
 int replay_launch(hipGraphExec_t exec, int nodes, hipStream_t st) {
   FLOW_CHECK_HIP(hipGraphLaunch(exec, st));
+  std::lock_guard<std::mutex> guard(g_lock);
   ++g_launches;             // one submission
   ++g_graph_replays;
   g_graph_nodes += static_cast<unsigned long long>(nodes);
@@ -170,6 +180,7 @@ using namespace flow;
 
 extern "C" int flow_graph_stats(unsigned long long* stats_host) {
   FLOW_REQUIRE(stats_host != nullptr, "flow_graph_stats argument");
+  std::lock_guard<std::mutex> guard(g_lock);
   stats_host[0] = g_cache.size();
   stats_host[1] = g_graph_captures;
   stats_host[2] = g_graph_replays;
@@ -186,6 +197,7 @@ extern "C" int flow_graph_mode(int mode, long long auto_rows) {
   const int sites = mode >> 4;
   mode &= 15;
   FLOW_REQUIRE(mode >= 0 && mode <= 2, "graph mode: 0 off, 1 on, 2 by size");
+  std::lock_guard<std::mutex> guard(g_lock);
   read_env();
   g_mode = mode;
   if (sites) g_sites = sites;
