@@ -25,6 +25,11 @@ for name in ('bench', 'driver_window', 'proxy', 'proxy_sharded', 'proxy_sharded_
     print(name, '%.2f steps/s %.3f ms' % (d['value'], d['ms_per_step']),
           'apps %.2f' % (sum(ap) / float(len(ap))),
           'roofline %.3f' % d['roofline']['frac'] if d.get('roofline') else '',
-          c.get('collectives_per_step'))
+          c.get('collectives_per_step'),
+          'developed %.2f (%.3f ms), period %.2f (%.3f ms)' % (
+              d['value_developed'], d['ms_per_step_developed'],
+              d.get('value_developed_period', 0),
+              d.get('ms_per_step_developed_period', 0))
+          if 'value_developed' in d else '')
 PY
 tail -3 $O/long_run.txt
