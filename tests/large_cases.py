@@ -161,9 +161,9 @@ LARGE = {
     # a quarter of the headline workload (2182 x 509): 2.5 M DoF, four
     # multigrid levels under the pressure solve
     'p2p1_1091x255': dict(nx=1091, ny=255, vdeg=2),
-    # half of it: 4.9 M DoF (the oracle's step at the full 9.87 M DoF does not
-    # fit the build container's memory)
-    'p2p1_1543x360': dict(nx=1543, ny=360, vdeg=2),
+    # (half of the workload, 1543 x 360 = 4.9 M DoF, was tried: SuperLU gives up
+    # on the Newton matrix -- "not enough memory to perform factorization"
+    # after 25 minutes, with 40 GB still free: the index range of its factors)
     }
 STRIDE = 87          # every 87th dof of each field is stored (a fixture
                      # says which stride it was written with)
