@@ -105,7 +105,10 @@ class ViscousCycle(object):
         if isbc1.any():
             K1c.vals[lay1.dev('diag_idx').long()[device.to_device(isbc1)]] = 1.0
         self.K1c = K1c
-        self.mg = Multigrid(K1c, isbc1, singular=not isbc1.any())
+        # (coarsest level <= 1500 rows: its dense inverse is formed on the host
+        # -- 0.9 s for the 2.7 k rows the default threshold leaves on a 2 M-DoF
+        # cavity, more than the whole MINRES iteration takes)
+        self.mg = Multigrid(K1c, isbc1, singular=not isbc1.any(), coarsest=1500)
         self.usable = self.mg.nlevels >= 2
         if not self.usable:
             return
