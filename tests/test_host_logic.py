@@ -5,6 +5,7 @@ maps, Dirichlet dof search, coefficients) and of the C-ABI library's symbol
 table.  No compute call is made: that needs a GPU.
 '''
 import os
+import sys
 import re
 
 import numpy
@@ -188,6 +189,24 @@ def test_library_exports_every_declared_symbol():
         re.search(r'FLOW_SPMV_NNZ_PER_BLOCK (\d+)', header).group(1))
     assert _hip.REDUCE_WORK == int(
         re.search(r'FLOW_REDUCE_WORK (\d+)', header).group(1))
+
+
+def test_graph_replay_is_off_unless_asked_for():
+    '''The HIP-graph replay of the iteration bodies (csrc/graph_replay.hip) is an
+    option: nothing is kept, captured or replayed by default; the switches and
+    the counters answer without a GPU.'''
+    import subprocess
+    code = ('import sys; sys.path.insert(0, %r); from flow_amd import _hip; '
+            's = _hip.graph_stats(); assert s["graphs"] == s["captures"] == 0, s; '
+            '_hip.graph_mode(1, sites=3); _hip.graph_mode(2, 1000); '
+            '_hip.graph_mode(0); print(_hip.graph_stats()["replays"])' % ROOT)
+    env = dict(os.environ)
+    env.pop('FLOW_AMD_GRAPHS', None)
+    out = subprocess.run([sys.executable, '-c', code], env=env,
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == '0', out.stderr
+    lib = _hip.load_library()
+    assert lib.flow_graph_mode(3, -1) != 0          # (modes are 0, 1, 2)
 
 
 def test_xcd_tile_mapping_is_a_permutation():
