@@ -18,7 +18,13 @@ the reference's Newton path -- start from u0, exact Newton steps -- which
 reproduces the reference's iterate to < 1e-6, tests/test_full_size_parity.py);
 at N = 1 the same window is then repeated from the same initial state in mode
 'fast' (extrapolated start vectors, looser Newton linear solves) and reported
-beside it in `config.fast_mode`.
+beside it in `config.fast_mode`.  The headline window sits on the early plateau
+of the run (symmetric flow, one Newton iteration per step); at N = 1 and the
+headline size the line also carries the DEVELOPED VORTEX STREET as a
+co-headline: `value_developed` (the same window 2400 steps later, t ~ 74: two
+Newton iterations per step, one of the bursts of the run) and
+`value_developed_period` (the 400 steps behind it, one shedding period, timed
+as a whole); details in `config.developed`.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): strong scaling,
 the mesh is fixed (flow_amd/parallel.py).
