@@ -105,6 +105,21 @@ class IluS(ctypes.Structure):
         ('lu', ctypes.c_void_p),
         ('packed', ctypes.c_void_p),
         ('single_vector', ctypes.c_int),
+        ('cycle', ctypes.c_void_p),
+        ]
+
+
+class TlS(ctypes.Structure):
+    '''flow_tl (include/flow_hip.h, K19)'''
+    _fields_ = [
+        ('fine', ctypes.POINTER(IluS)), ('coarse', ctypes.POINTER(IluS)),
+        ('fine_op', ctypes.c_void_p), ('coarse_op', ctypes.c_void_p),
+        ('pre', ctypes.c_int), ('post', ctypes.c_int),
+        ('coarse_sweeps', ctypes.c_int),
+        ('ends', ctypes.c_void_p), ('rptr', ctypes.c_void_p),
+        ('rsrc', ctypes.c_void_p),
+        ('bc_fine', ctypes.c_void_p), ('bc_coarse', ctypes.c_void_p),
+        ('rscale', ctypes.c_void_p), ('work', ctypes.c_void_p),
         ]
 
 
@@ -296,6 +311,7 @@ SYMBOLS = {
     'flow_pmg_cols16': [_I, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _VP, _P(_D), _VP],
     'flow_pmg_apply': [_P(PmgS), _VP, _VP, _VP],
+    'flow_tl_apply': [_P(TlS), _VP, _VP, _VP],
     'flow_mass_pack': [_I, _VP, _VP, _VP, _VP, _VP],
     'flow_mass_pack16': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_mass_solve': [_P(MassS), _VP, _VP, _D, _D, _I, _I, _VP,
@@ -365,7 +381,7 @@ class NotConverged(RuntimeError):
 
 # flow_abi_version() of the library these bindings describe (the structs above
 # and SYMBOLS): a stale libflow_hip.so is refused at load time
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 
 def load_library():

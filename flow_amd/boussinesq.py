@@ -100,6 +100,19 @@ class HeaterBox(object):
         self.walls = _Walls(self.box)
         self.no_slip = [fem.DirichletBC(self.W, (0.0, 0.0), 'on_boundary')]
 
+    def prepare(self):
+        '''What is built once per mesh on the HOST and would otherwise be built
+        inside the first time step that needs it: the ILU(0) plans (graph
+        colouring, sweep streams: ~1 s at a million rows) of the P2 and P1
+        levels the heat and Newton solves fall back to once the plume is too
+        fast for the Chebyshev cycle (flow_amd/fem/tlilu.py).'''
+        from . import device
+        if device.on_gpu():
+            from .fem.tlilu import TwoLevelIlu
+            heat.prepare(self.Q)
+            TwoLevelIlu.plans(self.W.layout)
+        return self
+
     def heater_temperature(self, t):
         '''Linear ramp from room temperature to heater_max in ramp_time.'''
         return self.room + min(1.0, t / self.ramp_time) * (
@@ -205,6 +218,8 @@ class FixedPointStepper(object):
     def __init__(self, problem, dt0, policy=Coupling):
         self.pb = problem
         self.policy = policy
+        if hasattr(problem, 'prepare'):
+            problem.prepare()
         self.u, self.p, self.theta = problem.state_of_rest()
         self.t = 0.0
         self.dt = dt0

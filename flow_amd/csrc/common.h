@@ -42,7 +42,16 @@ int ilu_check(const flow_ilu* ilu, int op_size);
 int pmg_apply(const flow_pmg* M, const double* r, double* z, hipStream_t st,
               const double* stop = nullptr);
 int pmg_check(const flow_pmg* M, int op_size);
+// tl_kernels.hip: the two-level cycle with ILU(0) smoothing (flow_tl; reached
+// through flow_ilu.cycle by ilu_apply / ilu_check)
+int tl_apply(const flow_tl* T, const double* r, double* z, hipStream_t st,
+             const double* stop = nullptr);
+int tl_check(const flow_tl* T, int op_size);
 // la_kernels.hip
+// y = A x for any operator kind (vectors of operator_size(A) entries)
+int operator_apply(const flow_operator* A, const double* x, double* y,
+                   hipStream_t st, const double* stop = nullptr);
+int operator_size(const flow_operator* A);
 int sum_partials_host(double* work, int nparts, double* host, hipStream_t st);
 int check_operator(const flow_operator* A);
 int fill(int n, double value, double* y, hipStream_t st);

@@ -568,6 +568,10 @@ static int apply_packed(const flow_ilu* ilu, const double* in, double* out,
 // out = blockdiag(LU_0[, LU_1])^-1 in ; work: nblocks * n doubles
 int ilu_apply(const flow_ilu* ilu, const double* in, double* out, double* work,
               hipStream_t st, const double* stop) {
+  // (flow_ilu.cycle: this preconditioner is the two-level cycle whose fine
+  // smoother these sweeps are -- tl_kernels.hip)
+  if (ilu->cycle)
+    return tl_apply(static_cast<const flow_tl*>(ilu->cycle), in, out, st, stop);
   const flow_ilu_plan* P = ilu->plan;
   const size_t lus = static_cast<size_t>(P->lu_size);
   constexpr int per_block = kBlock / kSlice;
@@ -622,6 +626,7 @@ int ilu_check(const flow_ilu* ilu, int op_size) {
                "packed alignment");
   FLOW_REQUIRE(!ilu->single_vector || ilu->packed != nullptr,
                "single_vector needs the packed streams");
+  if (ilu->cycle) return tl_check(static_cast<const flow_tl*>(ilu->cycle), op_size);
   return FLOW_OK;
 }
 

@@ -381,6 +381,12 @@ static int apply(const flow_operator* A, const double* x, double* y,
   return FLOW_OK;
 }
 
+int operator_apply(const flow_operator* A, const double* x, double* y,
+                   hipStream_t st, const double* stop) {
+  return apply(A, x, y, st, nullptr, stop);
+}
+int operator_size(const flow_operator* A) { return op_size(A); }
+
 __global__ void diag_inv_kernel(int n, int planes_kind,
                                 const int* __restrict__ diag_idx,
                                 const double* __restrict__ v0,
@@ -1341,7 +1347,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 28; }
+extern "C" int flow_abi_version(void) { return 29; }
 
 namespace flow {
 unsigned long long g_launches = 0;

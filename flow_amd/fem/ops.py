@@ -612,7 +612,8 @@ def krylov_solve(method, A, b, x, rtol, atol=0.0, maxit=1000, dinv='jacobi',
     out = SolveInfo(its.value, res.value,
                     method + ('+2level' if coarse is not None else '')
                     + ('+mg%d' % mg.nlevels if mg is not None else '')
-                    + ('+ilu0' if ilu is not None else '')
+                    + (('+tlilu' if hasattr(ilu, 'cycle') else '+ilu0')
+                       if ilu is not None else '')
                     + ('+pmg' if pmg is not None else ''))
     out.starts_dropped = dropped.value
     return out

@@ -55,10 +55,38 @@ solver_parameters = {'rtol': 1.0e-13, 'maxit': 2000, 'check_every': 10,
                      'pmg': {'pre': 1, 'post': 2, 'coarse_steps': 6,
                              'ratio_fine': 8.0, 'ratio_coarse': 12.0,
                              'coarse_auto': True, 'coarse_max': 48},
+                     # what a rejected Chebyshev cycle is replaced with (P2, one
+                     # GPU): 'tlilu' = the same two levels smoothed with ILU(0)
+                     # sweeps (flow_amd/fem/tlilu.py; tools/smoother_lab.py
+                     # --heat: 56 / 80 / 146 -> 14 / 17 / 28 GMRES iterations
+                     # at cell CFL 6 / 14 / 40 with two sweeps on the P1 level)
+                     # | 'ilu0' = the bare multicolour ILU(0)
+                     'fallback': 'tlilu',
+                     'tlilu': {'pre': 1, 'post': 1, 'coarse_sweeps': 2},
+                     'tl_select': 'rate', 'tl_probe_smooth': 4,
+                     'tl_probe_sweeps': 3,
                      # 'previous': the solve starts from the solution of the
                      # previous solve on the space; 'zero': no history
                      'start': 'previous'}
 last_solve_info = {}
+
+
+def prepare(V):
+    '''Host-side setup of the solve's fallback preconditioner for the space V
+    (ILU(0) plans of the P2 and P1 levels, transfer tables, workspaces): a
+    driver calls this before its time loop so that the first solve that needs
+    the fallback does not pay ~1 s of colouring inside a time step.'''
+    lay = V.layout
+    if lay.degree != 2 or not device.on_gpu() or parallel.active():
+        return
+    from .fem.tlilu import TwoLevelIlu
+    TwoLevelIlu.plans(lay)
+    if solver_parameters.get('fallback') == 'tlilu' and \
+            lay._dev.get('heat_tl') is None:
+        lay._dev['heat_tl'] = TwoLevelIlu(
+            V, scalar=True, packed=True, single_vector=False,
+            **solver_parameters.get('tlilu', {}))
+    return
 
 
 def _data(v):
@@ -284,11 +312,19 @@ class Heat(object):
             if not c < par.get('pmg_accept', 0.8):
                 pmg, kind = None, 'ilu0'
                 lay._dev['heat_pmg_rejected'] = int(par.get('pmg_retry', 8))
-        if kind == 'ilu0':
+        if kind == 'ilu0' and par.get('fallback', 'ilu0') == 'tlilu' \
+                and par.get('preconditioner') == 'pmg' and lay.degree == 2:
+            kind = 'tlilu'
+        if kind == 'tlilu':
+            # the two-level cycle with ILU(0) smoothing on the scaled system,
+            # or -- by the self-test below -- its fine smoother alone
+            pre = self._tl_or_bare(A, float(alpha), float(beta), dofs, dinv)
+            kind = 'tlilu' if hasattr(pre, 'cycle') else 'ilu0'
+        elif kind == 'ilu0':
             # The zero-mass edge rows and the skew convection make the diagonal
             # a poor preconditioner; the reference solves with LU (:116-121).
-            from .fem import ilu
-            pre = ilu.Ilu0(A)
+            pre = self._bare_ilu(A)
+        last_solve_info['heat_preconditioner'] = kind
         # GMRES(30) with the cycle or the ILU(0) (minimises the residual
         # monotonically; BiCGStab stagnates on very coarse meshes, where most
         # rows are zero-mass edge rows), BiCGStab + ILU(0) as the second try
@@ -303,9 +339,15 @@ class Heat(object):
         except _hip.NotConverged:
             if pmg is not None:
                 # (the cycle passed the probe and GMRES stalled all the same:
-                # the ILU(0) goes on from the iterate it left)
-                from .fem import ilu
-                pre = ilu.Ilu0(A)
+                # the fallback goes on from the iterate it left)
+                if par.get('fallback', 'ilu0') == 'tlilu':
+                    pre = self._tl_or_bare(A, float(alpha), float(beta), dofs,
+                                           dinv)
+                    last_solve_info['heat_preconditioner'] = \
+                        'tlilu' if hasattr(pre, 'cycle') else 'ilu0'
+                else:
+                    pre = self._bare_ilu(A)
+                    last_solve_info['heat_preconditioner'] = 'ilu0'
                 lay._dev['heat_pmg_rejected'] = int(par.get('pmg_retry', 8))
                 if not bool(torch.isfinite(u.data).all()):
                     ops.fill(u.data, 0.0)
@@ -395,6 +437,86 @@ class Heat(object):
         pmg.refactor(S, S1, mass_share=share)
         pmg.fine.dinv.fill_(1.0)
         return pmg
+
+    def _bare_ilu(self, A):
+        '''The multicolour ILU(0) of the scaled system, in buffers that live
+        with the space (refactored per solve).'''
+        from .fem import ilu
+        lay = self.V.layout
+        held = lay._dev.get('heat_ilu')
+        if held is None:
+            held = lay._dev['heat_ilu'] = ilu.Ilu0(A)
+        else:
+            held.refactor(A)
+        return held
+
+    def _tl_or_bare(self, S, alpha, beta, bc_dofs_host, dinv):
+        '''The two-level ILU cycle -- where it converges faster per unit of
+        time than its fine smoother alone (rate_verdict of
+        navier_stokes/newton_preconditioner.py: a few applications of both as
+        stationary iterations on the fixed probe vector, timed; at the first
+        use and every `pmg_retry` solves after.  On an under-resolved mesh --
+        cell Peclet numbers in the hundreds -- the P1 rediscretisation is no
+        coarse problem any more) --, else that smoother, the bare ILU(0), from
+        the same factors.'''
+        lay = self.V.layout
+        tl = self._tl(S, alpha, beta, bc_dofs_host, dinv)
+        choice = lay._dev.setdefault('heat_tl_choice', {'left': 0, 'cycle': True})
+        select = solver_parameters.get('tl_select', 'rate')
+        if select != 'rate':
+            choice['cycle'], choice['left'] = select == 'cycle', 1
+        if choice['left'] <= 0:
+            from .navier_stokes.newton_preconditioner import rate_verdict
+            import numpy
+            n = lay.N
+            hold = lay._dev.setdefault('heat_pmg_probe', {})
+            key = hash(numpy.asarray(bc_dofs_host).tobytes())
+            if hold.get('key') != key:
+                v = numpy.random.RandomState(7).standard_normal(n)
+                v[bc_dofs_host] = 0.0
+                hold.update(key=key, v=device.to_device(v), w=device.empty(n),
+                            z=device.empty(n))
+            v, w, z = hold['v'], hold['w'], hold['z']
+            choice['cycle'], probe = rate_verdict(
+                S.apply, tl.apply, tl.fine.solve, v, w, z,
+                smooth=int(solver_parameters.get('tl_probe_smooth', 4)),
+                sweeps=int(solver_parameters.get('tl_probe_sweeps', 3)))
+            choice['left'] = int(solver_parameters.get('pmg_retry', 8))
+            last_solve_info['heat_tl_contraction'] = probe
+        choice['left'] -= 1
+        return tl.front if choice['cycle'] else tl.fine
+
+    def _tl(self, S, alpha, beta, bc_dofs_host, dinv):
+        '''The two-level ILU cycle for the ROW-SCALED system S = diag(dinv)
+        (alpha M + beta A) (Dirichlet rows identity rows): ILU(0) of S on the
+        fine level (ILU(0) does not see a row scaling), the P1 discretisation
+        of the same operator in its finite-element scaling as the coarse
+        level, the fine residual scaled back (1 / dinv) before it is
+        restricted.'''
+        import numpy
+        from .fem.tlilu import TwoLevelIlu
+        lib = _hip.lib()
+        lay = self.V.layout
+        held = lay._dev.get('heat_tl')
+        if held is None:
+            held = lay._dev['heat_tl'] = TwoLevelIlu(
+                self.V, scalar=True, packed=True, single_vector=False,
+                **solver_parameters.get('tlilu', {}))
+        lay1 = held.lay1
+        M1, A1 = self._coarse_operators(lay1)
+        S1 = lay._dev.get('heat_pmg_S1')
+        if S1 is None:
+            S1 = lay._dev['heat_pmg_S1'] = ops.Matrix(lay1, 0)
+        ops.axpby(alpha, M1.vals, 0.0, S1.vals)
+        ops.axpby(beta, A1.vals, 1.0, S1.vals)
+        bc1_host, bc1 = held.set_bcs(numpy.asarray(bc_dofs_host))
+        if len(bc1_host):
+            _hip.check(lib.flow_bc_identity_rows(
+                ctypes.byref(S1.operator()), _hip.f64(S1.vals),
+                _hip.i32(lay1.dev('diag_idx')), len(bc1_host), _hip.i32(bc1),
+                _hip.stream()))
+        held.refactor(S, S1, rscale=torch.reciprocal(dinv))
+        return held
 
     def _contraction(self, pmg, A, bc_dofs_host):
         import numpy

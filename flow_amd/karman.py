@@ -142,8 +142,8 @@ class KarmanProblem(object):
         self.reset()
         # the factors of that step belong to another state and dt: the first
         # real Newton iteration computes its own (a few ms, no plan building)
-        for name in ('jacobian_ilu', 'jacobian_pmg', 'jacobian_ilu_strip',
-                     'jacobian_pmg_strip'):
+        for name in ('jacobian_ilu', 'jacobian_pmg', 'jacobian_tl',
+                     'jacobian_ilu_strip', 'jacobian_pmg_strip'):
             pre = self.W.layout._dev.get(name)
             if pre is not None:
                 pre.stale = True

@@ -88,6 +88,72 @@ def contraction(pre, operator, lay, bc_dofs_host, sweeps=1):
     return power_probe(operator.apply, pre.apply, v, w, z, sweeps)
 
 
+def choose_cycle(cycle, bare, operator, lay, bc_dofs_host, npar):
+    """The two-level ILU cycle (flow_amd/fem/tlilu.py) or its fine smoother
+    alone, for the Newton systems: `rate_verdict` on the fixed probe vector of
+    `contraction`.  -> (use the cycle?, (contraction per application of the
+    cycle, of the smoother, ms per application of the cycle, of the
+    smoother))."""
+    select = npar.get('tl_select', 'rate')
+    if select != 'rate':
+        return select == 'cycle', (float('nan'), float('nan'), 0.0, 0.0)
+    contraction(bare, operator, lay, bc_dofs_host)      # (builds the vectors)
+    hold = lay._dev['pmg_probe']
+    return rate_verdict(operator.apply, cycle.apply, bare.apply, hold['v'],
+                        hold['w'], hold['z'],
+                        smooth=int(npar.get('tl_probe_smooth', 6)),
+                        sweeps=int(npar.get('tl_probe_sweeps', 4)))
+
+
+def rate_verdict(apply_operator, apply_cycle, apply_bare, v, w, z, smooth=6,
+                 sweeps=4):
+    """Which of two preconditioners converges faster PER UNIT OF TIME on the
+    part of the spectrum that decides a solve?  Both are run as stationary
+    iterations e <- (I - M^-1 A) e for `sweeps` applications, timed, from the
+    SAME start: the probe vector v after `smooth` applications of the bare
+    smoother's error propagation -- what is left then is what the smoother is
+    slow on, which is what the Krylov iteration spends its time on (from the
+    raw random vector the two read 0.54 / 0.76 after six sweeps in a regime
+    where GMRES needs 100 applications with the cycle and 400 without: the
+    high frequencies, which both treat alike, still dominate).  The
+    contraction per application is the geometric mean over the sweeps; the
+    better -log(contraction) per millisecond wins.  Time, not launches or
+    bytes: which of them bounds an application changes with the size of the
+    problem.  (The verdict can flip from run to run where the two are within a
+    few per cent of each other, where it does not matter; a converged solve
+    does not depend on it.)  A preconditioner that does not contract loses to
+    one that does; of two that do not, the smaller growth wins.
+    -> (cycle wins?, (c_cycle, c_bare, ms_cycle, ms_bare) per application)."""
+    import time
+    sweeps = max(1, int(sweeps))
+    power_probe(apply_operator, apply_bare, v, w, z, sweeps=max(1, int(smooth)))
+    start = device.empty(v.numel())
+    ops.copy(start, z)
+    den = ops.vector_norm(start)
+    if not (den > 0.0 and numpy.isfinite(den)):
+        # (the smoother alone has blown up or annihilated the probe)
+        ops.copy(start, v)
+        den = ops.vector_norm(start)
+    out = []
+    for apply_pre in (apply_cycle, apply_bare):
+        power_probe(apply_operator, apply_pre, start, w, z, sweeps=1)  # (untimed)
+        device.synchronize()
+        t0 = time.time()
+        power_probe(apply_operator, apply_pre, start, w, z, sweeps=sweeps)
+        num = ops.vector_norm(z)
+        device.synchronize()
+        ms = 1.0e3 * (time.time() - t0) / sweeps
+        c = (num / den)**(1.0 / sweeps) if numpy.isfinite(num) else float('inf')
+        out.append((c, ms))
+    (c_tl, t_tl), (c_b, t_b) = out
+
+    def rate(c, t):
+        return -numpy.log(c) / t if 0.0 < c < 1.0 else -float(c)
+    if c_tl == 0.0:
+        return True, (c_tl, c_b, t_tl, t_b)
+    return bool(rate(c_tl, t_tl) > rate(c_b, t_b)), (c_tl, c_b, t_tl, t_b)
+
+
 def power_probe(apply_operator, apply_preconditioner, v, w, z, sweeps=3):
     """max_k |E^k v| / |E^(k-1) v|, k = 1 .. sweeps, E = I - M^-1 A: the
     first ratio is the contraction of one application on the full-spectrum

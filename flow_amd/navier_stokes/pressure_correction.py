@@ -76,7 +76,7 @@ from .start_vectors import (                                # noqa: F401
     newton_key as _newton_key,
     )
 from .newton_preconditioner import (
-    age as _age, contraction as _contraction,
+    age as _age, contraction as _contraction, choose_cycle as _choose_cycle,
     contraction_on_strips as _contraction_on_strips,
     coarse_jacobian as _coarse_jacobian, mass_share as _mass_share,
     )
@@ -146,6 +146,38 @@ solver_parameters = {
                # at least this factor (else: ILU(0)), and a GMRES that has not
                # converged after `pmg_maxit` applications is redone with ILU(0)
                'pmg_accept': 0.8, 'pmg_maxit': 150,
+               # ... what a rejected cycle is replaced with on one GPU: 'tlilu'
+               # = the same two levels with ILU(0) sweeps as smoothers
+               # (flow_amd/fem/tlilu.py: one before and one after the coarse
+               # correction, `coarse_sweeps` on the P1 level) or 'ilu0' = the
+               # bare multicolour ILU(0) (what the strips and P1 velocity
+               # spaces run).  tools/smoother_lab.py: 27 -> 13 applications on
+               # the structured channel at cell Peclet 3.5, 48 -> 17 on the
+               # graded unstructured one.
+               'fallback': 'tlilu',
+               # (coarse correction first, then one sweep: 0 / 1 / 1 is the
+               # variant with the fewest launches per application -- at the
+               # sizes where the Chebyshev cycle is rejected a time step is
+               # bound by its ~1300 launches of ~10 us, not by bytes.  Graded
+               # channel, 0.97 M DoF: 0/1/1 25.2 applications 13.5 ms per step,
+               # 0/1/2 20.8 / 13.4 ms, 1/1/1 22.1 / 17.1 ms; bare ILU(0) 52.6 /
+               # 16.3 ms -- profiles/tlilu_r06.txt)
+               'tlilu': {'pre': 0, 'post': 1, 'coarse_sweeps': 1},
+               # which of the two runs the solves until the next rebuild:
+               # 'rate' = the one with the better convergence rate per unit of
+               # TIME, both measured at the rebuild
+               # (newton_preconditioner.rate_verdict: `tl_probe_sweeps`
+               # applications of each as a stationary iteration on the probe
+               # vector pre-smoothed by `tl_probe_smooth` sweeps of the bare
+               # smoother, timed); 'cycle' / 'bare': no test.  On the
+               # structured channel at cell Peclet 3.5 the cycle saves a
+               # quarter of the applications (15.2 -> 11.7) at twice the
+               # launches each: 'rate' stays with the bare sweeps there (4.4
+               # against 5.4 ms per step) and takes the cycle on the graded
+               # mesh (16.3 -> 13.5 ms) and in the plume of config 4 (CFL 17,
+               # diffusion number 16: ~100 applications per solve against
+               # 200-800).
+               'tl_select': 'rate', 'tl_probe_smooth': 6, 'tl_probe_sweeps': 4,
                # the sweeps read the factors rounded to fp32 (fp64 arithmetic):
                # half the bytes per application, same iteration counts
                'ilu_storage': 'fp32',
@@ -360,6 +392,27 @@ def _bc_mask(dofs, n, comp=None):
     return mask
 
 
+def _as_ilu(kind, pre):
+    '''What ops.krylov_solve takes as `ilu`: the factors themselves, or the
+    front of the two-level cycle they smooth (flow_amd/fem/tlilu.py).'''
+    if kind == 'ilu0':
+        return pre
+    if kind == 'tlilu':
+        return pre.front if getattr(pre, 'use_cycle', True) else pre.fine
+    return None
+
+
+class _Bare(object):
+    '''An ILU(0) as the probe of newton_preconditioner.contraction sees a
+    preconditioner.'''
+
+    def __init__(self, factors):
+        self.factors = factors
+
+    def apply(self, r, z):
+        return self.factors.solve(r, z)
+
+
 def _remainder_tolerance(lay, npar, lin_atol, nrm, tol):
     """The absolute tolerance of a Newton system's linear solve, raised to
     `linear_remainder_fraction` of the remainder C ||F||^2 the quadratic model
@@ -570,10 +623,13 @@ def _compute_tentative_velocity(
         # the problem changes or the step size has halved
         if kind == 'pmg':
             rej = lay._dev.get('pmg_rejected')
-            if lay.degree != 2 or not use_gmres or (
-                    rej is not None and rej[0] == key and dt > 0.5 * rej[1]):
+            if lay.degree != 2 or not use_gmres:
                 kind = 'ilu0'
-        with_ilu = kind in ('ilu0', 'pmg')
+            elif rej is not None and rej[0] == key and dt > 0.5 * rej[1]:
+                kind = npar.get('fallback', 'ilu0')
+        if kind == 'tlilu' and (lay.degree != 2 or not use_gmres):
+            kind = 'ilu0'
+        with_ilu = kind in ('ilu0', 'pmg', 'tlilu')
         # matrix-free Newton-Krylov: J(ui) is applied cell by cell (as cheap
         # as the assembled 2x2-block SpMV) and only assembled when the lagged
         # preconditioner has to be rebuilt
@@ -596,7 +652,8 @@ def _compute_tentative_velocity(
             p-multigrid whose cycle does not contract is replaced by the
             ILU(0).'''
             from ..fem import ilu
-            slot = 'jacobian_ilu' if kind == 'ilu0' else 'jacobian_pmg'
+            slot = {'ilu0': 'jacobian_ilu', 'pmg': 'jacobian_pmg',
+                    'tlilu': 'jacobian_tl'}[kind]
             pre = lay._dev.get(slot)
             if not (pre is None or pre.key != key or pre.stale or (
                     it == 0 and not (1.0 / npar['ilu_lag'] <= dt / pre.dt
@@ -632,9 +689,36 @@ def _compute_tentative_velocity(
                     # (once the rejection lapses the cycle is refactored and
                     # tested again, not taken from the slot as it is)
                     pre.stale = True
-                    info('p-multigrid rejected (contraction %.2f): ILU(0)'
-                         % pre.contraction)
-                    return build('ilu0')
+                    fallback = npar.get('fallback', 'ilu0')
+                    info('p-multigrid rejected (contraction %.2f): %s'
+                         % (pre.contraction, fallback))
+                    # (J and the P1 level have just been reassembled in the
+                    # buffers the fallback's residuals read: it is refactored
+                    # from them, not taken from its slot as it is)
+                    for other in ('jacobian_ilu', 'jacobian_tl'):
+                        if lay._dev.get(other) is not None:
+                            lay._dev[other].stale = True
+                    return build(fallback)
+                return kind, pre, True
+            if kind == 'tlilu':
+                if pre is None:
+                    from ..fem.tlilu import TwoLevelIlu
+                    pre = TwoLevelIlu(W, **npar.get('tlilu', {}))
+                    lay._dev[slot] = pre
+                J1 = _coarse_jacobian(
+                    pre, W, P, ui, p0, f0, f1, prm, bfmask, bc_dofs_host)
+                pre.refactor(J, J1)
+                pre.dt, pre.key, pre.stale = dt, key, False
+                # the self-test of every rebuild: is the cycle worth what it
+                # costs?  (newton_preconditioner.choose_cycle)
+                pre.use_cycle, probe = _choose_cycle(
+                    pre, _Bare(pre.fine), operator, lay, bc_dofs_host, npar)
+                pre.contraction, pre.contraction_bare = probe[0], probe[1]
+                last_step_info['tl_contraction'] = probe
+                if not pre.use_cycle:
+                    info('two-level ILU cycle: contraction %.2f in %.2f ms, its '
+                         'smoother alone %.2f in %.2f ms: bare ILU(0)' % (
+                             probe[0], probe[2], probe[1], probe[3]))
                 return kind, pre, True
             if pre is None:
                 # (the fp32 sweep vector makes the application slightly
@@ -681,7 +765,7 @@ def _compute_tentative_velocity(
             def gmres(maxit):
                 return ops.krylov_solve(
                     'gmres', operator, F, dx, rtol=lin_rtol, atol=0.0,
-                    maxit=maxit, ilu=pre if kind == 'ilu0' else None,
+                    maxit=maxit, ilu=_as_ilu(kind, pre),
                     pmg=pre if kind == 'pmg' else None,
                     restart=npar['gmres_restart'], x_is_zero=dx_is_zero,
                     dinv='jacobi' if pre is None else None,
@@ -698,10 +782,11 @@ def _compute_tentative_velocity(
                 except _hip.NotConverged:
                     lay._dev['pmg_rejected'] = (key, dt)
                     pre.stale = True
-                    info('p-multigrid: GMRES stalled, redone with ILU(0)')
+                    fallback = npar.get('fallback', 'ilu0')
+                    info('p-multigrid: GMRES stalled, redone with %s' % fallback)
                     ops.fill(dx, 0.0)
                     dx_is_zero = True
-                    kind, pre, refactored = build('ilu0')
+                    kind, pre, refactored = build(fallback)
                     sol = gmres(npar['linear_maxit'])
             else:
                 sol = gmres(npar['linear_maxit'])
@@ -716,7 +801,8 @@ def _compute_tentative_velocity(
         last_linear_residual = sol.residual
         linear_residuals.append(sol.residual)
         linear_its.append(its)
-        last_step_info['newton_preconditioner'] = kind
+        last_step_info['newton_preconditioner'] = 'ilu0' if (
+            kind == 'tlilu' and not getattr(pre, 'use_cycle', True)) else kind
         if pre is not None:
             _age(pre, kind, refactored, its, sol.iterations, npar, it=it)
         if hkey is not None and npar.get('linear_start') == 'extrapolated':
@@ -735,7 +821,7 @@ def _compute_tentative_velocity(
                     'gmres', operator, F, dx,
                     rtol=max(npar['linear_rtol'], tight / nrm0), atol=0.0,
                     maxit=npar['linear_maxit'],
-                    ilu=pre if kind == 'ilu0' else None,
+                    ilu=_as_ilu(kind, pre),
                     pmg=pre if kind == 'pmg' else None,
                     restart=npar['gmres_restart'], x_is_zero=False,
                     dinv='jacobi' if pre is None else None, verify=False)

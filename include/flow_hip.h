@@ -321,6 +321,11 @@ typedef struct {
                                 then not exactly linear: for FLEXIBLE Krylov
                                 methods only -- flow_gmres_solve is one (it
                                 keeps Z_j = M^-1 V_j and updates x with it) */
+  const void* cycle;         /* NULL, or a const flow_tl* (K19 below): wherever a
+                                solver applies this preconditioner it runs the
+                                two-level cycle that flow_tl describes instead
+                                of the bare sweeps (the flow_ilu a flow_tl names
+                                as its smoothers must have cycle == NULL) */
 } flow_ilu;
 /* HOST routine (setup, no GPU needed): first-fit greedy colouring of the graph
  * of a CSR pattern in row order; colour: n ints out, *ncolors <= 63 */
@@ -457,6 +462,49 @@ int flow_pmg_lambda_max(const flow_pmg_level* level, int iterations, float* work
                         void* stream);
 /* z = M^-1 r (r, z: 2*fine.n doubles, component-blocked) */
 int flow_pmg_apply(const flow_pmg* pmg, const double* r, double* z, void* stream);
+
+/* ---- K19: two-level cycle with ILU(0) smoothing ----------------------------
+ * (the stand-in for the sparse LU of the Newton solve, pressure_correction.py:
+ * 224-254, and of the heat solve, heat.py:117-121, WHERE THE CHEBYSHEV CYCLE OF
+ * K17 IS REJECTED by its acceptance test: cell Peclet numbers beyond ~3 at
+ * CFL-sized steps put the spectrum of D^-1 A off the real axis; a polynomial
+ * smoother amplifies there, a multicolour ILU(0) sweep does not.)  The levels are
+ * those of K17 -- the diagonal block(s) of the assembled operator on the P2
+ * pattern and the P1 discretisation of the same operator on the same mesh, the
+ * same transfer tables -- with one ILU(0) application (K11) as the smoother on
+ * the fine level and `coarse_sweeps` of them as the treatment of the P1 level.
+ * One application z = M^-1 r (all vectors fp64, component-blocked):
+ *   x = pre ? ILU_f^-1 r : 0 ;  t = r - A_f x ;  rc = P^T (rscale .* t) ;
+ *   xc = ILU_c^-1 rc ; (coarse_sweeps - 1) x [ xc += ILU_c^-1 (rc - A_c xc) ] ;
+ *   x += P xc ;  post: x += ILU_f^-1 (r - A_f x) ;  z = x.
+ * Measured (tools/smoother_lab.py, flexible GMRES applications to 1e-8):
+ * structured channel at cell Peclet 3.5 27 -> 13, graded unstructured channel
+ * 48 -> 17, heat system at cell CFL 6 / 14 / 40: 56 / 80 / 146 -> 19 / 23 / 35
+ * (two coarse sweeps: 14 / 17 / 28).
+ * Dirichlet dofs: identity rows of both operators (ILU: z = r there); the
+ * prolongation leaves them alone (bc_fine), the restricted residual is zeroed
+ * on those of the P1 level (bc_coarse).  rscale (optional): the residual is
+ * multiplied row by row before it is restricted -- the heat solve works on the
+ * ROW-SCALED system (ILU(0) is invariant under a row scaling, the rediscretised
+ * P1 level is not).  Reached through flow_ilu.cycle by every solver that takes
+ * a flow_ilu. */
+typedef struct {
+  const flow_ilu* fine;          /* ILU(0) of the fine diagonal block(s); cycle == NULL */
+  const flow_ilu* coarse;        /* ILU(0) of the P1 level; same nblocks; cycle == NULL */
+  const flow_operator* fine_op;  /* A_f, size nblocks * fine->plan->n (kind 0, 1, 2 or 3) */
+  const flow_operator* coarse_op;/* A_c (needed for coarse_sweeps > 1) */
+  int pre, post;                 /* 0 | 1, not both 0 */
+  int coarse_sweeps;             /* 1 .. 8 */
+  const int* ends;               /* fine n int2: the coarse rows of a fine dof  } as in */
+  const int* rptr;               /* coarse n + 1: restriction lists ...         } flow_pmg */
+  const int* rsrc;               /* ... of fine dofs, the vertex's own dof first */
+  const unsigned char* bc_fine;  /* nblocks * n bytes or NULL */
+  const unsigned char* bc_coarse;/* nblocks * n1 bytes or NULL */
+  const double* rscale;          /* nblocks * n or NULL */
+  double* work;                  /* nblocks * (4 n + 5 n1) doubles, 16-B aligned */
+} flow_tl;
+/* z = M^-1 r (r, z: nblocks * n doubles, r != z) */
+int flow_tl_apply(const flow_tl* tl, const double* r, double* z, void* stream);
 
 /* ---- K18: mass-matrix solves by mixed-precision defect correction ---------
  * The velocity correction (pressure_correction.py:436-465: `solve(a3 == L3,

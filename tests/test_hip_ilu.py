@@ -174,7 +174,10 @@ def test_bicgstab_ilu0_on_convection_dominated_heat(hip):
     dt = 0.5
     u1 = time_steppers.ImplicitEuler(H).step(u, 0.0, dt)
     info = heat.last_solve_info['heat']
+    # (cell Peclet ~600: the self-test of the heat solve's fallback keeps the
+    # bare ILU(0) -- the P1 rediscretisation of a 2 x 2 mesh is no coarse level)
     assert 'ilu0' in info.method and info.iterations < 2000, info
+    assert heat.last_solve_info['heat_preconditioner'] == 'ilu0'
     dofs, vals = collect(bcs, Q.N)
     ref1 = orc.heat_solve(Mo, Ao, 1.0, -dt, Mo.dot(u.array()), dofs, vals)
     assert cases.rel_l2(u1.array(), ref1) < 1e-6

@@ -1,0 +1,225 @@
+# -*- coding: utf-8 -*-
+'''
+The two-level cycle with ILU(0) smoothing (flow_amd/fem/tlilu.py,
+flow_amd/csrc/tl_kernels.hip; `flow_tl` in include/flow_hip.h): the
+preconditioner of the Newton and heat solves where the Chebyshev cycle is
+rejected (the reference solves those systems with a sparse LU:
+flow/navier_stokes/pressure_correction.py:224-254, flow/heat.py:117-121).
+GPU: one application against a host composition of the same pieces (scipy
+products, the transfer matrix built from the mesh, the ILU sweeps through the
+library's own flow_ilu0_solve), GMRES with the cycle against a direct solve and
+against the bare ILU(0) at a cell Peclet number the Chebyshev cycle fails at,
+and a time step that runs on it.
+'''
+import numpy
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from flow_amd import fem
+
+import cases
+from test_pmg import _prolongation
+
+
+@pytest.fixture(scope='module')
+def peclet_system(hip):
+    '''A Karman channel at cell Peclet ~4 (coarse mesh, a viscosity between the
+    driver's and the one the Chebyshev cycle likes) after two CFL-sized steps
+    with the two-level ILU cycle as THE preconditioner: the assembled
+    Jacobians of both levels and the cycle built from them.'''
+    from flow_amd import karman
+    import flow_amd.navier_stokes as navsto
+    npar = navsto.solver_parameters['newton']
+    old = npar['preconditioner']
+    npar['preconditioner'] = 'tlilu'
+    npar['tl_select'] = 'cycle'
+    try:
+        prob = karman.KarmanProblem(150, 35, mu=0.008)
+        prob.set_initial_profile()
+        prob.dt = prob.hmax / 0.016
+        infos = [prob.step(adapt=False) for _ in range(2)]
+    finally:
+        npar['preconditioner'] = old
+        npar['tl_select'] = 'rate'
+    lay = prob.W.layout
+    pre = lay._dev['jacobian_tl']
+    return prob, infos, pre, lay._dev['jacobian'], lay._dev['pmg_coarse']['J1']
+
+
+def _host_cycle(pre, fine, coarse, A, A1, P, bc0, bc1, r, rscale=None):
+    '''flow_tl_apply restated: scipy products and transfers, the smoothers
+    through `fine` / `coarse` (callables r -> ILU^-1 r).'''
+    x = fine(r) if pre.pre else numpy.zeros_like(r)
+    t = r - A.dot(x) if pre.pre else r.copy()
+    if rscale is not None:
+        t = t * rscale
+    t[bc0] = 0.0
+    rc = P.T.dot(t)
+    rc[bc1] = 0.0
+    xc = coarse(rc)
+    for _ in range(1, pre.coarse_sweeps):
+        xc = xc + coarse(rc - A1.dot(xc))
+    e = P.dot(xc)
+    e[bc0] = 0.0
+    x = x + e
+    if pre.post:
+        x = x + fine(r - A.dot(x))
+    return x
+
+
+def _ilu_callable(factors):
+    from flow_amd import device
+
+    def solve(r):
+        z = device.zeros(len(r))
+        factors.solve(device.to_device(numpy.ascontiguousarray(r)), z)
+        return device.to_host(z).numpy()
+    return solve
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant', [(1, 1, 1), (0, 1, 2), (1, 0, 3)])
+def test_one_application_matches_the_host_composition(peclet_system, variant):
+    from flow_amd import device
+    from flow_amd.fem.tlilu import TwoLevelIlu
+    prob, infos, pre0, J, J1 = peclet_system
+    lay = prob.W.layout
+    n, n1 = lay.N, pre0.lay1.N
+    pre = TwoLevelIlu(prob.W, pre=variant[0], post=variant[1],
+                      coarse_sweeps=variant[2], packed=False,
+                      single_vector=False)
+    bc0 = device.to_host(pre0._keep['bc_fine']).numpy().astype(bool)
+    bc1 = device.to_host(pre0._keep['bc_coarse']).numpy().astype(bool)
+    assert bc0.sum() > 0 and bc1.sum() > 0
+    pre.set_bcs(numpy.nonzero(bc0)[0].astype(numpy.int32))
+    pre.refactor(J, J1)
+    Js, J1s = J.to_scipy().tocsr(), J1.to_scipy().tocsr()
+    # the cycle works with the DIAGONAL blocks on both levels
+    blk = lambda M, m: sp.block_diag(
+        [M[a * m:(a + 1) * m, a * m:(a + 1) * m] for a in (0, 1)], format='csr')
+    A = blk(Js, n)
+    A1 = blk(J1s, n1)
+    P1 = _prolongation(lay)[0]
+    P = sp.block_diag([P1, P1], format='csr')
+    fine, coarse = _ilu_callable(pre.fine), _ilu_callable(pre.coarse)
+    rng = numpy.random.RandomState(4)
+    for trial in range(2):
+        r = rng.standard_normal(2 * n)
+        if trial == 1:
+            r[bc0] = 0.0
+        z = device.zeros(2 * n)
+        pre.apply(device.to_device(r), z)
+        got = device.to_host(z).numpy()
+        ref = _host_cycle(pre, fine, coarse, A, A1, P, bc0, bc1, r)
+        assert cases.rel_l2(got, ref) < 1e-12, (variant, trial)
+        # Dirichlet rows are identity rows: z = r there
+        assert abs(got[bc0] - r[bc0]).max() <= 1e-14 * max(1.0, abs(r).max())
+
+
+@pytest.mark.gpu
+def test_gmres_with_the_cycle_against_direct_solve_and_bare_ilu(peclet_system):
+    from flow_amd import device
+    from flow_amd.fem import ilu, ops
+    prob, infos, pre, J, J1 = peclet_system
+    lay = prob.W.layout
+    n = lay.N
+    Js = J.to_scipy().tocsc()
+    rng = numpy.random.RandomState(8)
+    b = rng.standard_normal(2 * n)
+    ref = spla.splu(Js).solve(b)
+    counts = {}
+    for name, factors in (('tlilu', pre.front),
+                          ('ilu0', ilu.Ilu0(J, packed=True, single_vector=True))):
+        x = device.zeros(2 * n)
+        info = ops.krylov_solve('gmres', J, device.to_device(b), x, rtol=1e-10,
+                                maxit=400, restart=10, x_is_zero=True,
+                                dinv=None, ilu=factors)
+        assert cases.rel_l2(device.to_host(x).numpy(), ref) < 1e-8, (name, info)
+        counts[name] = info.iterations
+    print('GMRES(10) applications to 1e-10:', counts)
+    assert 1.3 * counts['tlilu'] < counts['ilu0'], counts
+    # the steps of the fixture ran on the cycle and converged
+    for i in infos:
+        assert i['newton_preconditioner'] == 'tlilu'
+        assert i['newton_residuals'][-1] < 1e-10
+
+
+@pytest.mark.gpu
+def test_a_rejected_chebyshev_cycle_is_replaced_by_the_ilu_cycle(hip):
+    '''The default life cycle: 'pmg' is tried, its acceptance test rejects it
+    (cell Peclet ~4), the step runs on the two-level ILU cycle -- to the same
+    velocities as with the bare ILU(0) fallback, in fewer applications.'''
+    from flow_amd import karman
+    import flow_amd.navier_stokes as navsto
+    npar = navsto.solver_parameters['newton']
+    assert npar['preconditioner'] == 'pmg' and npar['fallback'] == 'tlilu'
+    out = {}
+    for fallback in ('tlilu', 'ilu0'):
+        npar['fallback'] = fallback
+        npar['tl_select'] = 'cycle'
+        try:
+            prob = karman.KarmanProblem(150, 35, mu=0.008)
+            prob.set_initial_profile()
+            prob.dt = prob.hmax / 0.016
+            infos = [prob.step(adapt=False) for _ in range(3)]
+        finally:
+            npar['fallback'] = 'tlilu'
+            npar['tl_select'] = 'rate'
+        assert 'pmg_rejected' in prob.W.layout._dev
+        assert infos[-1]['newton_preconditioner'] == fallback
+        out[fallback] = (prob.u0.array().copy(), prob.p0.array().copy(),
+                         sum(sum(i['newton_linear_applications'])
+                             for i in infos))
+    assert cases.rel_l2(out['tlilu'][0], out['ilu0'][0]) < 1e-9
+    assert cases.rel_l2(out['tlilu'][1], out['ilu0'][1]) < 1e-8
+    print('GMRES applications over 3 steps: cycle %d, bare ILU(0) %d'
+          % (out['tlilu'][2], out['ilu0'][2]))
+    assert out['tlilu'][2] < out['ilu0'][2]
+
+
+@pytest.mark.gpu
+def test_the_rate_verdict_picks_what_converges_faster_per_time(peclet_system):
+    '''newton_preconditioner.rate_verdict on stand-ins with known contraction
+    and cost, and on the real pair: whatever it picks, the reported numbers
+    are the measured ones.'''
+    import time
+    from flow_amd import device
+    from flow_amd.fem import ops
+    from flow_amd.navier_stokes import newton_preconditioner as npre
+    # A = I; "preconditioners" M^-1 = (1 - c) I contract every vector by c
+    n = 1000
+    v = device.to_device(numpy.random.RandomState(0).standard_normal(n))
+    w, z = device.empty(n), device.empty(n)
+    ident = lambda x, y: ops.copy(y, x)
+
+    def scaled(c, delay):
+        def apply(r, out):
+            time.sleep(delay)
+            ops.copy(out, r)
+            return ops.axpby(0.0, r, 1.0 - c, out)
+        return apply
+    # 0.5 in 4 units against 0.7 in 1: -log 0.5 / 4 = 0.17 < -log 0.7 / 1 = 0.36
+    use, (c0, c1, t0, t1) = npre.rate_verdict(
+        ident, scaled(0.5, 0.004), scaled(0.7, 0.001), v, w, z, smooth=2,
+        sweeps=3)
+    assert not use and abs(c0 - 0.5) < 1e-12 and abs(c1 - 0.7) < 1e-12
+    assert t0 > 2.0 * t1
+    # ... at equal cost the better contraction wins, and a cycle that
+    # amplifies never does
+    assert npre.rate_verdict(ident, scaled(0.5, 0.002), scaled(0.7, 0.002), v, w,
+                             z, smooth=1, sweeps=2)[0]
+    assert not npre.rate_verdict(ident, scaled(1.3, 0.0), scaled(0.7, 0.002), v,
+                                 w, z, smooth=1, sweeps=2)[0]
+    prob, infos, pre, J, J1 = peclet_system
+    import flow_amd.navier_stokes as navsto
+    from flow_amd.fem.bcs import collect
+    from flow_amd.navier_stokes.pressure_correction import _Bare
+    bc = collect(prob.u_bcs, prob.W.size())[0]
+    npar = dict(navsto.solver_parameters['newton'], tl_select='rate')
+    use, probe = npre.choose_cycle(pre, _Bare(pre.fine), J, prob.W.layout, bc,
+                                   npar)
+    assert 0.0 < probe[0] < probe[1] <= 1.0    # the cycle contracts better ...
+    assert probe[2] > probe[3] > 0.0           # ... and costs more
+    assert use == (-numpy.log(probe[0]) / probe[2]
+                   > -numpy.log(probe[1]) / probe[3])

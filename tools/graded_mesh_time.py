@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run(prob, label, steps):
-    from flow_amd import device
+    from flow_amd import device, _hip
     import flow_amd.navier_stokes as navsto
     t0 = time.time()
     prob.prepare()
@@ -29,22 +29,39 @@ def run(prob, label, steps):
         prob.step()
     device.synchronize()
     t1 = time.time()
+    l0 = _hip.launch_count()
     infos = [prob.step() for _ in range(steps)]
     device.synchronize()
+    launches = _hip.launch_count() - l0
     ms = 1e3 * (time.time() - t1) / steps
     print('%-28s %7d DoF  hmin %.2e hmax %.2e  dt %.3e | %6.2f ms/step | '
           'Newton %.2f its, GMRES %.1f (%s), pressure %.1f, corrections %.1f | '
-          'setup %.1f s (%d settle steps)'
+          'setup %.1f s (%d settle steps) | launches/step %.0f, contraction '
+          'cycle / smoother %s'
           % (label, prob.num_dofs(), prob.mesh.hmin(), prob.mesh.hmax(), prob.dt,
              ms, sum(len(i['newton_residuals']) - 1 for i in infos) / float(steps),
              sum(sum(i['newton_linear_applications']) for i in infos) / float(steps),
              infos[-1].get('newton_preconditioner'),
              sum(i['pressure'].iterations for i in infos) / float(steps),
              sum(i['correction'].iterations for i in infos) / float(steps),
-             setup, n), flush=True)
+             setup, n, launches / float(steps),
+             infos[-1].get('tl_contraction', prob.W.layout._dev.get(
+                 'jacobian_tl') and (prob.W.layout._dev['jacobian_tl'].contraction,
+                                     prob.W.layout._dev['jacobian_tl'].contraction_bare))),
+          flush=True)
 
 
 def main():
+    # FALLBACK=ilu0|tlilu, TLILU=pre,post,coarse_sweeps: what replaces a
+    # rejected Chebyshev cycle (solver_parameters['newton'])
+    import flow_amd.navier_stokes as navsto
+    npar = navsto.solver_parameters['newton']
+    if os.environ.get('FALLBACK'):
+        npar['fallback'] = os.environ['FALLBACK']
+    if os.environ.get('TLILU'):
+        a, b, c = [int(x) for x in os.environ['TLILU'].split(',')]
+        npar['tlilu'] = {'pre': a, 'post': b, 'coarse_sweeps': c}
+    print('fallback %s %r' % (npar['fallback'], npar['tlilu']), flush=True)
     lcar = float(sys.argv[1]) if len(sys.argv) > 1 else 3.2e-4
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     from flow_amd import fem, karman
