@@ -13,18 +13,22 @@ onto the cylinder: body-fitted, flow_amd/fem/mesh.py).
 
   python bench.py --gpus N --steps K --warmup W
 
-The headline `value` is measured in mode 'parity' (flow_amd.navier_stokes:
-the reference's Newton path -- start from u0, exact Newton steps -- which
-reproduces the reference's iterate to < 1e-6, tests/test_full_size_parity.py);
-at N = 1 the same window is then repeated from the same initial state in mode
-'fast' (extrapolated start vectors, looser Newton linear solves) and reported
-beside it in `config.fast_mode`.  The headline window sits on the early plateau
-of the run (symmetric flow, one Newton iteration per step); at N = 1 and the
-headline size the line also carries the DEVELOPED VORTEX STREET as a
-co-headline: `value_developed` (the same window 2400 steps later, t ~ 74: two
-Newton iterations per step, one of the bursts of the run) and
-`value_developed_period` (the 400 steps behind it, one shedding period, timed
-as a whole); details in `config.developed`.
+Everything is measured in mode 'parity' (flow_amd.navier_stokes: the
+reference's Newton path -- start from u0, exact Newton steps -- which
+reproduces the reference's iterate to < 1e-6, tests/test_full_size_parity.py).
+
+The headline `value` (round 6: the metric names a vortex street) is the mean
+over ONE SHEDDING PERIOD OF THE DEVELOPED STREET: 2400 untimed steps behind the
+settled plateau (setup), W + K steps (the window the flags ask for, reported as
+`value_developed`: it happens to sit in one of the bursts of the run), then
+`--developed-period` (400) steps timed as a whole between two barriers --
+`value`, `ms_per_step`, `headline_steps`.  The K-step window on the early
+plateau of the run (symmetric flow, one Newton iteration per step: rounds 1-5's
+`value`) is `value_plateau`.  At N = 1 the plateau window is also repeated in
+mode 'fast' (`config.fast_mode`) and with every start vector off
+(`config.zero_start`).  `--headline plateau`, or a run without the developed
+phase (`--developed 0`, sizes other than the headline's unless asked for), has
+`value` = the plateau window and says so in `config.headline`.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): strong scaling,
 the mesh is fixed (flow_amd/parallel.py).
@@ -404,6 +408,11 @@ def main():
                          'the timed window, timed as a whole (about one '
                          'shedding period: bursts and calm phases averaged); '
                          'reported as value_developed_period; 0 = off')
+    ap.add_argument('--headline', default='street', choices=['street', 'plateau'],
+                    help="what `value` is: 'street' = the mean over one shedding "
+                         'period of the developed vortex street (needs the '
+                         "developed phase), 'plateau' = the K-step window on "
+                         'the early plateau (rounds 1-5)')
     ap.add_argument('--nx', type=int, default=2182,
                     help='cells along the channel (2182 x 509: ~10 M DoF)')
     ap.add_argument('--ny', type=int, default=None)
@@ -455,8 +464,8 @@ def main():
     if args.developed is None:
         args.developed = 2400 if (
             args.nx == 2182 and args.ny is None and args.velocity_degree == 2
-            and args.gpus == 1 and not args.no_settle and not args.spin_up
-            and args.mode == 'parity') else 0
+            and not args.no_settle and not args.spin_up
+            and args.mode == 'parity' and args.headline == 'street') else 0
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world == 1 and args.gpus > 1 and 'RANK' not in os.environ:
@@ -723,7 +732,7 @@ def main():
     # Newton iterate is left just above `tol`, every step takes two Newton
     # iterations and longer solves -- for the reference as for this build.
     developed = None
-    if world == 1 and args.developed > 0 and settled:
+    if args.developed > 0 and settled:
         navsto.set_mode(args.mode)
         apply_overrides()
         prob.restore(settled['state'])
@@ -785,14 +794,24 @@ def main():
             dist.destroy_process_group()
         return
 
+    # what `value` is: the street's period mean where the developed phase ran
+    street = developed is not None and 'period' in developed \
+        and args.headline == 'street'
+    headline = developed['period'] if street else head
     out = {
         'metric': 'ipcs_time_steps_per_sec',
-        'value': head['steps_per_s'],
+        'value': headline['steps_per_s'],
         'unit': 'time-steps/s',
         'n_gpus': world,
         'steps': args.steps,
         'warmup': args.warmup,
-        'ms_per_step': head['ms_per_step'],
+        'ms_per_step': headline['ms_per_step'],
+        # the steps `value` was timed over (one shedding period, timed as a
+        # whole between two barriers) -- `steps` is the K of the command line,
+        # the length of the windows value_developed / value_plateau
+        'headline_steps': developed['period']['steps'] if street else args.steps,
+        'value_plateau': head['steps_per_s'],
+        'ms_per_step_plateau': head['ms_per_step'],
         'higher_is_better': True,
         'scaling': 'strong',
         'vs_baseline': None,
@@ -802,12 +821,31 @@ def main():
             'workload': 'Karman vortex street %s, %d DoF '
                         '(%d x %d structured channel, body-fitted cylinder), '
                         '%s scheme, backward Euler, tol %.0e, mu %g, '
-                        'rho 998.2, dt0 1e-5 + CFL controller, start: %s'
+                        'rho 998.2, dt0 1e-5 + CFL controller, start: %s; '
+                        'value: %s'
                         % ('P2-P1 Taylor-Hood' if args.velocity_degree == 2
                            else 'P1-P1', prob.num_dofs(), args.nx, ny,
                            args.scheme, args.tol, args.mu,
                            'Stokes solution' if args.initial == 'stokes'
-                           else 'inflow profile'),
+                           else 'inflow profile',
+                           'the developed vortex street, mean over one shedding '
+                           'period (config.headline)' if street
+                           else 'the early plateau of the run (config.headline)'),
+            'headline': (
+                'value = mean over one shedding period of the DEVELOPED VORTEX '
+                'STREET: %d untimed steps behind the settled plateau, %d + %d '
+                'steps (value_developed: that K-step window, in a burst of the '
+                'run), then %d steps timed as a whole, t = %.1f .. %.1f s; '
+                'value_plateau = the K-step window on the early symmetric '
+                'plateau (the `value` of rounds 1-5)' % (
+                    developed['spin_up_steps'], max(args.warmup, 8), args.steps,
+                    developed['period']['steps'], developed['t'],
+                    developed['period']['t_end'])) if street else (
+                'value = the K-step window on the early plateau (symmetric '
+                'flow, one Newton iteration per step)%s' % (
+                    '' if args.headline == 'plateau' else
+                    ': the developed phase did not run (--developed 0 / not the '
+                    'headline size)')),
             'mode': args.mode,
             'mode_note': "headline = mode '%s'%s" % (
                 args.mode,

@@ -304,6 +304,70 @@ def _identity_rows(A, dofs):
     return A
 
 
+def solve_blockwise(A, b, n, rtol=1.0e-14, max_it=80):
+    '''A x = b for a matrix of 2 x 2 blocks of n rows each -- the SAME discrete
+    solution the sparse LU of the whole matrix defines (`linear='lu'`, what the
+    reference's default solver computes, pressure_correction.py:224-254),
+    reached by full GMRES right-preconditioned with the sparse LUs of the two
+    DIAGONAL blocks (block Gauss-Seidel: the second block sees the first one's
+    update), restarted on the TRUE residual until ||b - A x|| <= rtol ||b||,
+    which is checked at the end.  Exists because SuperLU gives up on the
+    coupled Newton matrix beyond ~2.5 M rows ("not enough memory": the index
+    range of its factors) while each diagonal block has a quarter of its
+    nonzeros; the coupling blocks (the reaction term of the linearisation) are
+    small, a handful of iterations per digit-complete solve.  A block-diagonal
+    A (the vector mass matrix of the velocity correction) is solved by the two
+    LUs directly.'''
+    A = A.tocsr()
+    A00, A01 = A[:n, :n].tocsc(), A[:n, n:].tocsr()
+    A10, A11 = A[n:, :n].tocsr(), A[n:, n:].tocsc()
+    lu0, lu1 = spla.splu(A00), spla.splu(A11)
+    del A00, A11
+
+    def precondition(r):
+        z0 = lu0.solve(r[:n])
+        z1 = lu1.solve(r[n:] - A10.dot(z0))
+        return numpy.concatenate([z0, z1])
+    bn = numpy.linalg.norm(b)
+    if bn == 0.0:
+        return numpy.zeros_like(b)
+    x = precondition(b)
+    if A01.nnz == 0 and A10.nnz == 0:
+        r = b - A.dot(x)
+        x = x + precondition(r)          # (one step of refinement)
+        assert numpy.linalg.norm(b - A.dot(x)) <= 1.0e-12 * bn
+        return x
+    for _outer in range(6):
+        r = b - A.dot(x)
+        beta = numpy.linalg.norm(r)
+        if beta <= rtol * bn:
+            break
+        V, Z = [r / beta], []
+        H = numpy.zeros((max_it + 1, max_it))
+        for j in range(max_it):
+            Z.append(precondition(V[j]))
+            w = A.dot(Z[j])
+            for _pass in range(2):                  # (re-orthogonalised)
+                for i in range(j + 1):
+                    h = w.dot(V[i])
+                    H[i, j] += h
+                    w = w - h * V[i]
+            H[j + 1, j] = numpy.linalg.norm(w)
+            V.append(w / H[j + 1, j])
+            g = numpy.zeros(j + 2)
+            g[0] = beta
+            y = numpy.linalg.lstsq(H[:j + 2, :j + 1], g, rcond=None)[0]
+            est = numpy.linalg.norm(g - H[:j + 2, :j + 1].dot(y))
+            if est <= 0.1 * rtol * bn or H[j + 1, j] <= 1e-300:
+                break
+        for yj, zj in zip(y, Z):
+            x = x + yj * zj
+    res = numpy.linalg.norm(b - A.dot(x))
+    if not res <= 10.0 * rtol * bn:
+        raise RuntimeError('solve_blockwise: true residual %.2e |b|' % (res / bn))
+    return x
+
+
 _THETA = {
     'forward euler': (0.0, 1.0),
     'backward euler': (1.0, 0.0),
@@ -312,10 +376,12 @@ _THETA = {
 
 
 def tentative_velocity(W, P, u0, p0, f0, f1, bc_dofs, bc_vals, method,
-                       rho, mu, dt, tol=1.0e-10, max_it=10):
+                       rho, mu, dt, tol=1.0e-10, max_it=10, linear='lu'):
     '''`_compute_tentative_velocity` (pressure_correction.py:147-255): Newton
     from ui = u0, exact Jacobian, LU, BCs as identity rows with residual x - g,
-    converged when ||F||_2 < tol (absolute); RuntimeError otherwise.'''
+    converged when ||F||_2 < tol (absolute); RuntimeError otherwise.
+    linear: 'lu' = one sparse LU of the Newton matrix; 'block' = the same
+    solution through `solve_blockwise` (sizes SuperLU cannot factor whole).'''
     assert method in _THETA
     th_i, th_e = _THETA[method]
     M = sp.block_diag([mass_matrix(W)] * 2, format='csr')
@@ -340,7 +406,13 @@ def tentative_velocity(W, P, u0, p0, f0, f1, bc_dofs, bc_vals, method,
             return ui, history
         if it == max_it:
             break
-        ui = ui - spla.splu(_identity_rows(J, bc_dofs).tocsc()).solve(F)
+        Jbc = _identity_rows(J, bc_dofs)
+        del J
+        if linear == 'block':
+            ui = ui - solve_blockwise(Jbc, F, W.N)
+        else:
+            ui = ui - spla.splu(Jbc.tocsc()).solve(F)
+        del Jbc
     raise RuntimeError('Newton solver did not converge: %r' % history)
 
 
@@ -418,7 +490,7 @@ def solve_pressure(P, b, bc_dofs=None, bc_vals=None):
 
 
 def velocity_correction(W, P, ui, p1, p0, bc_dofs, bc_vals, rho, mu, dt,
-                        rotational):
+                        rotational, linear='lu'):
     '''`_compute_velocity_correction` (pressure_correction.py:436-465).'''
     pts, w = duffy_rule(4)
     phi, _ = basis(W.deg, pts)
@@ -433,16 +505,18 @@ def velocity_correction(W, P, ui, p1, p0, bc_dofs, bc_vals, rho, mu, dt,
     M = sp.block_diag([mass_matrix(W)] * 2, format='csr')
     b = M.dot(ui) + _vec(W, Fe, 2)
     A, b = symmetric_bc(M, b, bc_dofs, bc_vals)
+    if linear == 'block':
+        return solve_blockwise(A, b, W.N)
     return spla.splu(A.tocsc()).solve(b)
 
 
 def step(W, P, u0, p0, f0, f1, u_bc, p_bc, rho, mu, dt,
-         scheme='ipcs', method='backward euler', info=None):
+         scheme='ipcs', method='backward euler', info=None, linear='lu'):
     '''`_step` (pressure_correction.py:468-518) with the scheme flags of
     Chorin (:545-548), IPCS (:575-584), Rotational (:607-617).
     u_bc / p_bc: (dofs, values) tuples; p_bc None or empty -> Neumann branch.
     Returns (u1, p1, ui); a dict handed in as `info` receives the Newton
-    iteration's residual norms.'''
+    iteration's residual norms.  linear: see `tentative_velocity`.'''
     assert dt > 0.0 and mu > 0.0
     rotational = False
     if scheme == 'chorin':
@@ -453,8 +527,8 @@ def step(W, P, u0, p0, f0, f1, u_bc, p_bc, rho, mu, dt,
     else:
         assert scheme == 'ipcs'
     ui, history = tentative_velocity(
-        W, P, u0, p0, f0, f1, u_bc[0], u_bc[1], method, rho, mu, dt
-        )
+        W, P, u0, p0, f0, f1, u_bc[0], u_bc[1], method, rho, mu, dt,
+        linear=linear)
     if info is not None:
         info['newton_history'] = history
     b = pressure_rhs(W, P, ui, p0, 1.0, rho, mu, dt, rotational)
@@ -463,8 +537,8 @@ def step(W, P, u0, p0, f0, f1, u_bc, p_bc, rho, mu, dt,
     else:
         p1 = solve_pressure(P, b)
     u1 = velocity_correction(
-        W, P, ui, p1, p0, u_bc[0], u_bc[1], rho, mu, dt, rotational
-        )
+        W, P, ui, p1, p0, u_bc[0], u_bc[1], rho, mu, dt, rotational,
+        linear=linear)
     return u1, p1, ui
 
 

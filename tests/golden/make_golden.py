@@ -160,6 +160,38 @@ def large_fixture(name):
     numpy.savez_compressed(path, **data)
 
 
+def check_block_solver(name):
+    '''--check-block NAME: recompute an EXISTING ns_large fixture with the
+    oracle's block-wise linear solver (fem_oracle.solve_blockwise) and print
+    how far it is from what the single sparse LU stored -- what pins the solver
+    of the half-size fixture to the one of all the others.'''
+    import large_cases
+    gold = numpy.load(os.path.join(HERE, 'ns_large_%s.npz' % name))
+    args = dict(large_cases.LARGE[name], linear='block')
+    case = large_cases.KarmanStepCase(**args)
+    assert numpy.allclose(case.fingerprint(), gold['fingerprint'], rtol=1e-9,
+                          atol=1e-12)
+    stride = int(gold['stride'])
+    for method in ('backward euler', 'crank-nicolson'):
+        info = {}
+        u1, p1, ui = case.oracle_step(method, info=info)
+        key = method.replace(' ', '_').replace('-', '_')
+        worst = 0.0
+        for fname, field, ncomp in (('ui', ui, 2), ('p1', p1, 1), ('u1', u1, 2)):
+            sample, l2, linf = large_cases.summary(field, ncomp, stride)
+            gs = gold['%s_%s_sample' % (key, fname)]
+            err = numpy.linalg.norm(sample - gs) / numpy.linalg.norm(gs)
+            dl2 = abs(l2 - gold['%s_%s_l2' % (key, fname)]).max() / l2.max()
+            worst = max(worst, err, dl2)
+            print('  %s %s %s: samples rel-l2 %.2e, norms %.2e' % (
+                name, method, fname, err, dl2), flush=True)
+        h0, h1 = numpy.array(info['newton_history']), gold[key + '_newton_history']
+        print('  Newton histories: %s | stored %s' % (
+            ' '.join('%.3e' % r for r in h0), ' '.join('%.3e' % r for r in h1)),
+            flush=True)
+        assert worst < 1e-10, worst
+
+
 def _store(data, key, fields, stride):
     import large_cases
     for fname, field, ncomp in fields:
@@ -219,6 +251,10 @@ def stokes_fixture(name):
 
 
 if __name__ == '__main__':
+    if '--check-block' in sys.argv[1:]:
+        for name in sys.argv[sys.argv.index('--check-block') + 1:]:
+            check_block_solver(name)
+        sys.exit(0)
     if LARGE:
         import large_cases
         asked = [a for a in sys.argv[1:] if not a.startswith('--')]

@@ -60,8 +60,14 @@ def force(x, t):
 
 class KarmanStepCase(object):
     def __init__(self, nx=None, ny=None, vdeg=2, dt=None, mu=0.002,
-                 rho=karman.RHO_WATER_293K, fitted=True, mesh=None):
+                 rho=karman.RHO_WATER_293K, fitted=True, mesh=None,
+                 linear='lu'):
+        '''linear: how the ORACLE solves its Newton and mass systems -- one
+        sparse LU ('lu') or, beyond what SuperLU factors whole, the same
+        solution through the LUs of the diagonal blocks ('block',
+        fem_oracle.solve_blockwise).'''
         self.args = dict(nx=nx, ny=ny, vdeg=vdeg, mu=mu, rho=rho, fitted=fitted)
+        self.linear = linear
         if mesh is None:
             mesh = fem.karman_channel(nx, ny, fitted=fitted)
         self.mesh = mesh
@@ -124,15 +130,17 @@ class KarmanStepCase(object):
         return (collect(self.u_bcs, self.W.size()),
                 collect(self.p_bcs, self.P.size()))
 
-    def oracle_step(self, method='backward euler', u0=None, p0=None, info=None):
+    def oracle_step(self, method='backward euler', u0=None, p0=None, info=None,
+                    linear=None):
         from oracle import fem_oracle as orc
+        linear = self.linear if linear is None else linear
         W, P = self.oracle_spaces()
         u_bc, p_bc = self.bc_data()
         return orc.step(
             W, P, self.u0 if u0 is None else u0, self.p0 if p0 is None else p0,
             self.lattice(self.f0), self.lattice(self.f1), u_bc, p_bc,
             self.rho, self.mu, self.dt, scheme='rotational', method=method,
-            info=info)
+            info=info, linear=linear)
 
     # -- product side ---------------------------------------------------------
     def product_step(self, method='backward euler', tol=1.0e-13, u0=None,
@@ -161,9 +169,12 @@ LARGE = {
     # a quarter of the headline workload (2182 x 509): 2.5 M DoF, four
     # multigrid levels under the pressure solve
     'p2p1_1091x255': dict(nx=1091, ny=255, vdeg=2),
-    # (half of the workload, 1543 x 360 = 4.9 M DoF, was tried: SuperLU gives up
-    # on the Newton matrix -- "not enough memory to perform factorization"
-    # after 25 minutes, with 40 GB still free: the index range of its factors)
+    # half of the headline workload: 4.9 M DoF.  SuperLU gives up on the
+    # coupled Newton matrix here ("not enough memory to perform factorization"
+    # after 25 minutes, with 40 GB still free: the index range of its
+    # factors); the oracle reaches the same discrete solution through the LUs
+    # of the two diagonal blocks (fem_oracle.solve_blockwise, `linear='block'`)
+    'p2p1_1543x360': dict(nx=1543, ny=360, vdeg=2, linear='block'),
     }
 STRIDE = 87          # every 87th dof of each field is stored (a fixture
                      # says which stride it was written with)

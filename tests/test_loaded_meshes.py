@@ -131,3 +131,31 @@ def test_step_on_a_loaded_graded_mesh_against_the_oracle(hip, tmp_path, method):
     assert cases.rel_l2(u1, u1o) < 1e-7
     assert len(navsto.last_step_info['newton_residuals']) == \
         len(info['newton_history'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('method', ['backward euler', 'crank-nicolson'])
+def test_step_on_the_references_own_mesh_against_the_oracle(hip, method):
+    """What the reference's driver really meshes (tests/
+    test_karman_vortex_street.py:35-45: ONE characteristic length for the
+    circle and the rectangle, `lcar = 5e-3` at the `__main__` setting): a
+    quasi-uniform unstructured channel of 3.9 k vertices, 34.6 k DoF, at the
+    driver's own viscosity (:167; cell Peclet ~20) -- the Karman step against
+    the oracle on the same mesh."""
+    import cases
+    import large_cases
+    import flow_amd.navier_stokes as navsto
+    mesh = fem.karman_channel_graded(5.0e-3, lcar_far=5.0e-3).reordered()
+    assert 30000 < 9 * mesh.num_vertices() < 40000
+    e = mesh._edge_lengths().max(axis=1)
+    assert e.max() < 2.5 * numpy.median(e)                   # not graded
+    case = large_cases.KarmanStepCase(mesh=mesh, mu=0.002)
+    info = {}
+    u1o, p1o, uio = case.oracle_step(method, info=info)
+    u1, p1, ui = case.product_step(method)
+    assert cases.rel_l2(ui, uio) < 1e-7
+    assert cases.rel_l2(p1, p1o) < 1e-7
+    assert cases.rel_l2(u1, u1o) < 1e-7
+    assert len(navsto.last_step_info['newton_residuals']) == \
+        len(info['newton_history'])
+    assert len(info['newton_history']) >= 3

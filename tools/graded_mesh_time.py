@@ -67,14 +67,19 @@ def main():
     from flow_amd import fem, karman
     from flow_amd.fem import io
     t0 = time.time()
-    m = fem.karman_channel_graded(lcar)
-    path = '/tmp/karman_graded_%g.msh' % lcar
+    # FAR=<ratio>: lcar_far = ratio * lcar (default 4: graded; 1: the ONE
+    # characteristic length the reference's driver hands gmsh,
+    # tests/test_karman_vortex_street.py:35-45 -- quasi-uniform)
+    far = float(os.environ.get('FAR', '4'))
+    m = fem.karman_channel_graded(lcar, lcar_far=far * lcar)
+    path = '/tmp/karman_graded_%g_%g.msh' % (lcar, far)
     io.write_msh(path, m, binary=True)
     print('generated %d vertices in %.1f s, written to %s' % (
         m.num_vertices(), time.time() - t0, path), flush=True)
     if os.environ.get('REORDER', '1') == '1':
         mesh = fem.Mesh(path)
-        label = 'graded Delaunay, reordered'
+        label = 'graded Delaunay, reordered' if far != 1.0 \
+            else 'uniform Delaunay, reordered'
     else:
         mesh = io.read_mesh(path, reorder=False)
         label = 'graded Delaunay, file order'
@@ -86,6 +91,8 @@ def main():
         mesh.bandwidth = types.MethodType(lambda self: 0, mesh)
         prob.__init__(mesh=mesh)
     run(prob, label, steps)
+    if os.environ.get('NO_STRUCTURED'):
+        return
     # the structured channel with as many DoF
     nv = mesh.num_vertices()
     nx = int(round((nv * 0.6 / 0.14)**0.5))
