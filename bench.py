@@ -210,6 +210,10 @@ def cpu_baseline(Kbc, isbc, b, tol, gpu, ndofs, budget_s=12.0):
     jac_rate = jits / (time.perf_counter() - t0)
     steps, fit = oracle_step_timing(ndofs)
     big = steps[-1]
+    try:
+        iterative = cpu_iterative_step()
+    except Exception as exc:                           # noqa: BLE001
+        iterative = {'error': repr(exc)}
     out = {
         # The whole step on the CPU, MEASURED: the oracle's step() (numpy /
         # scipy, sparse LU for every solve like the reference's dolfin
@@ -243,6 +247,9 @@ def cpu_baseline(Kbc, isbc, b, tol, gpu, ndofs, budget_s=12.0):
                     % (fit['exponent'], ' and '.join(fit['through']))},
         'oracle_step': steps,
         'oracle_step_fit': fit,
+        # the same step with ITERATIVE solvers on the host cores (the Krylov
+        # parts in C/OpenMP on all of them), measured on a 188 k-DoF channel
+        'iterative_step': iterative,
         # the same oracle step MEASURED at 0.75 - 2.5 M DoF (offline, build
         # container: what the parity fixtures at size were computed with)
         'oracle_steps_at_size': {
@@ -270,6 +277,65 @@ def cpu_baseline(Kbc, isbc, b, tol, gpu, ndofs, budget_s=12.0):
             },
         }
     return out, x_cpu
+
+
+def cpu_iterative_step(nx=300, ny=70):
+    '''One step on the HOST CORES with iterative solvers (oracle/cpu_step.py:
+    the oracle's numpy assembly, Newton systems by ILU-preconditioned GMRES,
+    pressure by CG + the GPU path's smoothed-aggregation V-cycle in C/OpenMP,
+    mass system by Jacobi-CG in C/OpenMP), MEASURED on a body-fitted channel
+    of nx x ny (a bounded sample of the workload: its numpy assembly runs on
+    one core and takes most of the time).  The hierarchy is the product's own
+    (built on the GPU side for the sample mesh and handed over as data).'''
+    import numpy
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import large_cases
+    from oracle import cpu_lib, cpu_step
+    from flow_amd import karman
+    from flow_amd.fem.bcs import collect
+    from flow_amd.fem.multigrid import Multigrid
+    try:
+        lib = cpu_lib.load(cpu_lib.build(native=True, out_dir='/tmp'))
+    except Exception:                                  # noqa: BLE001
+        lib = cpu_lib.load()
+    cores = lib.oracle_num_threads()
+    case = large_cases.KarmanStepCase(nx, ny)
+    # the product's pressure operator and hierarchy for this mesh
+    prob = karman.KarmanProblem(nx, ny)
+    prob.prepare()
+    lay = prob.P.layout
+    Kbc = [v for k, v in lay._dev.items()
+           if isinstance(k, tuple) and k[0] == 'K_bc'][0][0]
+    dofs, _v = collect(prob.p_bcs, lay.N)
+    isbc = numpy.zeros(lay.N, dtype=bool)
+    isbc[dofs] = True
+    mg = Multigrid(Kbc, isbc, keep_host=True)
+    hier = cpu_lib.MgHierarchy(lib, mg.host_levels, mg.Ainv_host, mg.omega) \
+        if mg.nlevels >= 2 else None
+    W, P = case.oracle_spaces()
+    u_bc, p_bc = case.bc_data()
+    t0 = time.perf_counter()
+    _u1, _p1, _ui, info = cpu_step.step(
+        W, P, case.u0, case.p0, case.lattice(case.f0), case.lattice(case.f1),
+        u_bc, p_bc, case.rho, case.mu, case.dt, lib, hierarchy=hier, tol=1e-10)
+    wall = time.perf_counter() - t0
+    return {
+        'kind': 'restatement, measured',
+        'workload': 'Karman channel %d x %d, P2-P1, %d DoF, one Rotational '
+                    'step from the analytic state of tests/large_cases.py (%d '
+                    'Newton iterations)' % (nx, ny, case.num_dofs(),
+                                            len(info['newton_history']) - 1),
+        'dofs': case.num_dofs(),
+        'step_s': wall,
+        'dofs_per_s': case.num_dofs() / wall,
+        'cores': {'assembly (numpy)': 1, 'ILU + GMRES (scipy / SuperLU)': 1,
+                  'pressure (%s, C/OpenMP)' % info['pressure_solver']: cores,
+                  'velocity correction (Jacobi-CG, C/OpenMP)': cores},
+        'seconds': info['seconds'],
+        'gmres_iterations': info['gmres_iterations'],
+        'pressure_iterations': info['pressure_iterations'],
+        'correction_iterations': info['correction_iterations'],
+        }
 
 
 def oracle_steps_at_size():

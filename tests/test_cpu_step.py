@@ -1,0 +1,31 @@
+# -*- coding: utf-8 -*-
+'''
+oracle/cpu_step.py -- the whole step on the host cores with iterative solvers
+(bench.py's measured CPU figure) -- against the sparse-LU oracle it restates
+(oracle/fem_oracle.step; reference flow/navier_stokes/pressure_correction.py:
+468-518): same fields to solver tolerance.  CPU only.
+'''
+import numpy
+
+import cases
+import large_cases
+
+
+def test_iterative_cpu_step_matches_the_sparse_lu_oracle():
+    from oracle import cpu_lib, cpu_step
+    lib = cpu_lib.load()
+    lib.oracle_set_threads(2)
+    c = large_cases.KarmanStepCase(60, 14)
+    W, P = c.oracle_spaces()
+    u_bc, p_bc = c.bc_data()
+    u1, p1, ui, info = cpu_step.step(
+        W, P, c.u0, c.p0, c.lattice(c.f0), c.lattice(c.f1), u_bc, p_bc, c.rho,
+        c.mu, c.dt, lib, tol=1e-10)
+    u1o, p1o, uio = c.oracle_step()
+    assert cases.rel_l2(ui, uio) < 1e-9
+    assert cases.rel_l2(p1, p1o) < 1e-8
+    assert cases.rel_l2(u1, u1o) < 1e-8
+    assert info['newton_history'][-1] < 1e-10
+    assert set(info['seconds']) == {'assembly', 'ilu', 'gmres', 'pressure',
+                                    'correction'}
+    assert all(numpy.isfinite(v) and v >= 0.0 for v in info['seconds'].values())
