@@ -64,7 +64,7 @@ solver_parameters = {'rtol': 1.0e-13, 'maxit': 2000, 'check_every': 10,
                      'fallback': 'tlilu',
                      'tlilu': {'pre': 1, 'post': 1, 'coarse_sweeps': 2},
                      'tl_select': 'rate', 'tl_probe_smooth': 4,
-                     'tl_probe_sweeps': 3,
+                     'tl_probe_sweeps': 3, 'tl_accept': 0.9,
                      # 'previous': the solve starts from the solution of the
                      # previous solve on the space; 'zero': no history
                      'start': 'previous'}
@@ -362,6 +362,13 @@ class Heat(object):
                 except _hip.NotConverged:
                     pass
             ops.fill(u.data, 0.0)
+            if hasattr(pre, 'cycle'):
+                # (the two-level ILU cycle stalled: its smoother alone, and no
+                # cycle for the next solves either)
+                pre = pre.cycle.fine
+                lay._dev['heat_tl_choice'] = {
+                    'left': int(par.get('pmg_retry', 8)), 'cycle': False}
+                last_solve_info['heat_preconditioner'] = 'ilu0'
             info = ops.krylov_solve(
                 'bicgstab', A, bvec, u.data, rtol=par['rtol'], atol=0.0,
                 maxit=par['maxit'], check_every=par['check_every'], ilu=pre
@@ -480,7 +487,8 @@ class Heat(object):
             choice['cycle'], probe = rate_verdict(
                 S.apply, tl.apply, tl.fine.solve, v, w, z,
                 smooth=int(solver_parameters.get('tl_probe_smooth', 4)),
-                sweeps=int(solver_parameters.get('tl_probe_sweeps', 3)))
+                sweeps=int(solver_parameters.get('tl_probe_sweeps', 3)),
+                accept=float(solver_parameters.get('tl_accept', 0.9)))
             choice['left'] = int(solver_parameters.get('pmg_retry', 8))
             last_solve_info['heat_tl_contraction'] = probe
         choice['left'] -= 1

@@ -178,6 +178,10 @@ solver_parameters = {
                # diffusion number 16: ~100 applications per solve against
                # 200-800).
                'tl_select': 'rate', 'tl_probe_smooth': 6, 'tl_probe_sweeps': 4,
+               # (the cycle is only taken where it contracts by at least this
+               # per application; and a GMRES that has not converged with it
+               # after `tl_maxit` applications is redone with the bare sweeps)
+               'tl_accept': 0.9, 'tl_maxit': 400,
                # the sweeps read the factors rounded to fp32 (fp64 arithmetic):
                # half the bytes per application, same iteration counts
                'ilu_storage': 'fp32',
@@ -787,6 +791,17 @@ def _compute_tentative_velocity(
                     ops.fill(dx, 0.0)
                     dx_is_zero = True
                     kind, pre, refactored = build(fallback)
+                    sol = gmres(npar['linear_maxit'])
+            elif kind == 'tlilu' and getattr(pre, 'use_cycle', False):
+                try:
+                    sol = gmres(min(npar['linear_maxit'],
+                                    npar.get('tl_maxit', 400)))
+                except _hip.NotConverged:
+                    info('two-level ILU cycle: GMRES stalled, redone with the '
+                         'bare ILU(0)')
+                    pre.use_cycle = False
+                    ops.fill(dx, 0.0)
+                    dx_is_zero = True
                     sol = gmres(npar['linear_maxit'])
             else:
                 sol = gmres(npar['linear_maxit'])

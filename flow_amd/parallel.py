@@ -928,14 +928,40 @@ def mass_solve(solver, b, x, rtol, atol=0.0, maxit=50, tag=None, xbase=None,
     first = solver.history.get(('strips', tag), 0) if tag is not None else 0
     its = ctypes.c_int(0)
     res = ctypes.c_double(0.0)
-    _hip.check(_hip.lib().flow_shard_mass_solve(
-        ctypes.byref(c.struct), ctypes.byref(ms.rows), ctypes.byref(ms.struct),
-        ctypes.byref(ms.levels), _hip.f64(b, n, 'b'),
-        _hip.f64(xbase, n, 'xbase') if xbase is not None else None,
-        _hip.f64(delta0, n, 'delta0') if delta0 is not None else None,
-        _hip.f64(x, n, 'x'), float(rtol), float(atol), int(maxit), int(first),
-        _hip.f64(wk), wk.numel(), ctypes.byref(its), ctypes.byref(res),
-        _hip.stream()))
+    base = _hip.clone(xbase) if xbase is not None and solver.guard \
+        and x.data_ptr() == xbase.data_ptr() else xbase
+    try:
+        _hip.check(_hip.lib().flow_shard_mass_solve(
+            ctypes.byref(c.struct), ctypes.byref(ms.rows),
+            ctypes.byref(ms.struct), ctypes.byref(ms.levels),
+            _hip.f64(b, n, 'b'),
+            _hip.f64(xbase, n, 'xbase') if xbase is not None else None,
+            _hip.f64(delta0, n, 'delta0') if delta0 is not None else None,
+            _hip.f64(x, n, 'x'), float(rtol), float(atol), int(maxit),
+            int(first), _hip.f64(wk), wk.numel(), ctypes.byref(its),
+            ctypes.byref(res), _hip.stream()))
+    except _hip.NotConverged as err:
+        # The verdict (an iteration that does not contract, a NaN) comes out
+        # of sums that are the same on every rank: all ranks land here
+        # together and all take the Jacobi-CG of the strips, like
+        # MassSolver._fallback on one GPU.
+        if not solver._bound_failed(err):
+            raise
+        info('sharded mass solve: %s -- falling back to Jacobi-CG' % err)
+        solver.fallbacks = getattr(solver, 'fallbacks', 0) + 1
+        if xbase is None:
+            if not bool(torch.isfinite(x).all()):
+                _hip.fill(x, 0.0)
+            sol = cg(solver.A, solver.dinv, b, x, rtol, atol, maxit=1000,
+                     check_every=2, tag=tag)
+        else:
+            delta = device.zeros(n)
+            sol = cg(solver.A, solver.dinv, b, delta, rtol, atol, maxit=1000,
+                     check_every=2, tag=tag)
+            ops.copy(x, base)
+            ops.axpby(1.0, delta, 1.0, x)
+        sol.method = 'defect correction -> ' + sol.method
+        return sol
     if tag is not None:
         solver.history[('strips', tag)] = its.value
     return _solve_info(its.value, res.value,

@@ -131,6 +131,10 @@ def test_step_on_a_loaded_graded_mesh_against_the_oracle(hip, tmp_path, method):
     assert cases.rel_l2(u1, u1o) < 1e-7
     assert len(navsto.last_step_info['newton_residuals']) == \
         len(info['newton_history'])
+    # the mass solver's defect correction ran as itself (a silent fallback to
+    # Jacobi-CG on a graded mesh would be a performance regression nobody sees)
+    assert 'cg' not in navsto.last_step_info['correction'].method, \
+        navsto.last_step_info['correction']
 
 
 @pytest.mark.gpu

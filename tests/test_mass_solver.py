@@ -208,3 +208,48 @@ def test_pair_mass_solve_with_identity_rows(hip, packed):
     xf = _dev(x1)
     solver.solve(_dev(b), xf, 1e-12)
     assert cases.rel_l2(xf.cpu().numpy(), uref) < 1e-9
+
+
+@pytest.mark.gpu
+def test_contraction_watch_adapts_and_falls_back(hip):
+    '''The run-time watch on the a-priori contraction (mass_scalar_kernel;
+    ADVICE r5): (a) a bound that is too OPTIMISTIC does not fail the solve --
+    the stopping test takes the contraction the iteration is seen to have --
+    and does not stop it early either; (b) a polynomial that does not contract
+    at all is given up for Jacobi-CG, the answer is still the direct solve's,
+    and the solver counts the fallback.'''
+    from flow_amd.fem import ops
+    rng = numpy.random.RandomState(5)
+    mesh = fem.karman_channel_graded(4.0e-3).reordered()     # graded: 1:4
+    V = fem.FunctionSpace(mesh, 'CG', 2)
+    M = ops.assemble_mass(V)
+    Ms = M.to_scipy().tocsc()
+    b = rng.standard_normal(V.N)
+    ref = spla.splu(Ms).solve(b)
+    good = fmass.MassSolver(M, M.diag_inv())
+    x = _dev(numpy.zeros(V.N))
+    base = good.solve(_dev(b), x, 1e-12)
+    assert cases.rel_l2(x.cpu().numpy(), ref) < 1e-9
+    assert getattr(good, 'fallbacks', 0) == 0            # graded mesh: no trip
+    # (a) the vouched contraction 100 x too small
+    opt = fmass.MassSolver(M, M.diag_inv())
+    opt.struct.contraction = 0.01 * good.struct.contraction
+    x = _dev(numpy.zeros(V.N))
+    info = opt.solve(_dev(b), x, 1e-12)
+    assert cases.rel_l2(x.cpu().numpy(), ref) < 1e-9, info
+    assert getattr(opt, 'fallbacks', 0) == 0
+    assert base.iterations - 1 <= info.iterations <= base.iterations
+    # (b) a Chebyshev interval that misses most of the spectrum: no contraction
+    bad = fmass.MassSolver(M, M.diag_inv())
+    bad.struct.lam_max = 0.3 * good.struct.lam_max
+    bad.struct.lam_min = 0.3 * good.struct.lam_min
+    x = _dev(numpy.zeros(V.N))
+    info = bad.solve(_dev(b), x, 1e-12)
+    assert 'cg' in info.method and bad.fallbacks == 1, info
+    # (Jacobi-CG from the last iterate, PETSc's test on the preconditioned
+    # residual: the error against the direct solve is a few 1e-9)
+    assert cases.rel_l2(x.cpu().numpy(), ref) < 1e-7, info
+    # ... and with the guard off it is an error like any non-convergence
+    bad.guard = False
+    with pytest.raises(RuntimeError):
+        bad.solve(_dev(b), _dev(numpy.zeros(V.N)), 1e-12)

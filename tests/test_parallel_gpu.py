@@ -178,6 +178,24 @@ def _worker(rank, world, port, out):
         whole3 = device.to_host(parallel.gather_field(z3.clone(), lay, 2)).numpy()
         res['ms3'] = (t3.iterations, _rel(whole3, device.to_host(x2).numpy()))
 
+        # a polynomial that does not contract (Chebyshev interval off the
+        # spectrum): every rank reads the same verdict and all of them fall
+        # back to the strips' Jacobi-CG, both forms
+        bad = MassSolver(Mrows, dinv2)
+        bad.struct.lam_max = 0.3 * ms2.struct.lam_max
+        bad.struct.lam_min = 0.3 * ms2.struct.lam_min
+        z4 = x2s.clone()
+        t4 = parallel.mass_solve(bad, b2, z4, 1e-11)
+        z5 = device.zeros(2 * n)
+        t5 = parallel.mass_solve(bad, g2, z5, 1e-11, xbase=x2s)
+        res['ms_fallback'] = (
+            t4.method, t5.method, bad.fallbacks,
+            _rel(device.to_host(parallel.gather_field(z4.clone(), lay, 2)
+                                ).numpy(), device.to_host(x2).numpy()),
+            _rel(device.to_host(parallel.gather_field(z5.clone(), lay, 2)
+                                ).numpy(), device.to_host(x2).numpy()))
+        res['ms_no_fallback'] = getattr(ms2, 'fallbacks', 0)
+
         yp = device.zeros(play.N)
         calls0 = parallel.comm().calls
         sp = parallel.mgcg(Kbc, kdinv, mg, bp, yp, 1e-11, maxit=500)
@@ -258,6 +276,11 @@ def test_strip_sharded_solvers_and_step(hip, world):
             # bitwise equal: same inputs, same order of summation per row
             assert ghosts, key
         assert res['ms3'][1] < 1e-9 and res['ms3'][0] <= res['ms2'][0], res['ms3']
+        # the watch's fallback on the strips: Jacobi-CG, both forms, right answer
+        m4, m5, nfall, e4, e5 = res['ms_fallback']
+        assert 'cg' in m4 and 'cg' in m5 and nfall == 2, res['ms_fallback']
+        assert e4 < 1e-9 and e5 < 1e-9, res['ms_fallback']
+        assert res['ms_no_fallback'] == 0
         # collectives of the sharded V-cycle CG: TWO per iteration -- [dots +
         # halo of w + the coarse image C w] and [halo of z]; the coarse
         # residual itself is carried by CG's recurrences -- plus the start
