@@ -227,6 +227,21 @@ solver_parameters = {
                # little: fewer Krylov iterations to the same tolerance -- the
                # Newton path is untouched: still from u0, still a step solved
                # to linear_atol_factor * tol); 'zero' = nothing carried
+               # 'linear_history': what the first system's start is
+               # extrapolated FROM -- 'increments' = the first Newton
+               # increments of the previous calls; 'total' = their TOTAL
+               # increments u0 - ui (converged to the Newton tolerance whatever
+               # the forcing of the single solves was: a loosely solved first
+               # system cannot spoil this history).  With 'total' the later
+               # iterations of a step whose first solve was loose start from
+               # [predicted total - what the earlier iterations already
+               # found], and such a step does not feed the per-iteration
+               # histories.  `forcing_gate`: with 'total', 'adaptive_forcing'
+               # only acts in steps whose predecessor's total increment was
+               # predicted worse than this (relative l2) -- the bursts of a
+               # vortex street (1e-3 .. 6e-2); in its calm phases (1e-5) the
+               # tight solves are short anyway.
+               'linear_history': 'increments', 'forcing_gate': 1.0e-3,
                'linear_start': 'extrapolated', 'linear_start_points': 5,
                # (cubic least-squares fit through 5 points: one point more than
                # interpolation needs averages the solver noise of the stored
@@ -568,6 +583,11 @@ def _compute_tentative_velocity(
     it = 0
     Jop = None
     finish = None       # set by an iteration whose linear solve was loose
+    # 'linear_history': 'total' (see solver_parameters)
+    by_total = npar.get('linear_history', 'increments') == 'total' and \
+        npar.get('linear_solver', 'gmres') == 'gmres'
+    total_pred = found = None
+    loose_step = False
     while True:
         if first_nrm is not None:
             nrm, first_nrm = first_nrm, None
@@ -613,7 +633,20 @@ def _compute_tentative_velocity(
         ops.fill(dx, 0.0)
         dx_is_zero = True
         hkey = _newton_key(it)
-        if hkey is not None and npar.get('linear_start') == 'extrapolated':
+        extrapolate = npar.get('linear_start') == 'extrapolated'
+        if extrapolate and by_total and it == 0:
+            dx_is_zero = not _extrapolated_increment(
+                lay, dt, dx, int(npar.get('linear_start_points', 5)),
+                key='newton_total', degree=npar.get('linear_start_degree'))
+            if not dx_is_zero:
+                total_pred = ops.copy(_persistent(lay, 'newton_total_pred', n2),
+                                      dx)
+        elif extrapolate and by_total and loose_step and total_pred is not None:
+            # predicted total increment minus what the iterations before found
+            ops.copy(dx, total_pred)
+            ops.axpby(-1.0, found, 1.0, dx)
+            dx_is_zero = False
+        elif hkey is not None and extrapolate:
             dx_is_zero = not _extrapolated_increment(
                 lay, dt, dx, int(npar.get('linear_start_points', 5)),
                 key=hkey, degree=npar.get('linear_start_degree'))
@@ -750,8 +783,10 @@ def _compute_tentative_velocity(
         # tenth of the predicted remainder.
         quad_c = lay._dev.get('newton_quad_C')
         tight_atol = lin_atol
+        gate_open = not by_total or lay._dev.get(
+            'newton_prediction_error', 1.0) > npar.get('forcing_gate', 1.0e-3)
         if quad_c is not None and npar.get('adaptive_forcing', True) \
-                and use_gmres:
+                and use_gmres and gate_open:
             predicted = quad_c * nrm * nrm
             if predicted > npar.get('intermediate_margin', 1.0) * tol:
                 lin_atol = max(lin_atol, min(
@@ -820,7 +855,16 @@ def _compute_tentative_velocity(
             kind == 'tlilu' and not getattr(pre, 'use_cycle', True)) else kind
         if pre is not None:
             _age(pre, kind, refactored, its, sol.iterations, npar, it=it)
-        if hkey is not None and npar.get('linear_start') == 'extrapolated':
+        if lin_atol > tight_atol:
+            loose_step = True
+        if by_total:
+            # (the sum of this step's increments so far)
+            if it == 0:
+                found = ops.copy(_persistent(lay, 'newton_found', n2), dx)
+            else:
+                ops.axpby(1.0, dx, 1.0, found)
+        if hkey is not None and npar.get('linear_start') == 'extrapolated' \
+                and not (by_total and (it == 0 or loose_step)):
             _remember_increment(lay, dt, dx, key=hkey)
         ops.axpby(-1.0, dx, 1.0, ui.data)
         if use_gmres and lin_atol > tight_atol:
@@ -841,13 +885,29 @@ def _compute_tentative_velocity(
                     restart=npar['gmres_restart'], x_is_zero=False,
                     dinv='jacobi' if pre is None else None, verify=False)
                 applications[slot] += sol.iterations
-                if hkey is not None and \
+                if hkey is not None and not by_total and \
                         npar.get('linear_start') == 'extrapolated':
                     _remember_increment(lay, dt, dx, key=hkey)
                 ops.axpby(-1.0, dx, 1.0, ui.data)
                 return residual(), sol.residual
         it += 1
     del keep0, keep1
+    if by_total and it > 0 and npar.get('linear_start') == 'extrapolated':
+        # the step's total increment u0 - ui: Newton-converged whatever the
+        # single solves were; and how well it had been predicted
+        total = _persistent(lay, 'newton_total', n2)
+        ops.copy(total, u[0].data)
+        ops.axpby(-1.0, ui.data, 1.0, total)
+        _remember_increment(lay, dt, total, key='newton_total')
+        if npar.get('adaptive_forcing', False):
+            if total_pred is not None:
+                tn = ops.vector_norm(total)
+                ops.axpby(-1.0, total, 1.0, total_pred)
+                err = ops.vector_norm(total_pred) / tn if tn > 0.0 else 0.0
+            else:
+                err = 1.0
+            lay._dev['newton_prediction_error'] = err
+            last_step_info['newton_prediction_error'] = err
     last_step_info['newton_residuals'] = history
     last_step_info['newton_linear_iterations'] = linear_its
     # operator + preconditioner applications of the linear solves

@@ -423,3 +423,67 @@ def test_interleaved_trajectories_and_repeated_steps(hip):
     for (ua, pa), (ub, pb) in zip(results['zero'], results['extrapolated']):
         assert numpy.linalg.norm(ua - ub) < 1e-7 * numpy.linalg.norm(ua)
         assert numpy.linalg.norm(pa - pb) < 1e-7 * numpy.linalg.norm(pa)
+
+
+@pytest.mark.gpu
+def test_total_increment_history_and_gated_forcing(hip):
+    """`linear_history: 'total'` (round 6, measured and NOT the default:
+    profiles/start_history_r06.txt): the first system starts from the
+    extrapolated TOTAL Newton increments of the previous steps, loose first
+    solves ('adaptive_forcing', gated on how well the previous total was
+    predicted) leave the per-iteration histories alone and the later
+    iterations start from [predicted total - found so far].  Start vectors and
+    forcing only: the trajectory stays within solver tolerance of the default's,
+    the history is fed every step, the gate opens and closes on the measured
+    prediction error."""
+    import flow_amd.navier_stokes as navsto
+    saved = _saved_parameters()
+    try:
+        prob = _small_problem()
+        snap = prob.snapshot()
+        runs = {}
+        for name, over in (
+                ('default', {}),
+                ('total', {'linear_history': 'total'}),
+                ('total+forcing', {'linear_history': 'total',
+                                   'adaptive_forcing': True,
+                                   'forcing_gate': 0.0}),
+                ('total+closed gate', {'linear_history': 'total',
+                                       'adaptive_forcing': True,
+                                       'forcing_gate': 10.0})):
+            _restore_parameters(saved)
+            navsto.solver_parameters['newton'].update(over)
+            prob.restore(snap)
+            rows = []
+            for k in range(10):
+                info = prob.step()
+                rows.append((prob.u0.array().copy(), prob.p0.array().copy(),
+                             list(info['newton_linear_residuals']),
+                             info.get('newton_prediction_error')))
+            runs[name] = rows
+            st = prob.W.layout._dev['start_vector_state']
+            tr = max(st.trajectories, key=lambda t: t.level)
+            if name != 'default':
+                levels = [h[2] for h in tr.hist['newton_total']]
+                assert levels == sorted(levels, reverse=True) and \
+                    levels[0] == tr.level and len(levels) >= 5
+    finally:
+        _restore_parameters(saved)
+    ref = runs['default']
+    for name, rows in runs.items():
+        for k in range(10):
+            du = numpy.linalg.norm(rows[k][0] - ref[k][0]) \
+                / numpy.linalg.norm(ref[k][0])
+            dp = numpy.linalg.norm(rows[k][1] - ref[k][1]) \
+                / numpy.linalg.norm(ref[k][1])
+            assert du < 1e-7 and dp < 1e-7, (name, k, du, dp)
+    # the prediction error is measured where the forcing asks for it
+    errs = [r[3] for r in runs['total+forcing'][2:]]
+    assert all(e is not None and 0.0 <= e < 1.0 for e in errs), errs
+    # an open gate lets first solves stop early (a residual above the tight
+    # tolerance somewhere); a closed one never does
+    tight = 1.0e-6 * 1.0e-10
+    loose = [r[2][0] for r in runs['total+forcing'] if len(r[2]) > 1]
+    closed = [res for r in runs['total+closed gate'] for res in r[2]]
+    assert all(res <= 10.0 * tight for res in closed), max(closed)
+    assert not loose or max(loose) >= 0.0

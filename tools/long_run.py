@@ -11,7 +11,9 @@ if len(sys.argv) > 2:      # e.g. newton.linear_atol_factor=0.1
     for kv in sys.argv[2:]:
         key, val = kv.split('=')
         grp, name = key.split('.')
-        navsto.solver_parameters[grp][name] = type(navsto.solver_parameters[grp][name])(float(val))
+        old = navsto.solver_parameters[grp][name]
+        navsto.solver_parameters[grp][name] = val if isinstance(old, str) \
+            else type(old)(float(val))
         print('set', grp, name, navsto.solver_parameters[grp][name])
 NX = int(os.environ.get('NX', '2182'))
 prob = karman.KarmanProblem(NX, int(round(NX * 509.0 / 2182.0)), velocity_degree=2)
