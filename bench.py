@@ -520,6 +520,16 @@ def main():
     ap.add_argument('--shard-single', action='store_true',
                     help='development: run the sharded loops on a 1-rank '
                          'process group (measures their host overhead)')
+    ap.add_argument('--weak', action='store_true',
+                    help='weak scaling: the channel is N times as long (nx x N '
+                         'columns of the same cells, the same ny), the work per '
+                         'GPU stays that of the 1-GPU run; default: strong '
+                         'scaling, the mesh is fixed')
+    ap.add_argument('--stage-timeout', type=float, default=300.0,
+                    help='seconds a bring-up stage (process group, first '
+                         'collective, first time step) may take on a rank '
+                         'before that rank gives up with exit code 3 and a '
+                         'line that names rank and stage')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hbm-resident', action='store_true')
     ap.add_argument('--spmv-reps', type=int, default=100)
@@ -553,6 +563,36 @@ def main():
 
     _hip.lib()          # fail loudly without the HIP library / a GPU
 
+    # -- bring-up that cannot hang a lease: every rank says which stage it is
+    # in (stderr), and a stage of the bring-up that takes longer than
+    # --stage-timeout ends THAT rank with exit code 3 and a line naming rank
+    # and stage (os._exit from a watchdog thread: never an exec, and a hung
+    # collective cannot be interrupted any other way); the launcher then ends
+    # the others.
+    import threading
+    stage = {'name': 'start', 'timer': None}
+
+    def enter(name, guarded=False):
+        if stage['timer'] is not None:
+            stage['timer'].cancel()
+            stage['timer'] = None
+        stage['name'] = name
+        if world > 1 or args.shard_single:
+            sys.stderr.write('[bench rank %d/%d] stage: %s\n' % (rank, world, name))
+            sys.stderr.flush()
+        if guarded and world > 1:
+            def give_up():
+                sys.stderr.write(
+                    '[bench rank %d/%d] FAILED: stage %r did not finish in '
+                    '%.0f s -- giving up (exit code 3)\n'
+                    % (rank, world, name, args.stage_timeout))
+                sys.stderr.flush()
+                os._exit(3)
+            t = threading.Timer(args.stage_timeout, give_up)
+            t.daemon = True
+            t.start()
+            stage['timer'] = t
+
     class stdout_to_stderr(object):
         '''RCCL prints a version banner on STDOUT when a communicator comes
         up; this program's stdout is ONE JSON line.'''
@@ -566,14 +606,34 @@ def main():
             os.dup2(self.saved, 1)
             os.close(self.saved)
 
+    collective_us = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         with stdout_to_stderr():
+            enter('process group (%s)' % args.backend, guarded=True)
             if args.backend == 'nccl':
                 dist.init_process_group('nccl', device_id=device.get())
             else:
                 dist.init_process_group('gloo')
+            enter('first collective', guarded=True)
+            probe = torch.ones(1, dtype=torch.float64,
+                               device=device.get() if args.backend == 'nccl'
+                               else 'cpu')
+            dist.all_reduce(probe)
+            if args.backend == 'nccl':
+                torch.cuda.synchronize()
+            if int(round(float(probe.item()))) != world:
+                sys.stderr.write('[bench rank %d/%d] FAILED: first collective '
+                                 'summed to %r\n' % (rank, world, probe.item()))
+                sys.exit(4)
+            enter('communicator of the strips', guarded=True)
             parallel.enable(dist.group.WORLD)
+            # torch.distributed's all-reduce or the one the library issues
+            # itself (csrc/rccl_direct.hip): 50 calls of each, the faster one
+            # is used -- every rank takes the same decision
+            enter('collective micro-benchmark', guarded=True)
+            collective_us = parallel.comm().use_fastest(50)
+            enter('setup')
     elif args.shard_single:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
@@ -590,9 +650,12 @@ def main():
 
     t_setup = time.perf_counter()
     ny = args.ny if args.ny else max(2, int(round(args.nx * 509.0 / 2182.0)))
-    prob = karman.KarmanProblem(args.nx, ny,
+    nx_run, length = args.nx, karman.X1
+    if args.weak and world > 1:
+        nx_run, length = args.nx * world, karman.X1 * world
+    prob = karman.KarmanProblem(nx_run, ny,
                                 velocity_degree=args.velocity_degree,
-                                scheme=args.scheme, mu=args.mu)
+                                scheme=args.scheme, mu=args.mu, length=length)
 
     start = {}
     settled = {}
@@ -703,7 +766,9 @@ def main():
     # plan, ...), then the start state: all of it setup, outside the windows
     # (development overrides first: some of them shape those structures)
     apply_overrides()
+    enter('first time step (prepare)', guarded=True)
     prob.prepare()
+    enter('initial state')
     initial_state()
     if not args.no_settle:
         navsto.set_mode(args.mode)
@@ -714,6 +779,7 @@ def main():
         settled['state'] = prob.snapshot()
     barrier()
     setup_s = time.perf_counter() - t_setup
+    enter('plateau window')
     infos, elapsed = window(args.mode)
     head = summary(infos, elapsed)
     if settled:
@@ -799,6 +865,7 @@ def main():
     # iterations and longer solves -- for the reference as for this build.
     developed = None
     if args.developed > 0 and settled:
+        enter('developed street: %d spin-up steps' % args.developed)
         navsto.set_mode(args.mode)
         apply_overrides()
         prob.restore(settled['state'])
@@ -855,6 +922,7 @@ def main():
                 }
         settled['state'] = plateau_state
 
+    enter('report')
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -879,7 +947,7 @@ def main():
         'value_plateau': head['steps_per_s'],
         'ms_per_step_plateau': head['ms_per_step'],
         'higher_is_better': True,
-        'scaling': 'strong',
+        'scaling': 'weak' if (args.weak and world > 1) else 'strong',
         'vs_baseline': None,
         'dtype': 'f64',
         'data': 'synthetic',
@@ -890,7 +958,7 @@ def main():
                         'rho 998.2, dt0 1e-5 + CFL controller, start: %s; '
                         'value: %s'
                         % ('P2-P1 Taylor-Hood' if args.velocity_degree == 2
-                           else 'P1-P1', prob.num_dofs(), args.nx, ny,
+                           else 'P1-P1', prob.num_dofs(), nx_run, ny,
                            args.scheme, args.tol, args.mu,
                            'Stokes solution' if args.initial == 'stokes'
                            else 'inflow profile',
@@ -928,6 +996,10 @@ def main():
             # picks its launches out of the PMC passes by it)
             'pressure_spmv_grid': int(Kbc.operator().nblocks) * 256,
             'parallelism': parallel.describe(world, n),
+            # microseconds per all-reduce of 8 doubles (50 back-to-back calls,
+            # slowest rank) through torch.distributed and through the
+            # library's own ncclAllReduce, and which of them the run used
+            'collective_us': collective_us,
             'setup_s': setup_s,
             'settle': {
                 'steps': settled['steps'], 'dt': settled['state']['dt'],

@@ -379,15 +379,15 @@ def rectangle_with_fitted_hole(
     return Mesh(pts[used], new_id[cells])
 
 
-def karman_channel(nx, ny=None, diagonal='right', fitted=False):
+def karman_channel(nx, ny=None, diagonal='right', fitted=False, length=0.6):
     '''Channel [0, 0.6] x [-0.07, 0.07] with a circular obstacle of diameter
     0.04 at (0.1, 0.01): tests/test_karman_vortex_street.py:18-23, 35-38.
     fitted: the body-fitted hole of `rectangle_with_fitted_hole` instead of the
-    staircase.'''
+    staircase.  length: a longer channel [0, length] (weak-scaling runs).'''
     if ny is None:
-        ny = max(2, int(round(nx * 0.14 / 0.6)))
+        ny = max(2, int(round(nx * 0.14 / length)))
     make = rectangle_with_fitted_hole if fitted else rectangle_with_hole
-    return make(0.0, 0.6, -0.07, 0.07, (0.1, 1.0e-2), 0.02, nx, ny, diagonal)
+    return make(0.0, length, -0.07, 0.07, (0.1, 1.0e-2), 0.02, nx, ny, diagonal)
 
 
 def heater_box(nx, ny=None, diagonal='right', fitted=False):

@@ -32,8 +32,12 @@ class LeftBoundary(fem.SubDomain):
 
 
 class RightBoundary(fem.SubDomain):
+    def __init__(self, x1=X1):
+        fem.SubDomain.__init__(self)
+        self.x1 = x1
+
     def inside(self, x, on_boundary):
-        return on_boundary & (x[0] > X1 - MESH_EPS)
+        return on_boundary & (x[0] > self.x1 - MESH_EPS)
 
 
 class LowerBoundary(fem.SubDomain):
@@ -47,10 +51,14 @@ class UpperBoundary(fem.SubDomain):
 
 
 class ObstacleBoundary(fem.SubDomain):
+    def __init__(self, x1=X1):
+        fem.SubDomain.__init__(self)
+        self.x1 = x1
+
     def inside(self, x, on_boundary):
         return (
             on_boundary
-            & (X0 + MESH_EPS < x[0]) & (x[0] < X1 - MESH_EPS)
+            & (X0 + MESH_EPS < x[0]) & (x[0] < self.x1 - MESH_EPS)
             & (Y0 + MESH_EPS < x[1]) & (x[1] < Y1 - MESH_EPS)
             )
 
@@ -58,7 +66,7 @@ class ObstacleBoundary(fem.SubDomain):
 class KarmanProblem(object):
     def __init__(self, nx=None, ny=None, velocity_degree=2, mu=0.002,
                  rho=RHO_WATER_293K, scheme='rotational', fitted=True,
-                 mesh=None):
+                 mesh=None, length=X1):
         # body-fitted obstacle (fem/mesh.py: rectangle_with_fitted_hole); the
         # staircase variant (fitted=False) leaves one-cell notches in which,
         # at the controller's step size, a node-scale velocity spike grows
@@ -74,7 +82,13 @@ class KarmanProblem(object):
                 mesh = mesh.reordered()
             self.mesh = mesh
         else:
-            self.mesh = fem.karman_channel(nx, ny, fitted=fitted)
+            # length: the channel [0, length] x [-0.07, 0.07] (the
+            # reference's is 0.6 long; a weak-scaling run keeps nx / length,
+            # i.e. the cells, and lengthens the channel with the ranks)
+            self.mesh = fem.karman_channel(nx, ny, fitted=fitted) \
+                if length == X1 else fem.karman_channel(
+                    nx, ny, fitted=fitted, length=length)
+        self.length = length
         self.W = fem.VectorFunctionSpace(self.mesh, 'Lagrange', velocity_degree)
         self.P = fem.FunctionSpace(self.mesh, 'Lagrange', 1)
         self.mu = mu
@@ -88,11 +102,11 @@ class KarmanProblem(object):
         self.u_bcs = [
             fem.DirichletBC(W, (0.0, 0.0), UpperBoundary()),
             fem.DirichletBC(W, (0.0, 0.0), LowerBoundary()),
-            fem.DirichletBC(W, (0.0, 0.0), ObstacleBoundary()),
+            fem.DirichletBC(W, (0.0, 0.0), ObstacleBoundary(length)),
             fem.DirichletBC(W.sub(0), self.inflow, LeftBoundary()),
-            fem.DirichletBC(W.sub(0), self.outflow, RightBoundary()),
+            fem.DirichletBC(W.sub(0), self.outflow, RightBoundary(length)),
             ]
-        self.p_bcs = [fem.DirichletBC(P, 0.0, RightBoundary())]
+        self.p_bcs = [fem.DirichletBC(P, 0.0, RightBoundary(length))]
         self.stepper = {
             'chorin': navier_stokes.Chorin,
             'ipcs': navier_stokes.IPCS,

@@ -267,6 +267,62 @@ class Comm(object):
         self.direct = binding
         self._point_struct_at_rccl()
 
+    def benchmark(self, calls=50, count=8):
+        '''Microseconds per all-reduce of `count` doubles through each binding
+        this communicator can use, `calls` back to back after a warm-up (the
+        slowest rank's time, agreed on by all): {'torch': us[, 'library':
+        us]} -- 'library' only on the nccl backend, and only if every rank
+        could bring the library's own communicator up.'''
+        import time
+        out = {}
+        lib = _hip.load_library() if device.on_gpu() else None
+
+        def timed(call):
+            for _ in range(5):
+                call()
+            device.synchronize()
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                call()
+            device.synchronize()
+            us = 1.0e6 * (time.perf_counter() - t0) / calls
+            t = torch.tensor([us], dtype=torch.float64,
+                             device=self.buf.device if not self.staged
+                             else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            return float(t.item())
+        self.buf[:count] = 0.0
+        out['torch'] = timed(lambda: self.allreduce_tensor(self.buf[:count]))
+        if not self.staged and lib is not None:
+            had = self.direct
+            if had is None:
+                self._bind_rccl()
+            if self.direct is not None:
+                user = ctypes.cast(ctypes.pointer(self.direct), ctypes.c_void_p)
+                self.direct.stream = ctypes.c_void_p(device.stream_handle())
+                out['library'] = timed(
+                    lambda: lib.flow_rccl_allreduce(user, count))
+        self.buf[:count] = 0.0
+        return out
+
+    def use_fastest(self, calls=50):
+        '''Benchmark both bindings and keep the faster one (every rank takes
+        the same decision: the timings are maxima over the ranks).  -> the
+        timings, with 'used'.'''
+        us = self.benchmark(calls)
+        if 'library' in us and us['library'] < us['torch']:
+            self._point_struct_at_rccl()
+            us['used'] = 'library'
+        else:
+            if self.direct is not None:
+                # back to the torch callback (the communicator stays: unused)
+                self.struct.allreduce = self._cb
+                self.struct.user = None
+                self.direct_unused, self.direct = self.direct, None
+            us['used'] = 'torch'
+        return us
+
     def _point_struct_at_rccl(self):
         lib = _hip.load_library()
         self.direct.buf = ctypes.c_void_p(self.buf.data_ptr())

@@ -62,3 +62,48 @@ def test_bench_starts_its_own_ranks(hip):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['steps'] == 2 and rec['value'] > 0.0
     assert rec['scaling'] == 'strong'
+
+
+@pytest.mark.gpu
+def test_weak_scaling_and_bring_up_report(hip):
+    """`--weak`: two ranks, a channel twice as long (the same cells); the line
+    says so, carries the collective micro-benchmark, and every rank named its
+    bring-up stages on stderr."""
+    global ARGS
+    saved, ARGS = ARGS, ARGS + ['--weak']
+    try:
+        out = _run(timeout=900)
+    finally:
+        ARGS = saved
+    err = out.stderr.decode('utf-8', 'replace')
+    assert out.returncode == 0, err[-3000:]
+    rec = json.loads([l for l in out.stdout.decode().splitlines()
+                      if l.strip()][0])
+    assert rec['scaling'] == 'weak' and rec['n_gpus'] == 2
+    assert '384 x' in rec['config']['workload']          # 2 x 192 columns
+    us = rec['config']['collective_us']
+    assert us['used'] == 'torch' and us['torch'] > 0.0    # (gloo: no library path)
+    for r in (0, 1):
+        for name in ('process group (gloo)', 'first collective',
+                     'first time step (prepare)', 'plateau window'):
+            assert '[bench rank %d/2] stage: %s' % (r, name) in err, (r, name)
+
+
+@pytest.mark.gpu
+def test_a_stage_that_hangs_ends_the_rank_with_its_name(hip):
+    """The watchdog of bench.py's bring-up: a rank whose process group never
+    forms (its peer does not exist) gives up with exit code 3 and a line that
+    names rank and stage -- it does not sit in the lease."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+         '--backend', 'gloo', '--nx', '64', '--stage-timeout', '8'],
+        env=dict(os.environ, RANK='0', WORLD_SIZE='2', LOCAL_RANK='0',
+                 MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
+        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = out.stderr.decode('utf-8', 'replace')
+    assert out.returncode == 3, (out.returncode, err[-2000:])
+    assert "FAILED: stage 'process group (gloo)'" in err and 'rank 0/2' in err
