@@ -520,6 +520,13 @@ def main():
     ap.add_argument('--shard-single', action='store_true',
                     help='development: run the sharded loops on a 1-rank '
                          'process group (measures their host overhead)')
+    ap.add_argument('--halos', default='allreduce', choices=['allreduce', 'peer'],
+                    help="N > 1: 'allreduce' = halos travel in the one all-reduce "
+                         "of the strips (default: the path every multi-rank "
+                         "test runs); 'peer' = from neighbour to neighbour "
+                         'through IPC-mapped landing buffers with sequence '
+                         'flags (flow_peer; self-tested at start, every rank '
+                         'falls back to the all-reduce if any rank fails it)')
     ap.add_argument('--weak', action='store_true',
                     help='weak scaling: the channel is N times as long (nx x N '
                          'columns of the same cells, the same ny), the work per '
@@ -633,6 +640,13 @@ def main():
             # is used -- every rank takes the same decision
             enter('collective micro-benchmark', guarded=True)
             collective_us = parallel.comm().use_fastest(50)
+            if args.halos == 'peer':
+                enter('peer halos: map + self-test', guarded=True)
+                collective_us['halos'] = 'peer' \
+                    if parallel.comm().enable_peer() else \
+                    'allreduce (the peer self-test failed)'
+            else:
+                collective_us['halos'] = 'allreduce'
             enter('setup')
     elif args.shard_single:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -215,11 +215,25 @@ class NsParams(ctypes.Structure):
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
 
 
+class PeerS(ctypes.Structure):
+    '''flow_peer (include/flow_hip.h): halos from neighbour to neighbour'''
+    _fields_ = [
+        ('flags', ctypes.c_void_p), ('land', ctypes.c_void_p),
+        ('land_cap', ctypes.c_int), ('spin_limit', ctypes.c_int),
+        ('nb_flags', ctypes.c_void_p * 2), ('nb_land', ctypes.c_void_p * 2),
+        ('seq_host', ctypes.POINTER(ctypes.c_ulonglong)),
+        ]
+
+
+PEER_FLAGS = 16
+
+
 class CommS(ctypes.Structure):
     _fields_ = [
         ('rank', ctypes.c_int), ('world', ctypes.c_int),
         ('buf', ctypes.c_void_p), ('capacity', ctypes.c_int),
         ('allreduce', ALLREDUCE_FN), ('user', ctypes.c_void_p),
+        ('peer', ctypes.POINTER(PeerS)),
         ]
 
 
@@ -312,6 +326,11 @@ SYMBOLS = {
     'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _VP, _P(_D), _VP],
     'flow_pmg_apply': [_P(PmgS), _VP, _VP, _VP],
     'flow_tl_apply': [_P(TlS), _VP, _VP, _VP],
+    'flow_peer_alloc': [ctypes.c_int, _P(ctypes.c_void_p), ctypes.c_char_p],
+    'flow_peer_open': [ctypes.c_char_p, _P(ctypes.c_void_p)],
+    'flow_peer_close': [_VP],
+    'flow_peer_free': [_VP],
+    'flow_peer_status': [_P(PeerS), _P(ctypes.c_ulonglong), _VP],
     'flow_mass_pack': [_I, _VP, _VP, _VP, _VP, _VP],
     'flow_mass_pack16': [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'flow_mass_solve': [_P(MassS), _VP, _VP, _D, _D, _I, _I, _VP,
@@ -381,7 +400,7 @@ class NotConverged(RuntimeError):
 
 # flow_abi_version() of the library these bindings describe (the structs above
 # and SYMBOLS): a stale libflow_hip.so is refused at load time
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 
 def load_library():

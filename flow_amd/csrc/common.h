@@ -74,6 +74,9 @@ int read_state(const double* S, double* host, hipStream_t st);
 int check_comm(const flow_comm* c, long long need);
 int check_rows(const flow_rows* R);
 int exchange(const flow_comm* c, int count);
+// [sums | ... | halo at hoff]: see la_kernels.hip
+int exchange_halo(const flow_comm* C, const flow_rows* R, int ncomp, int sum_count,
+                  int hoff, hipStream_t st);
 
 // assembly_kernels.hip: the matrix-free operator (flow_operator kind 3)
 int momentum_jvp_check(const flow_momentum_jvp* J);

@@ -16,6 +16,8 @@
 //    finisher => bitwise reproducible.
 //  * Krylov scalars (alpha, beta, ...) live in HBM; the host only reads the
 //    residual norm every `check_every` iterations.
+#include <cstring>
+
 #include "common.h"
 #include "csr_stream.h"
 
@@ -1347,7 +1349,7 @@ static int bicgstab(const flow_operator* A, const double* dinv,
 using namespace flow;
 
 extern "C" const char* flow_last_error(void) { return g_error; }
-extern "C" int flow_abi_version(void) { return 29; }
+extern "C" int flow_abi_version(void) { return 30; }
 
 namespace flow {
 unsigned long long g_launches = 0;
@@ -1452,6 +1454,68 @@ extern "C" int flow_profile_spmv_end(double* total_us, int* launches) {
   *launches = pf.used;
   pf = SpmvProfile();
   return rc;
+}
+
+// ---- flow_peer: the blocks and their IPC handles ---------------------------
+extern "C" int flow_peer_alloc(int land_cap, void** base_out, char* handle_out) {
+  FLOW_REQUIRE(land_cap > 0 && base_out && handle_out, "flow_peer_alloc arguments");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  const size_t bytes = sizeof(unsigned long long) * FLOW_PEER_FLAGS +
+                       2 * sizeof(double) * static_cast<size_t>(land_cap);
+  void* base = nullptr;
+  // fine-grained where the runtime grants it (flag words polled across GPUs);
+  // plain device memory otherwise -- all flag and landing traffic is system
+  // scope either way
+  if (hipExtMallocWithFlags(&base, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    FLOW_CHECK_HIP(hipMalloc(&base, bytes));
+  }
+  FLOW_CHECK_HIP(hipMemset(base, 0, bytes));
+  FLOW_CHECK_HIP(hipDeviceSynchronize());
+  hipIpcMemHandle_t h;
+  hipError_t err = hipIpcGetMemHandle(&h, base);
+  if (err != hipSuccess) {
+    // (some runtimes refuse to export fine-grained memory: plain memory then)
+    (void)hipGetLastError();
+    (void)hipFree(base);
+    FLOW_CHECK_HIP(hipMalloc(&base, bytes));
+    FLOW_CHECK_HIP(hipMemset(base, 0, bytes));
+    FLOW_CHECK_HIP(hipDeviceSynchronize());
+    FLOW_CHECK_HIP(hipIpcGetMemHandle(&h, base));
+  }
+  memcpy(handle_out, &h, sizeof(h));
+  *base_out = base;
+  return FLOW_OK;
+}
+
+extern "C" int flow_peer_open(const char* handle, void** base_out) {
+  FLOW_REQUIRE(handle && base_out, "flow_peer_open arguments");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  FLOW_CHECK_HIP(hipIpcOpenMemHandle(base_out, h, hipIpcMemLazyEnablePeerAccess));
+  return FLOW_OK;
+}
+
+extern "C" int flow_peer_close(void* mapped_base) {
+  FLOW_REQUIRE(mapped_base != nullptr, "flow_peer_close argument");
+  FLOW_CHECK_HIP(hipIpcCloseMemHandle(mapped_base));
+  return FLOW_OK;
+}
+
+extern "C" int flow_peer_free(void* base) {
+  FLOW_REQUIRE(base != nullptr, "flow_peer_free argument");
+  FLOW_CHECK_HIP(hipFree(base));
+  return FLOW_OK;
+}
+
+extern "C" int flow_peer_status(const flow_peer* peer,
+                                unsigned long long* error_host, void* stream) {
+  FLOW_REQUIRE(peer && peer->flags && error_host, "flow_peer_status arguments");
+  hipStream_t st = as_stream(stream);
+  FLOW_CHECK_HIP(hipMemcpyAsync(error_host, peer->flags + 4, sizeof(*error_host),
+                                hipMemcpyDeviceToHost, st));
+  FLOW_CHECK_HIP(hipStreamSynchronize(st));
+  return FLOW_OK;
 }
 
 extern "C" int flow_operator_apply(const flow_operator* A, const double* x,
@@ -2775,6 +2839,120 @@ int exchange(const flow_comm* c, int count) {
   return FLOW_OK;
 }
 
+// ---- halos from neighbour to neighbour (flow_peer) --------------------------
+// Every rank owns a LANDING area its two neighbours have mapped (hipIpc): two
+// buffers of land_cap doubles (exchange seq uses buffer seq & 1) and a block of
+// 64-bit flags.  One exchange = one push and one pull launch around whatever is
+// really summed:
+//   push  a workgroup per side: wait until that neighbour has pulled exchange
+//         seq - 2 (the landing buffer of this parity is free again: its
+//         `consumed` word in MY block), copy my send slots of the packed
+//         buffer into ITS landing buffer -- same slot numbering on all ranks --,
+//         fence, then write seq into its `arrived` word;
+//   pull  a workgroup per side: wait for my `arrived` word of that side, copy
+//         the landing buffer's receive slots into my packed buffer (where the
+//         unpack kernels look, as after an all-reduce), then write seq into the
+//         neighbour's `consumed` word.
+// Waits are bounded (spin_limit polls with a sleep in between): a neighbour
+// that never arrives sets the error word of this rank's block and the kernel
+// goes on -- nothing can hang the device; the host reads the word
+// (flow_peer_status) behind its next read-back.  All flag traffic is system
+// scope (past L2: the words live in another process, on another GPU).
+constexpr int kPeerBlock = 256;
+enum PeerFlag { kArrived = 0, kConsumed = 2, kPeerError = 4, kPeerFlags = 16 };
+
+__device__ __forceinline__ unsigned long long peer_load(const unsigned long long* p) {
+  return __hip_atomic_load(const_cast<unsigned long long*>(p), __ATOMIC_ACQUIRE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void peer_store(unsigned long long* p,
+                                           unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// thread 0 waits for *flag >= want; false on time-out (error word set)
+__device__ __forceinline__ bool peer_wait(const unsigned long long* flag,
+                                          unsigned long long want, int limit,
+                                          unsigned long long* err,
+                                          unsigned long long code) {
+  for (int it = 0; it < limit; ++it) {
+    if (peer_load(flag) >= want) return true;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  peer_store(err, code);
+  return false;
+}
+
+__global__ __launch_bounds__(kPeerBlock) void peer_push_kernel(
+    flow_rows R, int ncomp, flow_peer P, unsigned long long seq,
+    const double* __restrict__ packed) {
+  const int sd = blockIdx.x;
+  if (R.send_len[sd] <= 0 || P.nb_land[sd] == nullptr) return;
+  if (threadIdx.x == 0 && seq >= 3)
+    peer_wait(P.flags + kConsumed + sd, seq - 2, P.spin_limit,
+              P.flags + kPeerError, (seq << 8) | (1 + sd));
+  __syncthreads();
+  double* land = P.nb_land[sd] + static_cast<size_t>(seq & 1) * P.land_cap;
+  const int len = R.send_len[sd];
+  for (int t = threadIdx.x; t < ncomp * len; t += kPeerBlock) {
+    const int a = t / len, j = t - a * len;
+    const size_t k = static_cast<size_t>(a) * R.nhalo + R.send_slot[sd] + j;
+    __hip_atomic_store(land + k, packed[k], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  // I am this neighbour's neighbour on its OTHER side
+  if (threadIdx.x == 0) peer_store(P.nb_flags[sd] + kArrived + (1 - sd), seq);
+}
+
+__global__ __launch_bounds__(kPeerBlock) void peer_pull_kernel(
+    flow_rows R, int ncomp, flow_peer P, unsigned long long seq,
+    double* __restrict__ packed) {
+  const int sd = blockIdx.x;
+  if (R.recv_len[sd] <= 0 || P.nb_flags[sd] == nullptr) return;
+  if (threadIdx.x == 0)
+    peer_wait(P.flags + kArrived + sd, seq, P.spin_limit, P.flags + kPeerError,
+              (seq << 8) | (3 + sd));
+  __syncthreads();
+  const double* land = P.land + static_cast<size_t>(seq & 1) * P.land_cap;
+  const int len = R.recv_len[sd];
+  for (int t = threadIdx.x; t < ncomp * len; t += kPeerBlock) {
+    const int a = t / len, j = t - a * len;
+    const size_t k = static_cast<size_t>(a) * R.nhalo + R.recv_slot[sd] + j;
+    packed[k] = __hip_atomic_load(const_cast<double*>(land + k), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) peer_store(P.nb_flags[sd] + kConsumed + (1 - sd), seq);
+}
+
+// One exchange of a packed buffer [sums (sum_count doubles) | ... | halo slots
+// at hoff]: the sums through the all-reduce, the halo either with them (the
+// whole buffer is summed: every rank wrote zeros into the others' slots) or,
+// with a flow_peer, from neighbour to neighbour -- then only the first
+// sum_count doubles are a collective, and none at all for a pure halo.
+int exchange_halo(const flow_comm* C, const flow_rows* R, int ncomp, int sum_count,
+                  int hoff, hipStream_t st) {
+  const int nh = ncomp * R->nhalo;
+  const flow_peer* P = C->peer;
+  if (P == nullptr || C->world == 1 || nh == 0)
+    return (hoff + nh > 0) ? exchange(C, hoff + nh) : FLOW_OK;
+  FLOW_REQUIRE(P->flags && P->land && P->seq_host && nh <= P->land_cap,
+               "flow_peer: landing buffers too small for this halo");
+  const unsigned long long seq = ++*P->seq_host;
+  hipLaunchKernelGGL(peer_push_kernel, dim3(2), dim3(kPeerBlock), 0, st, *R, ncomp,
+                     *P, seq, C->buf + hoff);
+  FLOW_CHECK_LAUNCH();
+  if (sum_count > 0) {
+    int rc = exchange(C, sum_count);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(peer_pull_kernel, dim3(2), dim3(kPeerBlock), 0, st, *R, ncomp,
+                     *P, seq, C->buf + hoff);
+  FLOW_CHECK_LAUNCH();
+  return FLOW_OK;
+}
+
 // halo[a*nhalo + k] <- the own boundary entries of x (global row index,
 // component stride `stride`), zero in everybody else's slots
 __global__ void shard_pack_kernel(flow_rows R, int ncomp,
@@ -2817,7 +2995,8 @@ static int halo(const flow_comm* C, const flow_rows* R, int ncomp, double* x,
   hipLaunchKernelGGL(shard_pack_kernel, dim3(grid_for(count)), dim3(kBlock), 0,
                      st, *R, ncomp, x, stride, C->buf);
   FLOW_CHECK_LAUNCH();
-  int rc = exchange(C, count);
+  // (a pure halo: no sums -- with a flow_peer no collective at all)
+  int rc = exchange_halo(C, R, ncomp, 0, 0, st);
   if (rc) return rc;
   const int per = R->recv_len[0] + R->recv_len[1];
   if (per > 0) {
@@ -2933,11 +3112,11 @@ __global__ __launch_bounds__(kScalarBlock) void shard_finish_pack_kernel(
     flow_rows R, int ncomp, int np, int nd, const double* __restrict__ gpart,
     const double* __restrict__ rpart, const double* __restrict__ dpart,
     const double* __restrict__ extra, const double* __restrict__ w, int stride,
-    double* __restrict__ buf, const double* __restrict__ stop) {
+    double* __restrict__ buf, const double* __restrict__ stop, int hoff = 4) {
   if (stopped(stop)) return;
   if (blockIdx.x > 0) {
     const int total = ncomp * R.nhalo;
-    double* halo = buf + 4;
+    double* halo = buf + hoff;
     for (int t = (blockIdx.x - 1) * blockDim.x + threadIdx.x; t < total;
          t += (gridDim.x - 1) * blockDim.x) {
       const int a = t / R.nhalo, k = t - a * R.nhalo;
@@ -2995,13 +3174,14 @@ __global__ void shard_scalar_unpack_kernel(flow_rows R, int ncomp, int first,
                                            double* __restrict__ S,
                                            double* __restrict__ w, int stride,
                                            int ncopy = 0, int copy_off = 0,
-                                           double* __restrict__ copy_dst = nullptr) {
+                                           double* __restrict__ copy_dst = nullptr,
+                                           int hoff = 4) {
   if (stopped(S + kDone)) return;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncopy;
        t += gridDim.x * blockDim.x)
     copy_dst[t] = load_scalar(buf + copy_off + t);
   const int per = R.recv_len[0] + R.recv_len[1];
-  const double* halo = buf + 4;
+  const double* halo = buf + hoff;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ncomp * per;
        t += gridDim.x * blockDim.x) {
     const int a = t / per, k = t - a * per;
@@ -3321,10 +3501,13 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
                      c.r, c.z, c.z, c.z, c.partial, c.partial + 2 * kRedBlocks);
   const int gp = 1 + grid_for(ncomp * R->nhalo > 0 ? ncomp * R->nhalo : 1,
                               kScalarBlock, 64);
-  // [3 sums, |B b|^2 | halo of w | (two-collective form) this rank's share of
-  // the coarse image C w]
-  const int coff = 4 + ncomp * R->nhalo;
-  const int count = coff + n1;
+  // [3 sums, |B b|^2 | (two-collective form) this rank's share of the coarse
+  // image C w | halo of w]: everything that is SUMMED is a prefix, the halo
+  // behind it may travel from neighbour to neighbour instead (exchange_halo)
+  const int coff = 4;
+  const int hoff = coff + n1;
+  const int count = hoff + ncomp * R->nhalo;
+  (void)count;
   // C w: the rank's owned columns
   auto coarse_image_of_w = [&](const double* flag) -> int {
     return two ? apply(&G->Cg, c.w + (R->r0 - R->e0), C->buf + coff, st, nullptr,
@@ -3335,9 +3518,9 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
   hipLaunchKernelGGL(shard_finish_pack_kernel, dim3(gp), dim3(kScalarBlock), 0, st,
                      *R, ncomp, gu, nd, c.partial, c.partial + 2 * kRedBlocks,
                      c.dpart, c.S + kB2, c.sh(c.w), me, C->buf,
-                     static_cast<const double*>(nullptr));
+                     static_cast<const double*>(nullptr), hoff);
   FLOW_CHECK_LAUNCH();
-  if ((rc = exchange(C, count))) return rc;
+  if ((rc = exchange_halo(C, R, ncomp, hoff, hoff, st))) return rc;
 
   const int per = R->recv_len[0] + R->recv_len[1];
   int gs = grid_for(ncomp * per > 0 ? ncomp * per : 1);
@@ -3345,7 +3528,7 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
   // alpha, beta and the verdict on the start; ghost rows of w; rc_w
   hipLaunchKernelGGL(shard_scalar_unpack_kernel, dim3(gs), dim3(kBlock), 0, st, *R,
                      ncomp, rejected ? 2 : 1, rtol2, atol2, C->buf, c.S,
-                     c.sh(c.w), me, n1, coff, rc_w);
+                     c.sh(c.w), me, n1, coff, rc_w, hoff);
   FLOW_CHECK_LAUNCH();
   double state[kNumSlots];
   int launched = 0;
@@ -3405,12 +3588,12 @@ static int shard_cg(const flow_comm* C, const flow_rows* R,
       hipLaunchKernelGGL(shard_finish_pack_kernel, dim3(gp), dim3(kScalarBlock), 0,
                          st, *R, ncomp, np, nd, gpart, rpart, c.dpart,
                          static_cast<const double*>(nullptr), c.sh(c.w), me,
-                         C->buf, stop);
+                         C->buf, stop, hoff);
       FLOW_CHECK_LAUNCH();
-      if ((rc = exchange(C, count))) return rc;
+      if ((rc = exchange_halo(C, R, ncomp, hoff, hoff, st))) return rc;
       hipLaunchKernelGGL(shard_scalar_unpack_kernel, dim3(gs), dim3(kBlock), 0,
                          st, *R, ncomp, 0, rtol2, atol2, C->buf, c.S, c.sh(c.w),
-                         me, n1, coff, rc_w);
+                         me, n1, coff, rc_w, hoff);
     }
     FLOW_CHECK_LAUNCH();
     launched += todo;

@@ -751,7 +751,8 @@ static int shard_mass_solve(const flow_comm* C, const flow_rows* R,
                        C->buf, stop);
     FLOW_CHECK_LAUNCH();
     // (every rank issues the same sequence of collectives, whatever the flag)
-    if ((rc = exchange(C, count))) return rc;
+    (void)count;
+    if ((rc = exchange_halo(C, R, ncomp, 4, 4, st))) return rc;
     hipLaunchKernelGGL(shard_mass_unpack_kernel, dim3(gs), dim3(kBlock), 0, st, *R,
                        ncomp, k == 0 ? 1 : 0, k, c2, rtol * rtol, atol * atol,
                        C->buf, rho0, S);

@@ -69,6 +69,11 @@ def enable(group, force=False):
                     if dist.get_backend(group) != 'gloo' else 'cpu')
     dist.all_reduce(t, group=group)
     device.synchronize()
+    # halos from neighbour to neighbour instead of through the all-reduce
+    # (Comm.enable_peer): opt-in -- the path has only ever run between
+    # processes that share one device (the development box has one GPU)
+    if os.environ.get('FLOW_AMD_PEER_HALO', '0') == '1':
+        _STATE['comm'].enable_peer()
 
 
 def disable():
@@ -148,6 +153,9 @@ class Comm(object):
         self.direct = None          # RcclBinding when the library calls RCCL
         self._rccl_comm = None
         self.failed = False         # a collective failed: no further ones
+        self.peer = None            # _hip.PeerS: halos from neighbour to neighbour
+        self._peer_maps = []
+        self._peer_base = None
         self.ensure(capacity)
         # The all-reduce issued by the library itself (no Python, no event
         # hand-over per collective) is OPT-IN: it has only ever run on 1-rank
@@ -157,8 +165,154 @@ class Comm(object):
                 os.environ.get('FLOW_AMD_RCCL_DIRECT', '0') == '1':
             self._bind_rccl()
 
+    # -- halos from neighbour to neighbour (flow_peer, csrc/la_kernels.hip) -----
+    def enable_peer(self, land_cap=1 << 17, spin_limit=2000000, selftest=24):
+        '''Map the neighbours' landing buffers (hipIpc: xGMI peers on a node,
+        or processes sharing one device in a rehearsal) and take the halos off
+        the all-reduce: a pure halo then costs no collective, a [sums | halo]
+        exchange one of <= 8 doubles.  Every rank tries; a self-test of
+        `selftest` exchanges with known data (both directions, both buffer
+        parities, a deliberately late rank) must pass on EVERY rank --
+        agreed on through an all-reduce -- or all of them stay on the
+        all-reduce path.  Returns whether the peer path is on.'''
+        if self.world == 1 or not device.on_gpu():
+            return False
+        lib = _hip.lib()
+
+        def all_ok(ok):
+            flag = torch.tensor([float(ok)], dtype=torch.float64)
+            if not self.staged:
+                flag = flag.to(device.get())
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return float(flag.item()) >= 1.0
+        base = ctypes.c_void_p(None)
+        handle = ctypes.create_string_buffer(64)
+        ok = 1
+        try:
+            _hip.check(lib.flow_peer_alloc(int(land_cap), ctypes.byref(base),
+                                           handle))
+        except Exception:                                  # noqa: BLE001
+            traceback.print_exc()
+            ok = 0
+        if not all_ok(ok):
+            if ok:
+                lib.flow_peer_free(base)
+            return False
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle.raw), group=self.group)
+        maps = [None, None]
+        try:
+            for sd, nb in ((0, self.rank - 1), (1, self.rank + 1)):
+                if 0 <= nb < self.world:
+                    m = ctypes.c_void_p(None)
+                    _hip.check(lib.flow_peer_open(handles[nb], ctypes.byref(m)))
+                    maps[sd] = m
+        except Exception:                                  # noqa: BLE001
+            traceback.print_exc()
+            ok = 0
+        if not all_ok(ok):
+            for m in maps:
+                if m is not None:
+                    lib.flow_peer_close(m)
+            lib.flow_peer_free(base)
+            return False
+        fbytes = 8 * _hip.PEER_FLAGS
+        peer = _hip.PeerS()
+        peer.flags = base.value
+        peer.land = base.value + fbytes
+        peer.land_cap, peer.spin_limit = int(land_cap), int(spin_limit)
+        for sd in (0, 1):
+            if maps[sd] is not None:
+                peer.nb_flags[sd] = maps[sd].value
+                peer.nb_land[sd] = maps[sd].value + fbytes
+        self._peer_seq = ctypes.c_ulonglong(0)
+        peer.seq_host = ctypes.pointer(self._peer_seq)
+        self._peer_base, self._peer_maps = base, [m for m in maps if m is not None]
+        self.peer = peer
+        self.struct.peer = ctypes.pointer(peer)
+        good = 1
+        try:
+            good = int(self._peer_selftest(selftest))
+        except Exception:                                  # noqa: BLE001
+            traceback.print_exc()
+            good = 0
+        if not all_ok(good):
+            self.disable_peer()
+            return False
+        return True
+
+    def _peer_selftest(self, rounds):
+        '''Pure halos of a tiny 1-D decomposition (4 owned rows per rank, 2
+        ghost rows per side) with data that names rank, round and row; odd
+        ranks sleep before every third round so that their neighbours run
+        ahead into the flags.'''
+        import time
+        w = self.world
+        n = 4 * w
+        bounds = numpy.arange(w + 1) * 4
+        lo = numpy.maximum(bounds[:-1] - 2, 0)
+        hi = numpy.minimum(bounds[1:] + 2, n)
+        rows = RowBlocks(n, bounds, lo, hi).struct(self.rank)
+        self.ensure(2 * rows.nhalo + 8)
+        x = device.zeros(2 * n)
+        idx = torch.arange(n, dtype=torch.float64, device=x.device)
+        own = slice(rows.r0, rows.r1)
+        for k in range(rounds):
+            if k % 3 == 2 and self.rank % 2 == 1:
+                device.synchronize()
+                time.sleep(0.02)
+            x.fill_(-1.0)
+            for a in (0, 1):
+                x[a * n:(a + 1) * n][own] = \
+                    (1000.0 * k + 100.0 * a + idx)[own]
+            _hip.check(_hip.lib().flow_shard_halo(
+                ctypes.byref(self.struct), ctypes.byref(rows), 2,
+                _hip.f64(x, 2 * n), n, _hip.stream()))
+            got = device.to_host(x).numpy()
+            for a in (0, 1):
+                want = 1000.0 * k + 100.0 * a + numpy.arange(n)
+                seg = got[a * n:(a + 1) * n]
+                if not numpy.array_equal(seg[rows.e0:rows.e1],
+                                         want[rows.e0:rows.e1]):
+                    return False
+        return self.peer_error() == 0
+
+    def peer_error(self):
+        '''The error word of this rank's peer block (0: every wait was served;
+        else (sequence number << 8) | what timed out).'''
+        if self.peer is None:
+            return 0
+        err = ctypes.c_ulonglong(0)
+        _hip.check(_hip.lib().flow_peer_status(
+            ctypes.byref(self.peer), ctypes.byref(err), _hip.stream()))
+        return int(err.value)
+
+    def disable_peer(self):
+        '''Back to halos in the all-reduce; unmap and free (collective in
+        spirit: call it on every rank, neighbours first unmap, then owners
+        free).'''
+        if self.peer is None and self._peer_base is None:
+            return
+        lib = _hip.load_library()
+        self.peer = None
+        if self.struct is not None:
+            self.struct.peer = None
+        try:
+            device.synchronize()
+            for m in self._peer_maps:
+                lib.flow_peer_close(m)
+            self._peer_maps = []
+            if dist.is_initialized():
+                dist.barrier(group=self.group)
+            if self._peer_base is not None:
+                lib.flow_peer_free(self._peer_base)
+        except Exception:                                  # noqa: BLE001
+            traceback.print_exc()
+        self._peer_base = None
+
     def close(self):
         '''Destroy the library's own RCCL communicator (if one was made).'''
+        self.disable_peer()
         comm, self._rccl_comm = self._rccl_comm, None
         if comm is not None:
             self.direct = None
@@ -177,7 +331,9 @@ class Comm(object):
             # the struct is only ever handed to the numpy stand-ins)
             self.struct = _hip.CommS(
                 self.rank, self.world, ctypes.c_void_p(self.buf.data_ptr()),
-                self.buf.numel(), self._cb, None)
+                self.buf.numel(), self._cb, None,
+                ctypes.pointer(self.peer) if getattr(self, 'peer', None)
+                is not None else None)
             if self.direct is not None:
                 self._point_struct_at_rccl()
         if self.direct is not None:

@@ -711,13 +711,51 @@ int flow_gmres_solve(const flow_operator* A, const double* dinv,
  * e1 - e0; fields handed in by the caller (b, x, dinv, ...) are global-length
  * (stride n), valid on the rank's owned + ghost rows. */
 typedef int (*flow_allreduce_fn)(void* user, int count);
+/* Halos from neighbour to neighbour instead of through the all-reduce (round
+ * 6; optional).  Every rank owns a peer block its two neighbours have mapped
+ * with hipIpcOpenMemHandle (xGMI peers on a node; processes sharing one device
+ * in a rehearsal): FLOW_PEER_FLAGS 64-bit words, then two landing buffers of
+ * land_cap doubles.  One exchange is then a PUSH launch (my send slots of the
+ * packed buffer -> the neighbour's landing buffer, then its `arrived` word), the
+ * all-reduce of what is really summed (nothing for a pure halo), and a PULL
+ * launch (wait for my `arrived` words, landing buffer -> my packed buffer,
+ * acknowledge in the neighbour's `consumed` word: it may reuse the buffer two
+ * exchanges on).  Sequence numbers count the exchanges of the communicator:
+ * every rank issues the same sequence.  Waits are bounded (spin_limit polls):
+ * a neighbour that never arrives sets word 4 of the waiting rank's block
+ * ((seq << 8) | what it waited for) and the kernel goes on -- the device
+ * cannot hang; flow_peer_status reads that word. */
+#define FLOW_PEER_FLAGS 16
+typedef struct {
+  unsigned long long* flags;       /* this rank's block: [arrived L, arrived R,
+                                      consumed L, consumed R, error, ...] */
+  double* land;                    /* this rank's 2 * land_cap doubles */
+  int land_cap;
+  int spin_limit;                  /* polls before a wait gives up */
+  unsigned long long* nb_flags[2]; /* the neighbours' blocks as mapped HERE ... */
+  double* nb_land[2];              /* ... and their landing buffers; NULL: no
+                                      neighbour on that side (0 left, 1 right) */
+  unsigned long long* seq_host;    /* HOST counter of this communicator's
+                                      exchanges (the library increments it) */
+} flow_peer;
 typedef struct {
   int rank, world;
   double* buf;               /* exchange buffer (device), `capacity` doubles */
   int capacity;
   flow_allreduce_fn allreduce;
   void* user;
+  const flow_peer* peer;     /* NULL: halos travel in the all-reduce */
 } flow_comm;
+/* A peer block of FLOW_PEER_FLAGS words + 2 * land_cap doubles, zeroed, and its
+ * 64-byte IPC handle (handle_out); the neighbours map it with flow_peer_open
+ * and unmap it with flow_peer_close before the owner frees it. */
+int flow_peer_alloc(int land_cap, void** base_out, char* handle_out);
+int flow_peer_open(const char* handle, void** base_out);
+int flow_peer_close(void* mapped_base);
+int flow_peer_free(void* base);
+/* the error word of this rank's block (0: every wait so far was served) */
+int flow_peer_status(const flow_peer* peer, unsigned long long* error_host,
+                     void* stream);
 
 /* The same primitive issued by the library itself: ncclAllReduce on `stream`,
  * on a communicator of its own (flow_amd/csrc/rccl_direct.hip).  The RCCL

@@ -182,7 +182,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert declared - {'flow_last_error'} == set(_hip.SYMBOLS), \
         declared ^ set(_hip.SYMBOLS)
-    assert lib.flow_abi_version() == _hip.ABI_VERSION == 29
+    assert lib.flow_abi_version() == _hip.ABI_VERSION == 30
     assert _hip.SPMV_ROWS_PER_BLOCK == int(
         re.search(r'FLOW_SPMV_ROWS_PER_BLOCK (\d+)', header).group(1))
     assert _hip.SPMV_NNZ_PER_BLOCK == int(

@@ -52,10 +52,13 @@ def _karman_steps(nsteps=2, velocity_degree=2):
     return prob, infos
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, peer=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['LOCAL_RANK'] = '0'          # every rank shares cuda:0
+    # halos from neighbour to neighbour (flow_peer: IPC-mapped landing buffers
+    # between the processes that share the device) instead of in the all-reduce
+    os.environ['FLOW_AMD_PEER_HALO'] = '1' if peer else '0'
     import torch
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -239,13 +242,22 @@ def _worker(rank, world, port, out):
             p=device.to_host(parallel.gather_field(
                 prob1.p0.data.clone(), prob1.P.layout)).numpy(),
             newton=[len(i['newton_residuals']) - 1 for i in infos1])
+        res['peer'] = (parallel.comm().peer is not None,
+                       parallel.comm().peer_error(),
+                       int(parallel.comm()._peer_seq.value)
+                       if parallel.comm().peer is not None else 0)
         out[rank] = res
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('halos', ['allreduce', 'peer'])
 @pytest.mark.parametrize('world', [2, 3])
-def test_strip_sharded_solvers_and_step(hip, world):
+def test_strip_sharded_solvers_and_step(hip, world, halos):
+    '''halos 'peer': the same with the halos pushed from neighbour to
+    neighbour (flow_peer; here between processes that share the one device)
+    -- same results, fewer collectives.'''
+    peer = halos == 'peer'
     # the single-process run of the same two steps
     prob, infos = _karman_steps()
     u_ref = prob.u0.vector().get_local().copy()
@@ -255,10 +267,14 @@ def test_strip_sharded_solvers_and_step(hip, world):
     p1_ref = prob1.p0.vector().get_local().copy()
     manager = mp.get_context('spawn').Manager()
     out = manager.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, peer), nprocs=world,
+             join=True)
     covered = 0
     for r in range(world):
         res = out[r]
+        on, err, nseq = res['peer']
+        assert on == peer and err == 0, res['peer']
+        assert (nseq > 100) == peer, nseq      # (the exchanges that went that way)
         r0, r1, e0, e1, n = res['ranges']
         covered += r1 - r0
         assert res['halo_exact'] and res['halo_untouched']
@@ -313,8 +329,8 @@ def test_strip_sharded_solvers_and_step(hip, world):
         assert s1['newton'] == [len(i['newton_residuals']) - 1 for i in infos1]
         assert _rel(s1['u'], u1_ref) < 1e-7 and _rel(s1['p'], p1_ref) < 1e-7
     assert covered == out[0]['ranges'][4]
-    print('world %d: step vs single GPU: du %.2e dp %.2e, collectives per '
-          'rank %d' % (world, _rel(out[0]['step']['u'], u_ref),
+    print('world %d, halos %s: step vs single GPU: du %.2e dp %.2e, collectives '
+          'per rank %d' % (world, halos, _rel(out[0]['step']['u'], u_ref),
                        _rel(out[0]['step']['p'], p_ref),
                        out[0]['step']['calls']))
 
