@@ -1040,7 +1040,7 @@ def main():
             # entries, fp32 vectors; ILU(0): fp32 factors and sweep vector,
             # fp64 row sums) -- they only steer the Krylov path, the converged
             # step is the same (tests/test_full_size_parity.py; DESIGN.md
-            # sections 3 and 4)
+            # section 3; profiles/NOTES.md section 4)
             'preconditioner_storage': {
                 'pmg_matrix': 'fp16 (row-scaled)', 'pmg_vectors': 'fp32',
                 'ilu_factors': navsto.solver_parameters['newton'].get(

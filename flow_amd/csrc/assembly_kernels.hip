@@ -1372,7 +1372,7 @@ int flow::momentum_jvp_apply(const flow_momentum_jvp* J, const double* v,
   // results -- and 123 us per launch instead of 108: the kernel is bound by
   // fp64 issue, and the swaps, selects and the second copy of the geometry
   // and index loads add instructions where the extra waves only hide latency
-  // 
+  // (profiles/NOTES.md section 5, round 5)
   static const bool pair = [] {
     const char* e = getenv("FLOW_AMD_JVP_PAIR");
     return e && e[0] == '1';

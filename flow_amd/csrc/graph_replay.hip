@@ -13,7 +13,7 @@
 // of the structs' addresses: a caller that re-packs an operator into new
 // buffers gets a new key, never a graph over freed memory.
 //
-// What was measured on MI355X / ROCm 7.2:
+// What was measured on MI355X / ROCm 7.2 (profiles/NOTES.md section 6, round 5):
 // chains of EMPTY-ish kernels replay at 2.0-2.7 us per node against 3.5 us per
 // launch, with 5 us of host time per chain (tools/micro/graph_launch.hip) --
 // but from ~1 M doubles per kernel on a node costs 0.3-0.7 us MORE than the

@@ -70,7 +70,7 @@ class KarmanProblem(object):
         # body-fitted obstacle (fem/mesh.py: rectangle_with_fitted_hole); the
         # staircase variant (fitted=False) leaves one-cell notches in which,
         # at the controller's step size, a node-scale velocity spike grows
-        # once the wake becomes unsteady.
+        # once the wake becomes unsteady (profiles/NOTES.md section 5).
         # mesh: any triangulation of the channel instead (a file name, or a
         # Mesh: the reference's driver reads the one gmsh made,
         # tests/test_karman_vortex_street.py:26-53); renumbered along the

@@ -5,7 +5,7 @@ Index audit of the strip-sharded kernels (CPU; no GPU needed).
 The sharded solvers of flow_amd/parallel.py hand the CSR-stream kernels their
 input vector as a WINDOW [e0, e1) of the rank's strip, addressed by global row
 through a base pointer shifted by -e0.  Round 2 lost a GPU run to a memory
-access fault there ("The world-3 fault"): the kernels then
+access fault there (profiles/NOTES.md section 6, "The world-3 fault"): the kernels then
 gathered x[col] for every index pair a lane held -- idle lanes hold column 0 --
 and on rank 2 of 3 that address lay below the solver's work buffer.  An
 out-of-window read that lands on a mapped page is silent, so no GPU test can
