@@ -326,6 +326,8 @@ SYMBOLS = {
     'flow_pmg_lambda_max': [_P(PmgLevelS), _I, _VP, _VP, _VP, _P(_D), _VP],
     'flow_pmg_apply': [_P(PmgS), _VP, _VP, _VP],
     'flow_tl_apply': [_P(TlS), _VP, _VP, _VP],
+    'flow_aggregate_host': [_I, _VP, _VP, _VP, ctypes.c_double, _VP, _VP,
+                            _P(ctypes.c_int)],
     'flow_peer_alloc': [ctypes.c_int, _P(ctypes.c_void_p), ctypes.c_char_p],
     'flow_peer_open': [ctypes.c_char_p, _P(ctypes.c_void_p)],
     'flow_peer_close': [_VP],

@@ -663,6 +663,68 @@ extern "C" int flow_color_greedy_host(int n, const int* rowptr, const int* cols,
   return FLOW_OK;
 }
 
+// Algebraic aggregation for the smoothed-aggregation hierarchy -- HOST routine,
+// setup only (include/flow_hip.h).
+extern "C" int flow_aggregate_host(int n, const int* rowptr, const int* cols,
+                                   const double* vals, double theta,
+                                   const unsigned char* free_rows, int* agg,
+                                   int* naggregates) {
+  FLOW_REQUIRE(n > 0 && rowptr && cols && vals && agg && naggregates && theta >= 0.0,
+               "aggregation arguments");
+  std::vector<double> diag(n, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      FLOW_REQUIRE(cols[k] >= 0 && cols[k] < n, "aggregation: column out of range");
+      if (cols[k] == i) diag[i] = fabs(vals[k]);
+    }
+  auto is_free = [&](int i) { return free_rows == nullptr || free_rows[i] != 0; };
+  auto strong = [&](int i, int k) {
+    const int j = cols[k];
+    return j != i && is_free(j) &&
+           fabs(vals[k]) >= theta * sqrt(diag[i] * diag[j]) && vals[k] != 0.0;
+  };
+  for (int i = 0; i < n; ++i) agg[i] = -1;
+  int na = 0;
+  // pass 1: roots whose whole strong neighbourhood is still untouched
+  for (int i = 0; i < n; ++i) {
+    if (!is_free(i) || agg[i] >= 0) continue;
+    bool untouched = true, any = false;
+    for (int k = rowptr[i]; k < rowptr[i + 1] && untouched; ++k)
+      if (strong(i, k)) {
+        any = true;
+        if (agg[cols[k]] >= 0) untouched = false;
+      }
+    if (!untouched || !any) continue;
+    agg[i] = na;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if (strong(i, k)) agg[cols[k]] = na;
+    ++na;
+  }
+  // pass 2: join the aggregate (of pass 1) of the strongest coupling
+  std::vector<int> joined(n, -1);
+  for (int i = 0; i < n; ++i) {
+    if (!is_free(i) || agg[i] >= 0) continue;
+    double best = 0.0;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if (strong(i, k) && agg[cols[k]] >= 0 && fabs(vals[k]) > best) {
+        best = fabs(vals[k]);
+        joined[i] = agg[cols[k]];
+      }
+  }
+  for (int i = 0; i < n; ++i)
+    if (joined[i] >= 0) agg[i] = joined[i];
+  // pass 3: the rest, with their unaggregated strong neighbours
+  for (int i = 0; i < n; ++i) {
+    if (!is_free(i) || agg[i] >= 0) continue;
+    agg[i] = na;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if (strong(i, k) && agg[cols[k]] < 0) agg[cols[k]] = na;
+    ++na;
+  }
+  *naggregates = na;
+  return FLOW_OK;
+}
+
 extern "C" int flow_ilu0_factor(const flow_ilu_plan* plan, int nblocks,
                                 const double* avals0, const double* avals1,
                                 double* lu, void* stream) {

@@ -111,30 +111,61 @@ def _kd_aggregates(x, free, target):
     return agg, nagg
 
 
+def _algebraic_aggregates(Ah, free, theta):
+    '''Aggregates from the MATRIX alone (flow_aggregate_host, a host routine
+    of the library: strength of connection + the three passes of Vanek, Mandel
+    and Brezina) -- what the reference's BoomerAMG works from
+    (flow/navier_stokes/pressure_correction.py:331, 414): no coordinates.'''
+    Ah = Ah.tocsr()
+    n = Ah.shape[0]
+    agg = numpy.empty(n, dtype=numpy.int32)
+    na = ctypes.c_int(0)
+    rowptr = numpy.ascontiguousarray(Ah.indptr, dtype=numpy.int32)
+    cols = numpy.ascontiguousarray(Ah.indices, dtype=numpy.int32)
+    vals = numpy.ascontiguousarray(Ah.data, dtype=numpy.float64)
+    fr = numpy.ascontiguousarray(free, dtype=numpy.uint8)
+    as_p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _hip.check(_hip.load_library().flow_aggregate_host(
+        n, as_p(rowptr), as_p(cols), as_p(vals), float(theta), as_p(fr),
+        as_p(agg), ctypes.byref(na)))
+    return agg.astype(numpy.int64), na.value
+
+
 class Multigrid(object):
     '''Hierarchy for a scalar SPD Matrix `A` (kind 0).  isbc: Dirichlet dofs
     (identity rows of A); singular: pure Neumann operator -> pseudo-inverse on
     the coarsest level.'''
 
     def __init__(self, A, isbc=None, singular=False, s=3.0, coarsest=4200,
-                 omega=0.8, keep_host=False, two_launch=True):
+                 omega=0.8, keep_host=False, two_launch=True,
+                 aggregation='geometric', theta=0.08):
         '''two_launch: also form C = R (I - Ah) and the row blocks common to
         Ps and Ah per level, so that the device cycle runs its two-launch
-        form (include/flow_hip.h, flow_mg).'''
+        form (include/flow_hip.h, flow_mg).
+        aggregation: 'geometric' (default: patches of the dof coordinates --
+        bins on a uniform mesh, k-d-tree leaves on a graded one) or
+        'algebraic' (from the matrix alone: `_algebraic_aggregates`, strength
+        threshold `theta`, halved per level; for operators that come without
+        coordinates).'''
         import scipy.sparse as sp
         assert A.kind == 0
         lay = A.layout
         n = lay.N
         isbc = numpy.zeros(n, dtype=bool) if isbc is None else \
             numpy.asarray(isbc, dtype=bool)
-        x = lay.dof_coords.copy()
-        areas = lay.mesh.cell_areas()
-        width = s * numpy.sqrt(2.0 * areas.mean())
-        # a graded mesh (cell sizes a factor 3 apart and more): aggregates of
-        # equal count (s^2 points: what a bin of s widths holds on a uniform
-        # mesh) instead of bins of equal width
-        self.aggregation = 'kd-tree' if numpy.percentile(areas, 99) > \
-            9.0 * numpy.percentile(areas, 1) else 'bins'
+        assert aggregation in ('geometric', 'algebraic'), aggregation
+        if aggregation == 'algebraic':
+            x, width = None, 0.0
+            self.aggregation = 'algebraic'
+        else:
+            x = lay.dof_coords.copy()
+            areas = lay.mesh.cell_areas()
+            width = s * numpy.sqrt(2.0 * areas.mean())
+            # a graded mesh (cell sizes a factor 3 apart and more): aggregates
+            # of equal count (s^2 points: what a bin of s widths holds on a
+            # uniform mesh) instead of bins of equal width
+            self.aggregation = 'kd-tree' if numpy.percentile(areas, 99) > \
+                9.0 * numpy.percentile(areas, 1) else 'bins'
         free = ~isbc
         Ah = A.to_scipy().tocsr()
         self.levels = []          # device operators Ah, Ps, R + dinv, t per level
@@ -147,7 +178,10 @@ class Multigrid(object):
         while Ah.shape[0] > coarsest and len(self.levels) < _hip.MG_MAX_LEVELS - 1:
             m = Ah.shape[0]
             D = Ah.diagonal()
-            if self.aggregation == 'kd-tree':
+            if self.aggregation == 'algebraic':
+                agg, nc = _algebraic_aggregates(
+                    Ah, free, theta * 0.5**len(self.levels))
+            elif self.aggregation == 'kd-tree':
                 agg, nc = _kd_aggregates(x, free, s * s)
             else:
                 agg, nc = _bin_aggregates(x, free, width)
@@ -197,10 +231,11 @@ class Multigrid(object):
                 # the finest restriction, for the strip-sharded cycle
                 # (flow_amd/parallel.py cuts it by columns)
                 self.R0_host = R
-            cnt = numpy.bincount(agg[idx], minlength=nc)
-            x = numpy.stack([
-                numpy.bincount(agg[idx], weights=x[idx, d], minlength=nc) / cnt
-                for d in (0, 1)], axis=1)
+            if x is not None:
+                cnt = numpy.bincount(agg[idx], minlength=nc)
+                x = numpy.stack([
+                    numpy.bincount(agg[idx], weights=x[idx, d], minlength=nc)
+                    / cnt for d in (0, 1)], axis=1)
             free = numpy.ones(nc, dtype=bool)
             width *= s
             Ah = Ac

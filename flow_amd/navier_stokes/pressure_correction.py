@@ -260,6 +260,10 @@ solver_parameters = {
                  # rows below which the multigrid hierarchy stops coarsening
                  # (dense inverse there)
                  'mg_coarsest': 4200,
+                 # aggregates of the hierarchy: 'geometric' (patches of the
+                 # dof coordinates) or 'algebraic' (from the matrix alone, as
+                 # the reference's BoomerAMG: fem/multigrid.py)
+                 'aggregation': 'geometric',
                  # start vector: p0 ('zero') or p0 + the previous increments
                  # extrapolated in time ('extrapolated'; Dirichlet branch)
                  'start': 'extrapolated', 'start_points': 5, 'start_degree': 3},
@@ -1190,11 +1194,14 @@ def _preconditioner(lay, key, A, isbc, singular, par):
     if not par.get('two_level', False):
         return None, None
     if par.get('multigrid', True):
-        mkey = ('mg', key, par.get('mg_coarsest', 4200))
+        mkey = ('mg', key, par.get('mg_coarsest', 4200),
+                par.get('aggregation', 'geometric'))
         if mkey not in lay._dev:
             from ..fem.multigrid import Multigrid
-            lay._dev[mkey] = Multigrid(A, isbc, singular=singular,
-                                       coarsest=par.get('mg_coarsest', 4200))
+            lay._dev[mkey] = Multigrid(
+                A, isbc, singular=singular,
+                coarsest=par.get('mg_coarsest', 4200),
+                aggregation=par.get('aggregation', 'geometric'))
         if lay._dev[mkey].nlevels >= 2:
             return None, lay._dev[mkey]
     ckey = ('coarse', key, par['coarse_size'])

@@ -463,6 +463,22 @@ int flow_pmg_lambda_max(const flow_pmg_level* level, int iterations, float* work
 /* z = M^-1 r (r, z: 2*fine.n doubles, component-blocked) */
 int flow_pmg_apply(const flow_pmg* pmg, const double* r, double* z, void* stream);
 
+/* HOST routine (setup, no GPU needed): ALGEBRAIC aggregation of the rows of a
+ * scalar CSR matrix for the smoothed-aggregation hierarchy (flow_mg below;
+ * `hypre_amg` of pressure_correction.py:331, 414 needs no coordinates either).
+ * j is strongly coupled to i when |a_ij| >= theta sqrt(|a_ii a_jj|), i != j.
+ * Three passes in row order (Vanek, Mandel, Brezina 1996): (1) a free row none
+ * of whose strong neighbours is aggregated yet founds an aggregate with all of
+ * them; (2) every remaining row joins the aggregate of its strongest coupled
+ * aggregated neighbour; (3) what is left forms aggregates with its own
+ * unaggregated strong neighbours (isolated rows: singletons).  free[i] == 0
+ * (Dirichlet rows; NULL: all free): agg[i] = -1.  agg: n ints out,
+ * *naggregates the count.  Deterministic. */
+int flow_aggregate_host(int n, const int* rowptr, const int* cols,
+                        const double* vals, double theta,
+                        const unsigned char* free_rows, int* agg,
+                        int* naggregates);
+
 /* ---- K19: two-level cycle with ILU(0) smoothing ----------------------------
  * (the stand-in for the sparse LU of the Newton solve, pressure_correction.py:
  * 224-254, and of the heat solve, heat.py:117-121, WHERE THE CHEBYSHEV CYCLE OF
