@@ -9,6 +9,9 @@ three sub-steps as `fem_oracle.step` (reference: flow/navier_stokes/
 pressure_correction.py:468-518), assembled by the oracle's own numpy routines;
 what differs is how the linear systems are solved:
 
+  assembly             the oracle's numpy routines; the momentum residual and
+                       Jacobian over chunks of the cells on `assembly_threads`
+                       threads;
   tentative velocity   Newton as in the oracle; every system by GMRES(30),
                        right-preconditioned with SuperLU's incomplete LU of
                        the Newton matrix (scipy `spilu`), to 1e-6 of the Newton
@@ -33,8 +36,38 @@ from . import fem_oracle as orc
 from . import cpu_lib
 
 
+def momentum_rhs_threaded(W, P, U, p0, f, rho, mu, threads):
+    '''fem_oracle.momentum_rhs over chunks of the cells on `threads` threads
+    (numpy's einsum loops release the GIL): the same residual vector and
+    Jacobian, summed over the chunks.'''
+    from concurrent.futures import ThreadPoolExecutor
+    nc = len(W.cells)
+    threads = max(1, min(int(threads), nc // 64))
+    if threads == 1:
+        return orc.momentum_rhs(W, P, U, p0, f, rho, mu)
+    bc_cells, bc_lf = orc.boundary_facets(W)
+    chunks = numpy.array_split(numpy.arange(nc), threads)
+
+    def work(ch):
+        Ws = orc.Space(W.points, W.cells[ch], W.cell_dofs[ch], W.deg, W.N)
+        Ps = orc.Space(P.points, P.cells[ch], P.cell_dofs[ch], 1, P.N)
+        sel = (bc_cells >= ch[0]) & (bc_cells <= ch[-1])
+        Ws.bfacets = (bc_cells[sel] - ch[0], bc_lf[sel])
+        return orc.momentum_rhs(Ws, Ps, U, p0, (f[0], f[1][ch]), rho, mu)
+    with ThreadPoolExecutor(threads) as pool:
+        parts = list(pool.map(work, chunks))
+    R = parts[0][0].copy()
+    for r, _j in parts[1:]:
+        R += r
+    J = parts[0][1]
+    for _r, j in parts[1:]:
+        J = J + j
+    return R, J
+
+
 def step(W, P, u0, p0, f0, f1, u_bc, p_bc, rho, mu, dt, lib, hierarchy=None,
-         tol=1.0e-10, method='backward euler', fill_factor=4.0):
+         tol=1.0e-10, method='backward euler', fill_factor=4.0,
+         assembly_threads=1):
     '''One Rotational step.  lib: the loaded oracle/liboracle_cpu.so;
     hierarchy: a cpu_lib.MgHierarchy of the Dirichlet-eliminated pressure
     matrix (None: Jacobi-CG).  -> (u1, p1, ui, info); info['seconds'] has the
@@ -50,7 +83,8 @@ def step(W, P, u0, p0, f0, f1, u_bc, p_bc, rho, mu, dt, lib, hierarchy=None,
     history, gmres_its = [], []
     for it in range(11):
         t0 = time.perf_counter()
-        Ri, dRi = orc.momentum_rhs(W, P, ui, p0, f1, rho, mu)
+        Ri, dRi = momentum_rhs_threaded(W, P, ui, p0, f1, rho, mu,
+                                        assembly_threads)
         F = M.dot(ui - u0) - dt / rho * Ri
         F[bc_dofs] = ui[bc_dofs] - bc_vals
         nrm = numpy.linalg.norm(F)

@@ -184,7 +184,12 @@ def load_vector(S, lattice_pts, cell_values, dim=1):
 
 
 def boundary_facets(S):
-    '''(cell, local facet) of all boundary facets, from the cell-vertex table.'''
+    '''(cell, local facet) of all boundary facets, from the cell-vertex table.
+    (A Space that is a CHUNK of a mesh's cells -- oracle/cpu_step.py assembles
+    in chunks on several threads -- carries the true boundary facets among its
+    cells as `bfacets`: a chunk's own outline is not the domain's.)'''
+    if getattr(S, 'bfacets', None) is not None:
+        return S.bfacets
     c = S.cells
     nv = len(S.points)
     a = numpy.stack([c[:, 1], c[:, 0], c[:, 0]], axis=1)

@@ -20,7 +20,14 @@ def test_iterative_cpu_step_matches_the_sparse_lu_oracle():
     u_bc, p_bc = c.bc_data()
     u1, p1, ui, info = cpu_step.step(
         W, P, c.u0, c.p0, c.lattice(c.f0), c.lattice(c.f1), u_bc, p_bc, c.rho,
-        c.mu, c.dt, lib, tol=1e-10)
+        c.mu, c.dt, lib, tol=1e-10, assembly_threads=3)
+    # (the chunked assembly is the oracle's: same residual and Jacobian)
+    from oracle import fem_oracle as orc
+    R1, J1 = orc.momentum_rhs(W, P, c.u0, c.p0, c.lattice(c.f1), c.rho, c.mu)
+    R3, J3 = cpu_step.momentum_rhs_threaded(W, P, c.u0, c.p0, c.lattice(c.f1),
+                                            c.rho, c.mu, 3)
+    assert abs(R1 - R3).max() <= 1e-13 * abs(R1).max()
+    assert abs(J1 - J3).max() <= 1e-13 * abs(J1).max()
     u1o, p1o, uio = c.oracle_step()
     assert cases.rel_l2(ui, uio) < 1e-9
     assert cases.rel_l2(p1, p1o) < 1e-8
