@@ -119,7 +119,11 @@ int replay_prepare(unsigned long long key, int site, hipStream_t st,
   if (g_cache.size() >= kMaxEntries) {
     // (evict the older half -- behind a synchronisation: one of them may
     // still be executing)
+    // (the WHOLE device: entries are shared by every stream and thread that
+    // replays -- FLOW_AMD_FOLLOW_TORCH_STREAM, two solver threads --, a graph
+    // may still be executing on another stream than the caller's)
     (void)hipStreamSynchronize(st);
+    (void)hipDeviceSynchronize();
     std::vector<std::pair<unsigned long long, unsigned long long>> age;
     for (auto& kv : g_cache) age.push_back({kv.second.used, kv.first});
     std::sort(age.begin(), age.end());

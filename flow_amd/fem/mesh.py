@@ -28,18 +28,24 @@ class Mesh(object):
       bfacets      (Nb,)    ids of edges with exactly one incident cell
       bfacet_cell  (Nb,), bfacet_local (Nb,)  the cell and its local facet index
     '''
-    def __init__(self, points, cells=None):
-        # (ids the vertices had in the file / in the mesh this one was
+    def __init__(self, points, cells=None, reorder=True):
+        # (ids the vertices / cells had in the file / in the mesh this one was
         # renumbered from: `reordered`; None: this numbering is the original)
         self.vertex_origin = None
+        self.cell_origin = None
         if isinstance(points, str):
             # Mesh('test.xml') / Mesh('karman.msh') as the reference drivers do
             # (tests/test_karman_vortex_street.py:52-53); renumbered along the
-            # longest axis like the generators' meshes (io.read_mesh)
+            # longest axis like the generators' meshes (io.read_mesh) unless
+            # reorder=False -- the reference's Mesh(path) keeps the file's
+            # numbering; data indexed by the file's vertices or cells
+            # (markers, per-cell coefficients, fields written elsewhere) are
+            # carried over with vertex_origin / cell_origin
             from . import io
-            loaded = io.read_mesh(points)
+            loaded = io.read_mesh(points, reorder=reorder)
             points, cells = loaded.points, loaded.cell_vertices
             self.vertex_origin = loaded.vertex_origin
+            self.cell_origin = loaded.cell_origin
         self.points = numpy.ascontiguousarray(points, dtype=numpy.float64)
         self.cell_vertices = numpy.ascontiguousarray(cells, dtype=numpy.int32)
         assert self.points.ndim == 2 and self.points.shape[1] == 2
@@ -62,8 +68,9 @@ class Mesh(object):
         so that neighbouring threads of the cell kernels touch neighbouring
         dofs and a strip is a contiguous cell range.  A mesh from a generic
         generator (gmsh numbers boundary curves first, then the interior in
-        the order of its front) has none of that.  `vertex_origin[k]` = the id
-        vertex k had before.'''
+        the order of its front) has none of that.  `vertex_origin[k]` /
+        `cell_origin[c]` = the id vertex k / cell c had before (composed over
+        repeated reorderings: always the ORIGINAL ids).'''
         p = self.points
         ext = p.max(axis=0) - p.min(axis=0)
         major = int(numpy.argmax(ext))
@@ -76,6 +83,9 @@ class Mesh(object):
         origin = order if self.vertex_origin is None \
             else numpy.asarray(self.vertex_origin)[order]
         out.vertex_origin = origin.astype(numpy.int64)
+        corigin = corder if self.cell_origin is None \
+            else numpy.asarray(self.cell_origin)[corder]
+        out.cell_origin = corigin.astype(numpy.int64)
         return out
 
     def bandwidth(self):

@@ -109,6 +109,37 @@ def begin_step(lay, u0, p0):
     return st
 
 
+def _agree(st, code, which):
+    """Every rank must take the same decision (a start vector changes which
+    launches and collectives a solve issues): all or none.  -> (code, which)
+    if every rank found the same trajectory by the same code, else (0, None)."""
+    # ONE-HOT slots, summed: slot 0 = "no trajectory of mine matches",
+    # slot 1 + 2 k + (code - 1) = "my trajectory k matches by code".  A
+    # verdict stands only if ONE slot holds all `world` votes -- ranks whose
+    # local strips of two trajectories coincide (a zero or steady far
+    # field) can match different ones; sums of (code, which) alone do not
+    # see that (ADVICE r5).
+    nslots = 1 + 2 * (MAX_TRAJECTORIES + 1)
+    if st.agree is None or st.agree.numel() != nslots + 1:
+        st.agree = device.zeros(nslots + 1)
+    t = st.agree
+    votes = [0.0] * (nslots + 1)
+    mine = 0 if which is None else 1 + 2 * which + (code - 1)
+    votes[mine] = 1.0
+    votes[nslots] = 1.0
+    # (a host-to-device copy, the all-reduce and ONE read-back, all in
+    # stream order)
+    t.copy_(torch.tensor(votes, dtype=torch.float64))
+    c = parallel.comm()
+    c.calls += 1
+    c.allreduce_tensor(t)
+    h = device.to_host(t)
+    world = int(round(float(h[nslots])))
+    if which is None or int(round(float(h[mine]))) != world:
+        code, which = 0, None
+    return code, which
+
+
 def _resolve(st):
     if not st.unresolved:
         return st.current
@@ -134,27 +165,7 @@ def _resolve(st):
                 code, which = 2, k
                 break
     if parallel.active():
-        # every rank must take the same decision (a start vector changes
-        # which launches and collectives a solve issues): all or none
-        if st.agree is None:
-            st.agree = device.zeros(4)
-        t = st.agree
-        # (a host-to-device copy, the all-reduce and ONE read-back, all in
-        # stream order)
-        t.copy_(torch.tensor(
-            [1.0 if code == 1 else 0.0, 1.0 if code == 2 else 0.0,
-             float(which if which is not None else -1), 1.0],
-            dtype=torch.float64))
-        c = parallel.comm()
-        c.calls += 1
-        c.allreduce_tensor(t)
-        h = device.to_host(t)
-        world = int(round(float(h[3])))
-        same_slot = which is not None and \
-            abs(float(h[2]) - world * which) < 0.5
-        if not (same_slot and (int(round(float(h[0]))) == world
-                               or int(round(float(h[1]))) == world)):
-            code, which = 0, None
+        code, which = _agree(st, code, which)
     st.clock += 1
     if code == 0:
         tr = Trajectory()

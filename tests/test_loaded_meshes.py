@@ -67,8 +67,26 @@ def test_reordering_a_loaded_mesh(tmp_path):
     assert numpy.array_equal(raw.points, m.points)
     assert numpy.array_equal(raw.cell_vertices, m.cell_vertices)
     r = fem.Mesh(path)                              # reordered, as a driver gets it
-    assert r.vertex_origin is not None
+    assert r.vertex_origin is not None and r.cell_origin is not None
     assert numpy.array_equal(r.points, m.points[r.vertex_origin])
+    # data indexed by the FILE's vertices and cells round-trip through the maps
+    vdata = numpy.cos(17.0 * m.points[:, 0]) + m.points[:, 1]       # per vertex
+    cdata = m.points[m.cell_vertices].mean(axis=1)[:, 0]            # per cell
+    assert numpy.array_equal(vdata[r.vertex_origin],
+                             numpy.cos(17.0 * r.points[:, 0]) + r.points[:, 1])
+    assert numpy.allclose(cdata[r.cell_origin],
+                          r.points[r.cell_vertices].mean(axis=1)[:, 0],
+                          rtol=0, atol=1e-15)
+    assert sorted(r.cell_origin) == list(range(m.num_cells()))
+    # the opt-out: the file's numbering as it is (what dolfin's Mesh(path) gives)
+    keep = fem.Mesh(path, reorder=False)
+    assert keep.vertex_origin is None and keep.cell_origin is None
+    assert numpy.array_equal(keep.points, m.points)
+    assert numpy.array_equal(keep.cell_vertices, m.cell_vertices)
+    # ... and a second reordering composes the maps (still the file's ids)
+    rr2 = keep.reordered().reordered()
+    assert numpy.array_equal(rr2.vertex_origin, r.vertex_origin)
+    assert numpy.array_equal(rr2.cell_origin, r.cell_origin)
     # the same triangles (as sets of file vertex ids)
     def key(cells):
         c = numpy.sort(cells.astype(numpy.int64), axis=1)

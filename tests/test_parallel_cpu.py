@@ -625,3 +625,42 @@ def test_one_collective_two_level_cg_pattern_under_gloo(world):
         assert calls == its + 4, (calls, its)
         # owned rows and the first ghost layer carry the solution
         assert numpy.allclose(x[z0:z1], xref[z0:z1], rtol=1e-9, atol=1e-12)
+
+
+def _vote_worker(rank, world, port, cases_in, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from flow_amd import parallel
+        from flow_amd.navier_stokes import start_vectors as sv
+        parallel.enable(dist.group.WORLD)
+        st = sv._State()
+        out[rank] = [sv._agree(st, *case[rank]) for case in cases_in]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trajectory_verdicts_are_unanimous_or_void():
+    '''Which trajectory a call on the strips continues (start_vectors._agree):
+    every rank votes for (code, trajectory) in a one-hot slot; the verdict
+    stands only if one slot holds ALL the votes.  The split the sums of
+    (code, which) could not see (local matches 0, 1, 1, 2 on four
+    ranks, whose sum equals 4 x 1) is void on every rank.'''
+    world = 4
+    cases_in = [
+        [(1, 1)] * 4,                                  # unanimous: stands
+        [(1, 0), (1, 1), (1, 1), (1, 2)],              # the advisor's split
+        [(2, 0)] * 3 + [(1, 0)],                       # same trajectory, other code
+        [(0, None)] * 4,                               # nobody matches
+        [(1, 2), (0, None), (1, 2), (1, 2)],           # one rank sees nothing
+        [(2, 2)] * 4,
+        ]
+    manager = mp.get_context('spawn').Manager()
+    out = manager.dict()
+    mp.spawn(_vote_worker, args=(world, _free_port(), cases_in, out),
+             nprocs=world, join=True)
+    want = [(1, 1), (0, None), (0, None), (0, None), (0, None), (2, 2)]
+    for r in range(world):
+        assert list(out[r]) == want, (r, out[r])
