@@ -659,6 +659,10 @@ def main():
                                     **({'device_id': device.get()}
                                        if args.backend == 'nccl' else {}))
             parallel.enable(dist.group.WORLD, force=True)
+            # (the micro-benchmark of the N > 1 bring-up, on the 1-rank group:
+            # exercises both bindings where RCCL can run on this box)
+            collective_us = parallel.comm().use_fastest(50)
+            collective_us['halos'] = 'allreduce'
 
     def barrier():
         if world > 1:
