@@ -2935,10 +2935,12 @@ int exchange_halo(const flow_comm* C, const flow_rows* R, int ncomp, int sum_cou
                   int hoff, hipStream_t st) {
   const int nh = ncomp * R->nhalo;
   const flow_peer* P = C->peer;
-  if (P == nullptr || C->world == 1 || nh == 0)
+  // (a halo larger than the landing buffers -- the slot numbering spans ALL
+  // ranks' slots -- travels in the all-reduce like without a flow_peer: nh is
+  // the same on every rank, so is this decision)
+  if (P == nullptr || C->world == 1 || nh == 0 || nh > P->land_cap)
     return (hoff + nh > 0) ? exchange(C, hoff + nh) : FLOW_OK;
-  FLOW_REQUIRE(P->flags && P->land && P->seq_host && nh <= P->land_cap,
-               "flow_peer: landing buffers too small for this halo");
+  FLOW_REQUIRE(P->flags && P->land && P->seq_host, "flow_peer pointers");
   const unsigned long long seq = ++*P->seq_host;
   hipLaunchKernelGGL(peer_push_kernel, dim3(2), dim3(kPeerBlock), 0, st, *R, ncomp,
                      *P, seq, C->buf + hoff);

@@ -166,7 +166,7 @@ class Comm(object):
             self._bind_rccl()
 
     # -- halos from neighbour to neighbour (flow_peer, csrc/la_kernels.hip) -----
-    def enable_peer(self, land_cap=1 << 17, spin_limit=2000000, selftest=24):
+    def enable_peer(self, land_cap=1 << 20, spin_limit=2000000, selftest=24):
         '''Map the neighbours' landing buffers (hipIpc: xGMI peers on a node,
         or processes sharing one device in a rehearsal) and take the halos off
         the all-reduce: a pure halo then costs no collective, a [sums | halo]
