@@ -341,6 +341,7 @@ SYMBOLS = {
                                   ctypes.c_size_t, _P(_I), _P(_D), _VP],
     'flow_gather_rows': [_I, _VP, _I, _VP, _I, _VP, _I, _VP],
     'flow_color_greedy_host': [_I, _VP, _VP, _VP, _P(_I)],
+    'flow_color_iterate_host': [_I, _VP, _VP, _VP, _P(_I), _I],
     'flow_ilu0_factor': [_P(IluPlanS), _I, _VP, _VP, _VP, _VP],
     'flow_ilu0_pack': [_P(IluS), _VP, _VP],
     'flow_ilu0_solve': [_P(IluS), _VP, _VP, _VP, _VP],

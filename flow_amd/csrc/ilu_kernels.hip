@@ -663,6 +663,57 @@ extern "C" int flow_color_greedy_host(int n, const int* rowptr, const int* cols,
   return FLOW_OK;
 }
 
+// Iterated greedy (Culberson) on a proper colouring -- HOST routine, setup only.
+extern "C" int flow_color_iterate_host(int n, const int* rowptr, const int* cols,
+                                       int* colour, int* ncolors, int rounds) {
+  FLOW_REQUIRE(n > 0 && rowptr && cols && colour && ncolors && *ncolors >= 1 &&
+                   *ncolors <= 63 && rounds >= 0,
+               "iterated colouring arguments");
+  std::vector<int> order(n), next(n), count, start;
+  int nc = *ncolors;
+  for (int r = 0; r < rounds; ++r) {
+    // the classes in this pass's order
+    count.assign(nc, 0);
+    for (int v = 0; v < n; ++v) {
+      FLOW_REQUIRE(colour[v] >= 0 && colour[v] < nc, "iterated colouring: colour");
+      ++count[colour[v]];
+    }
+    std::vector<int> classes(nc);
+    for (int c = 0; c < nc; ++c) classes[c] = c;
+    if (r % 2 == 0)
+      std::reverse(classes.begin(), classes.end());
+    else
+      std::stable_sort(classes.begin(), classes.end(),
+                       [&](int a, int b) { return count[a] > count[b]; });
+    start.assign(nc + 1, 0);
+    std::vector<int> rank_of(nc);
+    for (int k = 0; k < nc; ++k) rank_of[classes[k]] = k;
+    for (int k = 0; k < nc; ++k) start[k + 1] = start[k] + count[classes[k]];
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int v = 0; v < n; ++v) order[fill[rank_of[colour[v]]]++] = v;
+    // first fit in that order
+    for (int v = 0; v < n; ++v) next[v] = -1;
+    int nn = 0;
+    for (int k = 0; k < n; ++k) {
+      const int v = order[k];
+      unsigned long long used = 0ull;
+      for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) {
+        const int u = cols[p];
+        if (u != v && next[u] >= 0) used |= 1ull << next[u];
+      }
+      const int c = __builtin_ctzll(~used);
+      next[v] = c;
+      if (c + 1 > nn) nn = c + 1;
+    }
+    if (nn <= nc) {            // (never more: kept for the next pass)
+      for (int v = 0; v < n; ++v) colour[v] = next[v];
+      nc = nn;
+    }
+  }
+  *ncolors = nc;
+  return FLOW_OK;
+}
+
 // Algebraic aggregation for the smoothed-aggregation hierarchy -- HOST routine,
 // setup only (include/flow_hip.h).
 extern "C" int flow_aggregate_host(int n, const int* rowptr, const int* cols,

@@ -20,6 +20,7 @@ Setup only (numpy, once per pattern); factorisation and sweeps are HIP kernels
 (flow_ilu0_factor / flow_ilu0_solve in include/flow_hip.h).
 '''
 import ctypes
+import os
 
 import numpy
 
@@ -27,21 +28,38 @@ from .. import _hip
 from .. import device
 
 
-def colour_graph(rowptr, cols):
+# passes of iterated greedy behind the first-fit colouring (0: none).  OFF:
+# measured on the ~1 M-DoF channels (round 6), 9 -> 7 / 8 colours cost more
+# GMRES applications (the factorisation in the recoloured order is weaker:
+# 15.2 -> 17.9 structured, 25.2 -> 26.4 graded) than the saved launches buy
+# (4.60 -> 4.86 / 14.3 -> 14.5 ms per step).
+COLOUR_ROUNDS = int(os.environ.get('FLOW_AMD_COLOUR_ROUNDS', '0'))
+
+
+def colour_graph(rowptr, cols, rounds=None):
     '''First-fit greedy colouring in mesh order (flow_color_greedy_host, a host
-    routine of the library -- no GPU needed).  On a mesh numbered along its
-    structure the colours come out locally periodic, which is what keeps the
-    gathers of the sweeps inside a few cache lines per wavefront.  Returns
-    (colour per vertex, number of colours <= 63).'''
+    routine of the library -- no GPU needed), then optionally `rounds` passes
+    of Culberson's iterated greedy (flow_color_iterate_host: first fit again,
+    class by class -- never more colours, usually fewer: P2 triangulations 9
+    -> 7, P1 6 -> 5; every colour less is two dependent launches less per
+    application -- and a weaker factorisation: see COLOUR_ROUNDS).  Within a
+    class the rows stay in mesh order, which is what keeps the gathers of the
+    sweeps inside a few cache lines per wavefront.
+    Returns (colour per vertex, number of colours <= 63).'''
     rowptr = numpy.ascontiguousarray(rowptr, dtype=numpy.int32)
     cols = numpy.ascontiguousarray(cols, dtype=numpy.int32)
     n = len(rowptr) - 1
     colour = numpy.empty(n, dtype=numpy.int32)
     nc = ctypes.c_int(0)
     as_p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    _hip.check(_hip.load_library().flow_color_greedy_host(
+    lib = _hip.load_library()
+    _hip.check(lib.flow_color_greedy_host(
         n, as_p(rowptr), as_p(cols), as_p(colour), ctypes.byref(nc)
         ))
+    rounds = COLOUR_ROUNDS if rounds is None else int(rounds)
+    if rounds > 0:
+        _hip.check(lib.flow_color_iterate_host(
+            n, as_p(rowptr), as_p(cols), as_p(colour), ctypes.byref(nc), rounds))
     return colour, nc.value
 
 

@@ -49,6 +49,10 @@ def test_colouring_is_proper():
             off = rows != ci
             assert (colour[rows[off]] != colour[ci[off]]).all()
             assert nc <= 40
+            # iterated greedy (optional): still proper, never more colours
+            c2, nc2 = ilu.colour_graph(rp, ci, rounds=6)
+            assert nc2 <= nc and c2.min() == 0 and c2.max() == nc2 - 1
+            assert (c2[rows[off]] != c2[ci[off]]).all()
 
 
 @pytest.mark.gpu
