@@ -600,7 +600,7 @@ def main():
     import threading
     stage = {'name': 'start', 'timer': None}
 
-    def enter(name, guarded=False):
+    def enter(name, guarded=False, limit=None):
         if stage['timer'] is not None:
             stage['timer'].cancel()
             stage['timer'] = None
@@ -609,14 +609,16 @@ def main():
             sys.stderr.write('[bench rank %d/%d] stage: %s\n' % (rank, world, name))
             sys.stderr.flush()
         if guarded and world > 1:
+            seconds = args.stage_timeout if limit is None else limit
+
             def give_up():
                 sys.stderr.write(
                     '[bench rank %d/%d] FAILED: stage %r did not finish in '
                     '%.0f s -- giving up (exit code 3)\n'
-                    % (rank, world, name, args.stage_timeout))
+                    % (rank, world, name, seconds))
                 sys.stderr.flush()
                 os._exit(3)
-            t = threading.Timer(args.stage_timeout, give_up)
+            t = threading.Timer(seconds, give_up)
             t.daemon = True
             t.start()
             stage['timer'] = t
@@ -903,8 +905,18 @@ def main():
     # Newton iterate is left just above `tol`, every step takes two Newton
     # iterations and longer solves -- for the reference as for this build.
     developed = None
+    developed_error = None
     if args.developed > 0 and settled:
-        enter('developed street: %d spin-up steps' % args.developed)
+        # (N > 1: the street has only ever run on strips in short gloo
+        # rehearsals -- a solver failure there, which every rank sees alike,
+        # must not cost the run its line: `value` then falls back to the
+        # plateau window and says so; a rank that hangs is ended by the
+        # watchdog, 6 x the bring-up limit)
+        enter('developed street: %d spin-up steps' % args.developed,
+              guarded=True, limit=6.0 * args.stage_timeout)
+    try:
+        if not (args.developed > 0 and settled):
+            raise StopIteration
         navsto.set_mode(args.mode)
         apply_overrides()
         prob.restore(settled['state'])
@@ -941,6 +953,11 @@ def main():
                        for _ in range(args.developed_period)]
             barrier()
             p_elapsed = time.perf_counter() - t_p
+            if world > 1:
+                tt = torch.tensor([p_elapsed], dtype=torch.float64,
+                                  device=device.get())
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                p_elapsed = float(tt.item())
             apps = [sum(i.get('newton_linear_applications', [])) for i in p_infos]
             developed['period'] = {
                 'steps': args.developed_period,
@@ -960,6 +977,17 @@ def main():
                         % args.developed_period,
                 }
         settled['state'] = plateau_state
+    except StopIteration:
+        pass
+    except RuntimeError as exc:
+        if world == 1:
+            raise
+        # (a solver verdict: the same on every rank of the strips)
+        developed = None
+        developed_error = repr(exc)
+        sys.stderr.write('[bench rank %d/%d] the developed street failed: %s -- '
+                         '`value` falls back to the plateau window\n'
+                         % (rank, world, developed_error))
 
     enter('report')
     if rank != 0:
@@ -1017,6 +1045,8 @@ def main():
                 'value = the K-step window on the early plateau (symmetric '
                 'flow, one Newton iteration per step)%s' % (
                     '' if args.headline == 'plateau' else
+                    ': the developed phase FAILED on the strips (%s)'
+                    % developed_error if developed_error else
                     ': the developed phase did not run (--developed 0 / not the '
                     'headline size)')),
             'mode': args.mode,
