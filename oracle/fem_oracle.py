@@ -309,7 +309,7 @@ def _identity_rows(A, dofs):
     return A
 
 
-def solve_blockwise(A, b, n, rtol=1.0e-14, max_it=80):
+def solve_blockwise(A, b, n, rtol=1.0e-14, max_it=80, single=False):
     '''A x = b for a matrix of 2 x 2 blocks of n rows each -- the SAME discrete
     solution the sparse LU of the whole matrix defines (`linear='lu'`, what the
     reference's default solver computes, pressure_correction.py:224-254),
@@ -322,24 +322,37 @@ def solve_blockwise(A, b, n, rtol=1.0e-14, max_it=80):
     nonzeros; the coupling blocks (the reaction term of the linearisation) are
     small, a handful of iterations per digit-complete solve.  A block-diagonal
     A (the vector mass matrix of the velocity correction) is solved by the two
-    LUs directly.'''
+    LUs directly.  single: the two LUs in fp32 (half the memory -- what lets
+    the full-size workload's blocks fit in 62 GB); they only precondition: the
+    Krylov vectors, the operator and the residual that is checked stay fp64.'''
     A = A.tocsr()
     A00, A01 = A[:n, :n].tocsc(), A[:n, n:].tocsr()
     A10, A11 = A[n:, :n].tocsr(), A[n:, n:].tocsc()
-    lu0, lu1 = spla.splu(A00), spla.splu(A11)
-    del A00, A11
+    if single:
+        lu0 = spla.splu(A00.astype(numpy.float32))
+        del A00
+        lu1 = spla.splu(A11.astype(numpy.float32))
+        del A11
+        solve0 = lambda v: lu0.solve(v.astype(numpy.float32)).astype(numpy.float64)
+        solve1 = lambda v: lu1.solve(v.astype(numpy.float32)).astype(numpy.float64)
+    else:
+        lu0, lu1 = spla.splu(A00), spla.splu(A11)
+        del A00, A11
+        solve0, solve1 = lu0.solve, lu1.solve
 
     def precondition(r):
-        z0 = lu0.solve(r[:n])
-        z1 = lu1.solve(r[n:] - A10.dot(z0))
+        z0 = solve0(r[:n])
+        z1 = solve1(r[n:] - A10.dot(z0))
         return numpy.concatenate([z0, z1])
     bn = numpy.linalg.norm(b)
     if bn == 0.0:
         return numpy.zeros_like(b)
     x = precondition(b)
     if A01.nnz == 0 and A10.nnz == 0:
-        r = b - A.dot(x)
-        x = x + precondition(r)          # (one step of refinement)
+        for _refine in range(1 if not single else 6):
+            x = x + precondition(b - A.dot(x))   # (refinement on the true residual)
+            if numpy.linalg.norm(b - A.dot(x)) <= 1.0e-13 * bn:
+                break
         assert numpy.linalg.norm(b - A.dot(x)) <= 1.0e-12 * bn
         return x
     for _outer in range(6):
@@ -386,7 +399,8 @@ def tentative_velocity(W, P, u0, p0, f0, f1, bc_dofs, bc_vals, method,
     from ui = u0, exact Jacobian, LU, BCs as identity rows with residual x - g,
     converged when ||F||_2 < tol (absolute); RuntimeError otherwise.
     linear: 'lu' = one sparse LU of the Newton matrix; 'block' = the same
-    solution through `solve_blockwise` (sizes SuperLU cannot factor whole).'''
+    solution through `solve_blockwise` (sizes SuperLU cannot factor whole);
+    'block32' = that with the block LUs held in fp32 (the full-size workload).'''
     assert method in _THETA
     th_i, th_e = _THETA[method]
     M = sp.block_diag([mass_matrix(W)] * 2, format='csr')
@@ -413,8 +427,8 @@ def tentative_velocity(W, P, u0, p0, f0, f1, bc_dofs, bc_vals, method,
             break
         Jbc = _identity_rows(J, bc_dofs)
         del J
-        if linear == 'block':
-            ui = ui - solve_blockwise(Jbc, F, W.N)
+        if linear in ('block', 'block32'):
+            ui = ui - solve_blockwise(Jbc, F, W.N, single=linear == 'block32')
         else:
             ui = ui - spla.splu(Jbc.tocsc()).solve(F)
         del Jbc
@@ -510,8 +524,8 @@ def velocity_correction(W, P, ui, p1, p0, bc_dofs, bc_vals, rho, mu, dt,
     M = sp.block_diag([mass_matrix(W)] * 2, format='csr')
     b = M.dot(ui) + _vec(W, Fe, 2)
     A, b = symmetric_bc(M, b, bc_dofs, bc_vals)
-    if linear == 'block':
-        return solve_blockwise(A, b, W.N)
+    if linear in ('block', 'block32'):
+        return solve_blockwise(A, b, W.N, single=linear == 'block32')
     return spla.splu(A.tocsc()).solve(b)
 
 

@@ -167,7 +167,8 @@ def check_block_solver(name):
     of the half-size fixture to the one of all the others.'''
     import large_cases
     gold = numpy.load(os.path.join(HERE, 'ns_large_%s.npz' % name))
-    args = dict(large_cases.LARGE[name], linear='block')
+    args = dict(large_cases.LARGE[name],
+                linear=os.environ.get('ORACLE_LINEAR', 'block'))
     case = large_cases.KarmanStepCase(**args)
     assert numpy.allclose(case.fingerprint(), gold['fingerprint'], rtol=1e-9,
                           atol=1e-12)
