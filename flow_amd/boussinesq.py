@@ -107,7 +107,8 @@ class HeaterBox(object):
         levels the heat and Newton solves fall back to once the plume is too
         fast for the Chebyshev cycle (flow_amd/fem/tlilu.py).'''
         from . import device
-        if device.on_gpu():
+        if device.on_gpu() and not parallel.active():
+            # (the strips build their own block plans where they need them)
             from .fem.tlilu import TwoLevelIlu
             heat.prepare(self.Q)
             TwoLevelIlu.plans(self.W.layout)
