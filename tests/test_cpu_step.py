@@ -36,3 +36,17 @@ def test_iterative_cpu_step_matches_the_sparse_lu_oracle():
     assert set(info['seconds']) == {'assembly', 'ilu', 'gmres', 'pressure',
                                     'correction'}
     assert all(numpy.isfinite(v) and v >= 0.0 for v in info['seconds'].values())
+
+
+def test_blockwise_newton_solve_equals_the_sparse_lu():
+    '''fem_oracle.solve_blockwise (what the oracle's offline goldens at 4.9 M
+    and 9.87 M DoF were computed with: SuperLU cannot factor the coupled
+    Newton matrix there) reaches the solution of the single sparse LU -- with
+    the block LUs in fp64 ('block') and in fp32 ('block32': they only
+    precondition, the true residual is driven to 1e-14 in fp64).'''
+    c = large_cases.KarmanStepCase(60, 14)
+    ref = c.oracle_step('crank-nicolson')
+    for linear in ('block', 'block32'):
+        got = c.oracle_step('crank-nicolson', linear=linear)
+        for a, b in zip(got, ref):
+            assert cases.rel_l2(a, b) < 1e-12, linear
