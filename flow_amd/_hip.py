@@ -440,12 +440,26 @@ def launch_count():
     return int(n.value)
 
 
+_GRAPHS = {'mode': None}
+
+
 def graph_mode(mode, auto_rows=-1, sites=0):
     '''Iteration bodies as HIP graphs: 0 never, 1 always, 2 by system size;
     sites: 1 CG | 2 GMRES | 4 mass solver (0: leave) (include/flow_hip.h:
     flow_graph_mode).'''
     check(load_library().flow_graph_mode(int(mode) | (int(sites) << 4),
                                          int(auto_rows)))
+    _GRAPHS['mode'] = int(mode)
+
+
+def graphs_possible():
+    '''Can a solver loop be replayed as a HIP graph in this process (the
+    option is off unless FLOW_AMD_GRAPHS or graph_mode() says otherwise)?
+    Host code that keeps operands at fixed addresses only for the replay's
+    sake asks here first.'''
+    if _GRAPHS['mode'] is not None:
+        return _GRAPHS['mode'] != 0
+    return os.environ.get('FLOW_AMD_GRAPHS', '0') not in ('', '0')
 
 
 def graph_stats():

@@ -674,11 +674,14 @@ def project_magnitude(u, mode=0, tol=1.0e-12, initial_guess=None):
     # (single GPU: right-hand side and iterate of the mass solve in buffers of
     # the layout -- a loop whose arguments repeat from call to call is replayed
     # as a HIP graph, csrc/graph_replay.hip; the result is copied out)
-    held = None if strips else lay._dev.get(('persistent', 'magnitude'))
-    if not strips and held is None:
+    # -- only where a replay is possible at all (the option is off by default:
+    # the two copies then are not made)
+    fixed = not strips and _hip.graphs_possible()
+    held = lay._dev.get(('persistent', 'magnitude')) if fixed else None
+    if fixed and held is None:
         held = lay._dev[('persistent', 'magnitude')] = (
             device.empty(lay.N), device.empty(lay.N))
-    b = device.zeros(lay.N) if strips else _hip.fill(held[0], 0.0)
+    b = _hip.fill(held[0], 0.0) if fixed else device.zeros(lay.N)
     buf = scratch(mesh, lay.nloc * mesh.num_cells())
     _hip.check(lib.flow_assemble_magnitude(
         ctypes.byref(parallel.mesh_view(mesh) if strips else mesh_struct(mesh)),
@@ -704,11 +707,12 @@ def project_magnitude(u, mode=0, tol=1.0e-12, initial_guess=None):
                                      maxit=1000, check_every=2, tag=tag)
     elif MASS_SOLVER['method'] == 'chebyshev':
         from .mass import MassSolver
-        x = copy(held[1], out.data)
+        x = copy(held[1], out.data) if fixed else out.data
         out.solve_info = MassSolver.cached(
             M, lay._dev[key], steps=MASS_SOLVER['steps']).solve(
                 b, x, tol, maxit=100, tag=tag)
-        copy(out.data, x)
+        if fixed:
+            copy(out.data, x)
     else:
         out.solve_info = krylov_solve(
             'cg', M, b, out.data, tol, maxit=1000, dinv=lay._dev[key],
