@@ -478,7 +478,12 @@ def _compute_tentative_velocity(
     # loop whose arguments do not change is replayed as a HIP graph --
     # csrc/graph_replay.hip.  The tentative velocity reported in
     # last_step_info lives until the next call on this space.)
-    ui = Function(W, ops.copy(_persistent(lay, 'newton_iterate', n2), u[0].data))
+    # (... only where a replay is possible: otherwise the iterate is a vector
+    # of its own and `last_step_info['tentative_velocity']` stays what this
+    # call computed)
+    ui = Function(W, ops.copy(
+        _persistent(lay, 'newton_iterate', n2) if _hip.graphs_possible()
+        else device.empty(n2), u[0].data))
     # ... or ('initial_guess': 'best'), when this call continues the trajectory
     # of the previous one (u[0] IS the velocity the last step returned), the
     # previous step's TENTATIVE velocity if its residual is smaller (choice (2)
