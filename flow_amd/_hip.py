@@ -221,7 +221,7 @@ class PeerS(ctypes.Structure):
         ('flags', ctypes.c_void_p), ('land', ctypes.c_void_p),
         ('land_cap', ctypes.c_int), ('spin_limit', ctypes.c_int),
         ('nb_flags', ctypes.c_void_p * 2), ('nb_land', ctypes.c_void_p * 2),
-        ('seq_host', ctypes.POINTER(ctypes.c_ulonglong)),
+        ('seq_host', ctypes.POINTER(ctypes.c_ulonglong * 5)),
         ]
 
 

@@ -2882,14 +2882,19 @@ __device__ __forceinline__ bool peer_wait(const unsigned long long* flag,
   return false;
 }
 
+// free0 / free1: the exchange in which this rank LAST pushed into the same
+// landing buffer of its left / right neighbour (0: never) -- that one must
+// have been pulled before the buffer is written again
 __global__ __launch_bounds__(kPeerBlock) void peer_push_kernel(
     flow_rows R, int ncomp, flow_peer P, unsigned long long seq,
+    unsigned long long free0, unsigned long long free1,
     const double* __restrict__ packed) {
   const int sd = blockIdx.x;
   if (R.send_len[sd] <= 0 || P.nb_land[sd] == nullptr) return;
-  if (threadIdx.x == 0 && seq >= 3)
-    peer_wait(P.flags + kConsumed + sd, seq - 2, P.spin_limit,
-              P.flags + kPeerError, (seq << 8) | (1 + sd));
+  const unsigned long long need = sd == 0 ? free0 : free1;
+  if (threadIdx.x == 0 && need > 0)
+    peer_wait(P.flags + kConsumed + sd, need, P.spin_limit, P.flags + kPeerError,
+              (seq << 8) | (1 + sd));
   __syncthreads();
   double* land = P.nb_land[sd] + static_cast<size_t>(seq & 1) * P.land_cap;
   const int len = R.send_len[sd];
@@ -2941,9 +2946,18 @@ int exchange_halo(const flow_comm* C, const flow_rows* R, int ncomp, int sum_cou
   if (P == nullptr || C->world == 1 || nh == 0 || nh > P->land_cap)
     return (hoff + nh > 0) ? exchange(C, hoff + nh) : FLOW_OK;
   FLOW_REQUIRE(P->flags && P->land && P->seq_host, "flow_peer pointers");
-  const unsigned long long seq = ++*P->seq_host;
+  // seq_host[0]: the exchange counter; seq_host[1 + 2 sd + parity]: my last
+  // push into that landing buffer of neighbour sd (what it must have pulled
+  // before this one may overwrite it -- not simply "two exchanges ago": an
+  // exchange of a space that sends nothing to a side skips that side)
+  unsigned long long* H = P->seq_host;
+  const unsigned long long seq = ++H[0];
+  const int par = static_cast<int>(seq & 1);
+  const unsigned long long free0 = H[1 + par], free1 = H[3 + par];
   hipLaunchKernelGGL(peer_push_kernel, dim3(2), dim3(kPeerBlock), 0, st, *R, ncomp,
-                     *P, seq, C->buf + hoff);
+                     *P, seq, free0, free1, C->buf + hoff);
+  for (int sd = 0; sd < 2; ++sd)
+    if (R->send_len[sd] > 0 && P->nb_land[sd] != nullptr) H[1 + 2 * sd + par] = seq;
   FLOW_CHECK_LAUNCH();
   if (sum_count > 0) {
     int rc = exchange(C, sum_count);

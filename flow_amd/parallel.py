@@ -225,7 +225,7 @@ class Comm(object):
             if maps[sd] is not None:
                 peer.nb_flags[sd] = maps[sd].value
                 peer.nb_land[sd] = maps[sd].value + fbytes
-        self._peer_seq = ctypes.c_ulonglong(0)
+        self._peer_seq = (ctypes.c_ulonglong * 5)()
         peer.seq_host = ctypes.pointer(self._peer_seq)
         self._peer_base, self._peer_maps = base, [m for m in maps if m is not None]
         self.peer = peer

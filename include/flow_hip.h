@@ -759,8 +759,10 @@ typedef struct {
   unsigned long long* nb_flags[2]; /* the neighbours' blocks as mapped HERE ... */
   double* nb_land[2];              /* ... and their landing buffers; NULL: no
                                       neighbour on that side (0 left, 1 right) */
-  unsigned long long* seq_host;    /* HOST counter of this communicator's
-                                      exchanges (the library increments it) */
+  unsigned long long* seq_host;    /* HOST, 5 words kept by the library: the
+                                      counter of this communicator's exchanges,
+                                      then per side and landing buffer the
+                                      exchange of this rank's last push into it */
 } flow_peer;
 typedef struct {
   int rank, world;

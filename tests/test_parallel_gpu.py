@@ -244,7 +244,7 @@ def _worker(rank, world, port, out, peer=False):
             newton=[len(i['newton_residuals']) - 1 for i in infos1])
         res['peer'] = (parallel.comm().peer is not None,
                        parallel.comm().peer_error(),
-                       int(parallel.comm()._peer_seq.value)
+                       int(parallel.comm()._peer_seq[0])
                        if parallel.comm().peer is not None else 0)
         out[rank] = res
     finally:
