@@ -328,16 +328,25 @@ def solve_blockwise(A, b, n, rtol=1.0e-14, max_it=80, single=False):
     A = A.tocsr()
     A00, A01 = A[:n, :n].tocsc(), A[:n, n:].tocsr()
     A10, A11 = A[n:, :n].tocsr(), A[n:, n:].tocsc()
+    # (column ordering: minimum degree on the pattern of A^T + A -- the blocks
+    # are structurally symmetric finite-element matrices; half the fill and a
+    # quarter of the time of SuperLU's default COLAMD, measured on a 0.15 M-row
+    # P2 block: 8.3 against 16.9 times the nonzeros of A.  Diagonal pivots are
+    # preferred: mass-dominated rows.  What the factors are worth is checked on
+    # the true residual below.)
+    opts = dict(permc_spec='MMD_AT_PLUS_A', diag_pivot_thresh=0.1)
     if single:
-        lu0 = spla.splu(A00.astype(numpy.float32))
+        lu0 = spla.splu(A00.astype(numpy.float32), **opts)
         del A00
-        lu1 = spla.splu(A11.astype(numpy.float32))
+        lu1 = spla.splu(A11.astype(numpy.float32), **opts)
         del A11
         solve0 = lambda v: lu0.solve(v.astype(numpy.float32)).astype(numpy.float64)
         solve1 = lambda v: lu1.solve(v.astype(numpy.float32)).astype(numpy.float64)
     else:
-        lu0, lu1 = spla.splu(A00), spla.splu(A11)
-        del A00, A11
+        lu0 = spla.splu(A00, **opts)
+        del A00
+        lu1 = spla.splu(A11, **opts)
+        del A11
         solve0, solve1 = lu0.solve, lu1.solve
 
     def precondition(r):
