@@ -326,7 +326,8 @@ def solve_blockwise(A, b, n, rtol=1.0e-14, max_it=80, single=False):
     the full-size workload's blocks fit in 62 GB); they only precondition: the
     Krylov vectors, the operator and the residual that is checked stay fp64.'''
     A = A.tocsr()
-    A00, A01 = A[:n, :n].tocsc(), A[:n, n:].tocsr()
+    A00 = A[:n, :n].tocsc()
+    coupled = A[:n, n:].nnz > 0
     A10, A11 = A[n:, :n].tocsr(), A[n:, n:].tocsc()
     # (column ordering: minimum degree on the pattern of A^T + A -- the blocks
     # are structurally symmetric finite-element matrices; half the fill and a
@@ -357,7 +358,7 @@ def solve_blockwise(A, b, n, rtol=1.0e-14, max_it=80, single=False):
     if bn == 0.0:
         return numpy.zeros_like(b)
     x = precondition(b)
-    if A01.nnz == 0 and A10.nnz == 0:
+    if not coupled and A10.nnz == 0:
         for _refine in range(1 if not single else 6):
             x = x + precondition(b - A.dot(x))   # (refinement on the true residual)
             if numpy.linalg.norm(b - A.dot(x)) <= 1.0e-13 * bn:
@@ -436,6 +437,8 @@ def tentative_velocity(W, P, u0, p0, f0, f1, bc_dofs, bc_vals, method,
             break
         Jbc = _identity_rows(J, bc_dofs)
         del J
+        if th_i != 0.0:
+            del dRi               # (GBs at the sizes the block-wise solve exists for)
         if linear in ('block', 'block32'):
             ui = ui - solve_blockwise(Jbc, F, W.N, single=linear == 'block32')
         else:
