@@ -294,3 +294,46 @@ def test_stokes_solve_at_50k_dofs(hip):
     assert W.size() + P.N > 50000
     assert cases.rel_l2(u0.array(), uo) < 1e-7
     assert cases.rel_l2(p0.array(), po) < 1e-7
+
+
+def test_a_step_of_the_developed_street_against_the_oracle(hip):
+    '''The regime the headline value is measured in: a Karman problem at the
+    driver's viscosity (53 k DoF: under-resolved, cell Peclet ~12 -- the
+    Newton systems run on the ILU fallback) stepped by the product from the
+    Stokes start until the wake sheds, then ONE step from that state by the
+    product and by the oracle (zero forcing, the controller's step size).'''
+    import flow_amd.navier_stokes as navsto
+    from flow_amd import karman
+    prob = karman.KarmanProblem(160, 37)
+    prob.prepare()
+    prob.reset(1.0e-5)
+    prob.set_initial_stokes()
+    navsto.set_mode('parity')
+    its = []
+    while prob.t < 75.0 and len(its) < 1500:
+        its.append(len(prob.step()['newton_residuals']) - 1)
+    u = prob.u0.array().copy()
+    p = prob.p0.array().copy()
+    n = prob.W.layout.N
+    # the wake is unsteady: a cross-stream velocity behind the cylinder of the
+    # order of the inflow's, and steps that need more than one Newton iteration
+    x = prob.W.layout.dof_coords
+    wake = (x[:, 0] > 0.16) & (x[:, 0] < 0.4) & (abs(x[:, 1] - 0.01) < 0.01)
+    assert abs(u[n:][wake]).max() > 0.2 * karman.ENTRANCE_VELOCITY, \
+        abs(u[n:][wake]).max()
+    assert max(its[-50:]) >= 2, its[-50:]
+    case = large_cases.KarmanStepCase(160, 37, dt=prob.dt)
+    zero = fem.Expression(lambda xx: numpy.zeros((2, xx.shape[1])), degree=2)
+    case.f0 = case.f1 = zero
+    info = {}
+    u1o, p1o, uio = case.oracle_step(u0=u, p0=p, info=info)
+    u1, p1, ui = case.product_step(u0=u, p0=p)
+    errs = (cases.rel_l2(ui, uio), cases.rel_l2(p1, p1o), cases.rel_l2(u1, u1o))
+    print('street state at t = %.1f (dt %.3f, %d steps): rel-L2 vs the oracle ui '
+          '%.1e p1 %.1e u1 %.1e; Newton %s' % (
+              prob.t, prob.dt, len(its), errs[0], errs[1], errs[2],
+              ' '.join('%.2e' % r for r in info['newton_history'])))
+    assert max(errs) < 1e-7, errs
+    _newton_history_matches(navsto.last_step_info['newton_residuals'],
+                            info['newton_history'])
+    assert len(info['newton_history']) >= 3
