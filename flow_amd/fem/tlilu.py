@@ -8,13 +8,19 @@ flow/navier_stokes/pressure_correction.py:224-254) and of the heat system
 is rejected by its acceptance test -- cell Peclet numbers beyond ~3 at
 CFL-sized steps.  Same two levels (the diagonal blocks of the assembled P2
 operator, the P1 discretisation of the same operator on the same mesh), same
-transfer tables; one multicolour ILU(0) application (flow_amd/fem/ilu.py) before
-and after the coarse correction, `coarse_sweeps` of them on the P1 level.
+transfer tables; a multicolour ILU(0) application (flow_amd/fem/ilu.py) before
+(`pre`) and / or after (`post`) the coarse correction, `coarse_sweeps` of them
+on the P1 level.  The Newton solver runs 0 / 1 / 1 (coarse correction first:
+the fewest launches per application), the heat solver 1 / 1 / 2.
 
 tools/smoother_lab.py (CPU, the oracle's matrices; flexible GMRES applications
-to 1e-8): structured channel at cell Peclet 3.5 27 -> 13, graded unstructured
-channel 48 -> 17, heat system at cell CFL 6 / 14 / 40 56 / 80 / 146 -> 19 / 23 /
-35 (two coarse sweeps: 14 / 17 / 28).
+to 1e-8, pre + post sweeps): structured channel at cell Peclet 3.5 27 -> 13,
+graded unstructured channel 48 -> 17, heat system at cell CFL 6 / 14 / 40 56 /
+80 / 146 -> 19 / 23 / 35 (two coarse sweeps: 14 / 17 / 28).  On the GPU
+(profiles/tlilu_r06.txt): graded 0.97 M-DoF channel 52.6 -> 25.2 applications,
+16.3 -> 13.5 ms per step; config 4's heat solve 60-90 -> 14-19 iterations.
+Whether the cycle or its smoother alone runs a solve is decided by measured
+convergence rate per time (navier_stokes/newton_preconditioner.rate_verdict).
 '''
 import ctypes
 
